@@ -1,0 +1,122 @@
+/*
+ * rodent_traversal.h -- C ABI of the MI355X traversal library (librodent_hip.so).
+ *
+ * This is the hand-written equivalent of the header AnyDSL generates for
+ * Rodent's bench_traversal ("traversal.h", git-ignored in the reference,
+ * produced by anydsl_runtime_wrap at tools/bench_traversal/CMakeLists.txt:13-17).
+ * Struct field order and sizes follow the Impala definitions:
+ *   Node2/Tri1        src/traversal/mapping_gpu.impala:3-16
+ *   Node4/Node8/Tri4  src/traversal/mapping_cpu.impala:3-22
+ *   Ray1/4/8 Hit1/4/8 tools/bench_traversal/bench_traversal.impala:25-65
+ *
+ * Every entry point takes plain pointers and sizes.  GPU entry points take
+ * DEVICE pointers that the caller allocated and filled (the reference does
+ * the same through anydsl::Array + anydsl::copy, tools/common/load_bvh.h:64-68,
+ * tools/common/load_rays.h:85-88); the callee neither allocates nor frees them.
+ * All entry points are synchronous unless their name ends in `_async`
+ * (the reference syncs the device before returning,
+ * tools/bench_traversal/bench_traversal.impala:509).
+ *
+ * Errors: like the reference (bench_traversal.impala:17-21) a runtime failure
+ * prints a message to stderr and abort()s; there are no return codes on the
+ * reference-named entry points.
+ */
+#ifndef RODENT_TRAVERSAL_H
+#define RODENT_TRAVERSAL_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- BVH / ray / hit layouts (bit-compatible with the reference) -------- */
+
+struct Node2 {              /* 64 B  mapping_gpu.impala:3-7 */
+    float   bounds[12];     /* child0: lo_x hi_x lo_y hi_y lo_z hi_z, then child1 */
+    int32_t child[2];       /* >0 inner (index+1), <0 leaf (~first tri), 0 none */
+    int32_t pad[2];
+};
+
+struct Tri1 {               /* 48 B  mapping_gpu.impala:9-16 */
+    float   v0[3];  int32_t pad;
+    float   e1[3];  int32_t geom_id;   /* e1 = v0 - v1 */
+    float   e2[3];  int32_t prim_id;   /* e2 = v2 - v0; bit 31 = last in leaf */
+};
+
+struct Node4 {              /* 128 B mapping_cpu.impala:12-16 */
+    float   bounds[6][4];   /* rows lo_x hi_x lo_y hi_y lo_z hi_z; column = child */
+    int32_t child[4];
+    int32_t pad[4];
+};
+
+struct Node8 {              /* 256 B mapping_cpu.impala:18-22 */
+    float   bounds[6][8];
+    int32_t child[8];
+    int32_t pad[8];
+};
+
+struct Tri4 {               /* 224 B mapping_cpu.impala:3-10 */
+    float   v0[3][4], e1[3][4], e2[3][4], n[3][4];
+    int32_t prim_id[4];     /* -1 = unused lane; bit 31 of [3] = last packet in leaf */
+    int32_t geom_id[4];
+};
+
+struct Ray1 { float org[3]; float tmin; float dir[3]; float tmax; };          /*  32 B */
+struct Ray4 { float org[3][4], dir[3][4], tmin[4], tmax[4]; };                /* 128 B */
+struct Ray8 { float org[3][8], dir[3][8], tmin[8], tmax[8]; };                /* 256 B */
+struct Hit1 { int32_t tri_id; float t, u, v; };                               /*  16 B */
+struct Hit4 { int32_t tri_id[4]; float t[4], u[4], v[4]; };                   /*  64 B */
+struct Hit8 { int32_t tri_id[8]; float t[8], u[8], v[8]; };                   /* 128 B */
+
+/* ---- Entry points that exist in the reference --------------------------- */
+
+/* Replaces tools/bench_traversal/bench_traversal.impala:495-511.
+ * Closest hit, one ray per lane, BVH2/Tri1.  hits[i] = {prim id or -1, t, u, v};
+ * a miss stores tri_id = -1 and t = rays[i].tmax (intersection.impala:134-136). */
+void amdgpu_intersect_single_ray1_bvh2_tri1(int32_t dev,
+        const struct Node2* nodes, const struct Tri1* tris,
+        const struct Ray1* rays, struct Hit1* hits, int32_t num_rays);
+
+/* Replaces tools/bench_traversal/bench_traversal.impala:513-529 (any-hit:
+ * returns at the first accepted triangle). */
+void amdgpu_occluded_single_ray1_bvh2_tri1(int32_t dev,
+        const struct Node2* nodes, const struct Tri1* tris,
+        const struct Ray1* rays, struct Hit1* hits, int32_t num_rays);
+
+/* ---- New entry points, same naming pattern ------------------------------ */
+
+/* BVH8/Tri4 on the GPU (the reference only has this layout on the CPU,
+ * cpu_intersect_single_ray1_bvh8_tri4, bench_traversal.impala:429-441). */
+void hip_intersect_single_ray1_bvh8_tri4(int32_t dev,
+        const struct Node8* nodes, const struct Tri4* tris,
+        const struct Ray1* rays, struct Hit1* hits, int32_t num_rays);
+void hip_occluded_single_ray1_bvh8_tri4(int32_t dev,
+        const struct Node8* nodes, const struct Tri4* tris,
+        const struct Ray1* rays, struct Hit1* hits, int32_t num_rays);
+
+/* Asynchronous forms: enqueue on `stream` (a hipStream_t passed as void*,
+ * NULL = the device's null stream) and return without synchronising, so a
+ * caller can bracket launches with its own HIP events.  `variant` selects the
+ * kernel mapping (see rodent_hip_variant_name); 0 is the default shipped one. */
+void hip_traverse_bvh2_tri1_async(int32_t dev,
+        const struct Node2* nodes, const struct Tri1* tris,
+        const struct Ray1* rays, struct Hit1* hits, int32_t num_rays,
+        int32_t any_hit, int32_t variant, void* stream);
+void hip_traverse_bvh8_tri4_async(int32_t dev,
+        const struct Node8* nodes, const struct Tri4* tris,
+        const struct Ray1* rays, struct Hit1* hits, int32_t num_rays,
+        int32_t any_hit, int32_t variant, void* stream);
+
+/* Introspection / plumbing. */
+int32_t     rodent_hip_device_count(void);              /* 0 when no GPU is visible */
+int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2 or 8 */
+const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant);
+const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t any_hit);
+const char* rodent_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RODENT_TRAVERSAL_H */

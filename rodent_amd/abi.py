@@ -1,0 +1,124 @@
+"""ctypes binding of librodent_hip.so (the C ABI declared in include/rodent_traversal.h).
+
+This is the Python-side mirror of what the reference's bench_traversal.cpp does
+with the AnyDSL-generated traversal.h: hand device pointers to the entry points.
+Device memory comes from torch (plumbing only); every entry point receives raw
+pointers.  There is NO CPU fallback: if the shared library is missing or no GPU is
+visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import formats as F
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "librodent_hip.so"
+
+EXPORTS = [
+    "amdgpu_intersect_single_ray1_bvh2_tri1", "amdgpu_occluded_single_ray1_bvh2_tri1",
+    "hip_intersect_single_ray1_bvh8_tri4", "hip_occluded_single_ray1_bvh8_tri4",
+    "hip_traverse_bvh2_tri1_async", "hip_traverse_bvh8_tri4_async",
+    "rodent_hip_device_count", "rodent_hip_num_variants", "rodent_hip_variant_name",
+    "rodent_hip_kernel_name", "rodent_hip_version",
+]
+
+_lib = None
+
+
+class MissingExtension(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads librodent_hip.so (built in-tree by rodent_amd.build); raises if absent."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise MissingExtension(f"{LIB_PATH} not built: run `python -m rodent_amd.build` (needs hipcc)")
+        l = C.CDLL(str(LIB_PATH))
+        vp, i32 = C.c_void_p, C.c_int32
+        for name in EXPORTS[:4]:
+            fn = getattr(l, name); fn.restype = None; fn.argtypes = [i32, vp, vp, vp, vp, i32]
+        for name in EXPORTS[4:6]:
+            fn = getattr(l, name); fn.restype = None; fn.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
+        l.rodent_hip_device_count.restype = i32; l.rodent_hip_device_count.argtypes = []
+        l.rodent_hip_num_variants.restype = i32; l.rodent_hip_num_variants.argtypes = [i32]
+        l.rodent_hip_variant_name.restype = C.c_char_p; l.rodent_hip_variant_name.argtypes = [i32, i32]
+        l.rodent_hip_kernel_name.restype = C.c_char_p; l.rodent_hip_kernel_name.argtypes = [i32, i32, i32]
+        l.rodent_hip_version.restype = C.c_char_p; l.rodent_hip_version.argtypes = []
+        _lib = l
+    return _lib
+
+
+def variants(width):
+    l = lib()
+    return [l.rodent_hip_variant_name(width, i).decode() for i in range(l.rodent_hip_num_variants(width))]
+
+
+def kernel_name(width, variant, any_hit=False):
+    return lib().rodent_hip_kernel_name(width, variant, int(any_hit)).decode()
+
+
+# ---- device buffers (torch is plumbing: allocation + copies) ---------------------------------
+
+def to_device(arr: np.ndarray, dev: int = 0):
+    """Structured numpy array -> torch uint8 CUDA tensor holding the same bytes."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("rodent_amd: no GPU visible (torch.cuda.is_available() is False)")
+    a = np.ascontiguousarray(arr)
+    t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy() if a.size else np.zeros(0, np.uint8))
+    return t.to(f"cuda:{dev}")
+
+
+def from_device(t, dtype: np.dtype) -> np.ndarray:
+    return t.cpu().numpy().view(dtype).copy()
+
+
+class DeviceBvh:
+    """A BVH resident in HBM: nodes + tris of one layout (2 = Node2/Tri1, 8 = Node8/Tri4)."""
+
+    def __init__(self, width, nodes, tris, dev=0):
+        assert width in (2, 8)
+        self.width, self.dev = width, dev
+        self.num_nodes, self.num_tris = len(nodes), len(tris)
+        self.nodes = to_device(nodes, dev)
+        self.tris = to_device(tris, dev)
+
+    @classmethod
+    def load(cls, path, width, dev=0):
+        nodes, tris = F.read_bvh(path, F.BVH2_TRI1 if width == 2 else F.BVH8_TRI4)
+        return cls(width, nodes, tris, dev)
+
+
+def traverse_async(bvh: DeviceBvh, rays_dev, hits_dev, num_rays, any_hit=False, variant=0, stream=None):
+    """Enqueues one traversal pass on `stream` (torch stream or None = torch's current stream)."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream(bvh.dev)
+    fn = lib().hip_traverse_bvh2_tri1_async if bvh.width == 2 else lib().hip_traverse_bvh8_tri4_async
+    fn(bvh.dev, bvh.nodes.data_ptr(), bvh.tris.data_ptr(), rays_dev.data_ptr(), hits_dev.data_ptr(),
+       int(num_rays), int(any_hit), int(variant), C.c_void_p(stream.cuda_stream))
+
+
+def traverse(bvh: DeviceBvh, rays: np.ndarray, any_hit=False, variant=None) -> np.ndarray:
+    """Synchronous convenience wrapper: host rays in, host Hit1 array out.
+
+    With variant=None it goes through the reference-named synchronous entry points
+    (amdgpu_intersect_single_ray1_bvh2_tri1 & co)."""
+    import torch
+    n = len(rays)
+    rays_dev = to_device(rays, bvh.dev)
+    hits_dev = torch.zeros(max(n, 1) * F.HIT1.itemsize, dtype=torch.uint8, device=f"cuda:{bvh.dev}")
+    if variant is None:
+        torch.cuda.synchronize(bvh.dev)
+        name = {(2, False): "amdgpu_intersect_single_ray1_bvh2_tri1", (2, True): "amdgpu_occluded_single_ray1_bvh2_tri1",
+                (8, False): "hip_intersect_single_ray1_bvh8_tri4", (8, True): "hip_occluded_single_ray1_bvh8_tri4"}[(bvh.width, bool(any_hit))]
+        getattr(lib(), name)(bvh.dev, bvh.nodes.data_ptr(), bvh.tris.data_ptr(), rays_dev.data_ptr(), hits_dev.data_ptr(), n)
+    else:
+        traverse_async(bvh, rays_dev, hits_dev, n, any_hit, variant)
+        torch.cuda.synchronize(bvh.dev)
+    return from_device(hits_dev, F.HIT1)[:n]

@@ -1,0 +1,141 @@
+"""In-tree native build for rodent_amd (no cmake: hipcc / g++ driven directly).
+
+Artefacts (all git-ignored, they travel to the GPU box with the snapshot):
+  rodent_amd/lib/librodent_hip.so   HIP kernels + C ABI (include/*.h)
+  rodent_amd/bin/<tool>             host tools: bvh_extractor, ray_gen, scene_gen,
+                                    fbuf2png, bench_traversal, rodent
+  oracle/liboracle.so               CPU parity oracle (test infrastructure only)
+
+`python -m rodent_amd.build` builds everything; `build_all()` is what
+__graft_entry__.build() calls.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG = ROOT / "rodent_amd"
+CSRC = PKG / "csrc"
+HOST = PKG / "host"
+LIB_DIR = PKG / "lib"
+BIN_DIR = PKG / "bin"
+OBJ_DIR = ROOT / "build"
+ORACLE = ROOT / "oracle"
+
+ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+HIPCC = os.environ.get("HIPCC", str(ROCM / "bin" / "hipcc"))
+CXX = os.environ.get("CXX", "g++")
+CC = os.environ.get("CC", "gcc")
+
+# -ffp-contract=off: fused multiply-adds are written explicitly (fmaf) in both the
+# kernels and the oracle so the two perform the same correctly-rounded operations.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+             "-Wall", "-Wno-unused-function", f"-I{ROOT / 'include'}"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-Wall", "-fPIC", f"-I{ROOT / 'include'}"]
+ORACLE_FLAGS = ["-O2", "-std=c11", "-Wall", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma"]
+
+HIP_SOURCES = ["traversal.hip"]
+HOST_LIB_SOURCES = ["mesh.cpp", "bvh_build.cpp", "atrium.cpp"]
+HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png"]
+HIP_TOOLS = ["bench_traversal"]
+
+
+def _newer(target: Path, *deps: Path) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.exists() and d.stat().st_mtime > t for d in deps)
+
+
+def _run(cmd, **kw):
+    print("+", " ".join(str(c) for c in cmd), flush=True)
+    subprocess.run([str(c) for c in cmd], check=True, **kw)
+
+
+def _headers():
+    return list((ROOT / "include").glob("*.h")) + list(HOST.glob("*.h")) + list(CSRC.glob("*.h")) + list(CSRC.glob("*.hpp"))
+
+
+def build_hip_lib(force: bool = False) -> Path:
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    out = LIB_DIR / "librodent_hip.so"
+    srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
+    if force or _newer(out, *srcs, *_headers()):
+        _run([HIPCC, *HIP_FLAGS, "-shared", *srcs, "-o", out])
+    return out
+
+
+def build_host(force: bool = False) -> list[Path]:
+    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+    BIN_DIR.mkdir(parents=True, exist_ok=True)
+    objs = []
+    for s in HOST_LIB_SOURCES:
+        o = OBJ_DIR / (Path(s).stem + ".o")
+        if force or _newer(o, HOST / s, *_headers()):
+            _run([CXX, *HOST_FLAGS, "-c", HOST / s, "-o", o])
+        objs.append(o)
+    outs = []
+    for t in HOST_TOOLS:
+        src = HOST / "tools" / f"{t}.cpp"
+        if not src.exists():
+            continue
+        out = BIN_DIR / t
+        if force or _newer(out, src, *objs, *_headers()):
+            _run([CXX, *HOST_FLAGS, src, *objs, "-pthread", "-o", out])
+        outs.append(out)
+    return outs
+
+
+def build_hip_tools(force: bool = False) -> list[Path]:
+    """Host CLIs that link the HIP library (bench_traversal, rodent)."""
+    lib = build_hip_lib(force)
+    outs = []
+    for t in HIP_TOOLS:
+        src = HOST / "tools" / f"{t}.cpp"
+        if not src.exists():
+            continue
+        out = BIN_DIR / t
+        if force or _newer(out, src, lib, *_headers()):
+            # plain g++: host code only uses the HIP runtime API (hipcc mistakes .o inputs for sources)
+            _run([CXX, "-O2", "-std=c++17", "-Wall", "-Wno-unused-result", "-D__HIP_PLATFORM_AMD__",
+                  f"-I{ROOT / 'include'}", f"-I{ROCM / 'include'}", src,
+                  f"-L{LIB_DIR}", "-lrodent_hip", f"-L{ROCM / 'lib'}", "-lamdhip64",
+                  "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{ROCM / 'lib'}", "-pthread", "-o", out])
+        outs.append(out)
+    return outs
+
+
+def build_oracle(force: bool = False) -> Path:
+    out = ORACLE / "liboracle.so"
+    srcs = sorted(ORACLE.glob("*.c"))
+    if force or _newer(out, *srcs):
+        _run([CC, *ORACLE_FLAGS, "-shared", *srcs, "-lm", "-o", out])
+    cpp = sorted(ORACLE.glob("*_baseline.cpp"))
+    if cpp:
+        out2 = ORACLE / "libcpu_baseline.so"
+        if force or _newer(out2, *cpp):
+            _run([CXX, "-O3", "-std=c++17", "-march=x86-64-v3", "-fPIC", "-shared", "-pthread", *cpp, "-o", out2])
+    return out
+
+
+def build_reference_tools(force: bool = False):
+    """oracle/_ref: the reference's own C++ pieces that compile here (optional)."""
+    mk = ORACLE / "Makefile.ref"
+    if mk.exists() and Path("/root/reference").exists():
+        _run(["make", "-s", "-f", mk, "-C", ORACLE])
+
+
+def build_all(force: bool = False):
+    build_host(force)
+    build_hip_lib(force)
+    build_hip_tools(force)
+    build_oracle(force)
+    build_reference_tools(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

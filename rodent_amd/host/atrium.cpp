@@ -1,0 +1,236 @@
+// Procedural "atrium": a seeded Sponza-class test scene.
+//
+// The benchmark assets BASELINE.json names (testing/sponza.bvh, sponza-*.rays)
+// are not in the reference checkout (.MISSING_LARGE_BLOBS) and no Sponza OBJ
+// exists on this machine, so every number this repo produces itself comes from
+// this regenerable stand-in: a two-storey colonnaded courtyard with arches,
+// balustrades, hanging drapes, vases with foliage and a relief, ~262 K
+// triangles, bounding box ~3700 x 1550 x 2300 units (so the reference's
+// tmax = 5000 / tmin = 0.01 flags stay meaningful).  Mixed large (walls, slabs)
+// and tiny (foliage, balusters) triangles make spatial splits matter.
+// Results on it are labelled "atrium", never "sponza".
+#include "atrium.h"
+
+#include <cmath>
+
+namespace rodent {
+namespace {
+
+struct Rng {                                   // splitmix64: portable, seedable
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}
+    uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+    float uni() { return (float)((next() >> 40) * (1.0 / 16777216.0)); }           // [0,1)
+    float range(float a, float b) { return a + (b - a) * uni(); }
+};
+
+const double kPi = 3.14159265358979323846;
+
+struct Builder {
+    TriMesh& m;
+    int mat = 0;
+    uint32_t vert(V3 p) { m.vertices.push_back(p); return (uint32_t)m.vertices.size() - 1; }
+    void tri(uint32_t a, uint32_t b, uint32_t c) { m.indices.insert(m.indices.end(), {a, b, c, (uint32_t)mat}); }
+    void quad(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { tri(a, b, c); tri(a, c, d); }
+
+    // Parametric grid patch: f(u,v) with nu x nv cells
+    template <typename F> void patch(int nu, int nv, F f, bool flip = false) {
+        const uint32_t base = (uint32_t)m.vertices.size();
+        for (int j = 0; j <= nv; j++) for (int i = 0; i <= nu; i++) vert(f((float)i / nu, (float)j / nv));
+        for (int j = 0; j < nv; j++) for (int i = 0; i < nu; i++) {
+            const uint32_t a = base + j * (nu + 1) + i, b = a + 1, c = a + nu + 2, d = a + nu + 1;
+            if (flip) quad(a, d, c, b); else quad(a, b, c, d);
+        }
+    }
+    void box(V3 lo, V3 hi) {
+        const uint32_t v[8] = {vert({lo.x, lo.y, lo.z}), vert({hi.x, lo.y, lo.z}), vert({hi.x, hi.y, lo.z}), vert({lo.x, hi.y, lo.z}),
+                               vert({lo.x, lo.y, hi.z}), vert({hi.x, lo.y, hi.z}), vert({hi.x, hi.y, hi.z}), vert({lo.x, hi.y, hi.z})};
+        quad(v[0], v[3], v[2], v[1]); quad(v[4], v[5], v[6], v[7]); quad(v[0], v[1], v[5], v[4]);
+        quad(v[3], v[7], v[6], v[2]); quad(v[0], v[4], v[7], v[3]); quad(v[1], v[2], v[6], v[5]);
+    }
+    // Surface of revolution around the vertical axis through c: radius(t), height(t), t in [0,1]
+    template <typename R, typename H> void lathe(V3 c, int seg, int rings, R radius, H height) {
+        patch(seg, rings, [&](float u, float v) {
+            const double a = 2 * kPi * u; const float r = radius(v);
+            return V3(c.x + r * (float)std::cos(a), c.y + height(v), c.z + r * (float)std::sin(a));
+        });
+    }
+};
+
+void column(Builder& b, V3 base, float h, float r) {
+    b.box(base + V3(-1.5f * r, 0, -1.5f * r), base + V3(1.5f * r, 0.06f * h, 1.5f * r));                // plinth
+    b.lathe(base + V3(0, 0.06f * h, 0), 32, 10,                                                        // fluted shaft with entasis
+            [&](float v) { return r * (1.0f - 0.15f * v * v); }, [&](float v) { return v * 0.82f * h; });
+    b.lathe(base + V3(0, 0.88f * h, 0), 32, 6,                                                          // capital
+            [&](float v) { return r * (0.85f + 0.75f * v * v); }, [&](float v) { return v * 0.08f * h; });
+    b.box(base + V3(-1.7f * r, 0.96f * h, -1.7f * r), base + V3(1.7f * r, h, 1.7f * r));               // abacus
+}
+
+// Semi-circular arch spanning p0..p1 (same height), extruded by `depth` along `n`
+void arch(Builder& b, V3 p0, V3 p1, V3 n, float depth, float thick) {
+    const V3 mid = (p0 + p1) * 0.5f; const V3 ax = (p1 - p0) * 0.5f; const float R = length(ax);
+    const V3 up(0, 1, 0);
+    for (int side = 0; side < 2; side++) {
+        const float rr = side == 0 ? R : R + thick;
+        b.patch(24, 2, [&](float u, float v) {
+            const double a = kPi * u;
+            return mid - ax * (float)std::cos(a) * (rr / R) + up * (rr * (float)std::sin(a)) + n * (depth * (v - 0.5f));
+        }, side == 0);
+    }
+    for (int face = 0; face < 2; face++)
+        b.patch(24, 1, [&](float u, float v) {
+            const double a = kPi * u; const float rr = R + thick * v;
+            return mid - ax * (float)std::cos(a) * (rr / R) + up * (rr * (float)std::sin(a)) + n * (depth * (face - 0.5f));
+        }, face == 1);
+}
+
+void baluster(Builder& b, V3 base, float h) {
+    b.lathe(base, 8, 6, [&](float v) { return 4.0f + 5.0f * (float)std::sin(kPi * v) * (0.6f + 0.4f * (float)std::cos(6.0 * v)); },
+            [&](float v) { return v * h; });
+}
+
+void drape(Builder& b, V3 top_left, V3 along, float height, Rng& rng) {
+    const float ph = rng.range(0.0f, 6.28f), amp = rng.range(18.0f, 40.0f), freq = rng.range(5.0f, 9.0f);
+    const V3 nrm = normalize(cross(along, V3(0, 1, 0)));
+    b.patch(64, 40, [&](float u, float v) {
+        const float fold = amp * (0.25f + 0.75f * v) * (float)std::sin(freq * 6.2831853 * u + ph + 2.0 * v);
+        const float sag = 30.0f * (float)std::sin(kPi * u) * v;
+        return top_left + along * u + V3(0, -height * v - sag, 0) + nrm * fold;
+    });
+}
+
+void vase_with_plant(Builder& b, V3 base, float s, Rng& rng, int mat_vase, int mat_leaf) {
+    b.mat = mat_vase;
+    b.lathe(base, 48, 32, [&](float v) { return s * (0.35f + 0.55f * (float)std::sin(kPi * (0.15 + 0.8 * v)) - 0.25f * v * v); },
+            [&](float v) { return v * 1.6f * s; });
+    b.mat = mat_leaf;
+    const V3 top = base + V3(0, 1.6f * s, 0);
+    for (int i = 0; i < 1800; i++) {                      // foliage: tiny incoherent triangles
+        const float a = rng.range(0, 6.2831853f), e = rng.range(0.1f, 1.5f), d = rng.range(0.2f, 1.0f) * 1.4f * s;
+        const V3 c = top + V3(d * (float)std::cos(a) * (float)std::cos(e), d * (float)std::sin(e) * 1.3f, d * (float)std::sin(a) * (float)std::cos(e));
+        const float l = rng.range(0.04f, 0.12f) * s;
+        const V3 t1(rng.range(-1, 1), rng.range(-1, 1), rng.range(-1, 1)), t2(rng.range(-1, 1), rng.range(-1, 1), rng.range(-1, 1));
+        const uint32_t v0 = b.vert(c), v1 = b.vert(c + t1 * l), v2 = b.vert(c + t2 * l);
+        b.tri(v0, v1, v2);
+    }
+}
+
+void relief(Builder& b, V3 c, float r, Rng& rng) {
+    const float p1 = rng.range(0, 6.28f), p2 = rng.range(0, 6.28f);
+    b.patch(128, 64, [&](float u, float v) {
+        const double th = kPi * v, ph = 2 * kPi * u;
+        const float bump = 1.0f + 0.08f * (float)std::sin(9 * ph + p1) * (float)std::sin(7 * th + p2) + 0.04f * (float)std::sin(23 * ph) * (float)std::sin(19 * th);
+        return c + V3((float)(std::sin(th) * std::cos(ph)), (float)std::cos(th), (float)(std::sin(th) * std::sin(ph)) * 0.5f) * (r * bump);
+    });
+}
+
+} // namespace
+
+void generate_atrium(TriMesh& mesh, uint64_t seed) {
+    mesh = TriMesh();
+    mesh.material_names = {"", "stone", "floor", "fabric_red", "fabric_green", "fabric_blue", "bronze", "leaf", "light", "plaster"};
+    mesh.mtl_libs = {"atrium.mtl"};
+    enum { STONE = 1, FLOOR, FAB_R, FAB_G, FAB_B, BRONZE, LEAF, LIGHT, PLASTER };
+    Builder b{mesh};
+    Rng rng(seed);
+
+    const float X = 1850, Y = 1550, Z = 1150;      // half extents in x/z, full height
+    const float cx = 1250, cz = 520;               // courtyard half extents (colonnade line)
+
+    // Floor (finely tessellated, slightly uneven) and outer shell (large triangles)
+    b.mat = FLOOR;
+    b.patch(96, 60, [&](float u, float v) {
+        const float x = -X + 2 * X * u, z = -Z + 2 * Z * v;
+        return V3(x, 1.5f * (float)std::sin(0.013 * x) * (float)std::cos(0.017 * z), z);
+    }, true);
+    b.mat = PLASTER;
+    b.patch(6, 3, [&](float u, float v) { return V3(-X + 2 * X * u, Y * v, -Z); }, true);
+    b.patch(6, 3, [&](float u, float v) { return V3(-X + 2 * X * u, Y * v,  Z); });
+    b.patch(4, 3, [&](float u, float v) { return V3(-X, Y * v, -Z + 2 * Z * u); });
+    b.patch(4, 3, [&](float u, float v) { return V3( X, Y * v, -Z + 2 * Z * u); }, true);
+    b.patch(8, 6, [&](float u, float v) { return V3(-X + 2 * X * u, Y, -Z + 2 * Z * v); });   // roof
+
+    // Ceiling lights (emissive quads just under the roof)
+    b.mat = LIGHT;
+    for (int i = 0; i < 6; i++) {
+        const float x = -1500.0f + 600.0f * i;
+        const V3 lo(x - 120, Y - 20, -90), hi(x + 120, Y - 20, 90);
+        const uint32_t v0 = b.vert({lo.x, lo.y, lo.z}), v1 = b.vert({hi.x, lo.y, lo.z}), v2 = b.vert({hi.x, lo.y, hi.z}), v3 = b.vert({lo.x, lo.y, hi.z});
+        b.quad(v0, v1, v2, v3);
+    }
+
+    // Two storeys of colonnade around the courtyard
+    const float storey[2] = {0.0f, 700.0f};
+    const float col_h[2] = {600.0f, 520.0f};
+    for (int s = 0; s < 2; s++) {
+        std::vector<V3> line;
+        const int nx = 12, nz = 5;
+        for (int i = 0; i <= nx; i++) line.push_back(V3(-cx + 2 * cx * i / nx, storey[s], -cz));
+        for (int i = 1; i <= nz; i++) line.push_back(V3(cx, storey[s], -cz + 2 * cz * i / nz));
+        for (int i = 1; i <= nx; i++) line.push_back(V3(cx - 2 * cx * i / nx, storey[s], cz));
+        for (int i = 1; i < nz; i++) line.push_back(V3(-cx, storey[s], cz - 2 * cz * i / nz));
+        b.mat = STONE;
+        for (auto& p : line) column(b, p, col_h[s], 34.0f - 6.0f * s);
+        for (size_t i = 0; i < line.size(); i++) {
+            const V3 p0 = line[i] + V3(0, col_h[s], 0), p1 = line[(i + 1) % line.size()] + V3(0, col_h[s], 0);
+            const V3 n = normalize(cross(p1 - p0, V3(0, 1, 0)));
+            const V3 d = normalize(p1 - p0) * 40.0f;
+            arch(b, p0 + d - V3(0, 95, 0), p1 - d - V3(0, 95, 0), n, 70.0f, 26.0f);
+        }
+        // gallery slab between the colonnade and the outer walls, and the entablature boxes
+        const float top = storey[s] + col_h[s];
+        b.box(V3(-X, top, -Z), V3(X, top + 60, -cz + 40)); b.box(V3(-X, top, cz - 40), V3(X, top + 60, Z));
+        b.box(V3(-X, top, -cz + 40), V3(-cx + 40, top + 60, cz - 40)); b.box(V3(cx - 40, top, -cz + 40), V3(X, top + 60, cz - 40));
+        // balustrade along the courtyard edge of the upper gallery
+        if (s == 0) {
+            b.mat = STONE;
+            const float y0 = top + 60;
+            for (size_t i = 0; i < line.size(); i++) {
+                const V3 p0 = line[i], p1 = line[(i + 1) % line.size()];
+                const int nb = 12;
+                for (int k = 0; k < nb; k++) {
+                    const V3 p = p0 + (p1 - p0) * ((k + 0.5f) / nb);
+                    baluster(b, V3(p.x, y0, p.z), 70.0f);
+                }
+                const V3 lo = vmin(p0, p1) - V3(7, 0, 7), hi = vmax(p0, p1) + V3(7, 0, 7);
+                b.box(V3(lo.x, y0 + 70, lo.z), V3(hi.x, y0 + 82, hi.z));
+            }
+        }
+    }
+
+    // Drapes hanging across the courtyard from the upper gallery
+    const int fabrics[3] = {FAB_R, FAB_G, FAB_B};
+    for (int i = 0; i < 8; i++) {
+        b.mat = fabrics[i % 3];
+        const float x = -1050.0f + 300.0f * i;
+        drape(b, V3(x, 1250.0f - 25.0f * (i % 3), -cz + 60), V3(rng.range(-40, 40), 0, 2 * cz - 120), rng.range(420, 640), rng);
+    }
+
+    // Vases with foliage on the courtyard floor, bronze relief at the far end
+    for (int i = 0; i < 10; i++) {
+        const float x = -1000.0f + 222.0f * i, z = (i & 1) ? 250.0f : -250.0f;
+        vase_with_plant(b, V3(x, 0, z), 70.0f, rng, BRONZE, LEAF);
+    }
+    b.mat = BRONZE;
+    relief(b, V3(X - 260, 420, 0), 170.0f, rng);
+    relief(b, V3(-X + 260, 420, 0), 170.0f, rng);
+
+    // Beams under the roof
+    b.mat = STONE;
+    for (int i = 0; i < 14; i++) { const float x = -1690.0f + 260.0f * i; b.box(V3(x - 18, Y - 90, -Z), V3(x + 18, Y - 30, Z)); }
+}
+
+const char* atrium_mtl_text() {
+    return
+        "newmtl stone\n  Ns 10\n  Ni 1\n  illum 2\n  Kd 0.62 0.58 0.50\n  Ks 0 0 0\n  Ke 0 0 0\n\n"
+        "newmtl plaster\n  Ns 10\n  Ni 1\n  illum 2\n  Kd 0.75 0.72 0.65\n  Ks 0 0 0\n  Ke 0 0 0\n\n"
+        "newmtl floor\n  Ns 40\n  Ni 1\n  illum 2\n  Kd 0.45 0.42 0.38\n  Ks 0.2 0.2 0.2\n  Ke 0 0 0\n\n"
+        "newmtl fabric_red\n  Ns 10\n  Ni 1\n  illum 2\n  Kd 0.60 0.08 0.06\n  Ks 0 0 0\n  Ke 0 0 0\n\n"
+        "newmtl fabric_green\n  Ns 10\n  Ni 1\n  illum 2\n  Kd 0.10 0.42 0.12\n  Ks 0 0 0\n  Ke 0 0 0\n\n"
+        "newmtl fabric_blue\n  Ns 10\n  Ni 1\n  illum 2\n  Kd 0.08 0.14 0.55\n  Ks 0 0 0\n  Ke 0 0 0\n\n"
+        "newmtl bronze\n  Ns 60\n  Ni 1\n  illum 2\n  Kd 0.30 0.20 0.08\n  Ks 0.5 0.4 0.2\n  Ke 0 0 0\n\n"
+        "newmtl leaf\n  Ns 10\n  Ni 1\n  illum 2\n  Kd 0.12 0.36 0.08\n  Ks 0 0 0\n  Ke 0 0 0\n\n"
+        "newmtl light\n  Ns 10\n  Ni 1\n  illum 2\n  Kd 0.78 0.78 0.78\n  Ks 0 0 0\n  Ke 40 38 32\n\n";
+}
+
+} // namespace rodent

@@ -1,0 +1,81 @@
+"""Regenerable benchmark inputs (scene -> .bvh -> ray dumps), built with the host tools.
+
+BASELINE.json's inputs (testing/sponza.bvh, sponza-primary.rays, sponza-random.rays)
+are absent from the reference checkout, so the workloads are:
+  * "sponza"  -- used as-is if data/sponza.bvh + data/sponza-{primary,random}.rays exist;
+  * "atrium"  -- seeded procedural Sponza-class scene (host/atrium.cpp), ~265 K triangles;
+  * "cornell" -- the reference's testing/cornell_box.obj (36 triangles).
+Ray dumps follow SURVEY.md 8(d): 1024x1024 primary rays (fov 60, unnormalised
+directions; README.md:34-37 uses --tmax 5000) and 1 Mi random segments (--tmax 1), seed 42.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+from pathlib import Path
+
+from . import build
+
+ROOT = Path(__file__).resolve().parent.parent
+DATA = Path(os.environ.get("RODENT_DATA_DIR", ROOT / "data"))
+GOLDEN = ROOT / "tests" / "golden"
+
+# camera used for the primary dumps: (eye, dir, up, fov)
+CAMERAS = {
+    "atrium": ((-1150.0, 350.0, 30.0), (1.0, 0.12, -0.05), (0.0, 1.0, 0.0), 60.0),
+    "cornell": ((0.0, 1.0, 2.7), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 60.0),
+}
+PRIMARY_TMAX, RANDOM_TMAX = 5000.0, 1.0
+
+
+def _tool(name) -> Path:
+    p = build.BIN_DIR / name
+    if not p.exists():
+        build.build_host()
+    return p
+
+
+def _run(cmd):
+    subprocess.run([str(c) for c in cmd], check=True, stdout=subprocess.DEVNULL)
+
+
+def scene_bvh(scene: str) -> Path:
+    DATA.mkdir(parents=True, exist_ok=True)
+    out = DATA / f"{scene}.bvh"
+    if out.exists():
+        return out
+    if scene == "atrium":
+        obj = DATA / "atrium.obj"
+        if not obj.exists():
+            _run([_tool("scene_gen"), "atrium", obj, 1])
+    elif scene == "cornell":
+        obj = GOLDEN / "cornell_box.obj"
+    else:
+        raise FileNotFoundError(f"{out} not found and scene '{scene}' cannot be generated")
+    _run([_tool("bvh_extractor"), "-obj", obj, "-o", out])
+    return out
+
+
+def primary_rays(scene: str, width=1024, height=1024) -> Path:
+    sfx = "" if (width, height) == (1024, 1024) else f"-{width}x{height}"
+    out = DATA / f"{scene}-primary{sfx}.rays"
+    if not out.exists():
+        scene_bvh(scene)
+        eye, d, up, fov = CAMERAS[scene]
+        _run([_tool("ray_gen"), "primary", *eye, *d, *up, fov, width, height, out])
+    return out
+
+
+def random_rays(scene: str, count=1 << 20, seed=42) -> Path:
+    sfx = "" if count == 1 << 20 else f"-{count}"
+    out = DATA / f"{scene}-random{sfx}.rays"
+    if not out.exists():
+        _run([_tool("ray_gen"), "random", scene_bvh(scene), count, seed, out])
+    return out
+
+
+def default_scene() -> str:
+    """'sponza' when the real blobs were dropped into data/, else the atrium."""
+    if all((DATA / f).exists() for f in ("sponza.bvh", "sponza-primary.rays", "sponza-random.rays")):
+        return "sponza"
+    return "atrium"
