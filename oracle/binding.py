@@ -44,7 +44,7 @@ def lib():
     if _lib is None:
         build()
         _lib = C.CDLL(str(LIB_PATH))
-        for name in ("oracle_bvh2_tri1", "oracle_bvh4_tri4", "oracle_bvh8_tri4"):
+        for name in ("oracle_bvh2_tri1", "oracle_bvh4_tri4", "oracle_bvh8_tri4", "oracle_gpu_bvh4_tri4", "oracle_gpu_bvh8_tri4"):
             fn = getattr(_lib, name)
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(OracleStats)]
@@ -61,10 +61,15 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def traverse(width, nodes, tris, rays, any_hit=False):
-    """Runs the reference algorithm for the given layout (2 = GPU single-ray BVH2/Tri1,
-    4 / 8 = CPU single-ray BVH4/BVH8 + Tri4).  Returns (hits, stats dict)."""
-    fn = {2: "oracle_bvh2_tri1", 4: "oracle_bvh4_tri4", 8: "oracle_bvh8_tri4"}[width]
+def traverse(width, nodes, tris, rays, any_hit=False, algo="ref"):
+    """Runs the reference algorithm for the given layout.  Returns (hits, stats dict).
+
+    algo="ref": 2 = GPU single-ray BVH2/Tri1 (B1); 4 / 8 = CPU single-ray BVH4/BVH8 + Tri4 (B2).
+    algo="gpu": 4 / 8 = the reference GPU kernel's general-arity branch on Node4/Node8 + Tri4 (B1g)."""
+    if algo == "gpu" and width != 2:
+        fn = {4: "oracle_gpu_bvh4_tri4", 8: "oracle_gpu_bvh8_tri4"}[width]
+    else:
+        fn = {2: "oracle_bvh2_tri1", 4: "oracle_bvh4_tri4", 8: "oracle_bvh8_tri4"}[width]
     nodes = np.ascontiguousarray(nodes)
     tris = np.ascontiguousarray(tris)
     rays = np.ascontiguousarray(rays)

@@ -170,7 +170,10 @@ int oracle_bvh2_tri1(const struct Node2* nodes, const struct Tri1* tris,
                                            fmax_ref(fmin_ref(t0z, t1z), ray.tmin));
                 const float texit  = fmin_ref(fmin_ref(fmax_ref(t0x, t1x), fmax_ref(t0y, t1y)),
                                            fmin_ref(fmax_ref(t0z, t1z), ray.tmax));
-                hk[k] = tentry <= texit; te[k] = tentry;
+                /* Deviation: an empty slot (child 0, bounds +inf/-inf, converter.cpp:343-350) is never
+                 * taken.  The unordered min/max test turns the inverted box into an infinite one, so the
+                 * reference would push node id 0 (= "stack empty") and stop early on single-leaf scenes. */
+                hk[k] = (tentry <= texit) && nd->child[k] != 0; te[k] = tentry;
             }
             if (!hk[0] && !hk[1]) { top = mem[ptr]; ptr--; }
             else if (hk[0] && hk[1]) {
@@ -351,6 +354,83 @@ int oracle_bvh8_tri4(const struct Node8* nodes, const struct Tri4* tris, const s
 int oracle_bvh4_tri4(const struct Node4* nodes, const struct Tri4* tris, const struct Ray1* rays,
                      struct Hit1* hits, int32_t n, int32_t any_hit, struct OracleStats* st) {
     return traverse_single_wide((const float*)nodes, 4, tris, rays, hits, n, any_hit, 1, st);
+}
+
+/* ------------------------------------------------------------------------- */
+/* B1g: the reference GPU kernel's "general case" for arity != 2              */
+/* (mapping_gpu.impala:136-153) on the CPU layouts Node4/Node8 + Tri4:         */
+/* pop the node; unordered box test of every child with fminf/fmaxf; the        */
+/* nearest hit child (strict <, starting from ray.tmax) is pushed on top, the   */
+/* others go underneath in slot order; nothing is culled on pop.  Triangles of  */
+/* a packet are tested one after the other, tmax shrinking in between            */
+/* (mapping_gpu.impala:160-169).  This is what k_bvh8_lane implements.          */
+/* ------------------------------------------------------------------------- */
+static int traverse_gpu_wide(const float* node_base, int arity, const struct Tri4* tris,
+                             const struct Ray1* rays, struct Hit1* hits, int32_t n,
+                             int32_t any_hit, struct OracleStats* stats_out) {
+    struct OracleStats st; memset(&st, 0, sizeof st);
+    const int node_floats = 8 * arity;
+    int overflow = 0;
+    for (int32_t i = 0; i < n; i++) {
+        struct RayX ray = make_ray(&rays[i]);
+        int32_t hit_id = -1; float hit_t = ray.tmax, hit_u = 0.0f, hit_v = 0.0f;
+        int32_t mem[STACK_CAP + 16];
+        int32_t ptr = 0, top = 1; mem[0] = 0;
+        int done = 0;
+        while (top != 0 && !done) {
+            const float* nd = node_base + (size_t)(top - 1) * node_floats;
+            const int32_t* child = (const int32_t*)(nd + 6 * arity);
+            top = mem[ptr]; ptr--;                                     /* pop (:138) */
+            st.inner_nodes++;
+            float tnear = ray.tmax;
+            for (int k = 0; k < arity; k++) {
+                const float t0x = fmaf(ray.idx, nd[0 * arity + k], ray.iox), t1x = fmaf(ray.idx, nd[1 * arity + k], ray.iox);
+                const float t0y = fmaf(ray.idy, nd[2 * arity + k], ray.ioy), t1y = fmaf(ray.idy, nd[3 * arity + k], ray.ioy);
+                const float t0z = fmaf(ray.idz, nd[4 * arity + k], ray.ioz), t1z = fmaf(ray.idz, nd[5 * arity + k], ray.ioz);
+                const float tentry = fmax_ref(fmax_ref(fmin_ref(t0x, t1x), fmin_ref(t0y, t1y)), fmax_ref(fmin_ref(t0z, t1z), ray.tmin));
+                const float texit  = fmin_ref(fmin_ref(fmax_ref(t0x, t1x), fmax_ref(t0y, t1y)), fmin_ref(fmax_ref(t0z, t1z), ray.tmax));
+                if (!(tentry <= texit) || child[k] == 0) continue;          /* empty slots: see B1 */
+                if (ptr + 1 >= STACK_CAP) { overflow = 1; continue; }
+                if (any_hit || tentry < tnear) { mem[++ptr] = top; top = child[k]; tnear = tentry; }
+                else mem[++ptr] = child[k];
+            }
+            if ((uint32_t)(ptr + 1) > st.max_stack) st.max_stack = (uint32_t)(ptr + 1);
+            while (top < 0) {
+                int32_t j = ~top; top = mem[ptr]; ptr--;
+                for (;;) {
+                    const struct Tri4* P = &tris[j++];
+                    st.prim_packets++;
+                    for (int k = 0; k < 4; k++) {
+                        if (P->prim_id[k] == -1) break;
+                        float t, u, v;
+                        if (!intersect_tri(&ray, P->v0[0][k], P->v0[1][k], P->v0[2][k],
+                                           P->e1[0][k], P->e1[1][k], P->e1[2][k],
+                                           P->e2[0][k], P->e2[1][k], P->e2[2][k],
+                                           P->n[0][k],  P->n[1][k],  P->n[2][k], &t, &u, &v)) continue;
+                        hit_id = P->prim_id[k] & 0x7FFFFFFF; hit_t = t; hit_u = u; hit_v = v;
+                        ray.tmax = t;
+                        if (any_hit) { done = 1; break; }
+                    }
+                    if (done || P->prim_id[3] < 0) break;
+                }
+                if (done) break;
+            }
+        }
+        hits[i].tri_id = hit_id; hits[i].t = hit_t; hits[i].u = hit_u; hits[i].v = hit_v;
+        st.hits += hit_id >= 0;
+    }
+    st.rays = (uint64_t)n;
+    stats_merge(stats_out, &st);
+    return overflow ? -1 : 0;
+}
+
+int oracle_gpu_bvh8_tri4(const struct Node8* nodes, const struct Tri4* tris, const struct Ray1* rays,
+                         struct Hit1* hits, int32_t n, int32_t any_hit, struct OracleStats* st) {
+    return traverse_gpu_wide((const float*)nodes, 8, tris, rays, hits, n, any_hit, st);
+}
+int oracle_gpu_bvh4_tri4(const struct Node4* nodes, const struct Tri4* tris, const struct Ray1* rays,
+                         struct Hit1* hits, int32_t n, int32_t any_hit, struct OracleStats* st) {
+    return traverse_gpu_wide((const float*)nodes, 4, tris, rays, hits, n, any_hit, st);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -164,8 +164,10 @@ __device__ __forceinline__ int node2_step(const Node2* __restrict__ nodes, int t
     const float4 b0 = p[0], b1 = p[1], b2 = p[2];
     const int4 ch = *reinterpret_cast<const int4*>(p + 3);
     float te0, te1;
-    const bool h0 = slab(ray, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, te0);
-    const bool h1 = slab(ray, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, te1);
+    // Empty slots (child 0, bounds +inf/-inf) are never taken: the unordered min/max test would
+    // turn the inverted box into an infinite one and push node id 0 (= "stack empty").
+    const bool h0 = slab(ray, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, te0) && ch.x != 0;
+    const bool h1 = slab(ray, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, te1) && ch.y != 0;
     if (!h0 && !h1) { const int t = st.get(ptr); ptr--; return t; }
     if (h0 && h1) {
         const bool c0first = te0 < te1;                               // strict <  (:128-129)
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kWave) void k_bvh8_lane(const Node8* __restrict__ n
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 float te;
-                if (slab(ray, blx[k], bhx[k], bly[k], bhy[k], blz[k], bhz[k], te)) {
+                if (slab(ray, blx[k], bhx[k], bly[k], bhy[k], blz[k], bhz[k], te) && chi[k] != 0) {
                     if (ANY || te < tnear) { st.put(++ptr, top); top = chi[k]; tnear = te; }   // push      (:145-147)
                     else st.put(++ptr, chi[k]);                                                   // push_after (:149)
                 }

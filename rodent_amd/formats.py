@@ -72,9 +72,9 @@ def write_bvh(path, blocks):
 
 def read_rays(path, tmin=0.0, tmax=1e9):
     """.rays -> Ray1 array with the given [tmin, tmax] (defaults: bench_traversal.cpp:141)."""
-    raw = np.fromfile(path, "<f4")
-    if raw.size % 6:
+    if Path(path).stat().st_size % 24:
         raise ValueError(f"{path}: size is not a multiple of 24 bytes")
+    raw = np.fromfile(path, "<f4")
     raw = raw.reshape(-1, 6)
     return make_rays(raw[:, :3], raw[:, 3:], tmin, tmax)
 

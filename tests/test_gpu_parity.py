@@ -1,0 +1,172 @@
+"""GPU parity tests: HIP kernels (through the C ABI) against the CPU oracle.
+
+Bar (BASELINE.json): primitive ids bit-exact, t within 1e-4 relative.  Kernels that keep the
+reference's per-ray visit order are held to the stronger bar: the whole Hit1 record
+(id, t, u, v) bit-identical to the oracle, ties and any-hit results included.
+"""
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ambiguous_mask
+from rodent_amd import formats as F
+
+pytestmark = pytest.mark.gpu
+
+# (bvh width, golden/oracle algorithm name, oracle algo flag)
+LAYOUTS = {2: ("bvh2_gpu", "ref"), 8: ("bvh8_gpu", "gpu")}
+
+
+@pytest.fixture(scope="module")
+def gpu(native_build):
+    import torch
+    from rodent_amd import abi
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    abi.lib()
+    return abi
+
+
+@pytest.fixture(scope="module")
+def cornell_dev(gpu, cornell):
+    return {w: gpu.DeviceBvh(w, *cornell.blocks[w], 0) for w in (2, 8)}
+
+
+@pytest.fixture(scope="module")
+def atrium(gpu, oracle):
+    from rodent_amd import scenes, raygen
+    path = scenes.scene_bvh("atrium")
+    blocks = {2: F.read_bvh(path, F.BVH2_TRI1), 8: F.read_bvh(path, F.BVH8_TRI4)}
+    eye, d, up, fov = scenes.CAMERAS["atrium"]
+    n4, _ = F.read_bvh(path, F.BVH4_TRI4)
+    lo, hi = raygen.scene_bounds(n4)
+
+    class A:
+        dev = {w: gpu.DeviceBvh(w, *blocks[w], 0) for w in (2, 8)}
+        host = blocks
+        primary = raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0)
+        random = raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)
+    return A
+
+
+def variants(gpu, width):
+    return list(range(len(gpu.variants(width))))
+
+
+@pytest.mark.parametrize("width", [2, 8])
+@pytest.mark.parametrize("rayset", ["primary", "primary_tmin", "random", "edge"])
+def test_cornell_golden_bit_exact(gpu, cornell, cornell_dev, width, rayset):
+    name, _ = LAYOUTS[width]
+    rays = cornell.ray_sets[rayset]
+    for any_hit in (False, True):
+        exp = cornell.expected[f"{name}.{rayset}.{'any' if any_hit else 'closest'}"]
+        for v in variants(gpu, width):
+            got = gpu.traverse(cornell_dev[width], rays, any_hit=any_hit, variant=v)
+            bad = np.nonzero(got.view("<u4").reshape(-1, 4) != exp.view("<u4").reshape(-1, 4))[0]
+            assert len(bad) == 0, f"width {width} variant {v} any={any_hit}: first diff ray {bad[0]}: {got[bad[0]]} vs {exp[bad[0]]}"
+
+
+@pytest.mark.parametrize("width", [2, 8])
+def test_reference_named_entry_points(gpu, cornell, cornell_dev, width):
+    """amdgpu_{intersect,occluded}_single_ray1_bvh2_tri1 / hip_*_bvh8_tri4 (synchronous)."""
+    name, _ = LAYOUTS[width]
+    for any_hit in (False, True):
+        got = gpu.traverse(cornell_dev[width], cornell.ray_sets["random"], any_hit=any_hit, variant=None)
+        assert got.tobytes() == cornell.expected[f"{name}.random.{'any' if any_hit else 'closest'}"].tobytes()
+
+
+@pytest.mark.parametrize("width", [2, 8])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000])
+def test_ragged_sizes(gpu, cornell, cornell_dev, width, n):
+    name, _ = LAYOUTS[width]
+    rays = cornell.ray_sets["primary"][:n]
+    exp = cornell.expected[f"{name}.primary.closest"][:n]
+    for v in variants(gpu, width):
+        got = gpu.traverse(cornell_dev[width], rays, variant=v)
+        assert got.tobytes() == exp.tobytes()
+
+
+@pytest.mark.parametrize("width", [2, 8])
+@pytest.mark.parametrize("kind", ["primary", "random"])
+def test_atrium_sample_bit_exact_vs_oracle(gpu, oracle, atrium, width, kind):
+    """64 Ki rays of the benchmark dumps (every 16th ray) against the oracle run live."""
+    _, algo = LAYOUTS[width]
+    rays = getattr(atrium, kind)[::16]
+    for any_hit in (False, True):
+        ref, st = oracle.traverse(width, *atrium.host[width], rays, any_hit=any_hit, algo=algo)
+        assert st["max_stack"] < 64
+        for v in variants(gpu, width):
+            got = gpu.traverse(atrium.dev[width], rays, any_hit=any_hit, variant=v)
+            assert np.array_equal(got["tri_id"], ref["tri_id"]), f"ids differ (variant {v})"
+            assert got.tobytes() == ref.tobytes(), f"t/u/v bits differ (variant {v})"
+
+
+@pytest.mark.parametrize("kind", ["primary", "random"])
+def test_atrium_cross_layout_parity(gpu, oracle, atrium, kind):
+    """North-star bar against the reference's CPU traversal (oracle B2 on the BVH8 block):
+    ids exact except on order-dependent ties, t within 1e-4 relative -- for both GPU layouts."""
+    rays = getattr(atrium, kind)[::64]
+    cpu, _ = oracle.traverse(8, *atrium.host[8], rays, algo="ref")
+    for width in (2, 8):
+        got = gpu.traverse(atrium.dev[width], rays, variant=0)
+        assert np.array_equal(got["tri_id"] >= 0, cpu["tri_id"] >= 0)
+        hit = cpu["tri_id"] >= 0
+        assert np.allclose(got["t"][hit], cpu["t"][hit], rtol=1e-4, atol=0)
+        differ = got["tri_id"] != cpu["tri_id"]
+        # every id difference must be a genuine tie: the two primitives are hit at (almost) the same t
+        assert differ.mean() < 0.02
+        if differ.any():
+            sub = rays[differ]
+            b2, s2 = oracle.brute_force(atrium.host[2][1], sub) if len(sub) <= 4096 else (None, None)
+            if b2 is not None:
+                assert ambiguous_mask(b2, s2).all()
+
+
+@pytest.mark.parametrize("kind", ["primary", "random"])
+def test_full_size_properties(gpu, atrium, kind):
+    """1 Mi rays (BASELINE size): properties that need no oracle run."""
+    rays = getattr(atrium, kind)
+    base = gpu.traverse(atrium.dev[2], rays, variant=0)
+    # all BVH2 mappings keep the per-ray order => identical bits
+    for v in variants(gpu, 2)[1:]:
+        assert gpu.traverse(atrium.dev[2], rays, variant=v).tobytes() == base.tobytes()
+    hit = base["tri_id"] >= 0
+    # misses return tmax untouched, hits lie inside [tmin, tmax]
+    assert np.array_equal(base["t"][~hit], rays["tmax"][~hit])
+    assert (base["t"][hit] >= rays["tmin"][hit]).all() and (base["t"][hit] <= rays["tmax"][hit]).all()
+    assert (base["u"][hit] >= 0).all() and (base["v"][hit] >= 0).all() and (base["u"][hit] + base["v"][hit] <= 1 + 1e-5).all()
+    # any-hit agrees with closest-hit on occlusion
+    occ = gpu.traverse(atrium.dev[2], rays, any_hit=True, variant=0)
+    assert np.array_equal(occ["tri_id"] >= 0, hit)
+    # BVH8 layout agrees on hit/miss and on t to 1e-4
+    w8 = gpu.traverse(atrium.dev[8], rays, variant=0)
+    assert np.array_equal(w8["tri_id"] >= 0, hit)
+    assert np.allclose(w8["t"][hit], base["t"][hit], rtol=1e-4, atol=0)
+    assert (w8["tri_id"] != base["tri_id"]).mean() < 0.02
+    # idempotence: shrinking tmax to just beyond the hit returns the same primitive
+    sub = rays[::8].copy()
+    sub["tmax"] = np.where(hit[::8], base["t"][::8] * np.float32(1.0001), sub["tmax"])
+    again = gpu.traverse(atrium.dev[2], sub, variant=0)
+    assert np.array_equal(again["tri_id"], base["tri_id"][::8])
+    if kind == "primary":
+        assert hit.all()                                  # closed scene seen from inside
+    else:
+        assert 0.05 < hit.mean() < 0.95
+
+
+def test_bench_traversal_cli(gpu, native_build, oracle, cornell, tmp_path):
+    """The CLI keeps the reference's stdout protocol (bench_traversal.cpp:294,381-391) and .fbuf."""
+    out = tmp_path / "o.fbuf"
+    cmd = [native_build.BIN_DIR / "bench_traversal", "-bvh", cornell.bvh_path, "-ray", cornell.bvh_path.parent / "cornell-primary-64x64.rays",
+           "--tmin", "0.01", "--tmax", "5000", "--bench", "3", "--warmup", "1", "-o", out]
+    for extra, name in ((["-gpu", "amdgpu"], "bvh2_gpu"), (["-gpu", "hip", "--variant", "1"], "bvh2_gpu"), (["-gpu", "hip", "--bvh-width", "8"], "bvh8_gpu")):
+        r = subprocess.run(cmd + extra, capture_output=True, text=True, check=True)
+        lines = r.stdout.strip().splitlines()
+        assert lines[0] == "4096 ray(s) in the distribution file."
+        assert lines[1].endswith("ms for 3 iteration(s)") and lines[2].endswith(" Mrays/sec")
+        assert lines[3].startswith("# Average: ") and lines[4].startswith("# Median: ") and lines[5].startswith("# Min: ")
+        assert lines[6] == "4096 intersection(s)"
+        exp = cornell.expected[f"{name}.primary_tmin.closest"]
+        assert np.array_equal(F.read_fbuf(out), exp["t"])
+    r = subprocess.run(cmd + ["-gpu", "amdgpu", "-any"], capture_output=True, text=True, check=True)
+    assert "4096 intersection(s)" in r.stdout
