@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--bvh-width", type=int, default=int(os.environ.get("RODENT_BENCH_WIDTH", "2")), choices=(2, 8))
     ap.add_argument("--variant", type=int, default=int(os.environ.get("RODENT_BENCH_VARIANT", "-1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only", choices=("primary", "random"), default=None, help="profiling aid: time only one ray set")
     return ap.parse_args()
 
 
@@ -118,16 +119,17 @@ def main():
     hits_rnd_dev = torch.zeros(len(rnd) * F.HIT1.itemsize, dtype=torch.uint8, device=f"cuda:{dev}")
 
     # ---- timed region ------------------------------------------------------------------------
-    wall, k_mean, k_med, k_min = time_passes(abi, torch, bvh, prim_dev, hits_dev, n, variant, args.steps, args.warmup, dist)
-    wall_r, kr_mean, kr_med, kr_min = time_passes(abi, torch, bvh, rnd_dev, hits_rnd_dev, len(rnd), variant, args.steps, args.warmup, dist)
+    steps_p, warm_p = (args.steps, args.warmup) if args.only != "random" else (1, 0)
+    steps_r, warm_r = (args.steps, args.warmup) if args.only != "primary" else (1, 0)
+    wall, k_mean, k_med, k_min = time_passes(abi, torch, bvh, prim_dev, hits_dev, n, variant, steps_p, warm_p, dist)
+    wall_r, kr_mean, kr_med, kr_min = time_passes(abi, torch, bvh, rnd_dev, hits_rnd_dev, len(rnd), variant, steps_r, warm_r, dist)
     abi.lib()  # keep the handle alive
     if dist is not None:
         t = torch.tensor([wall, wall_r], dtype=torch.float64, device=f"cuda:{dev}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, wall_r = float(t[0]), float(t[1])
-    total_rays = n * world * args.steps
-    value = total_rays / wall / 1e6
-    value_rnd = len(rnd) * world * args.steps / wall_r / 1e6
+    value = n * world * steps_p / wall / 1e6
+    value_rnd = len(rnd) * world * steps_r / wall_r / 1e6
 
     # ---- cross-check after the timed region: one gather of the per-rank hit counts -------------
     hits = abi.from_device(hits_dev, F.HIT1)
@@ -148,12 +150,12 @@ def main():
     # ---- rank 0: algorithmic bytes (oracle visit counts), roofline, CPU baseline ---------------
     out = {
         "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 5), "higher_is_better": True,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * wall / steps_p, 5), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{scene}.bvh + {scene}-primary.rays (1024x1024 primary rays, tmax 5000, closest hit) per GPU",
                    "rays_per_gpu_per_step": n, "bvh_layout": f"BVH{width}", "kernel": abi.kernel_name(width, variant),
                    "variant": abi.variants(width)[variant], "parallelism": f"replicated BVH x {world}, rays sharded by sub-pixel sample"},
-        "extra": {"random_Mrays_s": round(value_rnd, 3), "random_ms_per_step": round(1e3 * wall_r / args.steps, 5),
+        "extra": {"random_Mrays_s": round(value_rnd, 3), "random_ms_per_step": round(1e3 * wall_r / steps_r, 5),
                   "primary_kernel_ms": {"mean": round(k_mean, 5), "median": round(k_med, 5), "min": round(k_min, 5)},
                   "random_kernel_ms": {"mean": round(kr_mean, 5), "median": round(kr_med, 5), "min": round(kr_min, 5)},
                   "hit_counts_per_rank[primary,random]": counts_all},

@@ -115,6 +115,14 @@ int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2 or 8 */
 const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant);
 const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t any_hit);
 const char* rodent_hip_version(void);
+/* Debug aid: reads and clears the 8 phase counters of the instrumented "stats-*" variants
+ * ([0] descent iterations, [1] lanes active in them, [2] leaf iterations, [3] lanes, [4] refills,
+ * [5] lanes refilled, [6] outer iterations). */
+void        rodent_hip_read_stats(int32_t dev, uint64_t* out8);
+/* Debug aid: per-wave timeline of the instrumented variants.  First call (out may be NULL) arms it;
+ * later calls copy 16384 x 4 words {start tick, end tick (100 MHz), hw_id | xcc_id << 32,
+ * outer iterations | rays << 32} and clear the buffer. */
+void        rodent_hip_read_trace(int32_t dev, uint64_t* out);
 
 #ifdef __cplusplus
 }

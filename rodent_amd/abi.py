@@ -22,7 +22,7 @@ EXPORTS = [
     "hip_intersect_single_ray1_bvh8_tri4", "hip_occluded_single_ray1_bvh8_tri4",
     "hip_traverse_bvh2_tri1_async", "hip_traverse_bvh8_tri4_async",
     "rodent_hip_device_count", "rodent_hip_num_variants", "rodent_hip_variant_name",
-    "rodent_hip_kernel_name", "rodent_hip_version",
+    "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_read_stats", "rodent_hip_read_trace",
 ]
 
 _lib = None
@@ -49,6 +49,8 @@ def lib():
         l.rodent_hip_variant_name.restype = C.c_char_p; l.rodent_hip_variant_name.argtypes = [i32, i32]
         l.rodent_hip_kernel_name.restype = C.c_char_p; l.rodent_hip_kernel_name.argtypes = [i32, i32, i32]
         l.rodent_hip_version.restype = C.c_char_p; l.rodent_hip_version.argtypes = []
+        l.rodent_hip_read_trace.restype = None; l.rodent_hip_read_trace.argtypes = [i32, C.c_void_p]
+        l.rodent_hip_read_stats.restype = None; l.rodent_hip_read_stats.argtypes = [i32, C.POINTER(C.c_uint64)]
         _lib = l
     return _lib
 
@@ -122,3 +124,20 @@ def traverse(bvh: DeviceBvh, rays: np.ndarray, any_hit=False, variant=None) -> n
         traverse_async(bvh, rays_dev, hits_dev, n, any_hit, variant)
         torch.cuda.synchronize(bvh.dev)
     return from_device(hits_dev, F.HIT1)[:n]
+
+
+def read_stats(dev=0):
+    """Phase counters of the instrumented "stats-*" variants (reads and clears)."""
+    buf = (C.c_uint64 * 8)()
+    lib().rodent_hip_read_stats(dev, buf)
+    return list(buf)
+
+
+def read_trace(dev=0, arm_only=False):
+    """Per-wave timeline of the instrumented variants: array [16384, 4] of uint64 (see the header)."""
+    if arm_only:
+        lib().rodent_hip_read_trace(dev, None)
+        return None
+    buf = np.zeros((16384, 4), np.uint64)
+    lib().rodent_hip_read_trace(dev, buf.ctypes.data_as(C.c_void_p))
+    return buf

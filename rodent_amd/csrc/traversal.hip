@@ -178,7 +178,7 @@ __device__ __forceinline__ int node2_step(const Node2* __restrict__ nodes, int t
 }
 
 // ---------------------------------------------------------------------------------------------
-// BVH2 / Tri1, variant 0: literal one-ray-per-lane while-while (the reference mapping).
+// BVH2 / Tri1, "lane": literal one-ray-per-lane mapping of the reference kernel.
 // ---------------------------------------------------------------------------------------------
 template <bool ANY, int LDS_N>
 __global__ __launch_bounds__(kWave) void k_bvh2_lane(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
@@ -203,51 +203,322 @@ __global__ __launch_bounds__(kWave) void k_bvh2_lane(const Node2* __restrict__ n
 }
 
 // ---------------------------------------------------------------------------------------------
-// BVH2 / Tri1, variant 1: persistent wavefronts with dynamic ray fetch.  Same per-ray
-// visit order as variant 0 (results are bit-identical); lanes whose ray has finished
-// pull the next ray index from a global counter instead of idling until the slowest
-// lane of the wave is done.  One atomic per refill per wave (ballot + mbcnt).
+// BVH2 / Tri1, "while-while" variants.  Per ray, the sequence of node steps and leaf tests is
+// exactly the one of variant 0 (so results stay bit-identical); what changes is how the
+// wavefront schedules it: all lanes first descend until each holds a leaf (or is done), then
+// all lanes intersect their leaves together.  In variant 0 a single lane reaching a leaf makes
+// the whole wave execute the triangle code (measured: 24 % of VALU lanes active, one triangle
+// iteration per node iteration per wave although a ray tests ~3.5 triangles per ~36 nodes).
+// NODE_EXIT > 0: leave the descent phase early once fewer than NODE_EXIT lanes are still
+// descending (they resume after the leaf phase).
 // ---------------------------------------------------------------------------------------------
-template <bool ANY, int LDS_N, int REFILL_BELOW>
-__global__ __launch_bounds__(kWave) void k_bvh2_persistent(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
-                                                            const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                            int* counter, int* err) {
+template <bool ANY, int LDS_N, int NODE_EXIT>
+__global__ __launch_bounds__(kWave) void k_bvh2_ww(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                    const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n, int* err) {
     __shared__ int lds[LDS_N * kWave];
+    const int i = blockIdx.x * kWave + threadIdx.x;
+    if (i >= n) return;
+    RayX ray = load_ray(rays, i);
+    HitAcc hit{-1, ray.tmax, 0.0f, 0.0f};
     LaneStack<LDS_N> st; st.lds = lds + threadIdx.x; st.err = err;
+    int ptr = 0, top = 1; st.put(0, 0);
+    while (top != 0) {
+        while (top > 0) {
+            top = node2_step(nodes, top, ray, st, ptr);
+            if (NODE_EXIT > 0 && __popcll(__ballot(top > 0)) < NODE_EXIT) break;
+        }
+        while (top < 0) {
+            const int first = ~top; top = st.get(ptr); ptr--;
+            if (leaf_tri1<ANY>(tris, first, ray, hit)) { top = 0; break; }
+        }
+    }
+    store_hit(hits, i, hit.id, hit.t, hit.u, hit.v);
+}
+
+typedef __attribute__((address_space(3))) int lds_int;
+
+// Launch control block in device memory (zero between launches).
+struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; };
+
+// Per-lane stack of the fast / sched kernels: an LDS-only window of LDS_N entries behind an
+// address_space(3) pointer (plain ds_read / ds_write; LDS_N + 1 rows so the slot above the top
+// can always be written).  A ray that needs more is appended to the launch's "deep list" and
+// finished by k_bvh2_finish, a one-wave kernel enqueued right behind on the same stream that uses
+// a 64-entry stack in global memory (the reference's capacity, stack.impala:53).  Measured
+// alternatives: spilling to scratch inside the kernel costs ~6 % (scratch allocation per wave),
+// detecting the last wave with one atomic per wave ~15 % (a single counter saturates near
+// 88 atomics/us); the extra launch costs ~4 us per pass.
+struct GlobalStack {
+    int* base; int* err;
+    __device__ __forceinline__ void put(int e, int v) { if (e < kStackCap) base[e * kWave] = v; else *err = 1; }
+    __device__ __forceinline__ int  get(int e) const { return base[(e < kStackCap ? e : kStackCap - 1) * kWave]; }
+};
+
+template <bool ANY>
+__global__ __launch_bounds__(kWave) void k_bvh2_finish(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                        const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
+                                                        Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack) {
+    const int count = ctl->deep_count;
+    if (count > 0) {
+        GlobalStack st{deep_stack + threadIdx.x, &ctl->err};
+        for (int k = threadIdx.x; k < count; k += kWave) {
+            const int i = deep_list[k];
+            RayX ray = load_ray(rays, i);
+            HitAcc hit{-1, ray.tmax, 0.0f, 0.0f};
+            int ptr = 0, top = 1; st.put(0, 0);
+            while (top != 0) {
+                top = node2_step(nodes, top, ray, st, ptr);
+                bool done = false;
+                while (top < 0) {
+                    const int first = ~top; top = st.get(ptr); ptr--;
+                    if (leaf_tri1<ANY>(tris, first, ray, hit)) { done = true; break; }
+                }
+                if (ANY && done) break;
+            }
+            store_hit(hits, i, hit.id, hit.t, hit.u, hit.v);
+        }
+    }
+    if (threadIdx.x == 0) { ctl->counter = 0; ctl->deep_count = 0; }      // ready for the next launch
+}
+
+// ---------------------------------------------------------------------------------------------
+// BVH2 / Tri1, "fast" family.  Same per-ray visit order as variant 0 (bit-identical results),
+// engineered for the CDNA4 execution model:
+//  * LDS-only stack window accessed through address_space(3) pointers (plain ds_read/ds_write; the
+//    generic-pointer LDS+scratch stack of the variants above compiles to flat loads); deeper rays
+//    go to the deep list and k_bvh2_finish (see above);
+//  * branch-free node step: the would-be popped entry is read from LDS while the four 16-byte
+//    node loads are in flight, the far child is always written to the free slot above the top,
+//    and the new top / stack pointer are selected arithmetically (no divergent sub-branches);
+//  * while-while scheduling with an early exit from the descent phase (NODE_EXIT);
+//  * optional persistent wavefronts (PERSIST): lanes that finish pull new rays from a
+//    wave-local pool that is refilled CHUNK rays at a time from one global counter (first chunk
+//    static = block index, so the launch starts without atomics; a single counter saturates at
+//    ~88 dequeues/us on this chip).  The last wave to leave resets the counters, so no memset
+//    sits between launches.
+// ---------------------------------------------------------------------------------------------
+
+// Order in which 64-ray chunks are handed to wavefronts: ticket k -> chunk (k * mul) % count, mul
+// coprime to count.  Rays arrive in scan-line order, so expensive image regions (foliage at the
+// bottom of the frame) would otherwise all be started last and stretch the drain phase of the
+// launch; a large stride interleaves cheap and expensive regions in time.  mul = 1 keeps ray order.
+struct ChunkPerm {
+    int count, mul;
+    __device__ __forceinline__ int map(int k) const { return (int)(((long long)k * mul) % count); }
+};
+
+
+template <bool ANY, int LDS_N, int NODE_EXIT, bool PERSIST, int REFILL_IDLE, int CHUNK, bool STATS = false>
+__global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                      const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                      Ctl* ctl, int* __restrict__ deep_list) {
+    __shared__ int lds_raw[(LDS_N + 1) * kWave];
+    lds_int* col = (lds_int*)lds_raw + threadIdx.x;
     RayX ray; HitAcc hit{-1, 0.0f, 0.0f, 0.0f};
     int ray_id = -1, top = 0, ptr = 0;
-    bool exhausted = false;
+    // wave-uniform pool of ray indices [pool_next, pool_end)
+    int pool_next = blockIdx.x * (PERSIST ? CHUNK : kWave);
+    int pool_end = min(n, pool_next + (PERSIST ? CHUNK : kWave));
+    bool exhausted = !PERSIST;
+    // STATS build only: [0] descent iterations, [1] active lanes in them, [2] leaf iterations, [3] active lanes,
+    // [4] refills, [5] lanes refilled, [6] outer iterations (wave-uniform counts, lane 0 publishes)
+    unsigned c_n = 0, c_l = 0;                     // per-lane participations
+    __shared__ unsigned wst[8];                    // wave-level counts, bumped by an elected lane
+    if (STATS && threadIdx.x < 8) wst[threadIdx.x] = 0;
+#define WAVE_COUNT(slot, amount) do { const unsigned long long m_ = __ballot(true); if ((int)threadIdx.x == __ffsll((long long)m_) - 1) atomicAdd(&wst[slot], (unsigned)(amount)); } while (0)
+
     for (;;) {
+        if (STATS) WAVE_COUNT(6, 1);
         const bool idle = top == 0;
         if (idle && ray_id >= 0) { store_hit(hits, ray_id, hit.id, hit.t, hit.u, hit.v); ray_id = -1; }
         const unsigned long long idle_mask = __ballot(idle);
-        if (idle_mask == ~0ull && exhausted) break;
-        if (!exhausted && __popcll(idle_mask) >= (kWave - REFILL_BELOW + 1)) {
-            const int want = __popcll(idle_mask);
-            const int leader = __ffsll((long long)idle_mask) - 1;
-            int base = 0;
-            if ((int)threadIdx.x == leader) base = atomicAdd(counter, want);
-            base = __shfl(base, leader);
-            if (idle) {
-                const int k = base + __popcll(idle_mask & ((1ull << threadIdx.x) - 1ull));
-                if (k < n) {
-                    ray_id = k; ray = load_ray(rays, k);
+        const int num_idle = __popcll(idle_mask);
+        const bool pool_empty = pool_next >= pool_end;
+        if (num_idle == kWave && pool_empty && exhausted) break;
+        if (num_idle >= REFILL_IDLE || num_idle == kWave) {
+            if (PERSIST && pool_empty && !exhausted) {
+                int base = 0;
+                if (threadIdx.x == 0) base = atomicAdd(&ctl->counter, CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base) + gridDim.x * CHUNK;
+                pool_next = base; pool_end = min(n, base + CHUNK);
+                if (base + CHUNK >= n) exhausted = true;
+            }
+            const int avail = pool_end - pool_next;
+            if (avail > 0) {
+                const int r = __popcll(idle_mask & ((1ull << threadIdx.x) - 1ull));
+                if (idle && r < avail) {
+                    ray_id = pool_next + r; ray = load_ray(rays, ray_id);
                     hit.id = -1; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
-                    ptr = 0; top = 1; st.put(0, 0);
+                    ptr = 0; top = 1; col[0] = 0;
+                }
+                if (STATS) { WAVE_COUNT(4, 1); WAVE_COUNT(5, min(num_idle, avail)); }
+                pool_next += min(num_idle, avail);
+            }
+        }
+        // ---- descent phase ----
+        while (top > 0) {
+            if (STATS) { c_n++; WAVE_COUNT(0, 1); }
+            const float4* p = reinterpret_cast<const float4*>(nodes + (top - 1));
+            const float4 b0 = p[0], b1 = p[1], b2 = p[2];
+            const int4 ch = *reinterpret_cast<const int4*>(p + 3);
+            const int popped = col[ptr * kWave];
+            float te0, te1;
+            const bool h0 = slab(ray, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, te0) && ch.x != 0;
+            const bool h1 = slab(ray, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, te1) && ch.y != 0;
+            const bool c0first = te0 < te1;
+            const bool both = h0 && h1;
+            col[(ptr + 1) * kWave] = c0first ? ch.y : ch.x;                     // far child -> free slot above the top
+            top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
+            ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
+            if (ptr >= LDS_N) {                                                 // deeper than the LDS window: hand over
+                deep_list[atomicAdd(&ctl->deep_count, 1)] = ray_id;
+                ray_id = -1; top = 0;
+            }
+            if (NODE_EXIT > 0 && __popcll(__ballot(top > 0)) < NODE_EXIT) break;
+        }
+        // ---- leaf phase ----
+        while (top < 0) {
+            if (STATS) { c_l++; WAVE_COUNT(2, 1); }
+            const int first = ~top; top = col[ptr * kWave]; ptr--;
+            if (leaf_tri1<ANY>(tris, first, ray, hit)) { top = 0; break; }
+        }
+    }
+    if (STATS) {
+        for (int o = 32; o > 0; o >>= 1) { c_n += __shfl_xor((int)c_n, o); c_l += __shfl_xor((int)c_l, o); }
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < 7; k++) atomicAdd(&ctl->stats[k], (unsigned long long)(k == 1 ? c_n : (k == 3 ? c_l : atomicAdd(&wst[k], 0u))));
+        }
+    }
+#undef WAVE_COUNT
+}
+
+// ---------------------------------------------------------------------------------------------
+// BVH2 / Tri1, "sched" family: wave-level step scheduling.  Every lane is a small state machine
+//   cur > 0  : next action is a node step on node cur-1
+//   cur < 0  : next action is ONE triangle test on tris[~cur] (a leaf is walked by decrementing cur)
+//   cur == 0 : idle (ray finished; the result is stored when the lane is refilled or at exit)
+// and each trip of the wave loop executes exactly one kind of step, chosen by ballot: refill if
+// enough lanes are idle and rays are left, else the kind (node / triangle) more lanes are waiting
+// for.  A lane still performs its own node steps and triangle tests in the reference's order, so
+// results remain bit-identical to variant 0; only the interleaving across lanes changes.
+// Measured motivation (instrumented fast-lds16, 64 rays per wave): descent iterations run with
+// 57 % (primary) / 35 % (random) of the lanes, leaf visits with 20 % / 10 %.
+// ---------------------------------------------------------------------------------------------
+template <bool ANY, int LDS_N, bool PERSIST, int REFILL_IDLE, int CHUNK, int TRI_BIAS, bool STATS = false, bool TRACE = false>
+__global__ __launch_bounds__(kWave) void k_bvh2_sched(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                       const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                       Ctl* ctl, int* __restrict__ deep_list, ChunkPerm perm) {
+    __shared__ int lds_raw[(LDS_N + 1) * kWave];
+    lds_int* col = (lds_int*)lds_raw + threadIdx.x;
+    RayX ray; HitAcc hit{-1, 0.0f, 0.0f, 0.0f};
+    int ray_id = -1, cur = 0, ptr = 0;
+    constexpr int kChunk = PERSIST ? CHUNK : kWave;
+    int pool_next = perm.map(blockIdx.x) * kChunk;
+    int pool_end = min(n, pool_next + kChunk);
+    bool exhausted = !PERSIST;
+    unsigned c_n = 0, c_l = 0;
+    __shared__ unsigned wst[8];
+    if (STATS && threadIdx.x < 8) wst[threadIdx.x] = 0;
+    const unsigned long long t_start = (STATS || TRACE) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned traced_rays = 0;
+#define WAVE_COUNT(slot, amount) do { const unsigned long long m_ = __ballot(true); if ((int)threadIdx.x == __ffsll((long long)m_) - 1) atomicAdd(&wst[slot], (unsigned)(amount)); } while (0)
+
+    for (;;) {
+        if (STATS) WAVE_COUNT(6, 1);
+        const unsigned long long node_mask = __ballot(cur > 0), tri_mask = __ballot(cur < 0);
+        const int nn = __popcll(node_mask), nt = __popcll(tri_mask), ni = kWave - nn - nt;
+        const bool rays_left = pool_next < pool_end || !exhausted;
+        if (ni == kWave && !rays_left) break;
+        if (rays_left && (ni >= REFILL_IDLE || ni == kWave)) {
+            // ---- refill step ----
+            const bool idle = cur == 0;
+            if (idle && ray_id >= 0) { store_hit(hits, ray_id, hit.id, hit.t, hit.u, hit.v); ray_id = -1; }
+            if (PERSIST && pool_next >= pool_end) {
+                int base = 0;
+                if (threadIdx.x == 0) base = atomicAdd(&ctl->counter, 1);
+                const int c = __builtin_amdgcn_readfirstlane(base) + (int)gridDim.x;     // chunk ticket
+                if (c >= perm.count) { exhausted = true; pool_next = pool_end = 0; }
+                else { pool_next = perm.map(c) * CHUNK; pool_end = min(n, pool_next + CHUNK); }
+            }
+            const int avail = pool_end - pool_next;
+            if (avail > 0) {
+                const unsigned long long idle_mask = ~(node_mask | tri_mask);
+                const int r = __popcll(idle_mask & ((1ull << threadIdx.x) - 1ull));
+                if (idle && r < avail) {
+                    ray_id = pool_next + r; ray = load_ray(rays, ray_id);
+                    hit.id = -1; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
+                    ptr = 0; cur = 1; col[0] = 0;
+                }
+                if (STATS) { WAVE_COUNT(4, 1); WAVE_COUNT(5, min(ni, avail)); }
+                if (TRACE) traced_rays += min(ni, avail);
+                pool_next += min(ni, avail);
+            }
+            continue;
+        }
+        if (nn * 4 >= nt * TRI_BIAS) {
+            // ---- node step (branch-free, see k_bvh2_fast) ----
+            if (cur > 0) {
+                if (STATS) { c_n++; WAVE_COUNT(0, 1); }
+                const float4* p = reinterpret_cast<const float4*>(nodes + (cur - 1));
+                const float4 b0 = p[0], b1 = p[1], b2 = p[2];
+                const int4 ch = *reinterpret_cast<const int4*>(p + 3);
+                const int popped = col[ptr * kWave];
+                float te0, te1;
+                const bool h0 = slab(ray, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, te0) && ch.x != 0;
+                const bool h1 = slab(ray, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, te1) && ch.y != 0;
+                const bool c0first = te0 < te1;
+                const bool both = h0 && h1;
+                col[(ptr + 1) * kWave] = c0first ? ch.y : ch.x;
+                cur = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
+                ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
+                if (ptr >= LDS_N) {
+                    deep_list[atomicAdd(&ctl->deep_count, 1)] = ray_id;
+                    ray_id = -1; cur = 0;
                 }
             }
-            if (base + want >= n) exhausted = true;
-            if (__ballot(top != 0) == 0ull) { if (exhausted) break; else continue; }
-        }
-        if (top != 0) {
-            top = node2_step(nodes, top, ray, st, ptr);
-            while (top < 0) {
-                const int first = ~top; top = st.get(ptr); ptr--;
-                if (leaf_tri1<ANY>(tris, first, ray, hit)) { top = 0; break; }
+        } else {
+            // ---- triangle step: one Tri1 per waiting lane (mapping_gpu.impala:156-174) ----
+            if (cur < 0) {
+                if (STATS) { c_l++; WAVE_COUNT(2, 1); }
+                const float4* p = reinterpret_cast<const float4*>(tris + (~cur));
+                const float4 a = p[0], b = p[1], c = p[2];
+                const int popped = col[ptr * kWave];
+                const int prim_id = __float_as_int(c.w);
+                const float nx = cross_x(b.x, b.y, b.z, c.x, c.y, c.z);
+                const float ny = cross_y(b.x, b.y, b.z, c.x, c.y, c.z);
+                const float nz = cross_z(b.x, b.y, b.z, c.x, c.y, c.z);
+                float t, u, v;
+                const bool h = intersect_tri(ray, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, nx, ny, nz, t, u, v);
+                if (h) { hit.id = prim_id & 0x7FFFFFFF; hit.t = t; hit.u = u; hit.v = v; ray.tmax = t; }
+                const bool last = prim_id < 0;
+                cur = (ANY && h) ? 0 : (last ? popped : cur - 1);
+                ptr -= last ? 1 : 0;
             }
         }
     }
+    if (cur == 0 && ray_id >= 0) store_hit(hits, ray_id, hit.id, hit.t, hit.u, hit.v);
+    if (STATS) {
+        for (int o = 32; o > 0; o >>= 1) { c_n += __shfl_xor((int)c_n, o); c_l += __shfl_xor((int)c_l, o); }
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < 7; k++) atomicAdd(&ctl->stats[k], (unsigned long long)(k == 1 ? c_n : (k == 3 ? c_l : atomicAdd(&wst[k], 0u))));
+            if (ctl->trace && blockIdx.x < 16384) {       // per-wave timeline: start, end (100 MHz ticks), hw id, xcc id, work
+                unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
+                tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
+                tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+                tr[3] = ((unsigned long long)atomicAdd(&wst[5], 0u) << 32) | atomicAdd(&wst[6], 0u);
+            }
+        }
+    }
+#undef WAVE_COUNT
+    if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
+        unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
+        tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
+        tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+        tr[3] = (unsigned long long)traced_rays << 32;
+    }
 }
+
+
 
 // ---------------------------------------------------------------------------------------------
 // BVH8 / Tri4, variant 0: the reference's GPU "general case" for arity != 2
@@ -327,8 +598,13 @@ __global__ __launch_bounds__(kWave) void k_bvh8_lane(const Node8* __restrict__ n
 // ---------------------------------------------------------------------------------------------
 struct DeviceState {
     bool  init = false;
-    int*  scratch = nullptr;    // [0] = ray counter for persistent kernels, [1] = error flag
+    int*  scratch = nullptr;    // [0] ray counter of the first persistent kernels, [1] error flag, [16..19] Ctl
     int   num_cus = 0;
+    int*  deep_list = nullptr;  // ray indices whose stack overflowed the LDS window
+    int   deep_cap = 0;
+    int*  deep_stack = nullptr; // 64 x 64 ints: global-memory stack of k_bvh2_finish
+    unsigned long long* trace = nullptr;   // debug: 16384 x 4 words (instrumented variants)
+    Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
 };
 DeviceState g_dev[16];
 std::mutex  g_mutex;
@@ -348,47 +624,111 @@ DeviceState& device_state(int dev) {
         s.num_cus = prop.multiProcessorCount;
         HIP_CHECK(hipMalloc(&s.scratch, 64 * sizeof(int)));
         HIP_CHECK(hipMemset(s.scratch, 0, 64 * sizeof(int)));
+        HIP_CHECK(hipMalloc(&s.deep_stack, kStackCap * kWave * sizeof(int)));
         s.init = true;
     }
     return s;
 }
 
-struct VariantInfo { const char* name; const char* kernel_closest; const char* kernel_any; };
-const VariantInfo kVariants2[] = {
-    {"lane",       "k_bvh2_lane<false,24>",            "k_bvh2_lane<true,24>"},
-    {"persistent", "k_bvh2_persistent<false,24,64>",   "k_bvh2_persistent<true,24,64>"},
-    {"persistent-lazy", "k_bvh2_persistent<false,24,40>", "k_bvh2_persistent<true,24,40>"},
+void ensure_deep_list(DeviceState& s, int n) {
+    if (n <= s.deep_cap) return;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (n <= s.deep_cap) return;
+    HIP_CHECK(hipDeviceSynchronize());
+    if (s.deep_list) HIP_CHECK(hipFree(s.deep_list));
+    HIP_CHECK(hipMalloc(&s.deep_list, sizeof(int) * (size_t)n));
+    s.deep_cap = n;
+}
+
+int persistent_waves_per_cu() {
+    static const int v = [] { const char* e = getenv("RODENT_HIP_PERSISTENT_WAVES_PER_CU"); return e ? atoi(e) : 16; }();
+    return v;
+}
+
+void check_error_flag(DeviceState& s, hipStream_t stream) {
+    int flag[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(&flag[0], s.scratch + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(&flag[1], &s.ctl()->err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (flag[0] || flag[1]) { fprintf(stderr, "rodent_hip: traversal stack overflow (more than %d entries)\n", kStackCap); abort(); }
+}
+
+#define LAUNCH_ARGS DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
+inline int blocks_for(int n) { return (n + kWave - 1) / kWave; }
+
+template <bool ANY, int LDS_N> void L_lane(LAUNCH_ARGS) {
+    hipLaunchKernelGGL((k_bvh2_lane<ANY, LDS_N>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.scratch + 1);
+}
+template <bool ANY, int LDS_N, int NE> void L_ww(LAUNCH_ARGS) {
+    hipLaunchKernelGGL((k_bvh2_ww<ANY, LDS_N, NE>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.scratch + 1);
+}
+template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false> void L_fast(LAUNCH_ARGS) {
+    ensure_deep_list(s, n);
+    const int per_block = P ? CH : kWave;
+    int grid = (n + per_block - 1) / per_block;
+    if (P) grid = std::min(grid, s.num_cus * persistent_waves_per_cu());
+    hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
+}
+
+int coprime_stride(int count) {
+    if (count < 8) return 1;
+    auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+    int m = (int)(count * 0.6180339887) | 1;
+    while (gcd(m, count) != 1) m += 2;
+    return m % count;
+}
+
+template <bool ANY, int LDS_N, bool P, int RI, int CH, int TB, bool PERMUTE = false, bool ST = false, bool TR = false> void L_sched(LAUNCH_ARGS) {
+    ensure_deep_list(s, n);
+    const int per_block = P ? CH : kWave;
+    const int chunks = (n + per_block - 1) / per_block;
+    int grid = chunks;
+    if (P) grid = std::min(grid, s.num_cus * persistent_waves_per_cu());
+    const ChunkPerm perm{chunks, PERMUTE ? coprime_stride(chunks) : 1};
+    hipLaunchKernelGGL((k_bvh2_sched<ANY, LDS_N, P, RI, CH, TB, ST, TR>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, perm);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
+}
+
+using Launch2 = void (*)(LAUNCH_ARGS);
+struct Variant2 { const char* name; const char* kernel[2]; Launch2 launch[2]; };
+#define V2(name, fn, ...) {name, {#fn "<false," #__VA_ARGS__ ">", #fn "<true," #__VA_ARGS__ ">"}, {&fn<false, __VA_ARGS__>, &fn<true, __VA_ARGS__>}}
+#define K2(name, kname, fn, ...) {name, {kname "<false," #__VA_ARGS__ ">", kname "<true," #__VA_ARGS__ ">"}, {&fn<false, __VA_ARGS__>, &fn<true, __VA_ARGS__>}}
+const Variant2 kVariants2[] = {
+    // 0 = default (used by the reference-named entry points).  All variants keep the reference's per-ray
+    // visit order and are bit-identical; they differ in how a wavefront schedules its 64 rays.
+    //                                                      LDS_N NODE_EXIT PERSIST REFILL_IDLE CHUNK
+    K2("fast",               "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64),
+    K2("lane",               "k_bvh2_lane",          L_lane, 24),                      // literal reference mapping
+    K2("ww",                 "k_bvh2_ww",            L_ww, 24, 8),                     // while-while, LDS+scratch stack
+    K2("fast-exit0",         "k_bvh2_fast",          L_fast, 16, 0,  false, 64, 64),
+    K2("fast-exit16",        "k_bvh2_fast",          L_fast, 16, 16, false, 64, 64),
+    K2("fast-lds24",         "k_bvh2_fast",          L_fast, 24, 8,  false, 64, 64),
+    K2("fast-persistent",    "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 128),
+    //                                                       LDS_N PERSIST REFILL_IDLE CHUNK TRI_BIAS(x/4) PERMUTE
+    K2("sched",              "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false),
+    K2("sched-persistent",   "k_bvh2_sched",         L_sched, 16, true,  16, 64,  8, false),
+    K2("sched-perm",         "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, true),
+    // instrumented builds (phase / lane-utilisation counters, per-wave timeline); not for timing
+    K2("stats-fast",         "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64,  true),
+    K2("stats-sched",        "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false, true),
+    K2("stats-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, true),
+    K2("trace-sched",        "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false, false, true),
+    K2("trace-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, false, true),
 };
+constexpr int kNumVariants2 = sizeof(kVariants2) / sizeof(kVariants2[0]);
+
+struct VariantInfo { const char* name; const char* kernel_closest; const char* kernel_any; };
 const VariantInfo kVariants8[] = {
     {"lane", "k_bvh8_lane<false,24>", "k_bvh8_lane<true,24>"},
 };
-constexpr int kNumVariants2 = sizeof(kVariants2) / sizeof(kVariants2[0]);
 constexpr int kNumVariants8 = sizeof(kVariants8) / sizeof(kVariants8[0]);
-
-void check_error_flag(DeviceState& s, hipStream_t stream) {
-    int flag = 0;
-    HIP_CHECK(hipMemcpyAsync(&flag, s.scratch + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    if (flag) { fprintf(stderr, "rodent_hip: traversal stack overflow (more than %d entries)\n", kStackCap); abort(); }
-}
 
 template <bool ANY>
 void launch_bvh2(DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, int variant, hipStream_t stream) {
     if (n <= 0) return;
-    int* err = s.scratch + 1;
-    const int blocks = (n + kWave - 1) / kWave;
-    switch (variant) {
-        case 0: hipLaunchKernelGGL((k_bvh2_lane<ANY, 24>), dim3(blocks), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, err); break;
-        case 1:
-        case 2: {
-            HIP_CHECK(hipMemsetAsync(s.scratch, 0, sizeof(int), stream));
-            const int grid = std::min(blocks, s.num_cus * 20);
-            if (variant == 1) hipLaunchKernelGGL((k_bvh2_persistent<ANY, 24, 64>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.scratch, err);
-            else              hipLaunchKernelGGL((k_bvh2_persistent<ANY, 24, 40>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.scratch, err);
-            break;
-        }
-        default: fprintf(stderr, "rodent_hip: unknown BVH2 variant %d\n", variant); abort();
-    }
+    if (variant < 0 || variant >= kNumVariants2) { fprintf(stderr, "rodent_hip: unknown BVH2 variant %d\n", variant); abort(); }
+    kVariants2[variant].launch[ANY ? 1 : 0](s, nodes, tris, rays, hits, n, stream);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -458,10 +798,32 @@ const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant) {
     return "";
 }
 const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t any_hit) {
-    const VariantInfo* v = nullptr;
-    if (bvh_width == 2 && variant >= 0 && variant < kNumVariants2) v = &kVariants2[variant];
-    if (bvh_width == 8 && variant >= 0 && variant < kNumVariants8) v = &kVariants8[variant];
-    return v ? (any_hit ? v->kernel_any : v->kernel_closest) : "";
+    if (bvh_width == 2 && variant >= 0 && variant < kNumVariants2) return kVariants2[variant].kernel[any_hit ? 1 : 0];
+    if (bvh_width == 8 && variant >= 0 && variant < kNumVariants8) return any_hit ? kVariants8[variant].kernel_any : kVariants8[variant].kernel_closest;
+    return "";
+}
+/* Debug aid for the instrumented ("stats-*") variants: copies the 8 phase counters to out[] and clears them. */
+/* Debug aid: enables the per-wave timeline of the instrumented variants and copies it out
+ * (16384 records x 4 words: start tick, end tick, hw_id | xcc_id << 32, outer iterations | rays << 32). */
+void rodent_hip_read_trace(int32_t dev, uint64_t* out) {
+    DeviceState& s = device_state(dev);
+    HIP_CHECK(hipSetDevice(dev));
+    HIP_CHECK(hipDeviceSynchronize());
+    const size_t bytes = 16384 * 4 * sizeof(uint64_t);
+    if (!s.trace) {
+        HIP_CHECK(hipMalloc(&s.trace, bytes));
+        HIP_CHECK(hipMemset(s.trace, 0, bytes));
+        HIP_CHECK(hipMemcpy(&s.ctl()->trace, &s.trace, sizeof(void*), hipMemcpyHostToDevice));
+    }
+    if (out) HIP_CHECK(hipMemcpy(out, s.trace, bytes, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemset(s.trace, 0, bytes));
+}
+void rodent_hip_read_stats(int32_t dev, uint64_t* out) {
+    DeviceState& s = device_state(dev);
+    HIP_CHECK(hipSetDevice(dev));
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, s.ctl()->stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemset(s.ctl()->stats, 0, 8 * sizeof(uint64_t)));
 }
 const char* rodent_hip_version(void) { return "rodent_hip 0.1 (gfx950)"; }
 

@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Per-wave timeline of the instrumented sched kernels: lifetimes, per-CU placement, occupancy over time."""
+import sys
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+from rodent_amd import abi, formats as F, raygen, scenes
+
+path = scenes.scene_bvh("atrium")
+bvh = abi.DeviceBvh.load(path, 2, 0)
+eye, d, up, fov = scenes.CAMERAS["atrium"]
+n4, _ = F.read_bvh(path, F.BVH4_TRI4)
+lo, hi = raygen.scene_bounds(n4)
+sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0),
+        "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
+names = abi.variants(2)
+abi.read_trace(arm_only=True)
+want = sys.argv[1:] or ["stats-sched", "stats-sched-p16"]
+for name in want:
+    v = names.index(name)
+    for k, rays in sets.items():
+        n = len(rays)
+        rd = abi.to_device(rays, 0); hd = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
+        for _ in range(2):
+            abi.traverse_async(bvh, rd, hd, n, False, v); torch.cuda.synchronize(); abi.read_trace()
+        abi.traverse_async(bvh, rd, hd, n, False, v); torch.cuda.synchronize()
+        tr = abi.read_trace(); abi.read_stats()
+        tr = tr[tr[:, 1] > 0]
+        t0 = tr[:, 0].min(); start = (tr[:, 0] - t0) / 100.0; end = (tr[:, 1] - t0) / 100.0   # us (100 MHz)
+        hw = tr[:, 2] & 0xFFFFFFFF; xcc = (tr[:, 2] >> 32) & 0xF
+        cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+        cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+        rays_w = tr[:, 3] >> 32; outer = tr[:, 3] & 0xFFFFFFFF
+        life = end - start
+        uniq, cnt = np.unique(cuid, return_counts=True)
+        ts = np.linspace(0, end.max(), 21)[1:-1]
+        occ = [(int(((start <= t) & (end > t)).sum())) for t in ts]
+        print(f"{name} {k}: waves {len(tr)} span {end.max():.1f}us  life mean {life.mean():.1f} p50 {np.median(life):.1f} max {life.max():.1f}us | "
+              f"start max {start.max():.1f}us | CUs used {len(uniq)} waves/CU min {cnt.min()} max {cnt.max()} | rays/wave mean {rays_w.mean():.0f} max {rays_w.max()} | outer mean {outer.mean():.0f}")
+        print("   active waves at 5%..95% of span:", occ)
+        # per-CU busy time
+        busy = np.array([end[cuid == u].max() for u in uniq])
+        print(f"   per-CU last-wave-end: min {busy.min():.1f} p50 {np.median(busy):.1f} max {busy.max():.1f} us; per XCC waves: {np.bincount(xcc.astype(int), minlength=8).tolist()}")

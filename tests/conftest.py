@@ -55,3 +55,25 @@ def ambiguous_mask(brute_hits, second_t, rel=1e-4):
     variants disagree on those (tools/CMakeLists.txt:24-25, intersection.impala:181-182)."""
     t = brute_hits["t"]
     return (brute_hits["tri_id"] >= 0) & (np.abs(second_t - t) <= rel * np.maximum(np.abs(t), 1e-30))
+
+
+def chain_bvh2(depth, z0=200.0):
+    """Hand-made degenerate BVH2 whose traversal stack grows to `depth` entries for a ray along +z:
+    node i = {child0: inner chain (box z in [1,100], entered first), child1: leaf i (triangle at z0+i)}.
+    Every level pushes its leaf, so the stack holds `depth` entries before the first pop; the leaves
+    then pop far-to-near and each one is accepted, ending at triangle 0 (t = z0)."""
+    from rodent_amd import formats as F
+    nodes = np.zeros(depth, F.NODE2)
+    tris = np.zeros(depth + 1, F.TRI1)
+    for i in range(depth + 1):
+        z = z0 + i
+        v0, v1, v2 = np.float32([-10, -10, z]), np.float32([30, -10, z]), np.float32([-10, 30, z])
+        tris[i]["v0"] = v0; tris[i]["e1"] = v0 - v1; tris[i]["e2"] = v2 - v0
+        tris[i]["prim_id"] = np.int32(i) | np.int32(-2 ** 31)          # one triangle per leaf
+    for i in range(depth):
+        last = i == depth - 1
+        inner = [-5, 5, -5, 5, 1, 100] if not last else [-5, 5, -5, 5, z0 + depth, z0 + depth]
+        leaf = [-5, 5, -5, 5, z0 + i, z0 + i]
+        nodes[i]["bounds"] = inner + leaf
+        nodes[i]["child"] = [(i + 2) if not last else ~depth, ~i]
+    return nodes, tris

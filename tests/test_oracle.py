@@ -149,3 +149,17 @@ def test_stats_are_deterministic_and_plausible(oracle, cornell):
     _, s2 = oracle.traverse(2, *cornell.blocks[2], cornell.ray_sets["primary"])
     _, s8 = oracle.traverse(8, *cornell.blocks[8], cornell.ray_sets["primary"])
     assert s8["inner_per_ray"] < s2["inner_per_ray"]     # wider nodes => fewer node visits
+
+
+def test_deep_stack_chain(oracle):
+    """A 40-deep push chain (fits the reference's 64-entry stack); 70 deep overflows it."""
+    from conftest import chain_bvh2
+    nodes, tris = chain_bvh2(40)
+    rays = F.make_rays([[0.1, 0.2, 0.0], [0.1, 0.2, 0.0], [50.0, 0.2, 0.0]], [[0.001, 0.002, 1.0], [0.001, 0.002, 1.0], [0.001, 0.002, 1.0]], 0.0, 1000.0)
+    hits, st = oracle.traverse(2, nodes, tris, rays)
+    assert st["max_stack"] == 40
+    assert hits["tri_id"].tolist() == [0, 0, -1] and abs(hits["t"][0] - 200.0) < 1e-3
+    brute, _ = oracle.brute_force(tris, rays)
+    assert np.array_equal(brute["tri_id"], hits["tri_id"]) and np.array_equal(brute["t"], hits["t"])
+    with pytest.raises(RuntimeError):
+        oracle.traverse(2, *chain_bvh2(70), rays)
