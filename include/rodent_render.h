@@ -1,0 +1,108 @@
+/*
+ * rodent_render.h -- C ABI of the MI355X wavefront path tracer (librodent_hip.so).
+ *
+ * Stands where the reference has the AnyDSL-generated `interface.h` (src/CMakeLists.txt:76-79)
+ * plus the `extern "C"` services of src/driver/interface.cpp:565-675.  In the reference the
+ * scene is compiled into `render()` by the converter (src/driver/converter.cpp:613-967 emits
+ * Impala source); here the scene is DATA: tables uploaded once with rodent_hip_scene_create(),
+ * and spp / max path length are run-time values (rodent_hip_render_config) instead of
+ * converter flags (converter.cpp:1007-1012).
+ *
+ * Kept from the reference, same names and meaning:
+ *   Settings, get_spp(), render(settings, iter)                 src/dummy_main.impala:3-13
+ *   RayStream / PrimaryStream / SecondaryStream (SoA slabs)      src/render/driver.impala:24-61
+ *   setup_interface / get_pixels / clear_pixels / cleanup_interface   src/driver/interface.cpp:512-526
+ *   rodent_get_film_data, rodent_gpu_get_{first,second}_primary_stream,
+ *   rodent_gpu_get_secondary_stream, rodent_gpu_get_tmp_buffer, rodent_present   interface.cpp:567-582,631-663
+ * Device ids: `dev` is the HIP device ordinal (the reference packs platform and index,
+ * src/render/mapping_gpu.impala:538,596; 0 there means "host").
+ * Errors: message on stderr + abort(), like src/driver/common.h:43-59.
+ */
+#ifndef RODENT_RENDER_H
+#define RODENT_RENDER_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "rodent_traversal.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct Vec3 { float x, y, z; };
+struct Settings { struct Vec3 eye, dir, up, right; float width, height; };   /* width/height = tan(fov/2), that / ratio (driver.cpp:37-38) */
+
+struct RayStream { int32_t* id; float *org_x, *org_y, *org_z, *dir_x, *dir_y, *dir_z, *tmin, *tmax; };
+struct PrimaryStream {
+    struct RayStream rays; int32_t *geom_id, *prim_id; float *t, *u, *v;
+    uint32_t* rnd; float *mis, *contrib_r, *contrib_g, *contrib_b; int32_t* depth; int32_t size, pad;
+};
+struct SecondaryStream { struct RayStream rays; int32_t* prim_id; float *color_r, *color_g, *color_b; int32_t size, pad; };
+
+/* ---- scene tables (what the converter bakes into Impala source in the reference) ---- */
+enum RodentBsdf { RODENT_BSDF_BLACK = 0, RODENT_BSDF_DIFFUSE = 1, RODENT_BSDF_PHONG = 2,
+                  RODENT_BSDF_MIX = 3 /* diffuse (+) phong */, RODENT_BSDF_MIRROR = 4, RODENT_BSDF_GLASS = 5 };
+struct RodentMaterial {            /* 64 B; one per geometry id (converter.cpp:858-920) */
+    float kd[3]; int32_t type; float ks[3]; float ns; float tf[3]; float ni;
+    float mix_k;                   /* lum(ks) / (lum(ks) + lum(kd)) (converter.cpp:900-906) */
+    int32_t emissive; int32_t pad[2];
+};
+struct RodentLight {               /* 80 B; triangle area light (converter.cpp:831-851, light.impala:140-154) */
+    float v0[4], v1[4], v2[4]; float n[3]; float inv_area; float color[4];
+};
+struct RodentSceneDesc {           /* HOST pointers; copied to HBM by rodent_hip_scene_create */
+    const float* vertices;         /* float4 per vertex (padded like the GPU targets, converter.cpp:629-632) */
+    const float* normals;          /* float4 per vertex */
+    const float* face_normals;     /* float4 per triangle */
+    const int32_t* indices;        /* int4 per triangle: v0 v1 v2 material (obj.cpp:455-461) */
+    const struct Node2* nodes; const struct Tri1* tris;     /* BVH2/Tri1, geom_id = material id */
+    const struct RodentMaterial* materials; const struct RodentLight* lights;
+    const int32_t* light_ids;      /* per triangle: index into lights (0 if not a light) */
+    int32_t num_vertices, num_tris, num_nodes, num_bvh_tris, num_materials, num_lights;
+};
+
+void    rodent_hip_scene_create(int32_t dev, const struct RodentSceneDesc* desc);   /* replaces the device's current scene */
+void    rodent_hip_scene_destroy(int32_t dev);
+void    rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len);   /* defaults 4 / 64 (converter.cpp:1007-1012) */
+
+/* ---- the reference's renderer ABI ---- */
+int32_t get_spp(void);
+void    render(const struct Settings* settings, int32_t iter);       /* one frame: spp samples per pixel, accumulated into the film */
+void    setup_interface(size_t width, size_t height);
+float*  get_pixels(void);                                            /* host film, width*height*3 floats, valid after rodent_present */
+void    clear_pixels(void);
+void    cleanup_interface(void);
+void    rodent_get_film_data(int32_t dev, float** pixels, int32_t* width, int32_t* height);   /* DEVICE film */
+void    rodent_gpu_get_first_primary_stream(int32_t dev, struct PrimaryStream* primary, int32_t size);
+void    rodent_gpu_get_second_primary_stream(int32_t dev, struct PrimaryStream* primary, int32_t size);
+void    rodent_gpu_get_secondary_stream(int32_t dev, struct SecondaryStream* secondary, int32_t size);
+void    rodent_gpu_get_tmp_buffer(int32_t dev, int32_t** buf, int32_t size);
+void    rodent_present(int32_t dev);                                 /* film device -> host */
+
+/* ---- additions ---- */
+void    rodent_hip_set_device(int32_t dev);                          /* device used by render() (the reference bakes it in) */
+/* Renders only image rows [y0, y1) (tile sharding across GPUs: seeds depend on absolute (sample, iter, x, y),
+ * renderer.impala:28-33, so any tiling reproduces the same samples).  Asynchronous on `stream`. */
+void    rodent_hip_render_rows(int32_t dev, const struct Settings* settings, int32_t iter, int32_t y0, int32_t y1, void* stream);
+/* Counters of the last render call on this device: [0] primary rays traced, [1] shadow rays traced,
+ * [2] wavefront iterations, [3] rays generated. */
+void    rodent_hip_render_counters(int32_t dev, uint64_t* out4);
+
+/* The wavefront stages as separate entry points (the reference's device kernels,
+ * src/render/mapping_gpu.impala:18-30,47-80,82-134,166-221,223-265,267-300); all asynchronous on `stream`. */
+void    hip_generate_rays(int32_t dev, struct PrimaryStream* primary, int32_t capacity, int32_t first_ray_id, int32_t num_rays,
+                          const struct Settings* settings, int32_t iter, int32_t film_width, int32_t film_height,
+                          int32_t first_pixel, int32_t spp, void* stream);
+void    hip_traverse_primary(int32_t dev, struct PrimaryStream* primary, void* stream);
+/* Sorts by geometry id into `other` (stable, deterministic); ray_ends[g] (host, num_geometries+1 ints) receives the
+ * exclusive end of bin g like mapping_gpu.impala:203-207.  Synchronises the stream (the reference does too). */
+void    hip_sort_primary(int32_t dev, struct PrimaryStream* primary, struct PrimaryStream* other, int32_t* ray_ends, void* stream);
+void    hip_shade(int32_t dev, struct PrimaryStream* primary, struct SecondaryStream* secondary, int32_t num_rays, void* stream);
+void    hip_traverse_secondary(int32_t dev, struct SecondaryStream* secondary, void* stream);
+/* Order-preserving compaction of rays with id >= 0; returns the new size (synchronises the stream). */
+int32_t hip_compact_primary(int32_t dev, struct PrimaryStream* primary, struct PrimaryStream* other, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RODENT_RENDER_H */

@@ -90,3 +90,51 @@ def brute_force(tris, rays):
     fn = lib().oracle_brute_force_tri1 if tris.dtype.itemsize == 48 else lib().oracle_brute_force_tri4
     fn(_ptr(tris), len(tris), _ptr(rays), _ptr(hits), _ptr(second), len(rays))
     return hits, second
+
+
+# ---- renderer oracle (oracle/render_oracle.c) ------------------------------------------------
+
+class _Scene(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")] + \
+               [("num_tris", C.c_int32), ("num_materials", C.c_int32), ("num_lights", C.c_int32), ("pad", C.c_int32)]
+
+
+class _Settings(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("dir", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3), ("w", C.c_float), ("h", C.c_float)]
+
+
+def _scene_struct(scene):
+    keep = [np.ascontiguousarray(getattr(scene, n)) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")]
+    s = _Scene(*[_ptr(a) for a in keep], scene.num_tris, len(scene.materials), len(scene.lights), 0)
+    return s, keep
+
+
+def render(scene, cam, iter_, spp, max_path_len, width, height, film=None, rows=None, threads=8):
+    """CPU path tracer (one path at a time).  Accumulates into `film` (h, w, 3) float32 and returns
+    (film, [primary rays, shadow rays]).  Row bands run on `threads` host threads."""
+    import concurrent.futures as cf
+    l = lib()
+    l.oracle_render.restype = None
+    l.oracle_render.argtypes = [C.POINTER(_Scene), C.POINTER(_Settings), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    if film is None:
+        film = np.zeros((height, width, 3), "<f4")
+    s, keep = _scene_struct(scene)
+    st = _Settings((C.c_float * 3)(*cam["eye"]), (C.c_float * 3)(*cam["dir"]), (C.c_float * 3)(*cam["up"]), (C.c_float * 3)(*cam["right"]),
+                   float(cam["w"]), float(cam["h"]))
+    y0, y1 = rows if rows else (0, height)
+    bands = np.linspace(y0, y1, max(1, min(threads, y1 - y0)) + 1).astype(int)
+    counts = np.zeros((len(bands) - 1, 2), np.uint64)
+
+    def work(k):
+        l.oracle_render(C.byref(s), C.byref(st), iter_, spp, max_path_len, width, height, int(bands[k]), int(bands[k + 1]),
+                        _ptr(film), counts[k].ctypes.data_as(C.c_void_p))
+    with cf.ThreadPoolExecutor(max(1, threads)) as ex:
+        list(ex.map(work, range(len(bands) - 1)))
+    return film, counts.sum(axis=0)
+
+
+def tonemap(film, iters):
+    """(film / iter)^(1/2.2), clamp, x255 (src/driver/driver.cpp:144-157)."""
+    x = np.clip(np.power(np.maximum(film / np.float32(iters), 0), np.float32(1 / 2.2)), 0, 1)
+    return (x * 255.0).astype(np.uint8)

@@ -33,15 +33,15 @@ CC = os.environ.get("CC", "gcc")
 
 # -ffp-contract=off: fused multiply-adds are written explicitly (fmaf) in both the
 # kernels and the oracle so the two perform the same correctly-rounded operations.
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
              "-Wall", "-Wno-unused-function", f"-I{ROOT / 'include'}"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-Wall", "-fPIC", f"-I{ROOT / 'include'}"]
 ORACLE_FLAGS = ["-O2", "-std=c11", "-Wall", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma"]
 
-HIP_SOURCES = ["traversal.hip"]
-HOST_LIB_SOURCES = ["mesh.cpp", "bvh_build.cpp", "atrium.cpp"]
-HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png"]
-HIP_TOOLS = ["bench_traversal"]
+HIP_SOURCES = ["traversal.hip", "render.hip"]
+HOST_LIB_SOURCES = ["mesh.cpp", "bvh_build.cpp", "atrium.cpp", "scene.cpp"]
+HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png", "converter"]
+HIP_TOOLS = {"bench_traversal": [], "rodent": ["mesh.o", "bvh_build.o", "scene.o"]}   # tool -> host objects it links
 
 
 def _newer(target: Path, *deps: Path) -> bool:
@@ -93,16 +93,18 @@ def build_host(force: bool = False) -> list[Path]:
 def build_hip_tools(force: bool = False) -> list[Path]:
     """Host CLIs that link the HIP library (bench_traversal, rodent)."""
     lib = build_hip_lib(force)
+    build_host(force)
     outs = []
-    for t in HIP_TOOLS:
+    for t, needs in HIP_TOOLS.items():
         src = HOST / "tools" / f"{t}.cpp"
         if not src.exists():
             continue
         out = BIN_DIR / t
-        if force or _newer(out, src, lib, *_headers()):
+        objs = [OBJ_DIR / o for o in needs]
+        if force or _newer(out, src, lib, *objs, *_headers()):
             # plain g++: host code only uses the HIP runtime API (hipcc mistakes .o inputs for sources)
             _run([CXX, "-O2", "-std=c++17", "-Wall", "-Wno-unused-result", "-D__HIP_PLATFORM_AMD__",
-                  f"-I{ROOT / 'include'}", f"-I{ROCM / 'include'}", src,
+                  f"-I{ROOT / 'include'}", f"-I{ROCM / 'include'}", src, *objs,
                   f"-L{LIB_DIR}", "-lrodent_hip", f"-L{ROCM / 'lib'}", "-lamdhip64",
                   "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{ROCM / 'lib'}", "-pthread", "-o", out])
         outs.append(out)

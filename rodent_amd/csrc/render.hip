@@ -1,0 +1,679 @@
+// render.hip -- wavefront path tracer for MI355X (gfx950) behind the C ABI of include/rodent_render.h.
+//
+// Replaces (all Impala, compiled by AnyDSL in the reference):
+//   src/render/mapping_gpu.impala:223-265  gpu_generate_rays      -> k_generate
+//   src/render/mapping_gpu.impala:18-30    gpu_traverse_primary   -> k_trace_stream<false>
+//   src/render/mapping_gpu.impala:166-221  gpu_sort_primary       -> k_bin_count / k_bin_scan_blocks / k_bin_scan_bins / k_scatter
+//   src/render/mapping_gpu.impala:82-134   gpu_shade              -> k_shade  (one launch, material switch; rays arrive sorted)
+//   src/render/mapping_gpu.impala:47-80    gpu_traverse_secondary -> k_trace_stream<true> (+ film accumulation :32-45)
+//   src/render/mapping_gpu.impala:267-300  gpu_compact_primary    -> the same binning kernels with key = dead?1:0
+//   src/render/mapping_gpu.impala:308-369  gpu_streaming_trace    -> render_rows() host loop
+//   src/driver/interface.cpp:359-390,528-563,565-663  stream slabs, film, rodent_* services
+//
+// CDNA4 notes: SoA streams (one 20 x capacity / 13 x capacity float slab each, driver.impala:24-61) so a
+// wavefront's 64 lanes read 64 consecutive words; one wave per workgroup for the traversal kernels
+// (per-lane stack window in LDS, deeper entries in scratch); sort and compaction are deterministic
+// (per-block histograms + scans, wave ballots for the in-block rank) instead of the reference's global
+// atomics, so stream order -- and therefore every test -- is reproducible; the film uses hardware
+// fp32 atomic adds.  No MFMA: branchy scalar work.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "rodent_render.h"
+#include "shading.h"
+#include "traversal_device.h"
+
+#define HIP_CHECK(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t err_ = (expr);                                                              \
+        if (err_ != hipSuccess) {                                                              \
+            fprintf(stderr, "rodent_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(err_), __FILE__, __LINE__); \
+            abort();                                                                           \
+        }                                                                                      \
+    } while (0)
+
+namespace {
+
+using namespace rodent_dev;
+
+constexpr int kBlock = 256;                    // workgroup of the streaming (non-traversal) kernels
+constexpr int kMaxBins = 1025;                 // mapping_gpu.impala:200,342 (1024 geometries + the "miss" bin)
+constexpr int kCapacity = 1024 * 1024;         // mapping_gpu.impala:319
+
+struct CameraDev { float eye[3], dir[3], up[3], right[3]; float w, h; };
+
+// ---------------------------------------------------------------------------------------------
+// K3: ray generation (mapping_gpu.impala:223-265, renderer.impala:26-40, camera.impala:35-44)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_generate(PrimaryStream p, int first_dst, int first_ray_id, int num_rays, CameraDev cam,
+                                                      int iter, int film_w, int film_h, int first_pixel, int spp) {
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= num_rays) return;
+    const int ray_id = first_ray_id + gid, dst = first_dst + gid;
+    const int sample = ray_id % spp;
+    const int pixel = first_pixel + ray_id / spp;
+    const int y = pixel / film_w, x = pixel - y * film_w;          // the reference uses fast_div (common.impala:19-35): same quotient
+    uint32_t rnd = fnv_hash(fnv_hash(fnv_hash(fnv_hash(0x811C9DC5u, (uint32_t)sample), (uint32_t)iter), (uint32_t)x), (uint32_t)y);
+    const float kx = 2.0f * ((float)x + randf(&rnd)) / (float)film_w - 1.0f;
+    const float ky = 1.0f - 2.0f * ((float)y + randf(&rnd)) / (float)film_h;
+    const v3 d = normalize(add(add(mulf(LD3(cam.right), cam.w * kx), mulf(LD3(cam.up), cam.h * ky)), LD3(cam.dir)));
+    p.rays.id[dst] = pixel;
+    p.rays.org_x[dst] = cam.eye[0]; p.rays.org_y[dst] = cam.eye[1]; p.rays.org_z[dst] = cam.eye[2];
+    p.rays.dir_x[dst] = d.x; p.rays.dir_y[dst] = d.y; p.rays.dir_z[dst] = d.z;
+    p.rays.tmin[dst] = 0.0f; p.rays.tmax[dst] = FLT_MAX_REF;
+    p.rnd[dst] = rnd; p.mis[dst] = 0.0f; p.contrib_r[dst] = 1.0f; p.contrib_g[dst] = 1.0f; p.contrib_b[dst] = 1.0f; p.depth[dst] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 / K6: BVH2 traversal over an SoA ray stream.  Per-ray visit order = the reference kernel
+// (traversal/mapping_gpu.impala:94-178); wave scheduling = the "fast" mapping of traversal.hip
+// (while-while, branch-free node step).  Stack: 16-entry window in LDS, deeper entries in scratch.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLdsStack = 16;
+struct StreamStack {
+    lds_int* col; int spill[kStackCap - kLdsStack]; int* err;
+    __device__ __forceinline__ int get(int e) const {
+        if (__builtin_expect(e < kLdsStack, 1)) return col[e * kWave];
+        return spill[(e < kStackCap ? e : kStackCap - 1) - kLdsStack];
+    }
+    __device__ __forceinline__ void put(int e, int v) {
+        if (__builtin_expect(e < kLdsStack, 1)) col[e * kWave] = v;
+        else if (e < kStackCap) spill[e - kLdsStack] = v;
+        else *err = 1;
+    }
+};
+
+struct StreamHit { int prim, geom; float t, u, v; };
+
+template <bool ANY>
+__device__ __forceinline__ StreamHit trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, StreamStack& st) {
+    StreamHit hit{-1, -1, ray.tmax, 0.0f, 0.0f};
+    int ptr = 0, top = 1; st.put(0, 0);
+    while (top != 0) {
+        while (top > 0) {
+            const float4* p = reinterpret_cast<const float4*>(nodes + (top - 1));
+            const float4 b0 = p[0], b1 = p[1], b2 = p[2];
+            const int4 ch = *reinterpret_cast<const int4*>(p + 3);
+            const int popped = st.get(ptr);
+            float te0, te1;
+            const bool h0 = slab(ray, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, te0) && ch.x != 0;
+            const bool h1 = slab(ray, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, te1) && ch.y != 0;
+            const bool c0first = te0 < te1, both = h0 && h1;
+            st.put(ptr + 1, c0first ? ch.y : ch.x);
+            top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
+            ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
+            if (__popcll(__ballot(top > 0)) < 8) break;
+        }
+        while (top < 0) {
+            int j = ~top; top = st.get(ptr); ptr--;
+            for (;;) {
+                const float4* p = reinterpret_cast<const float4*>(tris + j++);
+                const float4 a = p[0], b = p[1], c = p[2];
+                const int prim_id = __float_as_int(c.w);
+                const float nx = cross_x(b.x, b.y, b.z, c.x, c.y, c.z), ny = cross_y(b.x, b.y, b.z, c.x, c.y, c.z), nz = cross_z(b.x, b.y, b.z, c.x, c.y, c.z);
+                float t, u, v;
+                if (intersect_tri(ray, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, nx, ny, nz, t, u, v)) {
+                    hit.prim = prim_id & 0x7FFFFFFF; hit.geom = __float_as_int(b.w); hit.t = t; hit.u = u; hit.v = v;
+                    ray.tmax = t;
+                    if (ANY) return hit;
+                }
+                if (prim_id < 0) break;
+            }
+        }
+    }
+    return hit;
+}
+
+__device__ __forceinline__ RayX load_stream_ray(const RayStream& r, int i) {   // driver.impala:63-84 + intersection.impala:88-99
+    RayX x;
+    x.ox = r.org_x[i]; x.oy = r.org_y[i]; x.oz = r.org_z[i]; x.dx = r.dir_x[i]; x.dy = r.dir_y[i]; x.dz = r.dir_z[i];
+    x.tmin = r.tmin[i]; x.tmax = r.tmax[i];
+    x.idx = safe_rcp(x.dx); x.idy = safe_rcp(x.dy); x.idz = safe_rcp(x.dz);
+    x.iox = -(x.ox * x.idx); x.ioy = -(x.oy * x.idy); x.ioz = -(x.oz * x.idz);
+    return x;
+}
+
+// primary: writes geom_id (num_geometries on a miss, driver.impala:106-115), prim_id, t, u, v
+__global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStream p, const int* size_ptr, int* err, unsigned long long* counters) {
+    __shared__ int lds[kLdsStack * kWave];
+    const int n = *size_ptr;
+    const int i = blockIdx.x * kWave + threadIdx.x;
+    if (blockIdx.x * kWave >= n) return;
+    if (i >= n) return;
+    StreamStack st; st.col = (lds_int*)lds + threadIdx.x; st.err = err;
+    const StreamHit h = trace_one<false>(sc.nodes, sc.tris, load_stream_ray(p.rays, i), st);
+    p.geom_id[i] = h.prim >= 0 ? h.geom : sc.num_materials;
+    p.prim_id[i] = h.prim; p.t[i] = h.t; p.u[i] = h.u; p.v[i] = h.v;
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)n);
+}
+
+// secondary: any-hit; unoccluded rays add their colour to the film (mapping_gpu.impala:32-45,47-80)
+__global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, SecondaryStream s, const int* size_ptr, float* film, float inv_spp,
+                                                           int* err, unsigned long long* counters) {
+    __shared__ int lds[kLdsStack * kWave];
+    const int n = *size_ptr;
+    const int i = blockIdx.x * kWave + threadIdx.x;
+    if (blockIdx.x * kWave >= n) return;
+    const int pixel = i < n ? s.rays.id[i] : -1;
+    const unsigned long long live = __ballot(pixel >= 0);
+    if (threadIdx.x == 0 && live) atomicAdd(&counters[1], (unsigned long long)__popcll(live));
+    if (pixel < 0) return;
+    StreamStack st; st.col = (lds_int*)lds + threadIdx.x; st.err = err;
+    const StreamHit h = trace_one<true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st);
+    if (h.prim < 0) {
+        float* px = film + 3 * (size_t)pixel;
+        unsafeAtomicAdd(px + 0, s.color_r[i] * inv_spp); unsafeAtomicAdd(px + 1, s.color_g[i] * inv_spp); unsafeAtomicAdd(px + 2, s.color_b[i] * inv_spp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: shading (mapping_gpu.impala:82-134; renderer.impala:69-152).  One launch over the sorted,
+// hit-only prefix of the stream; the material is a table entry, not generated code.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, SecondaryStream s, const int* size_ptr, float* film,
+                                                   float inv_spp, int max_path_len) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= *size_ptr) return;
+    const float offset = 0.001f;
+    const float pdf_lightpick = 1.0f / (float)sc.num_lights;
+    const int pixel = p.rays.id[i];
+    const v3 org = V(p.rays.org_x[i], p.rays.org_y[i], p.rays.org_z[i]), dir = V(p.rays.dir_x[i], p.rays.dir_y[i], p.rays.dir_z[i]);
+    const int prim = p.prim_id[i];
+    const float t = p.t[i];
+    uint32_t rnd = p.rnd[i];
+    const float mis_in = p.mis[i];
+    const v3 contrib = V(p.contrib_r[i], p.contrib_g[i], p.contrib_b[i]);
+    const int depth = p.depth[i];
+    const RodentMaterial* m = sc.materials + p.geom_id[i];
+    const Surf sf = surface_element(&sc, org, dir, prim, t, p.u[i], p.v[i]);
+    const v3 out_dir = neg(dir);
+    float* px = film + 3 * (size_t)pixel;
+
+    // on_hit (renderer.impala:113-128)
+    if (m->emissive && sf.entering) {
+        const RodentLight* L = sc.lights + sc.light_ids[prim];
+        const float pdf_dir = cosine_hemisphere_pdf(dot(LD3(L->n), out_dir));
+        const v3 intensity = pdf_dir > 0.0f ? LD3(L->color) : V(0, 0, 0);
+        const float pdf_area = pdf_dir > 0.0f ? L->inv_area : 1.0f;
+        const float next_mis = mis_in * t * t / dot(out_dir, sf.local.c2);
+        const float w = 1.0f / (1.0f + next_mis * pdf_lightpick * pdf_area);
+        const v3 c = mulf(mul(contrib, intensity), w);
+        unsafeAtomicAdd(px + 0, c.x * inv_spp); unsafeAtomicAdd(px + 1, c.y * inv_spp); unsafeAtomicAdd(px + 2, c.z * inv_spp);
+    }
+
+    // on_shadow (renderer.impala:69-111): the secondary ray is written at the SAME index (mapping_gpu.impala:111-115)
+    int sec_id = -1;
+    if (!bsdf_is_specular(m)) {
+        const int light_id = (int)(xorshift(&rnd) & 0x7FFFFFFFu) % sc.num_lights;
+        const RodentLight* L = sc.lights + light_id;
+        const float lu = randf(&rnd), lv = randf(&rnd);
+        const v3 pos = sample_triangle(lu, lv, LD3(L->v0), LD3(L->v1), LD3(L->v2));
+        const v3 from_dir = sub(sf.point, pos);
+        float lcos = dot(from_dir, LD3(L->n)) / len(from_dir);
+        v3 intensity = LD3(L->color); float pdf_area = L->inv_area;
+        if (!(pdf_area > 0.0f && cosine_hemisphere_pdf(lcos) > 0.0f && lcos > 0.0f)) { intensity = V(0, 0, 0); pdf_area = 1.0f; lcos = 0.0f; }
+        const v3 light_dir = sub(pos, sf.point);
+        const float vis = dot(light_dir, sf.local.c2);
+        if (vis > 0.0f && lcos > 0.0f) {
+            const float inv_d = 1.0f / len(light_dir), inv_d2 = inv_d * inv_d;
+            const v3 in_dir = mulf(light_dir, inv_d);
+            const float pdf_e = bsdf_pdf(m, &sf, in_dir, out_dir);
+            const float pdf_l = pdf_area * pdf_lightpick, inv_pdf_l = 1.0f / pdf_l;
+            const float cos_e = vis * inv_d, cos_l = lcos;
+            const float w = 1.0f / (1.0f + pdf_e * cos_l * inv_d2 * inv_pdf_l);
+            const float geom = cos_e * cos_l * inv_d2 * inv_pdf_l;
+            const v3 c = mulf(mul(intensity, mul(contrib, bsdf_eval(m, &sf, in_dir, out_dir))), geom * w);
+            s.rays.org_x[i] = sf.point.x; s.rays.org_y[i] = sf.point.y; s.rays.org_z[i] = sf.point.z;
+            s.rays.dir_x[i] = light_dir.x; s.rays.dir_y[i] = light_dir.y; s.rays.dir_z[i] = light_dir.z;
+            s.rays.tmin[i] = offset; s.rays.tmax[i] = 1.0f - offset;
+            s.color_r[i] = c.x; s.color_g[i] = c.y; s.color_b[i] = c.z;
+            sec_id = pixel;
+        }
+    }
+    s.rays.id[i] = sec_id;
+
+    // on_bounce (renderer.impala:130-152)
+    const float lum2 = 2.0f * luminance(contrib); const float rr = lum2 > 0.75f ? 0.75f : lum2;
+    if (depth >= max_path_len || randf(&rnd) >= rr) { p.rays.id[i] = -1; return; }
+    const BsdfSample bs = bsdf_sample(m, &sf, &rnd, out_dir);
+    const v3 c2 = mulf(mul(contrib, bs.color), bs.cos / (bs.pdf * rr));
+    p.rays.org_x[i] = sf.point.x; p.rays.org_y[i] = sf.point.y; p.rays.org_z[i] = sf.point.z;
+    p.rays.dir_x[i] = bs.in_dir.x; p.rays.dir_y[i] = bs.in_dir.y; p.rays.dir_z[i] = bs.in_dir.z;
+    p.rays.tmin[i] = offset; p.rays.tmax[i] = FLT_MAX_REF;
+    p.rnd[i] = rnd; p.mis[i] = bsdf_is_specular(m) ? 0.0f : 1.0f / bs.pdf;
+    p.contrib_r[i] = c2.x; p.contrib_g[i] = c2.y; p.contrib_b[i] = c2.z; p.depth[i] = depth + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 / K7: deterministic, stable binning of a primary stream (sort by geometry id, or compaction
+// with key = dead ? 1 : 0).  dst(ray) = bin_begin[key] + (rays with that key in earlier blocks)
+//                                      + (rank among the block's rays with that key).
+// The reference uses one global atomic per ray for both (mapping_gpu.impala:195,217,293), which
+// serialises and makes the output order nondeterministic.
+// ---------------------------------------------------------------------------------------------
+enum KeyMode { KEY_GEOM = 0, KEY_ALIVE = 1 };
+__device__ __forceinline__ int stream_key(const PrimaryStream& p, int i, int mode) {
+    return mode == KEY_GEOM ? p.geom_id[i] : (p.rays.id[i] >= 0 ? 0 : 1);
+}
+
+// in-block rank of thread `tid` among threads with the same key; also leaves the block's per-key counts in cnt[]
+__device__ __forceinline__ int block_rank(int key, bool valid, int num_bins, int* cnt /* LDS [4][num_bins] */) {
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    for (int k = threadIdx.x; k < 4 * num_bins; k += kBlock) cnt[k] = 0;
+    __syncthreads();
+    int rank = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {                                           // one round per distinct key present in the wave
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k0 = __shfl(key, leader);
+        const unsigned long long same = __ballot(valid && key == k0);
+        if (valid && key == k0) rank = __popcll(same & ((1ull << lane) - 1ull));
+        if (lane == leader) cnt[wave * num_bins + k0] = __popcll(same);
+        todo &= ~same;
+    }
+    __syncthreads();
+    if (valid) for (int w = 0; w < wave; w++) rank += cnt[w * num_bins + key];
+    return rank;
+}
+
+__global__ __launch_bounds__(kBlock) void k_bin_count(PrimaryStream p, const int* size_ptr, int mode, int num_bins, int num_blocks, int* hist /* [num_bins][num_blocks] */) {
+    extern __shared__ int cnt[];
+    const int n = *size_ptr;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    const int key = valid ? stream_key(p, i, mode) : 0;
+    block_rank(key, valid, num_bins, cnt);
+    for (int k = threadIdx.x; k < num_bins; k += kBlock)
+        hist[(size_t)k * num_blocks + blockIdx.x] = cnt[k] + cnt[num_bins + k] + cnt[2 * num_bins + k] + cnt[3 * num_bins + k];
+}
+
+// one workgroup per bin: exclusive scan of that bin's per-block counts (in place), total -> bin_total[bin]
+__global__ __launch_bounds__(kBlock) void k_bin_scan_blocks(int* hist, int num_blocks, int* bin_total) {
+    __shared__ int part[kBlock];
+    int* row = hist + (size_t)blockIdx.x * num_blocks;
+    const int per = (num_blocks + kBlock - 1) / kBlock;
+    const int b0 = threadIdx.x * per, b1 = min(num_blocks, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; b++) sum += row[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int k = 0; k < kBlock; k++) { const int v = part[k]; part[k] = acc; acc += v; } bin_total[blockIdx.x] = acc; }
+    __syncthreads();
+    int acc = part[threadIdx.x];
+    for (int b = b0; b < b1; b++) { const int v = row[b]; row[b] = acc; acc += v; }
+}
+
+// single workgroup: exclusive scan over bins; bin_begin[k], bin_end[k] (= ray_ends of mapping_gpu.impala:203-207)
+__global__ void k_bin_scan_bins(const int* bin_total, int num_bins, int* bin_begin, int* bin_end) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { int acc = 0; for (int k = 0; k < num_bins; k++) { bin_begin[k] = acc; acc += bin_total[k]; bin_end[k] = acc; } }
+}
+
+// copy_primary_ray (mapping_gpu.impala:136-164) to the computed slot
+__global__ __launch_bounds__(kBlock) void k_scatter(PrimaryStream p, PrimaryStream q, const int* size_ptr, int mode, int num_bins, int num_blocks,
+                                                     const int* hist, const int* bin_begin, int keep_hit, int drop_from_bin) {
+    extern __shared__ int cnt[];
+    const int n = *size_ptr;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    const int key = valid ? stream_key(p, i, mode) : 0;
+    const int rank = block_rank(key, valid, num_bins, cnt);
+    if (!valid || key >= drop_from_bin) return;
+    const int d = bin_begin[key] + hist[(size_t)key * num_blocks + blockIdx.x] + rank;
+    q.rays.id[d] = p.rays.id[i];
+    q.rays.org_x[d] = p.rays.org_x[i]; q.rays.org_y[d] = p.rays.org_y[i]; q.rays.org_z[d] = p.rays.org_z[i];
+    q.rays.dir_x[d] = p.rays.dir_x[i]; q.rays.dir_y[d] = p.rays.dir_y[i]; q.rays.dir_z[d] = p.rays.dir_z[i];
+    q.rays.tmin[d] = p.rays.tmin[i]; q.rays.tmax[d] = p.rays.tmax[i];
+    if (keep_hit) { q.geom_id[d] = p.geom_id[i]; q.prim_id[d] = p.prim_id[i]; q.t[d] = p.t[i]; q.u[d] = p.u[i]; q.v[d] = p.v[i]; }
+    q.rnd[d] = p.rnd[i]; q.mis[d] = p.mis[i];
+    q.contrib_r[d] = p.contrib_r[i]; q.contrib_g[d] = p.contrib_g[i]; q.contrib_b[d] = p.contrib_b[i]; q.depth[d] = p.depth[i];
+}
+
+__global__ void k_set_size(int* dst, const int* src, int index) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = index >= 0 ? src[index] : 0; }
+__global__ void k_add_size(int* dst, int amount) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst += amount; }
+
+// ---------------------------------------------------------------------------------------------
+// Host side: per-device state (interface.cpp:324-339), stream slabs, the streaming loop
+// ---------------------------------------------------------------------------------------------
+struct DevScene {
+    bool loaded = false;
+    SceneDev dev{};
+    std::vector<void*> allocs;
+};
+
+struct RenderDevice {
+    bool init = false;
+    int dev = 0;
+    DevScene scene;
+    int spp = 4, max_path_len = 64;
+    float* film = nullptr; int film_w = 0, film_h = 0;
+    float* slab[3] = {nullptr, nullptr, nullptr}; int slab_cap[3] = {0, 0, 0};       // first primary, second primary, secondary
+    int* tmp = nullptr; int tmp_cap = 0;
+    int* hist = nullptr; size_t hist_cap = 0;
+    int* ctl = nullptr;       // [0] primary size, [1] secondary size, [2] error flag, [8..] bin_total, bin_begin, bin_end (kMaxBins each)
+    unsigned long long* counters = nullptr;    // [0] primary rays, [1] shadow rays, [2] iterations, [3] generated
+    int* host_pinned = nullptr;
+};
+RenderDevice g_rdev[16];
+std::mutex g_rmutex;
+int g_current_dev = 0;
+std::vector<float> g_host_film; size_t g_host_w = 0, g_host_h = 0;
+
+RenderDevice& rdev(int dev) {
+    if (dev < 0 || dev >= 16) { fprintf(stderr, "rodent_hip: invalid device index %d\n", dev); abort(); }
+    std::lock_guard<std::mutex> lock(g_rmutex);
+    RenderDevice& r = g_rdev[dev];
+    if (!r.init) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || dev >= count) { fprintf(stderr, "rodent_hip: no HIP device %d (%d visible)\n", dev, count); abort(); }
+        HIP_CHECK(hipSetDevice(dev));
+        r.dev = dev;
+        HIP_CHECK(hipMalloc(&r.ctl, sizeof(int) * (8 + 3 * kMaxBins)));
+        HIP_CHECK(hipMemset(r.ctl, 0, sizeof(int) * (8 + 3 * kMaxBins)));
+        HIP_CHECK(hipMalloc(&r.counters, sizeof(unsigned long long) * 4));
+        HIP_CHECK(hipMemset(r.counters, 0, sizeof(unsigned long long) * 4));
+        HIP_CHECK(hipHostMalloc(&r.host_pinned, sizeof(int) * (8 + kMaxBins)));
+        r.init = true;
+    }
+    return r;
+}
+
+inline int round_cap(int size) { return (size & ~31) + 32; }                 // interface.cpp:359-366
+
+float* ensure_slab(RenderDevice& r, int which, int size, int multiplier) {
+    const int cap = round_cap(size);
+    if (r.slab_cap[which] < cap) {
+        HIP_CHECK(hipSetDevice(r.dev));
+        if (r.slab[which]) HIP_CHECK(hipFree(r.slab[which]));
+        HIP_CHECK(hipMalloc(&r.slab[which], sizeof(float) * (size_t)cap * multiplier));
+        HIP_CHECK(hipMemset(r.slab[which], 0, sizeof(float) * (size_t)cap * multiplier));
+        r.slab_cap[which] = cap;
+    }
+    return r.slab[which];
+}
+
+void carve_rays(RayStream& rays, float* ptr, size_t cap) {                    // interface.cpp:528-538
+    rays.id = (int32_t*)ptr; rays.org_x = ptr + 1 * cap; rays.org_y = ptr + 2 * cap; rays.org_z = ptr + 3 * cap;
+    rays.dir_x = ptr + 4 * cap; rays.dir_y = ptr + 5 * cap; rays.dir_z = ptr + 6 * cap; rays.tmin = ptr + 7 * cap; rays.tmax = ptr + 8 * cap;
+}
+void carve_primary(PrimaryStream& p, float* ptr, size_t cap) {               // interface.cpp:540-554
+    carve_rays(p.rays, ptr, cap);
+    p.geom_id = (int32_t*)ptr + 9 * cap; p.prim_id = (int32_t*)ptr + 10 * cap; p.t = ptr + 11 * cap; p.u = ptr + 12 * cap; p.v = ptr + 13 * cap;
+    p.rnd = (uint32_t*)ptr + 14 * cap; p.mis = ptr + 15 * cap; p.contrib_r = ptr + 16 * cap; p.contrib_g = ptr + 17 * cap; p.contrib_b = ptr + 18 * cap;
+    p.depth = (int32_t*)ptr + 19 * cap; p.size = 0; p.pad = 0;
+}
+void carve_secondary(SecondaryStream& s, float* ptr, size_t cap) {           // interface.cpp:556-563
+    carve_rays(s.rays, ptr, cap);
+    s.prim_id = (int32_t*)ptr + 9 * cap; s.color_r = ptr + 10 * cap; s.color_g = ptr + 11 * cap; s.color_b = ptr + 12 * cap; s.size = 0; s.pad = 0;
+}
+
+void ensure_hist(RenderDevice& r, size_t ints) {
+    if (r.hist_cap < ints) {
+        if (r.hist) HIP_CHECK(hipFree(r.hist));
+        HIP_CHECK(hipMalloc(&r.hist, sizeof(int) * ints));
+        r.hist_cap = ints;
+    }
+}
+
+int* bin_total(RenderDevice& r) { return r.ctl + 8; }
+int* bin_begin(RenderDevice& r) { return r.ctl + 8 + kMaxBins; }
+int* bin_end(RenderDevice& r)   { return r.ctl + 8 + 2 * kMaxBins; }
+
+// Bins `p` (size in *size_ptr, at most max_n) into `q`; bins >= drop_from_bin are not copied.
+void bin_stream(RenderDevice& r, const PrimaryStream& p, const PrimaryStream& q, const int* size_ptr, int max_n, int mode, int num_bins,
+                int keep_hit, int drop_from_bin, hipStream_t stream) {
+    const int blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
+    ensure_hist(r, (size_t)num_bins * blocks);
+    const size_t lds = sizeof(int) * 4 * num_bins;
+    hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kBlock), lds, stream, p, size_ptr, mode, num_bins, blocks, r.hist);
+    hipLaunchKernelGGL(k_bin_scan_blocks, dim3(num_bins), dim3(kBlock), 0, stream, r.hist, blocks, bin_total(r));
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1), 0, stream, bin_total(r), num_bins, bin_begin(r), bin_end(r));
+    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBlock), lds, stream, p, q, size_ptr, mode, num_bins, blocks, r.hist, bin_begin(r), keep_hit, drop_from_bin);
+    HIP_CHECK(hipGetLastError());
+}
+
+CameraDev to_cam(const Settings* s) {
+    CameraDev c;
+    c.eye[0] = s->eye.x; c.eye[1] = s->eye.y; c.eye[2] = s->eye.z; c.dir[0] = s->dir.x; c.dir[1] = s->dir.y; c.dir[2] = s->dir.z;
+    c.up[0] = s->up.x; c.up[1] = s->up.y; c.up[2] = s->up.z; c.right[0] = s->right.x; c.right[1] = s->right.y; c.right[2] = s->right.z;
+    c.w = s->width; c.h = s->height;
+    return c;
+}
+
+void require_scene(RenderDevice& r) {
+    if (!r.scene.loaded) { fprintf(stderr, "rodent_hip: no scene loaded on device %d (call rodent_hip_scene_create)\n", r.dev); abort(); }
+    if (r.scene.dev.num_lights <= 0) { fprintf(stderr, "rodent_hip: the scene has no light source\n"); abort(); }
+    if (!r.film) { fprintf(stderr, "rodent_hip: no film (call setup_interface)\n"); abort(); }
+}
+
+void ensure_film(RenderDevice& r) {
+    if (r.film && r.film_w == (int)g_host_w && r.film_h == (int)g_host_h) return;
+    HIP_CHECK(hipSetDevice(r.dev));
+    if (r.film) HIP_CHECK(hipFree(r.film));
+    r.film_w = (int)g_host_w; r.film_h = (int)g_host_h;
+    HIP_CHECK(hipMalloc(&r.film, sizeof(float) * 3 * (size_t)r.film_w * r.film_h));
+    HIP_CHECK(hipMemset(r.film, 0, sizeof(float) * 3 * (size_t)r.film_w * r.film_h));
+}
+
+// gpu_streaming_trace (mapping_gpu.impala:308-369) for image rows [y0, y1)
+void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, int y1, hipStream_t stream) {
+    HIP_CHECK(hipSetDevice(r.dev));
+    ensure_film(r);
+    require_scene(r);
+    const int G = r.scene.dev.num_materials;
+    if (G + 1 > kMaxBins) { fprintf(stderr, "rodent_hip: too many geometries (%d)\n", G); abort(); }
+    PrimaryStream a, b; SecondaryStream sec;
+    carve_primary(a, ensure_slab(r, 0, kCapacity, 20), round_cap(kCapacity));
+    carve_primary(b, ensure_slab(r, 1, kCapacity, 20), round_cap(kCapacity));
+    carve_secondary(sec, ensure_slab(r, 2, kCapacity, 13), round_cap(kCapacity));
+    PrimaryStream* primary = &a; PrimaryStream* other = &b;
+    int* d_size = r.ctl; int* d_sec_size = r.ctl + 1; int* err = r.ctl + 2;
+    const CameraDev cam = to_cam(settings);
+    const float inv_spp = 1.0f / (float)r.spp;
+    const long long num_rays = (long long)r.spp * r.film_w * (y1 - y0);
+    const int first_pixel = y0 * r.film_w;
+    long long id = 0; int size = 0;
+    HIP_CHECK(hipMemsetAsync(d_size, 0, sizeof(int) * 3, stream));
+    HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * 4, stream));
+    unsigned long long iterations = 0, generated = 0;
+    while (id < num_rays || size > 0) {
+        if (size < kCapacity && id < num_rays) {                                         // regenerate (mapping_gpu.impala:332-336)
+            const int n = (int)std::min<long long>(num_rays - id, kCapacity - size);
+            hipLaunchKernelGGL(k_generate, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, *primary, size, (int)id, n, cam, iter,
+                               r.film_w, r.film_h, first_pixel, r.spp);
+            hipLaunchKernelGGL(k_add_size, dim3(1), dim3(1), 0, stream, d_size, n);
+            id += n; size += n; generated += n;
+        }
+        const int waves = (size + kWave - 1) / kWave;
+        hipLaunchKernelGGL(k_trace_primary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, *primary, d_size, err, r.counters);
+        bin_stream(r, *primary, *other, d_size, size, KEY_GEOM, G + 1, 1, G, stream);     // misses (bin G) are dropped (:347-357)
+        std::swap(primary, other);
+        hipLaunchKernelGGL(k_set_size, dim3(1), dim3(1), 0, stream, d_size, bin_end(r), G - 1);
+        hipLaunchKernelGGL(k_set_size, dim3(1), dim3(1), 0, stream, d_sec_size, bin_end(r), G - 1);
+        const int blocks = (size + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, d_size, r.film, inv_spp, r.max_path_len);
+        hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, sec, d_sec_size, r.film, inv_spp, err, r.counters);
+        bin_stream(r, *primary, *other, d_size, size, KEY_ALIVE, 2, 0, 1, stream);        // compaction (:267-300)
+        std::swap(primary, other);
+        hipLaunchKernelGGL(k_set_size, dim3(1), dim3(1), 0, stream, d_size, bin_end(r), 0);
+        HIP_CHECK(hipMemcpyAsync(r.host_pinned, d_size, sizeof(int) * 3, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        size = r.host_pinned[0];
+        if (r.host_pinned[2]) { fprintf(stderr, "rodent_hip: traversal stack overflow in the renderer\n"); abort(); }
+        iterations++;
+    }
+    const unsigned long long host_counts[2] = {iterations, generated};
+    HIP_CHECK(hipMemcpyAsync(r.counters + 2, host_counts, sizeof(host_counts), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+template <typename T> T* upload(DevScene& s, const T* host, size_t count) {
+    T* d = nullptr;
+    HIP_CHECK(hipMalloc(&d, std::max<size_t>(sizeof(T) * count, 16)));
+    if (count) HIP_CHECK(hipMemcpy(d, host, sizeof(T) * count, hipMemcpyHostToDevice));
+    s.allocs.push_back(d);
+    return d;
+}
+
+} // namespace
+
+extern "C" {
+
+void rodent_hip_set_device(int32_t dev) { rdev(dev); g_current_dev = dev; }
+
+void rodent_hip_scene_destroy(int32_t dev) {
+    RenderDevice& r = rdev(dev);
+    HIP_CHECK(hipSetDevice(dev));
+    HIP_CHECK(hipDeviceSynchronize());
+    for (void* p : r.scene.allocs) HIP_CHECK(hipFree(p));
+    r.scene = DevScene();
+}
+
+void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
+    RenderDevice& r = rdev(dev);
+    rodent_hip_scene_destroy(dev);
+    HIP_CHECK(hipSetDevice(dev));
+    DevScene& s = r.scene;
+    s.dev.vertices = upload(s, d->vertices, 4 * (size_t)d->num_vertices);
+    s.dev.normals = upload(s, d->normals, 4 * (size_t)d->num_vertices);
+    s.dev.face_normals = upload(s, d->face_normals, 4 * (size_t)d->num_tris);
+    s.dev.indices = upload(s, d->indices, 4 * (size_t)d->num_tris);
+    s.dev.nodes = upload(s, d->nodes, (size_t)d->num_nodes);
+    s.dev.tris = upload(s, d->tris, (size_t)d->num_bvh_tris);
+    s.dev.materials = upload(s, d->materials, (size_t)d->num_materials);
+    s.dev.lights = upload(s, d->lights, (size_t)d->num_lights);
+    s.dev.light_ids = upload(s, d->light_ids, (size_t)d->num_tris);
+    s.dev.num_tris = d->num_tris; s.dev.num_materials = d->num_materials; s.dev.num_lights = d->num_lights;
+    s.loaded = true;
+}
+
+void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
+    if (spp < 1 || max_path_len < 0) { fprintf(stderr, "rodent_hip: invalid render configuration\n"); abort(); }
+    RenderDevice& r = rdev(dev); r.spp = spp; r.max_path_len = max_path_len;
+}
+
+int32_t get_spp(void) { return rdev(g_current_dev).spp; }
+
+void setup_interface(size_t width, size_t height) { g_host_w = width; g_host_h = height; g_host_film.assign(width * height * 3, 0.0f); }
+float* get_pixels(void) { return g_host_film.data(); }
+void cleanup_interface(void) {
+    for (auto& r : g_rdev) if (r.init && r.film) { hipSetDevice(r.dev); hipFree(r.film); r.film = nullptr; r.film_w = r.film_h = 0; }
+    g_host_film.clear(); g_host_w = g_host_h = 0;
+}
+void clear_pixels(void) {                                                    // interface.cpp:498-505
+    std::fill(g_host_film.begin(), g_host_film.end(), 0.0f);
+    for (auto& r : g_rdev) if (r.init && r.film) { HIP_CHECK(hipSetDevice(r.dev)); HIP_CHECK(hipMemset(r.film, 0, sizeof(float) * 3 * (size_t)r.film_w * r.film_h)); }
+}
+
+void rodent_get_film_data(int32_t dev, float** pixels, int32_t* width, int32_t* height) {
+    RenderDevice& r = rdev(dev); ensure_film(r);
+    *pixels = r.film; *width = r.film_w; *height = r.film_h;
+}
+void rodent_gpu_get_first_primary_stream(int32_t dev, PrimaryStream* p, int32_t size) { RenderDevice& r = rdev(dev); carve_primary(*p, ensure_slab(r, 0, size, 20), round_cap(size)); }
+void rodent_gpu_get_second_primary_stream(int32_t dev, PrimaryStream* p, int32_t size) { RenderDevice& r = rdev(dev); carve_primary(*p, ensure_slab(r, 1, size, 20), round_cap(size)); }
+void rodent_gpu_get_secondary_stream(int32_t dev, SecondaryStream* s, int32_t size) { RenderDevice& r = rdev(dev); carve_secondary(*s, ensure_slab(r, 2, size, 13), round_cap(size)); }
+void rodent_gpu_get_tmp_buffer(int32_t dev, int32_t** buf, int32_t size) {
+    RenderDevice& r = rdev(dev);
+    if (r.tmp_cap < round_cap(size)) { HIP_CHECK(hipSetDevice(dev)); if (r.tmp) HIP_CHECK(hipFree(r.tmp)); HIP_CHECK(hipMalloc(&r.tmp, sizeof(int) * round_cap(size))); r.tmp_cap = round_cap(size); }
+    *buf = r.tmp;
+}
+void rodent_present(int32_t dev) {                                           // interface.cpp:494-496,660-663
+    RenderDevice& r = rdev(dev);
+    if (!r.film) return;
+    HIP_CHECK(hipSetDevice(dev));
+    HIP_CHECK(hipMemcpy(g_host_film.data(), r.film, sizeof(float) * 3 * (size_t)r.film_w * r.film_h, hipMemcpyDeviceToHost));
+}
+
+void rodent_hip_render_rows(int32_t dev, const Settings* settings, int32_t iter, int32_t y0, int32_t y1, void* stream) {
+    RenderDevice& r = rdev(dev);
+    ensure_film(r);
+    if (y0 < 0 || y1 > r.film_h || y0 > y1) { fprintf(stderr, "rodent_hip: invalid row range [%d, %d)\n", y0, y1); abort(); }
+    render_rows(r, settings, iter, y0, y1, (hipStream_t)stream);
+}
+
+void render(const Settings* settings, int32_t iter) {                        // generated render(): converter.cpp:628-967
+    RenderDevice& r = rdev(g_current_dev);
+    ensure_film(r);
+    render_rows(r, settings, iter, 0, r.film_h, nullptr);
+    rodent_present(g_current_dev);                                           // device.present() (converter.cpp:965)
+}
+
+void rodent_hip_render_counters(int32_t dev, uint64_t* out4) {
+    RenderDevice& r = rdev(dev);
+    HIP_CHECK(hipSetDevice(dev));
+    HIP_CHECK(hipMemcpy(out4, r.counters, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
+}
+
+// ---- stage-level entry points ---------------------------------------------------------------
+void hip_generate_rays(int32_t dev, PrimaryStream* primary, int32_t capacity, int32_t first_ray_id, int32_t num_rays, const Settings* settings,
+                       int32_t iter, int32_t film_width, int32_t film_height, int32_t first_pixel, int32_t spp, void* stream) {
+    rdev(dev); HIP_CHECK(hipSetDevice(dev));
+    if (primary->size + num_rays > capacity) { fprintf(stderr, "rodent_hip: hip_generate_rays exceeds the stream capacity\n"); abort(); }
+    if (num_rays > 0)
+        hipLaunchKernelGGL(k_generate, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, *primary, primary->size, first_ray_id,
+                           num_rays, to_cam(settings), iter, film_width, film_height, first_pixel, spp);
+    primary->size += num_rays;
+    HIP_CHECK(hipGetLastError());
+}
+
+static void push_size(RenderDevice& r, int* slot, int size, hipStream_t stream) {
+    r.host_pinned[4] = size;
+    HIP_CHECK(hipMemcpyAsync(slot, r.host_pinned + 4, sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void hip_traverse_primary(int32_t dev, PrimaryStream* primary, void* stream) {
+    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
+    if (primary->size <= 0) return;
+    push_size(r, r.ctl, primary->size, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_trace_primary, dim3((primary->size + kWave - 1) / kWave), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *primary, r.ctl, r.ctl + 2, r.counters);
+    HIP_CHECK(hipGetLastError());
+}
+
+void hip_sort_primary(int32_t dev, PrimaryStream* primary, PrimaryStream* other, int32_t* ray_ends, void* stream) {
+    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
+    const int G = r.scene.dev.num_materials;
+    push_size(r, r.ctl, primary->size, (hipStream_t)stream);
+    bin_stream(r, *primary, *other, r.ctl, std::max(primary->size, 1), KEY_GEOM, G + 1, 1, G + 1, (hipStream_t)stream);
+    HIP_CHECK(hipMemcpyAsync(r.host_pinned + 8, bin_end(r), sizeof(int) * (G + 1), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    std::memcpy(ray_ends, r.host_pinned + 8, sizeof(int) * (G + 1));
+    other->size = primary->size;
+}
+
+void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, int32_t num_rays, void* stream) {
+    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
+    primary->size = num_rays; secondary->size = num_rays;
+    if (num_rays <= 0) return;
+    push_size(r, r.ctl, num_rays, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_shade, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, r.scene.dev, *primary, *secondary, r.ctl, r.film,
+                       1.0f / (float)r.spp, r.max_path_len);
+    HIP_CHECK(hipGetLastError());
+}
+
+void hip_traverse_secondary(int32_t dev, SecondaryStream* secondary, void* stream) {
+    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
+    if (secondary->size <= 0) return;
+    push_size(r, r.ctl + 1, secondary->size, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_trace_secondary, dim3((secondary->size + kWave - 1) / kWave), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *secondary, r.ctl + 1,
+                       r.film, 1.0f / (float)r.spp, r.ctl + 2, r.counters);
+    HIP_CHECK(hipGetLastError());
+}
+
+int32_t hip_compact_primary(int32_t dev, PrimaryStream* primary, PrimaryStream* other, void* stream) {
+    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev));
+    push_size(r, r.ctl, primary->size, (hipStream_t)stream);
+    bin_stream(r, *primary, *other, r.ctl, std::max(primary->size, 1), KEY_ALIVE, 2, 0, 1, (hipStream_t)stream);
+    HIP_CHECK(hipMemcpyAsync(r.host_pinned + 8, bin_end(r), sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    other->size = r.host_pinned[8];
+    return other->size;
+}
+
+} // extern "C"

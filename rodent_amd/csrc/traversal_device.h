@@ -1,0 +1,90 @@
+// traversal_device.h -- ray / box / triangle arithmetic shared by the traversal kernels
+// (traversal.hip) and the renderer's stream kernels (render.hip).  Same operation sequence as the
+// CPU parity oracle: explicit fmaf(), compiled with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "rodent_traversal.h"
+
+namespace rodent_dev {
+
+constexpr int   kWave = 64;
+constexpr int   kStackCap = 64;               // stack.impala:53-54
+constexpr float kFltMax = 3.4028234664e+38f;  // common.impala:4
+
+// ---------------------------------------------------------------------------------------------
+// Ray / box / triangle arithmetic (same operation sequence as oracle/traversal_oracle.c)
+// ---------------------------------------------------------------------------------------------
+struct RayX {
+    float ox, oy, oz, dx, dy, dz, idx, idy, idz, iox, ioy, ioz, tmin, tmax;
+};
+
+__device__ __forceinline__ float prodsign(float x, float y) {        // common.impala:78-80
+    return __int_as_float(__float_as_int(x) ^ (__float_as_int(y) & (int)0x80000000u));
+}
+__device__ __forceinline__ float safe_rcp(float x) {                 // common.impala:82-85
+    return (fabsf(x) < 1e-8f) ? prodsign(kFltMax, x) : 1.0f / x;
+}
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return fmaf(az, bz, fmaf(ay, by, ax * bx));
+}
+__device__ __forceinline__ float cross_x(float ax, float ay, float az, float bx, float by, float bz) { return fmaf(ay, bz, -(az * by)); }
+__device__ __forceinline__ float cross_y(float ax, float ay, float az, float bx, float by, float bz) { return fmaf(az, bx, -(ax * bz)); }
+__device__ __forceinline__ float cross_z(float ax, float ay, float az, float bx, float by, float bz) { return fmaf(ax, by, -(ay * bx)); }
+
+// bench_traversal.impala:67-76 (two 16-byte loads) + intersection.impala:88-99
+__device__ __forceinline__ RayX load_ray(const Ray1* rays, int i) {
+    const float4* p = reinterpret_cast<const float4*>(rays + i);
+    const float4 r0 = p[0], r1 = p[1];
+    RayX r;
+    r.ox = r0.x; r.oy = r0.y; r.oz = r0.z; r.tmin = r0.w;
+    r.dx = r1.x; r.dy = r1.y; r.dz = r1.z; r.tmax = r1.w;
+    r.idx = safe_rcp(r.dx); r.idy = safe_rcp(r.dy); r.idz = safe_rcp(r.dz);
+    r.iox = -(r.ox * r.idx); r.ioy = -(r.oy * r.idy); r.ioz = -(r.oz * r.idz);
+    return r;
+}
+
+// bench_traversal.impala:78-83 (one 16-byte store)
+__device__ __forceinline__ void store_hit(Hit1* hits, int i, int id, float t, float u, float v) {
+    *reinterpret_cast<float4*>(hits + i) = make_float4(__int_as_float(id), t, u, v);
+}
+
+// intersection.impala:194-208, unordered form, fminf/fmaxf like make_amdgpu_min_max
+// (mapping_gpu.impala:87-89).  Returns tentry; hit iff tentry <= texit.
+__device__ __forceinline__ bool slab(const RayX& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float& tentry) {
+    const float t0x = fmaf(r.idx, lox, r.iox), t1x = fmaf(r.idx, hix, r.iox);
+    const float t0y = fmaf(r.idy, loy, r.ioy), t1y = fmaf(r.idy, hiy, r.ioy);
+    const float t0z = fmaf(r.idz, loz, r.ioz), t1z = fmaf(r.idz, hiz, r.ioz);
+    tentry = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), r.tmin));
+    const float texit = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), r.tmax));
+    return tentry <= texit;
+}
+
+// intersection.impala:164-192, no back-face culling
+__device__ __forceinline__ bool intersect_tri(const RayX& r,
+                                              float v0x, float v0y, float v0z, float e1x, float e1y, float e1z,
+                                              float e2x, float e2y, float e2z, float nx, float ny, float nz,
+                                              float& t_out, float& u_out, float& v_out) {
+    const float cx = v0x - r.ox, cy = v0y - r.oy, cz = v0z - r.oz;
+    const float rx = cross_x(r.dx, r.dy, r.dz, cx, cy, cz);
+    const float ry = cross_y(r.dx, r.dy, r.dz, cx, cy, cz);
+    const float rz = cross_z(r.dx, r.dy, r.dz, cx, cy, cz);
+    const float det = dot3(nx, ny, nz, r.dx, r.dy, r.dz);
+    const float abs_det = fabsf(det);
+    const float u = prodsign(dot3(rx, ry, rz, e2x, e2y, e2z), det);
+    const float v = prodsign(dot3(rx, ry, rz, e1x, e1y, e1z), det);
+    if (!(u >= 0.0f) || !(v >= 0.0f) || !(u + v <= abs_det)) return false;
+    const float t = prodsign(dot3(cx, cy, cz, nx, ny, nz), det);
+    if (!(abs_det != 0.0f)) return false;
+    if (!(t >= abs_det * r.tmin) || !(t <= abs_det * r.tmax)) return false;
+    const float inv_det = 1.0f / abs_det;
+    t_out = t * inv_det; u_out = u * inv_det; v_out = v * inv_det;
+    return true;
+}
+
+
+struct HitAcc { int id; float t, u, v; };
+
+typedef __attribute__((address_space(3))) int lds_int;
+
+} // namespace rodent_dev

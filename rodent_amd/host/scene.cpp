@@ -1,0 +1,154 @@
+#include "scene.h"
+
+#include <algorithm>
+#include <cstring>
+#include <iostream>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "bvh_build.h"
+
+namespace rodent {
+namespace {
+
+bool same(V3 a, V3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+bool zero(V3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
+float lum(V3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }
+
+bool same_material(const Material& a, const Material& b) {            // converter.cpp:440-459
+    return same(a.ka, b.ka) && same(a.kd, b.kd) && same(a.ks, b.ks) && same(a.ke, b.ke) && a.ns == b.ns && a.ni == b.ni &&
+           same(a.tf, b.tf) && a.illum == b.illum && a.map_kd == b.map_kd && a.map_ks == b.map_ks && a.map_ke == b.map_ke;
+}
+
+RodentMaterial to_table(const Material& m) {                           // converter.cpp:872-918
+    RodentMaterial r; std::memset(&r, 0, sizeof r);
+    r.kd[0] = m.kd.x; r.kd[1] = m.kd.y; r.kd[2] = m.kd.z;
+    r.ks[0] = m.ks.x; r.ks[1] = m.ks.y; r.ks[2] = m.ks.z;
+    r.tf[0] = m.tf.x; r.tf[1] = m.tf.y; r.tf[2] = m.tf.z;
+    r.ns = m.ns; r.ni = m.ni;
+    if (m.illum == 5) r.type = RODENT_BSDF_MIRROR;
+    else if (m.illum == 7) r.type = RODENT_BSDF_GLASS;
+    else {
+        const bool diffuse = !zero(m.kd), specular = !zero(m.ks);
+        if (diffuse && specular) {
+            const float ls = lum(m.ks), ld = lum(m.kd);
+            r.type = RODENT_BSDF_MIX; r.mix_k = (ls + ld == 0.0f) ? 0.0f : ls / (ls + ld);
+        } else if (specular) r.type = RODENT_BSDF_PHONG;
+        else if (diffuse) r.type = RODENT_BSDF_DIFFUSE;
+        else r.type = RODENT_BSDF_BLACK;
+    }
+    r.emissive = !zero(m.ke);
+    return r;
+}
+
+} // namespace
+
+RodentSceneDesc SceneData::desc() const {
+    RodentSceneDesc d; std::memset(&d, 0, sizeof d);
+    d.vertices = vertices.data(); d.normals = normals.data(); d.face_normals = face_normals.data(); d.indices = indices.data();
+    d.nodes = nodes.data(); d.tris = tris.data(); d.materials = materials.data(); d.lights = lights.data(); d.light_ids = light_ids.data();
+    d.num_vertices = (int32_t)(vertices.size() / 4); d.num_tris = (int32_t)num_tris(); d.num_nodes = (int32_t)nodes.size();
+    d.num_bvh_tris = (int32_t)tris.size(); d.num_materials = (int32_t)materials.size(); d.num_lights = (int32_t)lights.size();
+    return d;
+}
+
+bool build_scene_from_obj(const std::string& obj_path, SceneData& scene) {
+    TriMesh mesh;
+    if (!load_obj(obj_path, mesh)) return false;
+    std::unordered_map<std::string, Material> lib;
+    for (auto& l : mesh.mtl_libs)
+        if (!load_mtl(l, lib)) { std::cerr << "Invalid MTL file '" << l << "'" << std::endl; return false; }
+
+    // dummy material for faces without (known) material (converter.cpp:469-486)
+    Material dummy; dummy.kd = V3(0.0f, 1.0f, 1.0f); dummy.ns = 1.0f; dummy.ni = 1.0f; dummy.tr = 1.0f; dummy.d = 1.0f; dummy.illum = 2;
+    lib[""] = dummy;
+    std::vector<std::string> names = mesh.material_names;
+    for (auto& n : names)
+        if (!n.empty() && !lib.count(n)) { std::clog << "Missing material definition for '" << n << "'. Replaced by dummy material." << std::endl; n = ""; }
+
+    // merge identical materials, drop unused ones (first occurrence keeps its place)
+    const size_t nt = mesh.num_tris();
+    std::vector<int> canon(names.size());
+    for (size_t i = 0; i < names.size(); i++) {
+        canon[i] = (int)i;
+        for (size_t j = 0; j < i; j++) if (same_material(lib[names[i]], lib[names[j]])) { canon[i] = canon[j]; break; }
+    }
+    std::vector<int> used(names.size(), 0);
+    for (size_t t = 0; t < nt; t++) used[canon[mesh.indices[4 * t + 3]]] = 1;
+    std::vector<int> new_id(names.size(), -1);
+    for (size_t i = 0; i < names.size(); i++)
+        if (canon[i] == (int)i && used[i]) {
+            new_id[i] = (int)scene.materials.size();
+            scene.materials.push_back(to_table(lib[names[i]]));
+            scene.material_names.push_back(names[i]);
+        }
+    for (size_t t = 0; t < nt; t++) mesh.indices[4 * t + 3] = (uint32_t)new_id[canon[mesh.indices[4 * t + 3]]];
+
+    // mesh buffers
+    auto pad4 = [](const std::vector<V3>& v) { std::vector<float> o(v.size() * 4, 0.0f); for (size_t i = 0; i < v.size(); i++) { o[4 * i] = v[i].x; o[4 * i + 1] = v[i].y; o[4 * i + 2] = v[i].z; } return o; };
+    scene.vertices = pad4(mesh.vertices); scene.normals = pad4(mesh.normals); scene.face_normals = pad4(mesh.face_normals);
+    scene.indices.assign(mesh.indices.begin(), mesh.indices.end());
+
+    // lights (converter.cpp:770-851): one per emissive triangle
+    scene.light_ids.assign(nt, 0);
+    for (size_t t = 0; t < nt; t++) {
+        const int mid = scene.indices[4 * t + 3];
+        if (!scene.materials[mid].emissive) continue;
+        const Material& m = lib[scene.material_names[mid]];
+        const Triangle tr = mesh.tri(t);
+        V3 n = cross(tr.v1 - tr.v0, tr.v2 - tr.v0);
+        const float inv_area = 1.0f / (0.5f * length(n));
+        n = normalize(n);
+        RodentLight L; std::memset(&L, 0, sizeof L);
+        for (int k = 0; k < 3; k++) { L.v0[k] = tr.v0[k]; L.v1[k] = tr.v1[k]; L.v2[k] = tr.v2[k]; L.n[k] = n[k]; L.color[k] = m.ke[k]; }
+        L.inv_area = inv_area;
+        scene.light_ids[t] = (int32_t)scene.lights.size();
+        scene.lights.push_back(L);
+    }
+
+    // BVH2/Tri1 with the material id as geometry id
+    const std::vector<Triangle> tris = mesh.triangles();
+    std::vector<uint32_t> geom(nt);
+    for (size_t t = 0; t < nt; t++) geom[t] = (uint32_t)scene.indices[4 * t + 3];
+    BuildParams p; p.arity = 2;
+    const WideBvh bvh = build_wide_bvh(tris, p);
+    layout_bvh2_tri1(bvh, tris, geom.data(), scene.nodes, scene.tris);
+    return true;
+}
+
+// ---- .rscene: magic, version, defaults, counts, then the arrays in declaration order ----
+namespace { const uint32_t kMagic = 0x43534452u /* "RDSC" */, kVersion = 1; }
+
+bool save_scene(const std::string& path, const SceneData& s) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const uint32_t hdr[10] = {kMagic, kVersion, (uint32_t)s.default_spp, (uint32_t)s.default_max_path_len,
+                              (uint32_t)(s.vertices.size() / 4), (uint32_t)s.num_tris(), (uint32_t)s.nodes.size(),
+                              (uint32_t)s.tris.size(), (uint32_t)s.materials.size(), (uint32_t)s.lights.size()};
+    bool ok = fwrite(hdr, 4, 10, f) == 10;
+    auto put = [&](const void* p, size_t bytes) { ok = ok && (bytes == 0 || fwrite(p, 1, bytes, f) == bytes); };
+    put(s.vertices.data(), s.vertices.size() * 4); put(s.normals.data(), s.normals.size() * 4);
+    put(s.face_normals.data(), s.face_normals.size() * 4); put(s.indices.data(), s.indices.size() * 4);
+    put(s.nodes.data(), s.nodes.size() * sizeof(Node2)); put(s.tris.data(), s.tris.size() * sizeof(Tri1));
+    put(s.materials.data(), s.materials.size() * sizeof(RodentMaterial)); put(s.lights.data(), s.lights.size() * sizeof(RodentLight));
+    put(s.light_ids.data(), s.light_ids.size() * 4);
+    fclose(f);
+    return ok;
+}
+
+bool load_scene(const std::string& path, SceneData& s) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint32_t hdr[10];
+    bool ok = fread(hdr, 4, 10, f) == 10 && hdr[0] == kMagic && hdr[1] == kVersion;
+    if (ok) {
+        s.default_spp = (int32_t)hdr[2]; s.default_max_path_len = (int32_t)hdr[3];
+        auto get = [&](auto& vec, size_t count) { vec.resize(count); ok = ok && (count == 0 || fread(vec.data(), sizeof(vec[0]), count, f) == count); };
+        get(s.vertices, 4ull * hdr[4]); get(s.normals, 4ull * hdr[4]); get(s.face_normals, 4ull * hdr[5]); get(s.indices, 4ull * hdr[5]);
+        get(s.nodes, hdr[6]); get(s.tris, hdr[7]); get(s.materials, hdr[8]); get(s.lights, hdr[9]); get(s.light_ids, hdr[5]);
+    }
+    fclose(f);
+    return ok;
+}
+
+} // namespace rodent

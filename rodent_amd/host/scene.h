@@ -1,0 +1,39 @@
+// Scene description for the renderer: OBJ + MTL -> tables (mesh, BVH2, materials, lights).
+//
+// Restates the DECISIONS of the reference's scene compiler (src/driver/converter.cpp) as data
+// instead of generated Impala source:
+//   material clean-up (missing -> dummy, duplicates merged, unused dropped)   converter.cpp:467-557
+//   BSDF choice from MTL: illum 5 mirror, illum 7 glass(1, Ni), else diffuse(Kd) / Phong(Ks, Ns)
+//     mixed by luminance ratio; emissive iff Ke != 0                          converter.cpp:858-920
+//   triangle lights with precomputed normal / inverse area                    converter.cpp:770-851
+//   mesh buffers padded to float4 / int4 like the GPU targets                 converter.cpp:629-632,403-426
+//   BVH2/Tri1 with geom_id = material id                                      converter.cpp:262-383,713-720
+// Textures (map_Kd/Ks/Ke) are not supported yet: such materials fall back to their constant colours.
+#pragma once
+#include <string>
+#include <vector>
+#include "../../include/rodent_render.h"
+#include "mesh.h"
+
+namespace rodent {
+
+struct SceneData {
+    std::vector<float>   vertices, normals, face_normals;   // float4 per element
+    std::vector<int32_t> indices;                            // int4 per triangle
+    std::vector<Node2>   nodes;
+    std::vector<Tri1>    tris;
+    std::vector<RodentMaterial> materials;
+    std::vector<RodentLight>    lights;
+    std::vector<int32_t> light_ids;
+    std::vector<std::string> material_names;
+    int32_t default_spp = 4, default_max_path_len = 64;      // converter.cpp:1007-1012
+
+    size_t num_tris() const { return indices.size() / 4; }
+    RodentSceneDesc desc() const;
+};
+
+bool build_scene_from_obj(const std::string& obj_path, SceneData& scene);
+bool save_scene(const std::string& path, const SceneData& scene);   // ".rscene" binary
+bool load_scene(const std::string& path, SceneData& scene);
+
+} // namespace rodent

@@ -1,0 +1,120 @@
+// rodent -- the renderer's command line, same options and output as the reference's driver
+// (src/driver/driver.cpp:169-232 options, :279-348 frame loop and "min/med/max Msamples/s" line,
+// :138-162 tone-mapped PNG), driving the HIP wavefront path tracer through include/rodent_render.h.
+//
+// The reference bakes scene, device, spp and max path length into the executable at configure time
+// (src/CMakeLists.txt:1-22,101-105); here they are run-time options:
+//   --scene file        .obj (converted on the fly) or .rscene written by `converter`   (required)
+//   --spp n             samples per pixel per frame        (default: the scene file's, 4)
+//   --max-path-len n    maximum path length                (default: the scene file's, 64)
+//   -dev n              HIP device                          (default 0)
+// Without --bench the reference opens an SDL window and renders until it is closed; this build is
+// headless (DISABLE_GUI, driver.cpp:236-242), so --bench or -o is required.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <vector>
+
+#include "../png_write.h"
+#include "../scene.h"
+
+using namespace rodent;
+
+static void usage() {
+    std::cout << "Usage: rodent [options]\n"
+              << "Available options:\n"
+              << "   --help              Shows this message\n"
+              << "   --scene  file       Scene to render (.obj or .rscene)\n"
+              << "   --spp    n          Samples per pixel per frame\n"
+              << "   --max-path-len n    Maximum path length\n"
+              << "   -dev     n          GPU device index\n"
+              << "   --width  pixels     Sets the viewport horizontal dimension (in pixels)\n"
+              << "   --height pixels     Sets the viewport vertical dimension (in pixels)\n"
+              << "   --eye    x y z      Sets the position of the camera\n"
+              << "   --dir    x y z      Sets the direction vector of the camera\n"
+              << "   --up     x y z      Sets the up vector of the camera\n"
+              << "   --fov    degrees    Sets the horizontal field of view (in degrees)\n"
+              << "   --bench  iterations Enables benchmarking mode and sets the number of iterations\n"
+              << "   -o       image.png  Writes the output image to a file" << std::endl;
+}
+
+[[noreturn]] static void fail(const std::string& msg) { std::cerr << msg << std::endl; exit(1); }   // common.h:43-59 error() aborts
+
+int main(int argc, char** argv) {
+    std::string out_file, scene_file;
+    size_t bench_iter = 0, width = 1080, height = 720;
+    float fov = 60.0f;
+    V3 eye(0.0f), dir(0.0f, 0.0f, 1.0f), up(0.0f, 1.0f, 0.0f);
+    int spp = 0, max_path_len = -1, dev = 0;
+
+    for (int i = 1; i < argc; ++i) {
+        if (argv[i][0] != '-') fail(std::string("Unexpected argument '") + argv[i] + "'");
+        auto need = [&](int n) { if (i + n >= argc) fail(std::string("Option '") + argv[i] + "' expects " + std::to_string(n) + " arguments, got " + std::to_string(argc - i)); };
+        if (!strcmp(argv[i], "--width")) { need(1); width = strtoul(argv[++i], nullptr, 10); }
+        else if (!strcmp(argv[i], "--height")) { need(1); height = strtoul(argv[++i], nullptr, 10); }
+        else if (!strcmp(argv[i], "--eye")) { need(3); eye = V3(strtof(argv[i + 1], nullptr), strtof(argv[i + 2], nullptr), strtof(argv[i + 3], nullptr)); i += 3; }
+        else if (!strcmp(argv[i], "--dir")) { need(3); dir = V3(strtof(argv[i + 1], nullptr), strtof(argv[i + 2], nullptr), strtof(argv[i + 3], nullptr)); i += 3; }
+        else if (!strcmp(argv[i], "--up")) { need(3); up = V3(strtof(argv[i + 1], nullptr), strtof(argv[i + 2], nullptr), strtof(argv[i + 3], nullptr)); i += 3; }
+        else if (!strcmp(argv[i], "--fov")) { need(1); fov = strtof(argv[++i], nullptr); }
+        else if (!strcmp(argv[i], "--bench")) { need(1); bench_iter = strtoul(argv[++i], nullptr, 10); }
+        else if (!strcmp(argv[i], "-o")) { need(1); out_file = argv[++i]; }
+        else if (!strcmp(argv[i], "--scene")) { need(1); scene_file = argv[++i]; }
+        else if (!strcmp(argv[i], "--spp")) { need(1); spp = strtol(argv[++i], nullptr, 10); }
+        else if (!strcmp(argv[i], "--max-path-len")) { need(1); max_path_len = strtol(argv[++i], nullptr, 10); }
+        else if (!strcmp(argv[i], "-dev")) { need(1); dev = strtol(argv[++i], nullptr, 10); }
+        else if (!strcmp(argv[i], "--help")) { usage(); return 0; }
+        else fail(std::string("Unknown option '") + argv[i] + "'");
+    }
+    if (scene_file.empty()) fail("No scene specified (--scene file.obj|file.rscene)");
+    if (bench_iter == 0 && out_file.empty()) fail("This build has no GUI: use --bench iterations and/or -o image.png");
+    if (bench_iter == 0) bench_iter = 1;
+
+    SceneData scene;
+    const bool is_obj = scene_file.size() > 4 && scene_file.substr(scene_file.size() - 4) == ".obj";
+    if (is_obj ? !build_scene_from_obj(scene_file, scene) : !load_scene(scene_file, scene)) fail("Cannot load scene '" + scene_file + "'");
+    if (scene.lights.empty()) fail("The scene has no light source");
+    if (spp <= 0) spp = scene.default_spp;
+    if (max_path_len < 0) max_path_len = scene.default_max_path_len;
+
+    // Camera (driver.cpp:22-39)
+    const V3 d = normalize(dir), r = normalize(cross(d, up)), u = normalize(cross(r, d));
+    const float w = std::tan(fov * 3.14159265359f / 360.0f), h = w / ((float)width / (float)height);
+    const Settings settings{{eye.x, eye.y, eye.z}, {d.x, d.y, d.z}, {u.x, u.y, u.z}, {r.x, r.y, r.z}, w, h};
+
+    rodent_hip_set_device(dev);
+    const RodentSceneDesc desc = scene.desc();
+    rodent_hip_scene_create(dev, &desc);
+    rodent_hip_render_config(dev, spp, max_path_len);
+    setup_interface(width, height);
+    clear_pixels();
+
+    std::vector<double> samples_sec;
+    uint32_t iter = 0;
+    while (samples_sec.size() < bench_iter) {
+        const auto ticks = std::chrono::high_resolution_clock::now();
+        render(&settings, iter++);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - ticks).count();
+        samples_sec.emplace_back(1000.0 * double(get_spp() * width * height) / ms);
+    }
+
+    if (!out_file.empty()) {                                             // driver.cpp:138-162
+        const float* film = get_pixels();
+        const float inv_iter = 1.0f / iter, inv_gamma = 1.0f / 2.2f;
+        std::vector<uint8_t> px(width * height * 4);
+        for (size_t k = 0; k < width * height; k++) {
+            for (int c = 0; c < 3; c++) px[4 * k + c] = (uint8_t)(std::min(std::max(std::pow(film[3 * k + c] * inv_iter, inv_gamma), 0.0f), 1.0f) * 255.0f);
+            px[4 * k + 3] = 255;
+        }
+        if (!write_png(out_file, px.data(), (int)width, (int)height, 4)) fail("Failed to save PNG file '" + out_file + "'");
+        std::cout << "Image saved to '" << out_file << "'" << std::endl;
+    }
+    cleanup_interface();
+    rodent_hip_scene_destroy(dev);
+
+    std::sort(samples_sec.begin(), samples_sec.end());
+    std::cout << "# " << samples_sec.front() * 1e-6 << "/" << samples_sec[samples_sec.size() / 2] * 1e-6 << "/" << samples_sec.back() * 1e-6
+              << " (min/med/max Msamples/s)" << std::endl;
+    return 0;
+}

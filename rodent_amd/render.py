@@ -1,0 +1,112 @@
+"""ctypes binding of the renderer ABI (include/rodent_render.h): scene upload, render(), film access.
+
+Mirrors what src/driver/driver.cpp does around the generated `render()`:
+setup_interface -> (clear_pixels) -> render(settings, iter++) ... -> get_pixels."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+i32, vp = C.c_int32, C.c_void_p
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Settings(C.Structure):
+    _fields_ = [("eye", Vec3), ("dir", Vec3), ("up", Vec3), ("right", Vec3), ("width", C.c_float), ("height", C.c_float)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [(n, vp) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")] + \
+               [(n, i32) for n in ("num_vertices", "num_tris", "num_nodes", "num_bvh_tris", "num_materials", "num_lights")]
+
+
+RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "get_spp", "render",
+                  "setup_interface", "get_pixels", "clear_pixels", "cleanup_interface", "rodent_get_film_data",
+                  "rodent_gpu_get_first_primary_stream", "rodent_gpu_get_second_primary_stream", "rodent_gpu_get_secondary_stream",
+                  "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows",
+                  "rodent_hip_render_counters", "hip_generate_rays", "hip_traverse_primary", "hip_sort_primary", "hip_shade",
+                  "hip_traverse_secondary", "hip_compact_primary"]
+
+_ready = False
+
+
+def lib():
+    global _ready
+    l = abi.lib()
+    if not _ready:
+        l.rodent_hip_scene_create.argtypes = [i32, C.POINTER(SceneDesc)]; l.rodent_hip_scene_create.restype = None
+        l.rodent_hip_scene_destroy.argtypes = [i32]; l.rodent_hip_scene_destroy.restype = None
+        l.rodent_hip_render_config.argtypes = [i32, i32, i32]; l.rodent_hip_render_config.restype = None
+        l.get_spp.argtypes = []; l.get_spp.restype = i32
+        l.render.argtypes = [C.POINTER(Settings), i32]; l.render.restype = None
+        l.setup_interface.argtypes = [C.c_size_t, C.c_size_t]; l.setup_interface.restype = None
+        l.get_pixels.argtypes = []; l.get_pixels.restype = C.POINTER(C.c_float)
+        l.clear_pixels.argtypes = []; l.clear_pixels.restype = None
+        l.cleanup_interface.argtypes = []; l.cleanup_interface.restype = None
+        l.rodent_present.argtypes = [i32]; l.rodent_present.restype = None
+        l.rodent_hip_set_device.argtypes = [i32]; l.rodent_hip_set_device.restype = None
+        l.rodent_hip_render_rows.argtypes = [i32, C.POINTER(Settings), i32, i32, i32, vp]; l.rodent_hip_render_rows.restype = None
+        l.rodent_hip_render_counters.argtypes = [i32, C.POINTER(C.c_uint64)]; l.rodent_hip_render_counters.restype = None
+        _ready = True
+    return l
+
+
+def make_settings(cam) -> Settings:
+    v = lambda a: Vec3(float(a[0]), float(a[1]), float(a[2]))
+    return Settings(v(cam["eye"]), v(cam["dir"]), v(cam["up"]), v(cam["right"]), float(cam["w"]), float(cam["h"]))
+
+
+class Renderer:
+    """One scene on one GPU.  render(cam, iter) accumulates `spp` samples per pixel into the film."""
+
+    def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("rodent_amd: no GPU visible (the renderer has no CPU fallback)")
+        self.dev, self.width, self.height, self.spp = dev, width, height, spp
+        l = lib()
+        keep = [np.ascontiguousarray(getattr(scene, n)) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")]
+        desc = SceneDesc(*[a.ctypes.data_as(vp) for a in keep], len(scene.vertices), scene.num_tris, len(scene.nodes), len(scene.tris),
+                         len(scene.materials), len(scene.lights))
+        l.rodent_hip_set_device(dev)
+        l.rodent_hip_scene_create(dev, C.byref(desc))
+        l.rodent_hip_render_config(dev, spp, max_path_len)
+        l.setup_interface(width, height)
+        l.clear_pixels()
+
+    def clear(self):
+        lib().clear_pixels()
+
+    def render(self, cam, iter_):
+        st = make_settings(cam)
+        lib().render(C.byref(st), iter_)
+
+    def render_rows(self, cam, iter_, y0, y1):
+        st = make_settings(cam)
+        lib().rodent_hip_render_rows(self.dev, C.byref(st), iter_, y0, y1, None)
+
+    def film(self):
+        lib().rodent_present(self.dev)
+        p = lib().get_pixels()
+        return np.ctypeslib.as_array(p, shape=(self.height, self.width, 3)).copy()
+
+    def counters(self):
+        buf = (C.c_uint64 * 4)()
+        lib().rodent_hip_render_counters(self.dev, buf)
+        return {"primary_rays": buf[0], "shadow_rays": buf[1], "iterations": buf[2], "generated": buf[3]}
+
+    def close(self):
+        lib().rodent_hip_scene_destroy(self.dev)
+        lib().cleanup_interface()
+
+
+def tonemap(film, iters):
+    """(film / iter)^(1/2.2), clamp, x255 -- src/driver/driver.cpp:144-157."""
+    x = np.clip(np.power(np.maximum(film / np.float32(iters), 0), np.float32(1 / 2.2)), 0, 1)
+    return (x * 255.0).astype(np.uint8)

@@ -1,0 +1,144 @@
+"""CPU tests pinning the renderer oracle (oracle/render_oracle.c) and the scene compiler.
+
+The reference's renderer cannot be compiled here; its golden image testing/ref-cornell.png
+(src/CMakeLists.txt:131-134: Cornell box, eye 0 1 2.7, dir 0 0 -1, up 0 1 0, fov 60, 1080x720)
+is the external pin, compared like the reference's CTest does (MSE of the tone-mapped image,
+cmake/test/run_rodent.cmake:1-8) at reduced resolution so the CPU run stays in seconds."""
+import ctypes as C
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import GOLDEN
+from rodent_amd import scene as S
+
+
+@pytest.fixture(scope="module")
+def cornell_scene(native_build, tmp_path_factory):
+    return S.convert(GOLDEN / "cornell_box.obj", tmp_path_factory.mktemp("scene") / "cornell.rscene")
+
+
+def test_scene_tables_follow_converter_rules(cornell_scene):
+    sc = cornell_scene
+    assert sc.num_tris == 36 and len(sc.nodes) >= 1
+    # cornell_box.mtl: 8 materials, 5 distinct after merging identical ones, "light" is the only emissive one;
+    # all have Ks = 0 -> plain diffuse (converter.cpp:881-913)
+    assert (sc.materials["type"] == 1).all() and sc.materials["emissive"].sum() == 1
+    assert len(sc.lights) == 2                                      # the light quad = 2 triangles (converter.cpp:783-850)
+    L = sc.lights[0]
+    assert np.allclose(L["color"][:3], [17, 12, 4])
+    n = np.cross(L["v1"][:3] - L["v0"][:3], L["v2"][:3] - L["v0"][:3])
+    assert np.isclose(L["inv_area"], 1.0 / (0.5 * np.linalg.norm(n)), rtol=1e-6) and np.allclose(L["n"], n / np.linalg.norm(n), atol=1e-6)
+    emissive_tris = np.nonzero(sc.materials["emissive"][sc.indices[:, 3]])[0]
+    assert sorted(sc.light_ids[emissive_tris].tolist()) == [0, 1]
+    assert (sc.tris["geom_id"] == sc.indices[sc.tris["prim_id"] & 0x7FFFFFFF, 3]).all()   # geom_id = material id
+    assert sc.default_spp == 4 and sc.default_max_path_len == 64    # converter.cpp:1007-1012
+
+
+def test_sincos_polynomial_accuracy(oracle):
+    l = oracle.lib()
+    u = np.linspace(0, 1, 100001, endpoint=False, dtype="<f4")
+    c = np.zeros_like(u); s = np.zeros_like(u)
+    l.oracle_sincos_2pi(u.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), C.c_int32(len(u)))
+    ang = 2 * np.pi * u.astype(np.float64)
+    assert np.abs(c - np.cos(ang)).max() < 3e-7 and np.abs(s - np.sin(ang)).max() < 3e-7
+
+
+def test_rng_and_seed(oracle):
+    l = oracle.lib()
+    out = np.zeros(8, "<f4")
+    l.oracle_randf(C.c_uint32(12345), out.ctypes.data_as(C.c_void_p), C.c_int32(8))
+    x, exp = 12345, []
+    for _ in range(8):                                              # xorshift32 (13,17,5) + mantissa trick, random.impala:7-11,22-30
+        x ^= (x << 13) & 0xFFFFFFFF; x ^= x >> 17; x ^= (x << 5) & 0xFFFFFFFF
+        exp.append(np.frombuffer(np.uint32(0x3F800000 | (x & 0x7FFFFF)).tobytes(), "<f4")[0] - np.float32(1))
+    assert np.array_equal(out, np.float32(exp))
+    l.oracle_seed.restype = C.c_uint32
+    h = 0x811C9DC5
+    for d in (3, 7, 100, 200):                                      # FNV order sample, iter, x, y (renderer.impala:28-33)
+        for k in range(4):
+            h = ((h * 16777619) & 0xFFFFFFFF) ^ ((d >> (8 * k)) & 0xFF)
+    assert l.oracle_seed(3, 7, 100, 200) == h
+
+
+@pytest.mark.parametrize("mtype,kd,ks,ns", [(1, (0.7, 0.6, 0.5), (0, 0, 0), 1.0), (2, (0, 0, 0), (0.8, 0.8, 0.8), 20.0), (3, (0.5, 0.4, 0.3), (0.3, 0.3, 0.3), 10.0)])
+def test_bsdf_sampling_is_consistent(oracle, mtype, kd, ks, ns):
+    """sample().pdf equals pdf() of the sampled direction, directions are unit and in the upper hemisphere,
+    and the estimator E[f cos / pdf] stays below 1 (energy conservation)."""
+    l = oracle.lib()
+    m = np.zeros(1, S.MATERIAL)
+    m["type"] = mtype; m["kd"] = kd; m["ks"] = ks; m["ns"] = ns
+    ls, ld = np.dot(ks, [0.2126, 0.7152, 0.0722]), np.dot(kd, [0.2126, 0.7152, 0.0722])
+    m["mix_k"] = ls / (ls + ld) if mtype == 3 else 0
+    out_dir = np.float32([0.3, 0.1, 0.9]); out_dir /= np.linalg.norm(out_dir)
+    n = 20000
+    res = np.zeros((n, 10), "<f4")
+    l.oracle_bsdf_samples(m.ctypes.data_as(C.c_void_p), out_dir.ctypes.data_as(C.c_void_p), C.c_uint32(99), res.ctypes.data_as(C.c_void_p), C.c_int32(n))
+    d, pdf, cosv, col, pdf_eval = res[:, :3], res[:, 3], res[:, 4], res[:, 5:8], res[:, 8]
+    valid = col.sum(axis=1) > 0
+    assert valid.mean() > 0.5
+    assert np.allclose(np.linalg.norm(d[valid], axis=1), 1.0, atol=2e-3)
+    assert (d[valid, 2] > 0).all()
+    assert np.allclose(pdf[valid], pdf_eval[valid], rtol=2e-2, atol=1e-4)      # fastpow is an approximation (common.impala:42-61)
+    est = np.where(valid[:, None], col * (cosv / pdf)[:, None], 0).mean(axis=0)
+    assert (est < 1.02).all() and est.max() > 0.2
+
+
+def test_cornell_matches_reference_image(oracle, cornell_scene):
+    W, H, SPP, ITERS = 270, 180, 4, 12
+    cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
+    film = None
+    for it in range(ITERS):
+        film, counts = oracle.render(cornell_scene, cam, it, SPP, 64, W, H, film)
+    img = oracle.tonemap(film, ITERS).astype(np.float32)
+    ref = np.array(Image.open(GOLDEN / "ref-cornell.png").convert("RGB").resize((W, H), Image.BOX)).astype(np.float32)
+    mse = ((img - ref) ** 2).mean() / 255.0 ** 2
+    assert mse < 2e-3, mse                                           # noise at 48 spp; a wrong BSDF/light/camera gives > 1e-2
+    # the mean colour (noise-free statistic) is tight
+    assert np.allclose(img.mean(axis=(0, 1)), ref.mean(axis=(0, 1)), rtol=0.03)
+    assert counts[0] > W * H * SPP and counts[1] > 0
+
+
+def test_render_is_deterministic_and_tileable(oracle, cornell_scene):
+    """Seeds depend on absolute (sample, iter, x, y) only (renderer.impala:28-33): row bands reproduce the full frame."""
+    W, H = 64, 48
+    cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
+    full, _ = oracle.render(cornell_scene, cam, 3, 2, 8, W, H, threads=1)
+    again, _ = oracle.render(cornell_scene, cam, 3, 2, 8, W, H, threads=4)
+    assert np.array_equal(full, again)
+    band = np.zeros_like(full)
+    oracle.render(cornell_scene, cam, 3, 2, 8, W, H, band, rows=(0, 20), threads=1)
+    oracle.render(cornell_scene, cam, 3, 2, 8, W, H, band, rows=(20, 48), threads=2)
+    assert np.array_equal(full, band)
+    other, _ = oracle.render(cornell_scene, cam, 4, 2, 8, W, H)
+    assert not np.array_equal(full, other)                           # a different iteration draws different samples
+
+
+def test_max_path_len_zero_is_direct_light_only(oracle, cornell_scene):
+    W, H = 64, 48
+    cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
+    direct, c0 = oracle.render(cornell_scene, cam, 0, 4, 0, W, H)
+    full, c1 = oracle.render(cornell_scene, cam, 0, 4, 64, W, H)
+    assert c0[0] == W * H * 4 and c1[0] > c0[0]                      # no bounce rays at max_path_len 0
+    assert full.mean() > direct.mean() > 0
+
+
+def test_converter_cli(native_build, tmp_path):
+    conv = native_build.BIN_DIR / "converter"
+    r = subprocess.run([conv], capture_output=True, text=True)
+    assert r.returncode == 1 and "Not enough arguments" in r.stderr           # converter.cpp:1001-1004
+    r = subprocess.run([conv, "--bogus", "x.obj"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unknown option" in r.stderr
+    out = tmp_path / "c.rscene"
+    r = subprocess.run([conv, GOLDEN / "cornell_box.obj", "-o", out, "--target", "amdgpu-streaming", "--device", "0",
+                        "--max-path-len", "4", "-spp", "64"], capture_output=True, text=True)
+    assert r.returncode == 0 and "converted successfully" in r.stdout
+    sc = S.Scene(out)
+    assert sc.default_spp == 64 and sc.default_max_path_len == 4
+    rod = native_build.BIN_DIR / "rodent"
+    r = subprocess.run([rod, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unknown option" in r.stderr
+    r = subprocess.run([rod, "--width"], capture_output=True, text=True)
+    assert r.returncode == 1 and "expects 1 arguments" in r.stderr             # driver.cpp:164-167
