@@ -45,6 +45,22 @@ def parse_args():
     return ap.parse_args()
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rNN_traffic.json, written by
+    scripts/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs; FETCH doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None if no profile of this kernel has been recorded."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_traffic.json")):
+        try:
+            data = json.loads(f.read_text())
+        except ValueError:
+            continue
+        for name, t in data.items():
+            if name.replace(" ", "").startswith(kernel.replace(" ", "").rstrip(">")) and "hbm_bytes_fetch_x2" in t:
+                best = int(t["hbm_bytes_fetch_x2"])
+    return best
+
+
 def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, dist, any_hit=False):
     """W untimed + K timed launches.  Returns (wall seconds for K steps [max over ranks is taken by
     the caller], mean kernel ms from HIP events recorded on the launch stream)."""
@@ -174,7 +190,7 @@ def main():
         bytes_per_ray = 32 + 16 + node_b * st["inner_per_ray"] + prim_b * st["prims_per_ray"]
         achieved = bytes_per_ray * n / (k_mean * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                           "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": measured_traffic(abi.kernel_name(width, variant)),
                            "bytes_per_ray": round(bytes_per_ray, 2),
                            "visits_per_ray": {"inner": round(st["inner_per_ray"], 3), "prim": round(st["prims_per_ray"], 3)},
                            "compulsory_bytes_per_ray": 48, "kernel_ms": round(k_mean, 5)}

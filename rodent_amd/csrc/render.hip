@@ -92,6 +92,34 @@ struct StreamStack {
 
 struct StreamHit { int prim, geom; float t, u, v; };
 
+// Film accumulation for a wavefront (mapping_gpu.impala:32-45 does one atomic per ray and channel).
+// With spp > 1 the rays of one pixel sit in neighbouring lanes, and 64 lanes hitting the same three
+// addresses serialise in the atomic unit (measured: the shadow pass took 4x the primary pass on the
+// Cornell box).  Lanes that share a pixel are therefore summed in the wave first (butterfly over the
+// lanes, a fixed order) and one lane issues the atomics; after kFilmRounds distinct pixels the remaining
+// lanes fall back to their own atomics.  Only the order of the fp32 additions differs from the reference.
+constexpr int kFilmRounds = 4;
+__device__ __forceinline__ void film_add_wave(float* film, int pixel, bool valid, float r, float g, float b) {
+    unsigned long long todo = __ballot(valid);
+    for (int round = 0; round < kFilmRounds && todo; round++) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int p0 = __shfl(pixel, leader);
+        const bool mine = valid && pixel == p0;
+        const unsigned long long same = __ballot(mine);
+        if (__popcll(same) > 1) {
+            float sr = mine ? r : 0.0f, sg = mine ? g : 0.0f, sb = mine ? b : 0.0f;
+            for (int o = 32; o > 0; o >>= 1) { sr += __shfl_xor(sr, o); sg += __shfl_xor(sg, o); sb += __shfl_xor(sb, o); }
+            if ((int)(threadIdx.x % kWave) == leader) { float* px = film + 3 * (size_t)p0; unsafeAtomicAdd(px, sr); unsafeAtomicAdd(px + 1, sg); unsafeAtomicAdd(px + 2, sb); }
+            if (mine) valid = false;
+        } else if (mine) {
+            float* px = film + 3 * (size_t)pixel; unsafeAtomicAdd(px, r); unsafeAtomicAdd(px + 1, g); unsafeAtomicAdd(px + 2, b);
+            valid = false;
+        }
+        todo &= ~same;
+    }
+    if (valid) { float* px = film + 3 * (size_t)pixel; unsafeAtomicAdd(px, r); unsafeAtomicAdd(px + 1, g); unsafeAtomicAdd(px + 2, b); }
+}
+
 template <bool ANY>
 __device__ __forceinline__ StreamHit trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, StreamStack& st) {
     StreamHit hit{-1, -1, ray.tmax, 0.0f, 0.0f};
@@ -164,13 +192,12 @@ __global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, Secondar
     const int pixel = i < n ? s.rays.id[i] : -1;
     const unsigned long long live = __ballot(pixel >= 0);
     if (threadIdx.x == 0 && live) atomicAdd(&counters[1], (unsigned long long)__popcll(live));
-    if (pixel < 0) return;
-    StreamStack st; st.col = (lds_int*)lds + threadIdx.x; st.err = err;
-    const StreamHit h = trace_one<true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st);
-    if (h.prim < 0) {
-        float* px = film + 3 * (size_t)pixel;
-        unsafeAtomicAdd(px + 0, s.color_r[i] * inv_spp); unsafeAtomicAdd(px + 1, s.color_g[i] * inv_spp); unsafeAtomicAdd(px + 2, s.color_b[i] * inv_spp);
+    bool lit = false;
+    if (pixel >= 0) {
+        StreamStack st; st.col = (lds_int*)lds + threadIdx.x; st.err = err;
+        lit = trace_one<true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st).prim < 0;
     }
+    film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -180,7 +207,9 @@ __global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, Secondar
 __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, SecondaryStream s, const int* size_ptr, float* film,
                                                    float inv_spp, int max_path_len) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= *size_ptr) return;
+    const int n_valid = *size_ptr;
+    if ((int)(blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave) >= n_valid) return;     // whole wave beyond the stream
+    if (i >= n_valid) { film_add_wave(film, -1, false, 0.0f, 0.0f, 0.0f); return; }
     const float offset = 0.001f;
     const float pdf_lightpick = 1.0f / (float)sc.num_lights;
     const int pixel = p.rays.id[i];
@@ -194,19 +223,20 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, 
     const RodentMaterial* m = sc.materials + p.geom_id[i];
     const Surf sf = surface_element(&sc, org, dir, prim, t, p.u[i], p.v[i]);
     const v3 out_dir = neg(dir);
-    float* px = film + 3 * (size_t)pixel;
 
     // on_hit (renderer.impala:113-128)
-    if (m->emissive && sf.entering) {
+    v3 emitted = V(0, 0, 0);
+    const bool emits = m->emissive && sf.entering;
+    if (emits) {
         const RodentLight* L = sc.lights + sc.light_ids[prim];
         const float pdf_dir = cosine_hemisphere_pdf(dot(LD3(L->n), out_dir));
         const v3 intensity = pdf_dir > 0.0f ? LD3(L->color) : V(0, 0, 0);
         const float pdf_area = pdf_dir > 0.0f ? L->inv_area : 1.0f;
         const float next_mis = mis_in * t * t / dot(out_dir, sf.local.c2);
         const float w = 1.0f / (1.0f + next_mis * pdf_lightpick * pdf_area);
-        const v3 c = mulf(mul(contrib, intensity), w);
-        unsafeAtomicAdd(px + 0, c.x * inv_spp); unsafeAtomicAdd(px + 1, c.y * inv_spp); unsafeAtomicAdd(px + 2, c.z * inv_spp);
+        emitted = mulf(mulf(mul(contrib, intensity), w), 1.0f);
     }
+    film_add_wave(film, pixel, emits, emitted.x * inv_spp, emitted.y * inv_spp, emitted.z * inv_spp);
 
     // on_shadow (renderer.impala:69-111): the secondary ray is written at the SAME index (mapping_gpu.impala:111-115)
     int sec_id = -1;
