@@ -138,3 +138,34 @@ def tonemap(film, iters):
     """(film / iter)^(1/2.2), clamp, x255 (src/driver/driver.cpp:144-157)."""
     x = np.clip(np.power(np.maximum(film / np.float32(iters), 0), np.float32(1 / 2.2)), 0, 1)
     return (x * 255.0).astype(np.uint8)
+
+
+# ---- CPU baseline (oracle/hybrid_baseline.cpp): Rodent's hybrid ray8 x bvh8 kernel restated with AVX2 ----
+_base = None
+
+
+def baseline_lib():
+    global _base
+    if _base is None:
+        out = HERE / "libcpu_baseline.so"
+        src = HERE / "hybrid_baseline.cpp"
+        if not out.exists() or src.stat().st_mtime > out.stat().st_mtime:
+            subprocess.run(["g++", "-O3", "-std=c++17", "-march=x86-64-v3", "-fPIC", "-shared", "-pthread", str(src), "-o", str(out)], check=True)
+        _base = C.CDLL(str(out))
+        _base.cpu_baseline_traverse.restype = None
+        _base.cpu_baseline_traverse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        _base.cpu_baseline_hardware_threads.restype = C.c_int32
+    return _base
+
+
+def cpu_baseline(nodes8, tris4, rays, any_hit=False, mode="hybrid", threads=1):
+    """mode "hybrid" (ray8 x bvh8 packets with single-ray fallback) or "single".  Rays beyond a multiple of 8 are dropped."""
+    nodes8 = np.ascontiguousarray(nodes8); tris4 = np.ascontiguousarray(tris4); rays = np.ascontiguousarray(rays)
+    n = len(rays) // 8 * 8
+    hits = np.zeros(n, HIT1)
+    baseline_lib().cpu_baseline_traverse(_ptr(nodes8), _ptr(tris4), _ptr(rays), _ptr(hits), n, int(any_hit), 0 if mode == "hybrid" else 1, int(threads))
+    return hits
+
+
+def hardware_threads():
+    return int(baseline_lib().cpu_baseline_hardware_threads())
