@@ -235,7 +235,7 @@ struct ChunkPerm {
 };
 
 
-template <bool ANY, int LDS_N, int NODE_EXIT, bool PERSIST, int REFILL_IDLE, int CHUNK, bool STATS = false>
+template <bool ANY, int LDS_N, int NODE_EXIT, bool PERSIST, int REFILL_IDLE, int CHUNK, bool STATS = false, int XCD = 0>
 __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                       const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                       Ctl* ctl, int* __restrict__ deep_list) {
@@ -244,7 +244,21 @@ __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ n
     RayX ray; HitAcc hit{-1, 0.0f, 0.0f, 0.0f};
     int ray_id = -1, top = 0, ptr = 0;
     // wave-uniform pool of ray indices [pool_next, pool_end)
-    int pool_next = blockIdx.x * (PERSIST ? CHUNK : kWave);
+    // XCD > 0: XCD-aware block -> chunk mapping.  Workgroups are dispatched round-robin over the 8 XCDs
+    // (block b runs on XCD b % 8; observed, used for speed only) and each XCD has its own 4 MB L2.  Chunks
+    // are taken in groups of XCD consecutive 64-ray chunks (XCD = 16 is one 1024-pixel scan line) and group j
+    // goes to XCD j % 8, so an XCD works on whole image bands instead of every 8th 64-pixel strip while the
+    // bands of one XCD stay spread over the frame (a contiguous eighth per XCD was measured 37 % slower: the
+    // expensive bottom of the frame then lands on one XCD).
+    int first_chunk = blockIdx.x;
+    if (XCD > 0 && !PERSIST) {
+        const int span = 8 * XCD, full = ((int)gridDim.x / span) * span;          // region where the mapping is a bijection
+        if ((int)blockIdx.x < full) {
+            const int x = blockIdx.x % 8, l = blockIdx.x / 8;
+            first_chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
+        }
+    }
+    int pool_next = first_chunk * (PERSIST ? CHUNK : kWave);
     int pool_end = min(n, pool_next + (PERSIST ? CHUNK : kWave));
     bool exhausted = !PERSIST;
     // STATS build only: [0] descent iterations, [1] active lanes in them, [2] leaf iterations, [3] active lanes,
@@ -589,12 +603,12 @@ template <bool ANY, int LDS_N> void L_lane(LAUNCH_ARGS) {
 template <bool ANY, int LDS_N, int NE> void L_ww(LAUNCH_ARGS) {
     hipLaunchKernelGGL((k_bvh2_ww<ANY, LDS_N, NE>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.scratch + 1);
 }
-template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false> void L_fast(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false, int XCD = 0> void L_fast(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     const int per_block = P ? CH : kWave;
     int grid = (n + per_block - 1) / per_block;
     if (P) grid = std::min(grid, s.num_cus * persistent_waves_per_cu());
-    hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
+    hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
 }
 
@@ -624,14 +638,17 @@ struct Variant2 { const char* name; const char* kernel[2]; Launch2 launch[2]; };
 const Variant2 kVariants2[] = {
     // 0 = default (used by the reference-named entry points).  All variants keep the reference's per-ray
     // visit order and are bit-identical; they differ in how a wavefront schedules its 64 rays.
-    //                                                      LDS_N NODE_EXIT PERSIST REFILL_IDLE CHUNK
-    K2("fast",               "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64),
+    //                                                      LDS_N NODE_EXIT PERSIST REFILL_IDLE CHUNK STATS XCD_GROUP
+    K2("fast",               "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32),   // default: XCD-aware, 32-chunk groups
     K2("lane",               "k_bvh2_lane",          L_lane, 24),                      // literal reference mapping
     K2("ww",                 "k_bvh2_ww",            L_ww, 24, 8),                     // while-while, LDS+scratch stack
-    K2("fast-exit0",         "k_bvh2_fast",          L_fast, 16, 0,  false, 64, 64),
-    K2("fast-exit16",        "k_bvh2_fast",          L_fast, 16, 16, false, 64, 64),
-    K2("fast-lds24",         "k_bvh2_fast",          L_fast, 24, 8,  false, 64, 64),
+    K2("fast-noxcd",         "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64),
+    K2("fast-exit0",         "k_bvh2_fast",          L_fast, 16, 0,  false, 64, 64, false, 32),
+    K2("fast-exit16",        "k_bvh2_fast",          L_fast, 16, 16, false, 64, 64, false, 32),
+    K2("fast-lds24",         "k_bvh2_fast",          L_fast, 24, 8,  false, 64, 64, false, 32),
     K2("fast-persistent",    "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 128),
+    K2("fast-xcd-g16",       "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 16),
+    K2("fast-xcd-g64",       "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 64),
     //                                                       LDS_N PERSIST REFILL_IDLE CHUNK TRI_BIAS(x/4) PERMUTE
     K2("sched",              "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false),
     K2("sched-persistent",   "k_bvh2_sched",         L_sched, 16, true,  16, 64,  8, false),

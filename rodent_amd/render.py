@@ -110,3 +110,44 @@ def tonemap(film, iters):
     """(film / iter)^(1/2.2), clamp, x255 -- src/driver/driver.cpp:144-157."""
     x = np.clip(np.power(np.maximum(film / np.float32(iters), 0), np.float32(1 / 2.2)), 0, 1)
     return (x * 255.0).astype(np.uint8)
+
+
+# ---- stage-level API (the reference's device kernels as separate entry points) ----------------
+class RayStream(C.Structure):
+    _fields_ = [(n, vp) for n in ("id", "org_x", "org_y", "org_z", "dir_x", "dir_y", "dir_z", "tmin", "tmax")]
+
+
+class PrimaryStream(C.Structure):
+    _fields_ = [("rays", RayStream)] + [(n, vp) for n in ("geom_id", "prim_id", "t", "u", "v", "rnd", "mis", "contrib_r", "contrib_g", "contrib_b", "depth")] + \
+               [("size", i32), ("pad", i32)]
+
+
+class SecondaryStream(C.Structure):
+    _fields_ = [("rays", RayStream)] + [(n, vp) for n in ("prim_id", "color_r", "color_g", "color_b")] + [("size", i32), ("pad", i32)]
+
+
+def stage_lib():
+    l = lib()
+    l.rodent_gpu_get_first_primary_stream.argtypes = [i32, C.POINTER(PrimaryStream), i32]; l.rodent_gpu_get_first_primary_stream.restype = None
+    l.rodent_gpu_get_second_primary_stream.argtypes = [i32, C.POINTER(PrimaryStream), i32]; l.rodent_gpu_get_second_primary_stream.restype = None
+    l.rodent_gpu_get_secondary_stream.argtypes = [i32, C.POINTER(SecondaryStream), i32]; l.rodent_gpu_get_secondary_stream.restype = None
+    l.rodent_get_film_data.argtypes = [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]; l.rodent_get_film_data.restype = None
+    l.hip_generate_rays.argtypes = [i32, C.POINTER(PrimaryStream), i32, i32, i32, C.POINTER(Settings), i32, i32, i32, i32, i32, vp]; l.hip_generate_rays.restype = None
+    l.hip_traverse_primary.argtypes = [i32, C.POINTER(PrimaryStream), vp]; l.hip_traverse_primary.restype = None
+    l.hip_sort_primary.argtypes = [i32, C.POINTER(PrimaryStream), C.POINTER(PrimaryStream), C.POINTER(i32), vp]; l.hip_sort_primary.restype = None
+    l.hip_shade.argtypes = [i32, C.POINTER(PrimaryStream), C.POINTER(SecondaryStream), i32, vp]; l.hip_shade.restype = None
+    l.hip_traverse_secondary.argtypes = [i32, C.POINTER(SecondaryStream), vp]; l.hip_traverse_secondary.restype = None
+    l.hip_compact_primary.argtypes = [i32, C.POINTER(PrimaryStream), C.POINTER(PrimaryStream), vp]; l.hip_compact_primary.restype = i32
+    return l
+
+
+def read_stream_array(ptr, count, dtype):
+    """Copies `count` words of one stream array (device pointer) to the host."""
+    import torch
+    if count == 0:
+        return np.zeros(0, dtype)
+    nbytes = count * 4
+    t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    abi.lib()  # same process / same HIP runtime
+    C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(nbytes), 3)
+    return t.cpu().numpy().view(dtype).copy()

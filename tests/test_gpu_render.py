@@ -99,3 +99,60 @@ def test_rodent_cli(native_build, tmp_path):
     im = np.array(Image.open(out))
     assert im.shape == (240, 320, 4) and im[..., :3].mean() > 40 and (im[..., 3] == 255).all()
     assert (im[:80, 100:220, :3].min(axis=2) > 250).sum() > 50                     # the ceiling light (top centre) is saturated
+
+
+def test_stage_level_api_reproduces_render(R, oracle, cornell_scene):
+    """Drive the wavefront loop from the host through the stage entry points exactly like the reference's
+    gpu_streaming_trace (mapping_gpu.impala:308-369) and check stream invariants after every stage:
+    sorted by geometry and stable, ray_ends = exclusive ends, dead rays removed in order, film = render()."""
+    import ctypes as C
+    W, H, SPP, MAXLEN, IT = 96, 64, 2, 5, 1
+    cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
+    r = R.Renderer(cornell_scene, W, H, SPP, MAXLEN)
+    r.render(cam, IT)
+    film_ref = r.film(); counters = r.counters()
+    r.clear()
+    l = R.stage_lib()
+    cap = 4096                                                    # small capacity => several refills
+    p, q, s = R.PrimaryStream(), R.PrimaryStream(), R.SecondaryStream()
+    l.rodent_gpu_get_first_primary_stream(0, C.byref(p), cap)
+    l.rodent_gpu_get_second_primary_stream(0, C.byref(q), cap)
+    l.rodent_gpu_get_secondary_stream(0, C.byref(s), cap)
+    st = R.make_settings(cam)
+    G = len(cornell_scene.materials)
+    num_rays, ray_id, traced = SPP * W * H, 0, 0
+    ends = (C.c_int32 * (G + 1))()
+    while ray_id < num_rays or p.size > 0:
+        if p.size < cap and ray_id < num_rays:
+            n = min(num_rays - ray_id, cap - p.size)
+            l.hip_generate_rays(0, C.byref(p), cap, ray_id, n, C.byref(st), IT, W, H, 0, SPP, None)
+            ray_id += n
+        ids_before = R.read_stream_array(p.rays.id, p.size, "<i4")
+        l.hip_traverse_primary(0, C.byref(p), None)
+        traced += p.size
+        geom_before = R.read_stream_array(p.geom_id, p.size, "<i4")
+        rnd_before = R.read_stream_array(p.rnd, p.size, "<u4")
+        l.hip_sort_primary(0, C.byref(p), C.byref(q), ends, None)
+        p, q = q, p
+        geom = R.read_stream_array(p.geom_id, p.size, "<i4")
+        assert (np.diff(geom) >= 0).all() and geom.max(initial=0) <= G            # sorted, misses (bin G) last
+        assert list(ends) == np.cumsum(np.bincount(geom_before, minlength=G + 1)).tolist()
+        order = np.argsort(geom_before, kind="stable")                            # stable: ties keep stream order
+        assert np.array_equal(R.read_stream_array(p.rnd, p.size, "<u4"), rnd_before[order])
+        assert np.array_equal(R.read_stream_array(p.rays.id, p.size, "<i4"), ids_before[order])
+        valid = ends[G - 1]
+        l.hip_shade(0, C.byref(p), C.byref(s), valid, None)
+        l.hip_traverse_secondary(0, C.byref(s), None)
+        alive = R.read_stream_array(p.rays.id, valid, "<i4") >= 0
+        depth_before = R.read_stream_array(p.depth, valid, "<i4")
+        n_alive = l.hip_compact_primary(0, C.byref(p), C.byref(q), None)
+        p, q = q, p
+        assert n_alive == alive.sum() == p.size
+        assert np.array_equal(R.read_stream_array(p.depth, p.size, "<i4"), depth_before[alive])   # order preserved
+        assert (R.read_stream_array(p.rays.id, p.size, "<i4") >= 0).all()
+    assert traced == counters["primary_rays"]
+    film = r.film()
+    r.close()
+    assert np.allclose(film, film_ref, rtol=FILM_RTOL, atol=FILM_ATOL)
+    ref, _ = oracle.render(cornell_scene, cam, IT, SPP, MAXLEN, W, H)
+    assert np.allclose(film, ref, rtol=FILM_RTOL, atol=FILM_ATOL)
