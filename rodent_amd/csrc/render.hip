@@ -49,6 +49,10 @@ constexpr int kCapacity = 1024 * 1024;         // mapping_gpu.impala:319
 
 struct CameraDev { float eye[3], dir[3], up[3], right[3]; float w, h; };
 
+// Stream sizes are either known on the host (passed by value) or live on the device (the valid-hit count
+// after sorting): size_ptr != nullptr wins.
+__device__ __forceinline__ int stream_size(const int* size_ptr, int n_value) { return size_ptr ? *size_ptr : n_value; }
+
 // ---------------------------------------------------------------------------------------------
 // K3: ray generation (mapping_gpu.impala:223-265, renderer.impala:26-40, camera.impala:35-44)
 // ---------------------------------------------------------------------------------------------
@@ -169,9 +173,9 @@ __device__ __forceinline__ RayX load_stream_ray(const RayStream& r, int i) {   /
 }
 
 // primary: writes geom_id (num_geometries on a miss, driver.impala:106-115), prim_id, t, u, v
-__global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStream p, const int* size_ptr, int* err, unsigned long long* counters) {
+__global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStream p, const int* size_ptr, int n_value, int* err, unsigned long long* counters) {
     __shared__ int lds[kLdsStack * kWave];
-    const int n = *size_ptr;
+    const int n = stream_size(size_ptr, n_value);
     const int i = blockIdx.x * kWave + threadIdx.x;
     if (blockIdx.x * kWave >= n) return;
     if (i >= n) return;
@@ -183,15 +187,16 @@ __global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStr
 }
 
 // secondary: any-hit; unoccluded rays add their colour to the film (mapping_gpu.impala:32-45,47-80)
-__global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, SecondaryStream s, const int* size_ptr, float* film, float inv_spp,
+__global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
                                                            int* err, unsigned long long* counters) {
     __shared__ int lds[kLdsStack * kWave];
-    const int n = *size_ptr;
+    const int n = stream_size(size_ptr, n_value);
     const int i = blockIdx.x * kWave + threadIdx.x;
     if (blockIdx.x * kWave >= n) return;
     const int pixel = i < n ? s.rays.id[i] : -1;
     const unsigned long long live = __ballot(pixel >= 0);
-    if (threadIdx.x == 0 && live) atomicAdd(&counters[1], (unsigned long long)__popcll(live));
+    // striped over 64 words: one counter word saturates near 88 atomics/us and made this kernel 3x slower
+    if (threadIdx.x == 0 && live) atomicAdd(&counters[4 + (blockIdx.x & 63)], (unsigned long long)__popcll(live));
     bool lit = false;
     if (pixel >= 0) {
         StreamStack st; st.col = (lds_int*)lds + threadIdx.x; st.err = err;
@@ -204,10 +209,10 @@ __global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, Secondar
 // K5: shading (mapping_gpu.impala:82-134; renderer.impala:69-152).  One launch over the sorted,
 // hit-only prefix of the stream; the material is a table entry, not generated code.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, SecondaryStream s, const int* size_ptr, float* film,
+__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, SecondaryStream s, const int* size_ptr, int n_value, float* film,
                                                    float inv_spp, int max_path_len) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int n_valid = *size_ptr;
+    const int n_valid = stream_size(size_ptr, n_value);
     if ((int)(blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave) >= n_valid) return;     // whole wave beyond the stream
     if (i >= n_valid) { film_add_wave(film, -1, false, 0.0f, 0.0f, 0.0f); return; }
     const float offset = 0.001f;
@@ -313,9 +318,9 @@ __device__ __forceinline__ int block_rank(int key, bool valid, int num_bins, int
     return rank;
 }
 
-__global__ __launch_bounds__(kBlock) void k_bin_count(PrimaryStream p, const int* size_ptr, int mode, int num_bins, int num_blocks, int* hist /* [num_bins][num_blocks] */) {
+__global__ __launch_bounds__(kBlock) void k_bin_count(PrimaryStream p, const int* size_ptr, int n_value, int mode, int num_bins, int num_blocks, int* hist /* [num_bins][num_blocks] */) {
     extern __shared__ int cnt[];
-    const int n = *size_ptr;
+    const int n = stream_size(size_ptr, n_value);
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i < n;
     const int key = valid ? stream_key(p, i, mode) : 0;
@@ -346,10 +351,10 @@ __global__ void k_bin_scan_bins(const int* bin_total, int num_bins, int* bin_beg
 }
 
 // copy_primary_ray (mapping_gpu.impala:136-164) to the computed slot
-__global__ __launch_bounds__(kBlock) void k_scatter(PrimaryStream p, PrimaryStream q, const int* size_ptr, int mode, int num_bins, int num_blocks,
+__global__ __launch_bounds__(kBlock) void k_scatter(PrimaryStream p, PrimaryStream q, const int* size_ptr, int n_value, int mode, int num_bins, int num_blocks,
                                                      const int* hist, const int* bin_begin, int keep_hit, int drop_from_bin) {
     extern __shared__ int cnt[];
-    const int n = *size_ptr;
+    const int n = stream_size(size_ptr, n_value);
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i < n;
     const int key = valid ? stream_key(p, i, mode) : 0;
@@ -365,8 +370,6 @@ __global__ __launch_bounds__(kBlock) void k_scatter(PrimaryStream p, PrimaryStre
     q.contrib_r[d] = p.contrib_r[i]; q.contrib_g[d] = p.contrib_g[i]; q.contrib_b[d] = p.contrib_b[i]; q.depth[d] = p.depth[i];
 }
 
-__global__ void k_set_size(int* dst, const int* src, int index) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = index >= 0 ? src[index] : 0; }
-__global__ void k_add_size(int* dst, int amount) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst += amount; }
 
 // ---------------------------------------------------------------------------------------------
 // Host side: per-device state (interface.cpp:324-339), stream slabs, the streaming loop
@@ -387,7 +390,7 @@ struct RenderDevice {
     int* tmp = nullptr; int tmp_cap = 0;
     int* hist = nullptr; size_t hist_cap = 0;
     int* ctl = nullptr;       // [0] primary size, [1] secondary size, [2] error flag, [8..] bin_total, bin_begin, bin_end (kMaxBins each)
-    unsigned long long* counters = nullptr;    // [0] primary rays, [1] shadow rays, [2] iterations, [3] generated
+    unsigned long long* counters = nullptr;    // [0] primary rays, [1] unused, [2] iterations, [3] generated, [4..67] shadow rays (striped)
     int* host_pinned = nullptr;
 };
 RenderDevice g_rdev[16];
@@ -404,10 +407,10 @@ RenderDevice& rdev(int dev) {
         if (hipGetDeviceCount(&count) != hipSuccess || dev >= count) { fprintf(stderr, "rodent_hip: no HIP device %d (%d visible)\n", dev, count); abort(); }
         HIP_CHECK(hipSetDevice(dev));
         r.dev = dev;
-        HIP_CHECK(hipMalloc(&r.ctl, sizeof(int) * (8 + 3 * kMaxBins)));
-        HIP_CHECK(hipMemset(r.ctl, 0, sizeof(int) * (8 + 3 * kMaxBins)));
-        HIP_CHECK(hipMalloc(&r.counters, sizeof(unsigned long long) * 4));
-        HIP_CHECK(hipMemset(r.counters, 0, sizeof(unsigned long long) * 4));
+        HIP_CHECK(hipMalloc(&r.ctl, sizeof(int) * (8 + 6 * kMaxBins)));
+        HIP_CHECK(hipMemset(r.ctl, 0, sizeof(int) * (8 + 6 * kMaxBins)));
+        HIP_CHECK(hipMalloc(&r.counters, sizeof(unsigned long long) * 68));
+        HIP_CHECK(hipMemset(r.counters, 0, sizeof(unsigned long long) * 68));
         HIP_CHECK(hipHostMalloc(&r.host_pinned, sizeof(int) * (8 + kMaxBins)));
         r.init = true;
     }
@@ -451,20 +454,21 @@ void ensure_hist(RenderDevice& r, size_t ints) {
     }
 }
 
-int* bin_total(RenderDevice& r) { return r.ctl + 8; }
-int* bin_begin(RenderDevice& r) { return r.ctl + 8 + kMaxBins; }
-int* bin_end(RenderDevice& r)   { return r.ctl + 8 + 2 * kMaxBins; }
+// two sets of bin arrays: set 0 = sort by geometry, set 1 = compaction (the compaction reads its input size from set 0)
+int* bin_total(RenderDevice& r, int set) { return r.ctl + 8 + set * 3 * kMaxBins; }
+int* bin_begin(RenderDevice& r, int set) { return r.ctl + 8 + set * 3 * kMaxBins + kMaxBins; }
+int* bin_end(RenderDevice& r, int set)   { return r.ctl + 8 + set * 3 * kMaxBins + 2 * kMaxBins; }
 
-// Bins `p` (size in *size_ptr, at most max_n) into `q`; bins >= drop_from_bin are not copied.
-void bin_stream(RenderDevice& r, const PrimaryStream& p, const PrimaryStream& q, const int* size_ptr, int max_n, int mode, int num_bins,
+// Bins `p` (size = *size_ptr if given, else max_n; never more than max_n) into `q`; bins >= drop_from_bin are not copied.
+void bin_stream(RenderDevice& r, int set, const PrimaryStream& p, const PrimaryStream& q, const int* size_ptr, int max_n, int mode, int num_bins,
                 int keep_hit, int drop_from_bin, hipStream_t stream) {
     const int blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
     ensure_hist(r, (size_t)num_bins * blocks);
     const size_t lds = sizeof(int) * 4 * num_bins;
-    hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kBlock), lds, stream, p, size_ptr, mode, num_bins, blocks, r.hist);
-    hipLaunchKernelGGL(k_bin_scan_blocks, dim3(num_bins), dim3(kBlock), 0, stream, r.hist, blocks, bin_total(r));
-    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1), 0, stream, bin_total(r), num_bins, bin_begin(r), bin_end(r));
-    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBlock), lds, stream, p, q, size_ptr, mode, num_bins, blocks, r.hist, bin_begin(r), keep_hit, drop_from_bin);
+    hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kBlock), lds, stream, p, size_ptr, max_n, mode, num_bins, blocks, r.hist);
+    hipLaunchKernelGGL(k_bin_scan_blocks, dim3(num_bins), dim3(kBlock), 0, stream, r.hist, blocks, bin_total(r, set));
+    hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1), 0, stream, bin_total(r, set), num_bins, bin_begin(r, set), bin_end(r, set));
+    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBlock), lds, stream, p, q, size_ptr, max_n, mode, num_bins, blocks, r.hist, bin_begin(r, set), keep_hit, drop_from_bin);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -503,44 +507,41 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     carve_primary(b, ensure_slab(r, 1, kCapacity, 20), round_cap(kCapacity));
     carve_secondary(sec, ensure_slab(r, 2, kCapacity, 13), round_cap(kCapacity));
     PrimaryStream* primary = &a; PrimaryStream* other = &b;
-    int* d_size = r.ctl; int* d_sec_size = r.ctl + 1; int* err = r.ctl + 2;
+    int* err = r.ctl + 2;
     const CameraDev cam = to_cam(settings);
     const float inv_spp = 1.0f / (float)r.spp;
     const long long num_rays = (long long)r.spp * r.film_w * (y1 - y0);
     const int first_pixel = y0 * r.film_w;
     long long id = 0; int size = 0;
-    HIP_CHECK(hipMemsetAsync(d_size, 0, sizeof(int) * 3, stream));
-    HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * 4, stream));
+    HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 3, stream));
+    HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * 68, stream));
     unsigned long long iterations = 0, generated = 0;
+    const int* d_valid = bin_end(r, 0) + (G - 1);      // rays that hit something = exclusive end of the last geometry bin (:347-357)
     while (id < num_rays || size > 0) {
         if (size < kCapacity && id < num_rays) {                                         // regenerate (mapping_gpu.impala:332-336)
             const int n = (int)std::min<long long>(num_rays - id, kCapacity - size);
             hipLaunchKernelGGL(k_generate, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, *primary, size, (int)id, n, cam, iter,
                                r.film_w, r.film_h, first_pixel, r.spp);
-            hipLaunchKernelGGL(k_add_size, dim3(1), dim3(1), 0, stream, d_size, n);
             id += n; size += n; generated += n;
         }
-        const int waves = (size + kWave - 1) / kWave;
-        hipLaunchKernelGGL(k_trace_primary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, *primary, d_size, err, r.counters);
-        bin_stream(r, *primary, *other, d_size, size, KEY_GEOM, G + 1, 1, G, stream);     // misses (bin G) are dropped (:347-357)
+        const int waves = (size + kWave - 1) / kWave, blocks = (size + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_trace_primary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, *primary, (const int*)nullptr, size, err, r.counters);
+        bin_stream(r, 0, *primary, *other, nullptr, size, KEY_GEOM, G + 1, 1, G, stream);    // misses (bin G) are dropped (:347-357)
         std::swap(primary, other);
-        hipLaunchKernelGGL(k_set_size, dim3(1), dim3(1), 0, stream, d_size, bin_end(r), G - 1);
-        hipLaunchKernelGGL(k_set_size, dim3(1), dim3(1), 0, stream, d_sec_size, bin_end(r), G - 1);
-        const int blocks = (size + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, d_size, r.film, inv_spp, r.max_path_len);
-        hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, sec, d_sec_size, r.film, inv_spp, err, r.counters);
-        bin_stream(r, *primary, *other, d_size, size, KEY_ALIVE, 2, 0, 1, stream);        // compaction (:267-300)
+        hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, d_valid, 0, r.film, inv_spp, r.max_path_len);
+        hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, sec, d_valid, 0, r.film, inv_spp, err, r.counters);
+        bin_stream(r, 1, *primary, *other, d_valid, size, KEY_ALIVE, 2, 0, 1, stream);       // compaction (:267-300)
         std::swap(primary, other);
-        hipLaunchKernelGGL(k_set_size, dim3(1), dim3(1), 0, stream, d_size, bin_end(r), 0);
-        HIP_CHECK(hipMemcpyAsync(r.host_pinned, d_size, sizeof(int) * 3, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(r.host_pinned, bin_end(r, 1), sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         size = r.host_pinned[0];
-        if (r.host_pinned[2]) { fprintf(stderr, "rodent_hip: traversal stack overflow in the renderer\n"); abort(); }
         iterations++;
     }
     const unsigned long long host_counts[2] = {iterations, generated};
     HIP_CHECK(hipMemcpyAsync(r.counters + 2, host_counts, sizeof(host_counts), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(r.host_pinned + 2, err, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    if (r.host_pinned[2]) { fprintf(stderr, "rodent_hip: traversal stack overflow in the renderer\n"); abort(); }
 }
 
 template <typename T> T* upload(DevScene& s, const T* host, size_t count) {
@@ -637,7 +638,10 @@ void render(const Settings* settings, int32_t iter) {                        // 
 void rodent_hip_render_counters(int32_t dev, uint64_t* out4) {
     RenderDevice& r = rdev(dev);
     HIP_CHECK(hipSetDevice(dev));
-    HIP_CHECK(hipMemcpy(out4, r.counters, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
+    uint64_t all[68];
+    HIP_CHECK(hipMemcpy(all, r.counters, sizeof(all), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; k++) out4[k] = all[k];
+    for (int k = 4; k < 68; k++) out4[1] += all[k];                         // shadow rays are counted in 64 stripes
 }
 
 // ---- stage-level entry points ---------------------------------------------------------------
@@ -652,26 +656,18 @@ void hip_generate_rays(int32_t dev, PrimaryStream* primary, int32_t capacity, in
     HIP_CHECK(hipGetLastError());
 }
 
-static void push_size(RenderDevice& r, int* slot, int size, hipStream_t stream) {
-    r.host_pinned[4] = size;
-    HIP_CHECK(hipMemcpyAsync(slot, r.host_pinned + 4, sizeof(int), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-}
-
 void hip_traverse_primary(int32_t dev, PrimaryStream* primary, void* stream) {
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
     if (primary->size <= 0) return;
-    push_size(r, r.ctl, primary->size, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_trace_primary, dim3((primary->size + kWave - 1) / kWave), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *primary, r.ctl, r.ctl + 2, r.counters);
+    hipLaunchKernelGGL(k_trace_primary, dim3((primary->size + kWave - 1) / kWave), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *primary, (const int*)nullptr, primary->size, r.ctl + 2, r.counters);
     HIP_CHECK(hipGetLastError());
 }
 
 void hip_sort_primary(int32_t dev, PrimaryStream* primary, PrimaryStream* other, int32_t* ray_ends, void* stream) {
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
     const int G = r.scene.dev.num_materials;
-    push_size(r, r.ctl, primary->size, (hipStream_t)stream);
-    bin_stream(r, *primary, *other, r.ctl, std::max(primary->size, 1), KEY_GEOM, G + 1, 1, G + 1, (hipStream_t)stream);
-    HIP_CHECK(hipMemcpyAsync(r.host_pinned + 8, bin_end(r), sizeof(int) * (G + 1), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    bin_stream(r, 0, *primary, *other, nullptr, primary->size, KEY_GEOM, G + 1, 1, G + 1, (hipStream_t)stream);
+    HIP_CHECK(hipMemcpyAsync(r.host_pinned + 8, bin_end(r, 0), sizeof(int) * (G + 1), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     std::memcpy(ray_ends, r.host_pinned + 8, sizeof(int) * (G + 1));
     other->size = primary->size;
@@ -681,8 +677,7 @@ void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, 
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
     primary->size = num_rays; secondary->size = num_rays;
     if (num_rays <= 0) return;
-    push_size(r, r.ctl, num_rays, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_shade, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, r.scene.dev, *primary, *secondary, r.ctl, r.film,
+    hipLaunchKernelGGL(k_shade, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, r.scene.dev, *primary, *secondary, (const int*)nullptr, num_rays, r.film,
                        1.0f / (float)r.spp, r.max_path_len);
     HIP_CHECK(hipGetLastError());
 }
@@ -690,17 +685,15 @@ void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, 
 void hip_traverse_secondary(int32_t dev, SecondaryStream* secondary, void* stream) {
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
     if (secondary->size <= 0) return;
-    push_size(r, r.ctl + 1, secondary->size, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_trace_secondary, dim3((secondary->size + kWave - 1) / kWave), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *secondary, r.ctl + 1,
+    hipLaunchKernelGGL(k_trace_secondary, dim3((secondary->size + kWave - 1) / kWave), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *secondary, (const int*)nullptr, secondary->size,
                        r.film, 1.0f / (float)r.spp, r.ctl + 2, r.counters);
     HIP_CHECK(hipGetLastError());
 }
 
 int32_t hip_compact_primary(int32_t dev, PrimaryStream* primary, PrimaryStream* other, void* stream) {
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev));
-    push_size(r, r.ctl, primary->size, (hipStream_t)stream);
-    bin_stream(r, *primary, *other, r.ctl, std::max(primary->size, 1), KEY_ALIVE, 2, 0, 1, (hipStream_t)stream);
-    HIP_CHECK(hipMemcpyAsync(r.host_pinned + 8, bin_end(r), sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    bin_stream(r, 1, *primary, *other, nullptr, primary->size, KEY_ALIVE, 2, 0, 1, (hipStream_t)stream);
+    HIP_CHECK(hipMemcpyAsync(r.host_pinned + 8, bin_end(r, 1), sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     other->size = r.host_pinned[8];
     return other->size;
