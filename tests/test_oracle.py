@@ -184,3 +184,21 @@ def test_cpu_baseline_agrees_with_oracle(oracle, cornell, rayset, mode):
                 assert np.array_equal(got["tri_id"][~amb], ref["tri_id"][~amb])
                 hit = ref["tri_id"] >= 0
                 assert np.allclose(got["t"][hit], ref["t"][hit], rtol=1e-4, atol=0)
+
+
+def test_config0_cpu_bench_traversal_plumbing(oracle, cornell, tmp_path):
+    """BASELINE.json config 0: the CPU single-ray bench_traversal run (-s --bvh-width 8) end to end:
+    .bvh + .rays in, reference stdout protocol out, .fbuf = the oracle's t values."""
+    import subprocess, sys
+    from conftest import ROOT, GOLDEN
+    out = tmp_path / "cpu.fbuf"
+    cmd = [sys.executable, str(ROOT / "oracle" / "cpu_bench_traversal.py"), "-bvh", str(cornell.bvh_path), "-ray", str(GOLDEN / "cornell-primary-64x64.rays"),
+           "--tmin", "0.01", "--tmax", "5000", "-s", "--bvh-width", "8", "--warmup", "1", "--bench", "2", "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, check=True)
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "4096 ray(s) in the distribution file." and lines[1].endswith("ms for 2 iteration(s)")
+    assert lines[2].endswith(" Mrays/sec") and lines[3].startswith("# Average: ") and lines[-1] == "4096 intersection(s)"
+    assert np.array_equal(F.read_fbuf(out), cornell.expected["bvh8_cpu.primary_tmin.closest"]["t"])
+    hy = subprocess.run([c for c in cmd if c != "-s"], capture_output=True, text=True, check=True)
+    assert "4096 intersection(s)" in hy.stdout
+    assert np.allclose(F.read_fbuf(out), cornell.expected["bvh8_cpu.primary_tmin.closest"]["t"], rtol=1e-4)
