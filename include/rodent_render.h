@@ -64,6 +64,11 @@ struct RodentSceneDesc {           /* HOST pointers; copied to HBM by rodent_hip
 void    rodent_hip_scene_create(int32_t dev, const struct RodentSceneDesc* desc);   /* replaces the device's current scene */
 void    rodent_hip_scene_destroy(int32_t dev);
 void    rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len);   /* defaults 4 / 64 (converter.cpp:1007-1012) */
+/* 0 = streaming wavefront loop (src/render/mapping_gpu.impala:308-369, the default), 1 = persistent-threads megakernel
+ * (mapping_gpu.impala:371-474; the reference selects it at configure time with the converter target
+ * amdgpu-megakernel / nvvm-megakernel, converter.cpp:30-35,1032-1037; `rodent --target amdgpu-megakernel` here).
+ * The initial value can also be set with the environment variable RODENT_HIP_MAPPING=streaming|mega. */
+void    rodent_hip_render_mapping(int32_t dev, int32_t mapping);
 
 /* ---- the reference's renderer ABI ---- */
 int32_t get_spp(void);

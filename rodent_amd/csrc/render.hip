@@ -8,6 +8,7 @@
 //   src/render/mapping_gpu.impala:47-80    gpu_traverse_secondary -> k_trace_stream<true> (+ film accumulation :32-45)
 //   src/render/mapping_gpu.impala:267-300  gpu_compact_primary    -> the same binning kernels with key = dead?1:0
 //   src/render/mapping_gpu.impala:308-369  gpu_streaming_trace    -> render_rows() host loop
+//   src/render/mapping_gpu.impala:371-474  gpu_mega_kernel_trace  -> k_mega / render_rows_mega()
 //   src/driver/interface.cpp:359-390,528-563,565-663  stream slabs, film, rodent_* services
 //
 // CDNA4 notes: SoA streams (one 20 x capacity / 13 x capacity float slab each, driver.impala:24-61) so a
@@ -46,6 +47,7 @@ using namespace rodent_dev;
 constexpr int kBlock = 256;                    // workgroup of the streaming (non-traversal) kernels
 constexpr int kMaxBins = 1025;                 // mapping_gpu.impala:200,342 (1024 geometries + the "miss" bin)
 constexpr int kCapacity = 1024 * 1024;         // mapping_gpu.impala:319
+constexpr int kNumCounters = 100;              // [0..3] host-visible totals, [4..67] shadow rays (striped), [68..99] megakernel primary rays (striped)
 
 struct CameraDev { float eye[3], dir[3], up[3], right[3]; float w, h; };
 
@@ -56,6 +58,15 @@ __device__ __forceinline__ int stream_size(const int* size_ptr, int n_value) { r
 // ---------------------------------------------------------------------------------------------
 // K3: ray generation (mapping_gpu.impala:223-265, renderer.impala:26-40, camera.impala:35-44)
 // ---------------------------------------------------------------------------------------------
+// on_emit (renderer.impala:26-40): the sample's seed and its camera ray direction
+__device__ __forceinline__ v3 emit_sample(const CameraDev& cam, int iter, int film_w, int film_h, int x, int y, int sample, uint32_t* rnd_out) {
+    uint32_t rnd = fnv_hash(fnv_hash(fnv_hash(fnv_hash(0x811C9DC5u, (uint32_t)sample), (uint32_t)iter), (uint32_t)x), (uint32_t)y);
+    const float kx = 2.0f * ((float)x + randf(&rnd)) / (float)film_w - 1.0f;
+    const float ky = 1.0f - 2.0f * ((float)y + randf(&rnd)) / (float)film_h;
+    *rnd_out = rnd;
+    return normalize(add(add(mulf(LD3(cam.right), cam.w * kx), mulf(LD3(cam.up), cam.h * ky)), LD3(cam.dir)));
+}
+
 __global__ __launch_bounds__(kBlock) void k_generate(PrimaryStream p, int first_dst, int first_ray_id, int num_rays, CameraDev cam,
                                                       int iter, int film_w, int film_h, int first_pixel, int spp) {
     const int gid = blockIdx.x * kBlock + threadIdx.x;
@@ -64,10 +75,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(PrimaryStream p, int first_
     const int sample = ray_id % spp;
     const int pixel = first_pixel + ray_id / spp;
     const int y = pixel / film_w, x = pixel - y * film_w;          // the reference uses fast_div (common.impala:19-35): same quotient
-    uint32_t rnd = fnv_hash(fnv_hash(fnv_hash(fnv_hash(0x811C9DC5u, (uint32_t)sample), (uint32_t)iter), (uint32_t)x), (uint32_t)y);
-    const float kx = 2.0f * ((float)x + randf(&rnd)) / (float)film_w - 1.0f;
-    const float ky = 1.0f - 2.0f * ((float)y + randf(&rnd)) / (float)film_h;
-    const v3 d = normalize(add(add(mulf(LD3(cam.right), cam.w * kx), mulf(LD3(cam.up), cam.h * ky)), LD3(cam.dir)));
+    uint32_t rnd;
+    const v3 d = emit_sample(cam, iter, film_w, film_h, x, y, sample, &rnd);
     p.rays.id[dst] = pixel;
     p.rays.org_x[dst] = cam.eye[0]; p.rays.org_y[dst] = cam.eye[1]; p.rays.org_z[dst] = cam.eye[2];
     p.rays.dir_x[dst] = d.x; p.rays.dir_y[dst] = d.y; p.rays.dir_z[dst] = d.z;
@@ -163,13 +172,15 @@ __device__ __forceinline__ StreamHit trace_one(const Node2* __restrict__ nodes, 
     return hit;
 }
 
-__device__ __forceinline__ RayX load_stream_ray(const RayStream& r, int i) {   // driver.impala:63-84 + intersection.impala:88-99
+__device__ __forceinline__ RayX make_rayx(float ox, float oy, float oz, float dx, float dy, float dz, float tmin, float tmax) {   // intersection.impala:88-99
     RayX x;
-    x.ox = r.org_x[i]; x.oy = r.org_y[i]; x.oz = r.org_z[i]; x.dx = r.dir_x[i]; x.dy = r.dir_y[i]; x.dz = r.dir_z[i];
-    x.tmin = r.tmin[i]; x.tmax = r.tmax[i];
+    x.ox = ox; x.oy = oy; x.oz = oz; x.dx = dx; x.dy = dy; x.dz = dz; x.tmin = tmin; x.tmax = tmax;
     x.idx = safe_rcp(x.dx); x.idy = safe_rcp(x.dy); x.idz = safe_rcp(x.dz);
     x.iox = -(x.ox * x.idx); x.ioy = -(x.oy * x.idy); x.ioz = -(x.oz * x.idz);
     return x;
+}
+__device__ __forceinline__ RayX load_stream_ray(const RayStream& r, int i) {   // driver.impala:63-84
+    return make_rayx(r.org_x[i], r.org_y[i], r.org_z[i], r.dir_x[i], r.dir_y[i], r.dir_z[i], r.tmin[i], r.tmax[i]);
 }
 
 // primary: writes geom_id (num_geometries on a miss, driver.impala:106-115), prim_id, t, u, v
@@ -209,42 +220,42 @@ __global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, Secondar
 // K5: shading (mapping_gpu.impala:82-134; renderer.impala:69-152).  One launch over the sorted,
 // hit-only prefix of the stream; the material is a table entry, not generated code.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, SecondaryStream s, const int* size_ptr, int n_value, float* film,
-                                                   float inv_spp, int max_path_len) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int n_valid = stream_size(size_ptr, n_value);
-    if ((int)(blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave) >= n_valid) return;     // whole wave beyond the stream
-    if (i >= n_valid) { film_add_wave(film, -1, false, 0.0f, 0.0f, 0.0f); return; }
-    const float offset = 0.001f;
+// One path vertex in registers: what a primary-stream entry holds (driver.impala:63-104).
+struct PathVertex {
+    int pixel; v3 org, dir; int prim, geom; float t, u, v;
+    uint32_t rnd; float mis; v3 contrib; int depth;
+};
+// What shading a vertex produces: an emission sample, at most one shadow ray, at most one continuation.
+struct ShadeOut {
+    bool emits; v3 emitted;
+    bool shadow; v3 s_org, s_dir, s_color;
+    bool bounce; v3 b_org, b_dir, contrib; uint32_t rnd; float mis;
+};
+constexpr float kRayOffset = 0.001f;           // renderer.impala:46
+
+__device__ __forceinline__ ShadeOut shade_vertex(const SceneDev& sc, const PathVertex& pv, int max_path_len) {
+    ShadeOut o;
     const float pdf_lightpick = 1.0f / (float)sc.num_lights;
-    const int pixel = p.rays.id[i];
-    const v3 org = V(p.rays.org_x[i], p.rays.org_y[i], p.rays.org_z[i]), dir = V(p.rays.dir_x[i], p.rays.dir_y[i], p.rays.dir_z[i]);
-    const int prim = p.prim_id[i];
-    const float t = p.t[i];
-    uint32_t rnd = p.rnd[i];
-    const float mis_in = p.mis[i];
-    const v3 contrib = V(p.contrib_r[i], p.contrib_g[i], p.contrib_b[i]);
-    const int depth = p.depth[i];
-    const RodentMaterial* m = sc.materials + p.geom_id[i];
-    const Surf sf = surface_element(&sc, org, dir, prim, t, p.u[i], p.v[i]);
-    const v3 out_dir = neg(dir);
+    uint32_t rnd = pv.rnd;
+    const RodentMaterial* m = sc.materials + pv.geom;
+    const Surf sf = surface_element(&sc, pv.org, pv.dir, pv.prim, pv.t, pv.u, pv.v);
+    const v3 out_dir = neg(pv.dir);
 
     // on_hit (renderer.impala:113-128)
-    v3 emitted = V(0, 0, 0);
-    const bool emits = m->emissive && sf.entering;
-    if (emits) {
-        const RodentLight* L = sc.lights + sc.light_ids[prim];
+    o.emitted = V(0, 0, 0);
+    o.emits = m->emissive && sf.entering;
+    if (o.emits) {
+        const RodentLight* L = sc.lights + sc.light_ids[pv.prim];
         const float pdf_dir = cosine_hemisphere_pdf(dot(LD3(L->n), out_dir));
         const v3 intensity = pdf_dir > 0.0f ? LD3(L->color) : V(0, 0, 0);
         const float pdf_area = pdf_dir > 0.0f ? L->inv_area : 1.0f;
-        const float next_mis = mis_in * t * t / dot(out_dir, sf.local.c2);
+        const float next_mis = pv.mis * pv.t * pv.t / dot(out_dir, sf.local.c2);
         const float w = 1.0f / (1.0f + next_mis * pdf_lightpick * pdf_area);
-        emitted = mulf(mulf(mul(contrib, intensity), w), 1.0f);
+        o.emitted = mulf(mulf(mul(pv.contrib, intensity), w), 1.0f);
     }
-    film_add_wave(film, pixel, emits, emitted.x * inv_spp, emitted.y * inv_spp, emitted.z * inv_spp);
 
-    // on_shadow (renderer.impala:69-111): the secondary ray is written at the SAME index (mapping_gpu.impala:111-115)
-    int sec_id = -1;
+    // on_shadow (renderer.impala:69-111)
+    o.shadow = false;
     if (!bsdf_is_specular(m)) {
         const int light_id = (int)(xorshift(&rnd) & 0x7FFFFFFFu) % sc.num_lights;
         const RodentLight* L = sc.lights + light_id;
@@ -264,26 +275,126 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, 
             const float cos_e = vis * inv_d, cos_l = lcos;
             const float w = 1.0f / (1.0f + pdf_e * cos_l * inv_d2 * inv_pdf_l);
             const float geom = cos_e * cos_l * inv_d2 * inv_pdf_l;
-            const v3 c = mulf(mul(intensity, mul(contrib, bsdf_eval(m, &sf, in_dir, out_dir))), geom * w);
-            s.rays.org_x[i] = sf.point.x; s.rays.org_y[i] = sf.point.y; s.rays.org_z[i] = sf.point.z;
-            s.rays.dir_x[i] = light_dir.x; s.rays.dir_y[i] = light_dir.y; s.rays.dir_z[i] = light_dir.z;
-            s.rays.tmin[i] = offset; s.rays.tmax[i] = 1.0f - offset;
-            s.color_r[i] = c.x; s.color_g[i] = c.y; s.color_b[i] = c.z;
-            sec_id = pixel;
+            o.s_color = mulf(mul(intensity, mul(pv.contrib, bsdf_eval(m, &sf, in_dir, out_dir))), geom * w);
+            o.s_org = sf.point; o.s_dir = light_dir;
+            o.shadow = true;
         }
     }
-    s.rays.id[i] = sec_id;
 
     // on_bounce (renderer.impala:130-152)
-    const float lum2 = 2.0f * luminance(contrib); const float rr = lum2 > 0.75f ? 0.75f : lum2;
-    if (depth >= max_path_len || randf(&rnd) >= rr) { p.rays.id[i] = -1; return; }
+    const float lum2 = 2.0f * luminance(pv.contrib); const float rr = lum2 > 0.75f ? 0.75f : lum2;
+    o.bounce = false;
+    if (pv.depth >= max_path_len || randf(&rnd) >= rr) return o;
     const BsdfSample bs = bsdf_sample(m, &sf, &rnd, out_dir);
-    const v3 c2 = mulf(mul(contrib, bs.color), bs.cos / (bs.pdf * rr));
-    p.rays.org_x[i] = sf.point.x; p.rays.org_y[i] = sf.point.y; p.rays.org_z[i] = sf.point.z;
-    p.rays.dir_x[i] = bs.in_dir.x; p.rays.dir_y[i] = bs.in_dir.y; p.rays.dir_z[i] = bs.in_dir.z;
-    p.rays.tmin[i] = offset; p.rays.tmax[i] = FLT_MAX_REF;
-    p.rnd[i] = rnd; p.mis[i] = bsdf_is_specular(m) ? 0.0f : 1.0f / bs.pdf;
-    p.contrib_r[i] = c2.x; p.contrib_g[i] = c2.y; p.contrib_b[i] = c2.z; p.depth[i] = depth + 1;
+    o.contrib = mulf(mul(pv.contrib, bs.color), bs.cos / (bs.pdf * rr));
+    o.b_org = sf.point; o.b_dir = bs.in_dir;
+    o.rnd = rnd; o.mis = bsdf_is_specular(m) ? 0.0f : 1.0f / bs.pdf;
+    o.bounce = true;
+    return o;
+}
+
+__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, SecondaryStream s, const int* size_ptr, int n_value, float* film,
+                                                   float inv_spp, int max_path_len) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int n_valid = stream_size(size_ptr, n_value);
+    if ((int)(blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave) >= n_valid) return;     // whole wave beyond the stream
+    if (i >= n_valid) { film_add_wave(film, -1, false, 0.0f, 0.0f, 0.0f); return; }
+    PathVertex pv;
+    pv.pixel = p.rays.id[i];
+    pv.org = V(p.rays.org_x[i], p.rays.org_y[i], p.rays.org_z[i]); pv.dir = V(p.rays.dir_x[i], p.rays.dir_y[i], p.rays.dir_z[i]);
+    pv.prim = p.prim_id[i]; pv.geom = p.geom_id[i]; pv.t = p.t[i]; pv.u = p.u[i]; pv.v = p.v[i];
+    pv.rnd = p.rnd[i]; pv.mis = p.mis[i];
+    pv.contrib = V(p.contrib_r[i], p.contrib_g[i], p.contrib_b[i]);
+    pv.depth = p.depth[i];
+    const ShadeOut o = shade_vertex(sc, pv, max_path_len);
+
+    film_add_wave(film, pv.pixel, o.emits, o.emitted.x * inv_spp, o.emitted.y * inv_spp, o.emitted.z * inv_spp);
+
+    // the secondary ray is written at the SAME index (mapping_gpu.impala:111-115)
+    if (o.shadow) {
+        s.rays.org_x[i] = o.s_org.x; s.rays.org_y[i] = o.s_org.y; s.rays.org_z[i] = o.s_org.z;
+        s.rays.dir_x[i] = o.s_dir.x; s.rays.dir_y[i] = o.s_dir.y; s.rays.dir_z[i] = o.s_dir.z;
+        s.rays.tmin[i] = kRayOffset; s.rays.tmax[i] = 1.0f - kRayOffset;
+        s.color_r[i] = o.s_color.x; s.color_g[i] = o.s_color.y; s.color_b[i] = o.s_color.z;
+    }
+    s.rays.id[i] = o.shadow ? pv.pixel : -1;
+
+    if (!o.bounce) { p.rays.id[i] = -1; return; }
+    p.rays.org_x[i] = o.b_org.x; p.rays.org_y[i] = o.b_org.y; p.rays.org_z[i] = o.b_org.z;
+    p.rays.dir_x[i] = o.b_dir.x; p.rays.dir_y[i] = o.b_dir.y; p.rays.dir_z[i] = o.b_dir.z;
+    p.rays.tmin[i] = kRayOffset; p.rays.tmax[i] = FLT_MAX_REF;
+    p.rnd[i] = o.rnd; p.mis[i] = o.mis;
+    p.contrib_r[i] = o.contrib.x; p.contrib_g[i] = o.contrib.y; p.contrib_b[i] = o.contrib.z; p.depth[i] = pv.depth + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8: persistent-threads megakernel (mapping_gpu.impala:371-474): one 64-lane workgroup per film tile
+// of ~1024 samples; every lane carries a whole path in registers (traverse, shade, shadow-traverse,
+// bounce) and fetches the next (pixel, sample) of the tile when its path ends; the path's colour is
+// summed locally and added to the film once (:405-407,442,469).  The workgroup is one wavefront, so
+// the reference's LDS work counter (:389-395,410) is a wave-uniform register here and the hand-out is
+// a ballot prefix: lane order = sample order, deterministic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void k_mega(SceneDev sc, CameraDev cam, float* film, int film_w, int film_h, int y0, int y1, int iter, int spp,
+                                                int max_path_len, int log2_tile, float inv_spp, int* err, unsigned long long* counters) {
+    __shared__ int lds[kLdsStack * kWave];
+    const int tile = 1 << log2_tile;
+    const int tile_x = blockIdx.x * tile, tile_y = y0 + blockIdx.y * tile;
+    const int tile_w = min(film_w - tile_x, tile), tile_h = min(y1 - tile_y, tile);
+    const int ray_count = tile_w * tile_h * spp;
+    StreamStack st; st.col = (lds_int*)lds + threadIdx.x; st.err = err;
+    int next = 0;                                   // wave-uniform
+    bool has_path = false;
+    PathVertex pv; pv.pixel = -1; pv.org = V(0, 0, 0); pv.dir = V(0, 0, 1); pv.rnd = 0; pv.mis = 0.0f; pv.contrib = V(0, 0, 0); pv.depth = 0;
+    float tmin = 0.0f;
+    v3 final_color = V(0, 0, 0);
+    unsigned n_primary = 0, n_shadow = 0;
+    for (;;) {
+        const unsigned long long need = __ballot(!has_path);
+        if (need && next < ray_count) {
+            const int id = next + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            next += __popcll(need);
+            if (!has_path && id < ray_count) {
+                const int ray_id = id / spp, sample = id - ray_id * spp;
+                const int in_y = ray_id / tile_w, in_x = ray_id - in_y * tile_w;
+                const int x = tile_x + in_x, y = tile_y + in_y;
+                pv.dir = emit_sample(cam, iter, film_w, film_h, x, y, sample, &pv.rnd);
+                pv.org = LD3(cam.eye);
+                pv.pixel = y * film_w + x; pv.mis = 0.0f; pv.contrib = V(1, 1, 1); pv.depth = 0;
+                tmin = 0.0f; final_color = V(0, 0, 0);
+                has_path = true;
+            }
+        }
+        if (!__ballot(has_path)) break;
+
+        bool done = false;
+        ShadeOut o; o.shadow = false; o.s_org = V(0, 0, 0); o.s_dir = V(0, 0, 1); o.s_color = V(0, 0, 0);
+        if (has_path) {
+            n_primary++;
+            const StreamHit h = trace_one<false>(sc.nodes, sc.tris, make_rayx(pv.org.x, pv.org.y, pv.org.z, pv.dir.x, pv.dir.y, pv.dir.z, tmin, FLT_MAX_REF), st);
+            if (h.prim < 0) done = true;
+            else {
+                pv.prim = h.prim; pv.geom = h.geom; pv.t = h.t; pv.u = h.u; pv.v = h.v;
+                o = shade_vertex(sc, pv, max_path_len);
+                if (o.emits) final_color = add(final_color, o.emitted);
+                if (o.bounce) { pv.org = o.b_org; pv.dir = o.b_dir; pv.rnd = o.rnd; pv.mis = o.mis; pv.contrib = o.contrib; pv.depth++; tmin = kRayOffset; }
+                else done = true;
+            }
+        }
+        if (o.shadow) {
+            n_shadow++;
+            const bool lit = trace_one<true>(sc.nodes, sc.tris, make_rayx(o.s_org.x, o.s_org.y, o.s_org.z, o.s_dir.x, o.s_dir.y, o.s_dir.z, kRayOffset, 1.0f - kRayOffset), st).prim < 0;
+            if (lit) final_color = add(final_color, o.s_color);
+        }
+        film_add_wave(film, pv.pixel, done, final_color.x * inv_spp, final_color.y * inv_spp, final_color.z * inv_spp);
+        if (done) has_path = false;
+    }
+    for (int off = 32; off > 0; off >>= 1) { n_primary += __shfl_xor(n_primary, off); n_shadow += __shfl_xor(n_shadow, off); }
+    if (threadIdx.x == 0) {
+        const int stripe = (blockIdx.y * gridDim.x + blockIdx.x) & 31;
+        atomicAdd(&counters[68 + stripe], (unsigned long long)n_primary);
+        atomicAdd(&counters[4 + stripe], (unsigned long long)n_shadow);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -385,6 +496,7 @@ struct RenderDevice {
     int dev = 0;
     DevScene scene;
     int spp = 4, max_path_len = 64;
+    int mapping = 0;                           // 0 = streaming wavefront (mapping_gpu.impala:308-369), 1 = megakernel (:371-474)
     float* film = nullptr; int film_w = 0, film_h = 0;
     float* slab[3] = {nullptr, nullptr, nullptr}; int slab_cap[3] = {0, 0, 0};       // first primary, second primary, secondary
     int* tmp = nullptr; int tmp_cap = 0;
@@ -409,9 +521,13 @@ RenderDevice& rdev(int dev) {
         r.dev = dev;
         HIP_CHECK(hipMalloc(&r.ctl, sizeof(int) * (8 + 6 * kMaxBins)));
         HIP_CHECK(hipMemset(r.ctl, 0, sizeof(int) * (8 + 6 * kMaxBins)));
-        HIP_CHECK(hipMalloc(&r.counters, sizeof(unsigned long long) * 68));
-        HIP_CHECK(hipMemset(r.counters, 0, sizeof(unsigned long long) * 68));
+        HIP_CHECK(hipMalloc(&r.counters, sizeof(unsigned long long) * kNumCounters));
+        HIP_CHECK(hipMemset(r.counters, 0, sizeof(unsigned long long) * kNumCounters));
         HIP_CHECK(hipHostMalloc(&r.host_pinned, sizeof(int) * (8 + kMaxBins)));
+        if (const char* m = getenv("RODENT_HIP_MAPPING")) {
+            if (!strcmp(m, "mega") || !strcmp(m, "megakernel") || !strcmp(m, "1")) r.mapping = 1;
+            else if (strcmp(m, "streaming") && strcmp(m, "0")) { fprintf(stderr, "rodent_hip: RODENT_HIP_MAPPING must be 'streaming' or 'mega'\n"); abort(); }
+        }
         r.init = true;
     }
     return r;
@@ -514,7 +630,7 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     const int first_pixel = y0 * r.film_w;
     long long id = 0; int size = 0;
     HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 3, stream));
-    HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * 68, stream));
+    HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * kNumCounters, stream));
     unsigned long long iterations = 0, generated = 0;
     const int* d_valid = bin_end(r, 0) + (G - 1);      // rays that hit something = exclusive end of the last geometry bin (:347-357)
     while (id < num_rays || size > 0) {
@@ -542,6 +658,34 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     HIP_CHECK(hipMemcpyAsync(r.host_pinned + 2, err, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     if (r.host_pinned[2]) { fprintf(stderr, "rodent_hip: traversal stack overflow in the renderer\n"); abort(); }
+}
+
+// gpu_mega_kernel_trace (mapping_gpu.impala:371-474) for image rows [y0, y1)
+void render_rows_mega(RenderDevice& r, const Settings* settings, int iter, int y0, int y1, hipStream_t stream) {
+    HIP_CHECK(hipSetDevice(r.dev));
+    ensure_film(r);
+    require_scene(r);
+    int ilog2_spp = 0; while ((2 << ilog2_spp) <= r.spp) ilog2_spp++;                 // common.impala ilog2
+    const int log2_tile = std::max(0, (10 - ilog2_spp) / 2);                          // tiles of ~2^10 samples (:374-377)
+    const int tile = 1 << log2_tile;
+    const dim3 grid((r.film_w + tile - 1) >> log2_tile, (y1 - y0 + tile - 1) >> log2_tile);
+    int* err = r.ctl + 2;
+    HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 3, stream));
+    HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * kNumCounters, stream));
+    if (y1 > y0)
+        hipLaunchKernelGGL(k_mega, grid, dim3(kWave), 0, stream, r.scene.dev, to_cam(settings), r.film, r.film_w, r.film_h, y0, y1, iter, r.spp,
+                           r.max_path_len, log2_tile, 1.0f / (float)r.spp, err, r.counters);
+    HIP_CHECK(hipGetLastError());
+    const unsigned long long host_counts[2] = {1ull, (unsigned long long)r.spp * r.film_w * (unsigned long long)(y1 - y0)};
+    HIP_CHECK(hipMemcpyAsync(r.counters + 2, host_counts, sizeof(host_counts), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(r.host_pinned + 2, err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (r.host_pinned[2]) { fprintf(stderr, "rodent_hip: traversal stack overflow in the renderer\n"); abort(); }
+}
+
+void render_rows_any(RenderDevice& r, const Settings* settings, int iter, int y0, int y1, hipStream_t stream) {
+    if (r.mapping == 1) render_rows_mega(r, settings, iter, y0, y1, stream);
+    else render_rows(r, settings, iter, y0, y1, stream);
 }
 
 template <typename T> T* upload(DevScene& s, const T* host, size_t count) {
@@ -589,6 +733,11 @@ void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
     RenderDevice& r = rdev(dev); r.spp = spp; r.max_path_len = max_path_len;
 }
 
+void rodent_hip_render_mapping(int32_t dev, int32_t mapping) {
+    if (mapping != 0 && mapping != 1) { fprintf(stderr, "rodent_hip: unknown mapping %d (0 = streaming, 1 = megakernel)\n", mapping); abort(); }
+    rdev(dev).mapping = mapping;
+}
+
 int32_t get_spp(void) { return rdev(g_current_dev).spp; }
 
 void setup_interface(size_t width, size_t height) { g_host_w = width; g_host_h = height; g_host_film.assign(width * height * 3, 0.0f); }
@@ -625,23 +774,24 @@ void rodent_hip_render_rows(int32_t dev, const Settings* settings, int32_t iter,
     RenderDevice& r = rdev(dev);
     ensure_film(r);
     if (y0 < 0 || y1 > r.film_h || y0 > y1) { fprintf(stderr, "rodent_hip: invalid row range [%d, %d)\n", y0, y1); abort(); }
-    render_rows(r, settings, iter, y0, y1, (hipStream_t)stream);
+    render_rows_any(r, settings, iter, y0, y1, (hipStream_t)stream);
 }
 
 void render(const Settings* settings, int32_t iter) {                        // generated render(): converter.cpp:628-967
     RenderDevice& r = rdev(g_current_dev);
     ensure_film(r);
-    render_rows(r, settings, iter, 0, r.film_h, nullptr);
+    render_rows_any(r, settings, iter, 0, r.film_h, nullptr);
     rodent_present(g_current_dev);                                           // device.present() (converter.cpp:965)
 }
 
 void rodent_hip_render_counters(int32_t dev, uint64_t* out4) {
     RenderDevice& r = rdev(dev);
     HIP_CHECK(hipSetDevice(dev));
-    uint64_t all[68];
+    uint64_t all[kNumCounters];
     HIP_CHECK(hipMemcpy(all, r.counters, sizeof(all), hipMemcpyDeviceToHost));
     for (int k = 0; k < 4; k++) out4[k] = all[k];
     for (int k = 4; k < 68; k++) out4[1] += all[k];                         // shadow rays are counted in 64 stripes
+    for (int k = 68; k < kNumCounters; k++) out4[0] += all[k];              // the megakernel's primary rays, 32 stripes
 }
 
 // ---- stage-level entry points ---------------------------------------------------------------

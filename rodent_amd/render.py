@@ -26,7 +26,7 @@ class SceneDesc(C.Structure):
                [(n, i32) for n in ("num_vertices", "num_tris", "num_nodes", "num_bvh_tris", "num_materials", "num_lights")]
 
 
-RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "get_spp", "render",
+RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "get_spp", "render",
                   "setup_interface", "get_pixels", "clear_pixels", "cleanup_interface", "rodent_get_film_data",
                   "rodent_gpu_get_first_primary_stream", "rodent_gpu_get_second_primary_stream", "rodent_gpu_get_secondary_stream",
                   "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows",
@@ -43,6 +43,7 @@ def lib():
         l.rodent_hip_scene_create.argtypes = [i32, C.POINTER(SceneDesc)]; l.rodent_hip_scene_create.restype = None
         l.rodent_hip_scene_destroy.argtypes = [i32]; l.rodent_hip_scene_destroy.restype = None
         l.rodent_hip_render_config.argtypes = [i32, i32, i32]; l.rodent_hip_render_config.restype = None
+        l.rodent_hip_render_mapping.argtypes = [i32, i32]; l.rodent_hip_render_mapping.restype = None
         l.get_spp.argtypes = []; l.get_spp.restype = i32
         l.render.argtypes = [C.POINTER(Settings), i32]; l.render.restype = None
         l.setup_interface.argtypes = [C.c_size_t, C.c_size_t]; l.setup_interface.restype = None
@@ -65,7 +66,9 @@ def make_settings(cam) -> Settings:
 class Renderer:
     """One scene on one GPU.  render(cam, iter) accumulates `spp` samples per pixel into the film."""
 
-    def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0):
+    MAPPINGS = {"streaming": 0, "megakernel": 1}       # mapping_gpu.impala:308-369 / :371-474
+
+    def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming"):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("rodent_amd: no GPU visible (the renderer has no CPU fallback)")
@@ -77,6 +80,7 @@ class Renderer:
         l.rodent_hip_set_device(dev)
         l.rodent_hip_scene_create(dev, C.byref(desc))
         l.rodent_hip_render_config(dev, spp, max_path_len)
+        l.rodent_hip_render_mapping(dev, self.MAPPINGS[mapping])
         l.setup_interface(width, height)
         l.clear_pixels()
 

@@ -156,3 +156,43 @@ def test_stage_level_api_reproduces_render(R, oracle, cornell_scene):
     assert np.allclose(film, film_ref, rtol=FILM_RTOL, atol=FILM_ATOL)
     ref, _ = oracle.render(cornell_scene, cam, IT, SPP, MAXLEN, W, H)
     assert np.allclose(film, ref, rtol=FILM_RTOL, atol=FILM_ATOL)
+
+
+@pytest.mark.parametrize("spp,max_len,W,H", [(1, 64, 203, 121), (4, 64, 200, 120), (3, 2, 77, 50), (64, 4, 40, 30), (2048, 1, 5, 3)])
+def test_megakernel_matches_oracle(R, oracle, cornell_scene, spp, max_len, W, H):
+    """The persistent-threads mapping (mapping_gpu.impala:371-474): same paths, same ray counts, per-path colour sums;
+    ragged tiles (film not a multiple of the tile side), spp that is not a power of two, spp > 1024 (tile side 1)."""
+    cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
+    r = R.Renderer(cornell_scene, W, H, spp, max_len, mapping="megakernel")
+    film_o = None
+    for it in range(2):
+        r.render(cam, it)
+        c = r.counters()
+        film_o, counts = oracle.render(cornell_scene, cam, it, spp, max_len, W, H, film_o)
+        assert (c["primary_rays"], c["shadow_rays"], c["generated"]) == (counts[0], counts[1], W * H * spp)
+    film_g = r.film()
+    r.clear()
+    for y0, y1 in ((0, H // 3), (H // 3, H)):          # row bands (multi-GPU sharding) through the megakernel
+        r.render_rows(cam, 0, y0, y1)
+        r.render_rows(cam, 1, y0, y1)
+    bands = r.film()
+    r.close()
+    assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
+    assert np.allclose(bands, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
+
+
+def test_rodent_cli_megakernel_target(native_build, tmp_path):
+    """`rodent --target amdgpu-megakernel` renders the same samples as the streaming target: PNGs equal to one 8-bit level."""
+    imgs = {}
+    for target in ("amdgpu-streaming", "amdgpu-megakernel"):
+        out = tmp_path / (target + ".png")
+        cmd = [str(native_build.BIN_DIR / "rodent"), "--scene", str(GOLDEN / "cornell_box.obj"), "--eye", "0", "1", "2.7", "--dir", "0", "0", "-1",
+               "--up", "0", "1", "0", "--width", "300", "--height", "200", "--spp", "8", "--bench", "4", "--target", target, "-o", str(out)]
+        res = subprocess.run(cmd, capture_output=True, text=True, check=True)
+        assert "(min/med/max Msamples/s)" in res.stdout
+        imgs[target] = np.asarray(Image.open(out).convert("RGB"), dtype=np.int32)
+    diff = np.abs(imgs["amdgpu-streaming"] - imgs["amdgpu-megakernel"])
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01
+    assert imgs["amdgpu-megakernel"].mean() > 40
+    bad = subprocess.run(cmd[:-4] + ["--target", "nvvm-streaming"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "Unknown target" in bad.stderr
