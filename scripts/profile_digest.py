@@ -33,7 +33,9 @@ def counters(path):
 
 
 kernel_stats(out / f"{tag}_trace", "bench.py (primary + random passes)")
+kernel_stats(out / f"{tag}_trace_primary", "bench.py --only primary (the pass `value` and `roofline` are quoted on)")
 kernel_stats(out / f"{tag}_render", "rodent cfg4 (Cornell 1920x1080, 64 spp, max path length 4)")
+kernel_stats(out / f"{tag}_render_mega", "rodent cfg4, --target amdgpu-megakernel")
 traffic = {}
 for sub, title in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("tcc", "TCC"), ("sq", "SQ (primary)"), ("sqr", "SQ (random)")):
     c = counters(out / f"{tag}_{sub}")
