@@ -65,11 +65,16 @@ struct LaneStack {
 
 // One leaf of Tri1 records (mapping_gpu.impala:156-174).  Returns true when an
 // any-hit query is finished.
-template <bool ANY>
+// WIDE = false: 32-bit byte offsets from a uniform base (global_load ... v_off, s[base:base+1]: one VALU
+// instruction of address arithmetic per step instead of two 64-bit ones); the host picks WIDE = true when an
+// array is 4 GiB or larger.
+template <bool ANY, bool WIDE = true>
 __device__ __forceinline__ bool leaf_tri1(const Tri1* __restrict__ tris, int first, RayX& ray, HitAcc& hit) {
     int j = first;
     for (;;) {
-        const float4* p = reinterpret_cast<const float4*>(tris + j++);
+        const float4* p = WIDE ? reinterpret_cast<const float4*>(tris + j)
+                               : reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + (unsigned)j * (unsigned)sizeof(Tri1));
+        j++;
         const float4 a = p[0], b = p[1], c = p[2];
         const int prim_id = __float_as_int(c.w);
         const float nx = cross_x(b.x, b.y, b.z, c.x, c.y, c.z);       // mapping_gpu.impala:57
@@ -235,10 +240,69 @@ struct ChunkPerm {
 };
 
 
-template <bool ANY, int LDS_N, int NODE_EXIT, bool PERSIST, int REFILL_IDLE, int CHUNK, bool STATS = false, int XCD = 0>
+// Latency-oriented schedule for the LAST waves of a launch ("late" blocks).  While the chip is full the
+// while-while loop below is the right trade (it keeps VALU lanes busy); but the waves dispatched last run on
+// an emptying chip, where nothing hides a load and a wave's time is (number of wave-level iterations) x
+// (slowest lane's load latency).  Measured on the atrium (scripts/trace.py trace-fast): the waves that end a
+// 1 Mi-ray launch make 200+ descent iterations and 40+ leaf visits although no single ray needs more than
+// ~140 node steps, because lanes in the other phase wait.  Here every lane advances by ONE step per
+// iteration whatever its kind -- a node step or one triangle test -- with the loads of both kinds issued
+// together: iterations = max over lanes of (node steps + triangle tests).  The per-ray sequence of node
+// and triangle tests is unchanged, so results stay bit-identical.
+template <bool ANY, int LDS_N>
+__device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, const Ray1* __restrict__ rays,
+                                              Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray) {
+    int ray_id = first_ray + (int)threadIdx.x;
+    if (ray_id >= n) ray_id = -1;
+    RayX ray = load_ray(rays, ray_id >= 0 ? ray_id : first_ray);
+    HitAcc hit{-1, ray.tmax, 0.0f, 0.0f};
+    int top = ray_id >= 0 ? 1 : 0, ptr = 0;
+    col[0] = 0;
+    while (__ballot(top != 0)) {
+        if (top != 0) {
+            const bool is_node = top > 0;
+            const char* addr = is_node ? reinterpret_cast<const char*>(nodes - 1) + ((size_t)(unsigned)top << 6)
+                                       : reinterpret_cast<const char*>(tris) + (size_t)(unsigned)(~top) * sizeof(Tri1);
+            const float4* p = reinterpret_cast<const float4*>(addr);
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            const int popped = col[ptr * kWave];
+            if (is_node) {
+                const int2 ch = *reinterpret_cast<const int2*>(p + 3);
+                float te0, te1;
+                const bool h0 = slab(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
+                const bool h1 = slab(ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
+                const bool c0first = te0 < te1, both = h0 && h1;
+                col[(ptr + 1) * kWave] = c0first ? ch.y : ch.x;
+                top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
+                ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
+                if (ptr >= LDS_N) {
+                    deep_list[atomicAdd(&ctl->deep_count, 1)] = ray_id;
+                    ray_id = -1; top = 0;
+                }
+            } else {
+                const int prim_id = __float_as_int(q2.w);
+                const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
+                const float ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
+                const float nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
+                float t, u, v;
+                bool found = false;
+                if (intersect_tri(ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v)) {
+                    hit.id = prim_id & 0x7FFFFFFF; hit.t = t; hit.u = u; hit.v = v;
+                    ray.tmax = t; found = true;
+                }
+                if (ANY && found) top = 0;
+                else if (prim_id < 0) { top = popped; ptr--; }        // sentinel: leave the leaf
+                else top--;                                          // ~(j + 1)
+            }
+        }
+    }
+    if (ray_id >= 0) store_hit(hits, ray_id, hit.id, hit.t, hit.u, hit.v);
+}
+
+template <bool ANY, int LDS_N, int NODE_EXIT, bool PERSIST, int REFILL_IDLE, int CHUNK, bool STATS = false, int XCD = 0, bool WIDE = false, bool TRACE = false, bool STATIC = false>
 __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                       const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                      Ctl* ctl, int* __restrict__ deep_list) {
+                                                      Ctl* ctl, int* __restrict__ deep_list, int late_start, int late_prio) {
     __shared__ int lds_raw[(LDS_N + 1) * kWave];
     lds_int* col = (lds_int*)lds_raw + threadIdx.x;
     RayX ray; HitAcc hit{-1, 0.0f, 0.0f, 0.0f};
@@ -250,22 +314,43 @@ __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ n
     // goes to XCD j % 8, so an XCD works on whole image bands instead of every 8th 64-pixel strip while the
     // bands of one XCD stay spread over the frame (a contiguous eighth per XCD was measured 37 % slower: the
     // expensive bottom of the frame then lands on one XCD).
-    int first_chunk = blockIdx.x;
-    if (XCD > 0 && !PERSIST) {
-        const int span = 8 * XCD, full = ((int)gridDim.x / span) * span;          // region where the mapping is a bijection
-        if ((int)blockIdx.x < full) {
-            const int x = blockIdx.x % 8, l = blockIdx.x / 8;
-            first_chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
+    const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // STATIC (with PERSIST): no queue at all -- the grid is one wave per resident slot and wave b owns the
+    // tickets b, b + grid, b + 2 grid, ...; every wave starts at t = 0 and pairs chunks from distant parts
+    // of the stream, so no expensive chunk is started late (the drain of a plain launch is set by the
+    // expensive waves of the LAST dispatch round).
+    const int total_chunks = (n + kWave - 1) / kWave;
+    auto chunk_of = [&](int ticket) {
+        if (XCD > 0 && (!PERSIST || STATIC)) {
+            const int span = 8 * XCD, full = (total_chunks / span) * span;        // region where the mapping is a bijection
+            if (ticket < full) {
+                const int x = ticket % 8, l = ticket / 8;
+                return ((l / XCD) * 8 + x) * XCD + l % XCD;
+            }
         }
+        return ticket;
+    };
+    int ticket = blockIdx.x;
+    const int first_chunk = chunk_of(ticket);
+    if (!PERSIST && !STATS && (int)blockIdx.x >= late_start) {        // the launch's last waves: see unified_chunk
+        if (late_prio) __builtin_amdgcn_s_setprio(3);
+        unified_chunk<ANY, LDS_N>(nodes, tris, rays, hits, n, ctl, deep_list, col, first_chunk * kWave);
+        if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
+            unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
+            tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
+            tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+            tr[3] = 0;
+        }
+        return;
     }
     int pool_next = first_chunk * (PERSIST ? CHUNK : kWave);
     int pool_end = min(n, pool_next + (PERSIST ? CHUNK : kWave));
-    bool exhausted = !PERSIST;
+    bool exhausted = !PERSIST || (STATIC && ticket + (int)gridDim.x >= total_chunks);
     // STATS build only: [0] descent iterations, [1] active lanes in them, [2] leaf iterations, [3] active lanes,
     // [4] refills, [5] lanes refilled, [6] outer iterations (wave-uniform counts, lane 0 publishes)
     unsigned c_n = 0, c_l = 0;                     // per-lane participations
     __shared__ unsigned wst[8];                    // wave-level counts, bumped by an elected lane
-    if (STATS && threadIdx.x < 8) wst[threadIdx.x] = 0;
+    if ((STATS || TRACE) && threadIdx.x < 8) wst[threadIdx.x] = 0;
 #define WAVE_COUNT(slot, amount) do { const unsigned long long m_ = __ballot(true); if ((int)threadIdx.x == __ffsll((long long)m_) - 1) atomicAdd(&wst[slot], (unsigned)(amount)); } while (0)
 
     for (;;) {
@@ -277,7 +362,11 @@ __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ n
         const bool pool_empty = pool_next >= pool_end;
         if (num_idle == kWave && pool_empty && exhausted) break;
         if (num_idle >= REFILL_IDLE || num_idle == kWave) {
-            if (PERSIST && pool_empty && !exhausted) {
+            if (PERSIST && STATIC && pool_empty && !exhausted) {
+                ticket += gridDim.x;
+                if (ticket < total_chunks) { pool_next = chunk_of(ticket) * kWave; pool_end = min(n, pool_next + kWave); }
+                if (ticket + (int)gridDim.x >= total_chunks) exhausted = true;
+            } else if (PERSIST && pool_empty && !exhausted) {
                 int base = 0;
                 if (threadIdx.x == 0) base = atomicAdd(&ctl->counter, CHUNK);
                 base = __builtin_amdgcn_readfirstlane(base) + gridDim.x * CHUNK;
@@ -299,9 +388,11 @@ __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ n
         // ---- descent phase ----
         while (top > 0) {
             if (STATS) { c_n++; WAVE_COUNT(0, 1); }
-            const float4* p = reinterpret_cast<const float4*>(nodes + (top - 1));
+            if (TRACE) WAVE_COUNT(0, 1);
+            const float4* p = WIDE ? reinterpret_cast<const float4*>(nodes + (top - 1))
+                                   : reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes - 1) + ((unsigned)top << 6));
             const float4 b0 = p[0], b1 = p[1], b2 = p[2];
-            const int4 ch = *reinterpret_cast<const int4*>(p + 3);
+            const int2 ch = *reinterpret_cast<const int2*>(p + 3);                 // child ids; the last 8 bytes of a Node2 are padding
             const int popped = col[ptr * kWave];
             float te0, te1;
             const bool h0 = slab(ray, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, te0) && ch.x != 0;
@@ -320,8 +411,9 @@ __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ n
         // ---- leaf phase ----
         while (top < 0) {
             if (STATS) { c_l++; WAVE_COUNT(2, 1); }
+            if (TRACE) WAVE_COUNT(2, 1);
             const int first = ~top; top = col[ptr * kWave]; ptr--;
-            if (leaf_tri1<ANY>(tris, first, ray, hit)) { top = 0; break; }
+            if (leaf_tri1<ANY, WIDE>(tris, first, ray, hit)) { top = 0; break; }
         }
     }
     if (STATS) {
@@ -331,6 +423,12 @@ __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ n
         }
     }
 #undef WAVE_COUNT
+    if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
+        unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
+        tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
+        tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+        tr[3] = ((unsigned long long)atomicAdd(&wst[0], 0u) << 32) | atomicAdd(&wst[2], 0u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -359,7 +457,7 @@ __global__ __launch_bounds__(kWave) void k_bvh2_sched(const Node2* __restrict__ 
     bool exhausted = !PERSIST;
     unsigned c_n = 0, c_l = 0;
     __shared__ unsigned wst[8];
-    if (STATS && threadIdx.x < 8) wst[threadIdx.x] = 0;
+    if ((STATS || TRACE) && threadIdx.x < 8) wst[threadIdx.x] = 0;
     const unsigned long long t_start = (STATS || TRACE) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned traced_rays = 0;
 #define WAVE_COUNT(slot, amount) do { const unsigned long long m_ = __ballot(true); if ((int)threadIdx.x == __ffsll((long long)m_) - 1) atomicAdd(&wst[slot], (unsigned)(amount)); } while (0)
@@ -586,12 +684,42 @@ int persistent_waves_per_cu() {
     return v;
 }
 
+// Blocks [frac * grid, grid) of a fast-family launch use the latency-oriented schedule (unified_chunk).
+struct LateConfig { double frac; int prio; };
+LateConfig late_config() {
+    static const LateConfig c = [] {
+        LateConfig v{1.0, 0};
+        if (const char* e = getenv("RODENT_HIP_LATE_FRAC")) v.frac = std::min(1.0, std::max(0.0, atof(e)));
+        if (const char* e = getenv("RODENT_HIP_LATE_PRIO")) v.prio = atoi(e);
+        return v;
+    }();
+    return c;
+}
+
+int static_waves_per_cu() {
+    static const int v = [] { const char* e = getenv("RODENT_HIP_STATIC_WAVES_PER_CU"); return e ? atoi(e) : 32; }();
+    return v;
+}
+
 void check_error_flag(DeviceState& s, hipStream_t stream) {
     int flag[2] = {0, 0};
     HIP_CHECK(hipMemcpyAsync(&flag[0], s.scratch + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(&flag[1], &s.ctl()->err, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     if (flag[0] || flag[1]) { fprintf(stderr, "rodent_hip: traversal stack overflow (more than %d entries)\n", kStackCap); abort(); }
+}
+
+// True if node or triangle byte offsets may not fit 32 bits: the arrays' allocations are asked for their extent
+// (the C ABI of the reference passes no sizes, traversal.impala:1-9).  Unknown pointers count as wide.
+bool needs_wide_offsets(const void* nodes, const void* tris) {
+    bool wide = false;
+    for (const void* p : {nodes, tris}) {
+        hipDeviceptr_t base = nullptr; size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) { (void)hipGetLastError(); wide = true; continue; }
+        const size_t extent = (size_t)((const char*)base + size - (const char*)p);
+        if (extent >= (1ull << 32)) wide = true;
+    }
+    return wide;
 }
 
 #define LAUNCH_ARGS DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
@@ -603,12 +731,17 @@ template <bool ANY, int LDS_N> void L_lane(LAUNCH_ARGS) {
 template <bool ANY, int LDS_N, int NE> void L_ww(LAUNCH_ARGS) {
     hipLaunchKernelGGL((k_bvh2_ww<ANY, LDS_N, NE>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.scratch + 1);
 }
-template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false, int XCD = 0> void L_fast(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false, int XCD = 0, bool TR = false, bool SC = false> void L_fast(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     const int per_block = P ? CH : kWave;
     int grid = (n + per_block - 1) / per_block;
-    if (P) grid = std::min(grid, s.num_cus * persistent_waves_per_cu());
-    hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
+    if (P) grid = std::min(grid, s.num_cus * (SC ? static_waves_per_cu() : persistent_waves_per_cu()));
+    const LateConfig late = late_config();
+    const int late_start = (P || ST) ? grid : (int)((double)grid * late.frac);
+    if (needs_wide_offsets(nodes, tris))
+        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, true, TR, SC>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, late_start, late.prio);
+    else
+        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, false, TR, SC>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, late_start, late.prio);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
 }
 
@@ -659,6 +792,13 @@ const Variant2 kVariants2[] = {
     K2("stats-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, true),
     K2("trace-sched",        "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false, false, true),
     K2("trace-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, false, true),
+    K2("trace-fast",         "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32, true),
+    //   static-stride persistent waves: one wave per resident slot, tickets b, b + grid, ... (no atomics)
+    K2("fast-static-r64",    "k_bvh2_fast",          L_fast, 16, 8,  true,  64, 64, false, 32, false, true),
+    K2("fast-static-r32",    "k_bvh2_fast",          L_fast, 16, 8,  true,  32, 64, false, 32, false, true),
+    K2("fast-static-r16",    "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 64, false, 32, false, true),
+    K2("fast-static-r8",     "k_bvh2_fast",          L_fast, 16, 8,  true,  8,  64, false, 32, false, true),
+    K2("trace-fast-static",  "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 64, false, 32, true,  true),
 };
 constexpr int kNumVariants2 = sizeof(kVariants2) / sizeof(kVariants2[0]);
 

@@ -51,12 +51,15 @@ __device__ __forceinline__ void store_hit(Hit1* hits, int i, int id, float t, fl
 
 // intersection.impala:194-208, unordered form, fminf/fmaxf like make_amdgpu_min_max
 // (mapping_gpu.impala:87-89).  Returns tentry; hit iff tentry <= texit.
+// The six fused multiply-adds are written on 2-vectors (lo, hi) so that they issue as three
+// v_pk_fma_f32 (two IEEE fmas per lane per instruction on gfx950): same operations, same results.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool slab(const RayX& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float& tentry) {
-    const float t0x = fmaf(r.idx, lox, r.iox), t1x = fmaf(r.idx, hix, r.iox);
-    const float t0y = fmaf(r.idy, loy, r.ioy), t1y = fmaf(r.idy, hiy, r.ioy);
-    const float t0z = fmaf(r.idz, loz, r.ioz), t1z = fmaf(r.idz, hiz, r.ioz);
-    tentry = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), r.tmin));
-    const float texit = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), r.tmax));
+    const f32x2 tx = __builtin_elementwise_fma((f32x2){r.idx, r.idx}, (f32x2){lox, hix}, (f32x2){r.iox, r.iox});
+    const f32x2 ty = __builtin_elementwise_fma((f32x2){r.idy, r.idy}, (f32x2){loy, hiy}, (f32x2){r.ioy, r.ioy});
+    const f32x2 tz = __builtin_elementwise_fma((f32x2){r.idz, r.idz}, (f32x2){loz, hiz}, (f32x2){r.ioz, r.ioz});
+    tentry = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), r.tmin));
+    const float texit = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), r.tmax));
     return tentry <= texit;
 }
 

@@ -15,6 +15,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--variants", default=None)
 ap.add_argument("--scene", default="atrium")
 ap.add_argument("--any", action="store_true")
+ap.add_argument("--reverse", action="store_true", help="experiment: trace the ray sets in reverse order")
 a = ap.parse_args()
 
 path = scenes.scene_bvh(a.scene)
@@ -24,6 +25,8 @@ n4, _ = F.read_bvh(path, F.BVH4_TRI4)
 lo, hi = raygen.scene_bounds(n4)
 sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0),
         "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
+if a.reverse:
+    sets = {k: np.ascontiguousarray(v[::-1]) for k, v in sets.items()}
 names = abi.variants(a.width)
 todo = [int(x) for x in a.variants.split(",")] if a.variants else range(len(names))
 base = {}

@@ -32,6 +32,18 @@ for name in want:
         cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
         cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
         rays_w = tr[:, 3] >> 32; outer = tr[:, 3] & 0xFFFFFFFF
+        if name == "trace-fast":                       # word 3 = node iterations << 32 | leaf iterations
+            itn, itl = rays_w.astype(float), outer.astype(float)
+            life_ = end - start
+            print(f"   iterations/wave: node mean {itn.mean():.1f} p50 {np.median(itn):.0f} p99 {np.percentile(itn, 99):.0f} max {itn.max():.0f}; leaf mean {itl.mean():.1f} max {itl.max():.0f}")
+            A = np.stack([itn, itl, np.ones_like(itn)], 1); coef = np.linalg.lstsq(A, life_, rcond=None)[0]
+            print(f"   life ~ {coef[0]:.3f} us/node-iter + {coef[1]:.3f} us/leaf-iter + {coef[2]:.2f} us")
+            early = start < np.percentile(start, 25); late = start > np.percentile(start, 90)
+            for lab, m in (("first 25% started", early), ("last 10% started", late)):
+                c = np.linalg.lstsq(A[m], life_[m], rcond=None)[0]
+                print(f"   {lab}: life mean {life_[m].mean():.1f} us, node-iter mean {itn[m].mean():.1f}, fit {c[0]:.3f}/{c[1]:.3f}/{c[2]:.2f}")
+            order = np.argsort(-end)[:8]
+            print("   last waves to end: " + "; ".join(f"blk {int(np.flatnonzero(tr[:, 0] == tr[o, 0])[0])} start {start[o]:.0f} life {life_[o]:.0f} n{itn[o]:.0f}/l{itl[o]:.0f}" for o in order))
         life = end - start
         uniq, cnt = np.unique(cuid, return_counts=True)
         ts = np.linspace(0, end.max(), 21)[1:-1]
