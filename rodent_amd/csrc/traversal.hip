@@ -240,15 +240,16 @@ struct ChunkPerm {
 };
 
 
-// Latency-oriented schedule for the LAST waves of a launch ("late" blocks).  While the chip is full the
-// while-while loop below is the right trade (it keeps VALU lanes busy); but the waves dispatched last run on
-// an emptying chip, where nothing hides a load and a wave's time is (number of wave-level iterations) x
-// (slowest lane's load latency).  Measured on the atrium (scripts/trace.py trace-fast): the waves that end a
-// 1 Mi-ray launch make 200+ descent iterations and 40+ leaf visits although no single ray needs more than
-// ~140 node steps, because lanes in the other phase wait.  Here every lane advances by ONE step per
-// iteration whatever its kind -- a node step or one triangle test -- with the loads of both kinds issued
-// together: iterations = max over lanes of (node steps + triangle tests).  The per-ray sequence of node
-// and triangle tests is unchanged, so results stay bit-identical.
+// Single-step schedule (the default "fast" variant).  Every lane advances by ONE step per wave iteration,
+// whatever its kind -- a node step or one triangle test -- and the loads of both kinds are issued together,
+// so a wave needs max over its lanes of (node steps + triangle tests) iterations, one memory round trip each.
+// A 1 Mi-ray launch is only two rounds of resident waves on this chip (2 rays per lane slot): there is no
+// steady state to amortise a drain in, the kernel time is (start of the last expensive waves) + (their
+// iteration count) x (round-trip latency), and the while-while loop further down -- which keeps more lanes
+// busy per instruction -- loses because lanes in the other phase wait (scripts/trace.py: the waves that end
+// the launch made 200+ descent iterations and 40+ leaf visits where no ray needs more than ~140 node steps;
+// letting triangle lanes queue up until N of them are ready was measured too: every N > 1 is slower).
+// The per-ray sequence of node and triangle tests is unchanged, so results stay bit-identical.
 template <bool ANY, int LDS_N>
 __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, const Ray1* __restrict__ rays,
                                               Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray) {
@@ -258,16 +259,24 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
     HitAcc hit{-1, ray.tmax, 0.0f, 0.0f};
     int top = ray_id >= 0 ? 1 : 0, ptr = 0;
     col[0] = 0;
+    const char* const node_base = reinterpret_cast<const char*>(nodes - 1);          // node ids are 1-based
+    const char* const tri_base = reinterpret_cast<const char*>(tris);
     while (__ballot(top != 0)) {
         if (top != 0) {
             const bool is_node = top > 0;
-            const char* addr = is_node ? reinterpret_cast<const char*>(nodes - 1) + ((size_t)(unsigned)top << 6)
-                                       : reinterpret_cast<const char*>(tris) + (size_t)(unsigned)(~top) * sizeof(Tri1);
+            // one address for both kinds, by selects (no divergent address code)
+            const size_t off = is_node ? ((size_t)(unsigned)top << 6) : (size_t)(unsigned)(~top) * sizeof(Tri1);
+            const char* addr = (is_node ? node_base : tri_base) + off;
             const float4* p = reinterpret_cast<const float4*>(addr);
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            // child ids of a node; a triangle lane re-reads its own last 8 bytes so that the load stays inside the array
+            int2 ch = *reinterpret_cast<const int2*>(addr + (is_node ? 48 : 40));
             const int popped = col[ptr * kWave];
+            // All four loads must be in flight together: without this barrier the compiler narrows the shared loads to
+            // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
+            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
+                              "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(ch.x), "+v"(ch.y));
             if (is_node) {
-                const int2 ch = *reinterpret_cast<const int2*>(p + 3);
                 float te0, te1;
                 const bool h0 = slab(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
                 const bool h1 = slab(ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
@@ -284,25 +293,25 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
                 const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
                 const float ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
                 const float nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
-                float t, u, v;
-                bool found = false;
-                if (intersect_tri(ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v)) {
-                    hit.id = prim_id & 0x7FFFFFFF; hit.t = t; hit.u = u; hit.v = v;
-                    ray.tmax = t; found = true;
-                }
-                if (ANY && found) top = 0;
-                else if (prim_id < 0) { top = popped; ptr--; }        // sentinel: leave the leaf
-                else top--;                                          // ~(j + 1)
+                float t = 0.0f, u = 0.0f, v = 0.0f;
+                const bool found = intersect_tri(ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v);
+                hit.id = found ? (prim_id & 0x7FFFFFFF) : hit.id;
+                hit.t = found ? t : hit.t; hit.u = found ? u : hit.u; hit.v = found ? v : hit.v;
+                ray.tmax = found ? t : ray.tmax;
+                const bool leave = prim_id < 0;                               // sentinel: the leaf is done
+                top = (ANY && found) ? 0 : (leave ? popped : top - 1);        // top - 1 == ~(j + 1)
+                ptr -= (leave && !(ANY && found)) ? 1 : 0;
             }
         }
     }
     if (ray_id >= 0) store_hit(hits, ray_id, hit.id, hit.t, hit.u, hit.v);
 }
 
-template <bool ANY, int LDS_N, int NODE_EXIT, bool PERSIST, int REFILL_IDLE, int CHUNK, bool STATS = false, int XCD = 0, bool WIDE = false, bool TRACE = false, bool STATIC = false>
+template <bool ANY, int LDS_N, int NODE_EXIT, bool PERSIST, int REFILL_IDLE, int CHUNK, bool STATS = false, int XCD = 0, bool WIDE = false, bool TRACE = false,
+          bool STATIC = false, bool SINGLE = false>
 __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                       const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                      Ctl* ctl, int* __restrict__ deep_list, int late_start, int late_prio) {
+                                                      Ctl* ctl, int* __restrict__ deep_list) {
     __shared__ int lds_raw[(LDS_N + 1) * kWave];
     lds_int* col = (lds_int*)lds_raw + threadIdx.x;
     RayX ray; HitAcc hit{-1, 0.0f, 0.0f, 0.0f};
@@ -332,8 +341,8 @@ __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ n
     };
     int ticket = blockIdx.x;
     const int first_chunk = chunk_of(ticket);
-    if (!PERSIST && !STATS && (int)blockIdx.x >= late_start) {        // the launch's last waves: see unified_chunk
-        if (late_prio) __builtin_amdgcn_s_setprio(3);
+    if (SINGLE) {                                                     // single-step schedule: see unified_chunk
+        static_assert(!SINGLE || (!PERSIST && !STATS), "the single-step schedule is one chunk per wave");
         unified_chunk<ANY, LDS_N>(nodes, tris, rays, hits, n, ctl, deep_list, col, first_chunk * kWave);
         if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
             unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
@@ -684,18 +693,6 @@ int persistent_waves_per_cu() {
     return v;
 }
 
-// Blocks [frac * grid, grid) of a fast-family launch use the latency-oriented schedule (unified_chunk).
-struct LateConfig { double frac; int prio; };
-LateConfig late_config() {
-    static const LateConfig c = [] {
-        LateConfig v{1.0, 0};
-        if (const char* e = getenv("RODENT_HIP_LATE_FRAC")) v.frac = std::min(1.0, std::max(0.0, atof(e)));
-        if (const char* e = getenv("RODENT_HIP_LATE_PRIO")) v.prio = atoi(e);
-        return v;
-    }();
-    return c;
-}
-
 int static_waves_per_cu() {
     static const int v = [] { const char* e = getenv("RODENT_HIP_STATIC_WAVES_PER_CU"); return e ? atoi(e) : 32; }();
     return v;
@@ -731,17 +728,15 @@ template <bool ANY, int LDS_N> void L_lane(LAUNCH_ARGS) {
 template <bool ANY, int LDS_N, int NE> void L_ww(LAUNCH_ARGS) {
     hipLaunchKernelGGL((k_bvh2_ww<ANY, LDS_N, NE>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.scratch + 1);
 }
-template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false, int XCD = 0, bool TR = false, bool SC = false> void L_fast(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false, int XCD = 0, bool TR = false, bool SC = false, bool SG = false> void L_fast(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     const int per_block = P ? CH : kWave;
     int grid = (n + per_block - 1) / per_block;
     if (P) grid = std::min(grid, s.num_cus * (SC ? static_waves_per_cu() : persistent_waves_per_cu()));
-    const LateConfig late = late_config();
-    const int late_start = (P || ST) ? grid : (int)((double)grid * late.frac);
     if (needs_wide_offsets(nodes, tris))
-        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, true, TR, SC>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, late_start, late.prio);
+        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, true, TR, SC, SG>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
     else
-        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, false, TR, SC>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, late_start, late.prio);
+        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, false, TR, SC, SG>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
 }
 
@@ -772,16 +767,16 @@ const Variant2 kVariants2[] = {
     // 0 = default (used by the reference-named entry points).  All variants keep the reference's per-ray
     // visit order and are bit-identical; they differ in how a wavefront schedules its 64 rays.
     //                                                      LDS_N NODE_EXIT PERSIST REFILL_IDLE CHUNK STATS XCD_GROUP
-    K2("fast",               "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32),   // default: XCD-aware, 32-chunk groups
+    K2("fast",               "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32, false, false, true),   // default: single-step schedule, XCD-aware 32-chunk groups
     K2("lane",               "k_bvh2_lane",          L_lane, 24),                      // literal reference mapping
     K2("ww",                 "k_bvh2_ww",            L_ww, 24, 8),                     // while-while, LDS+scratch stack
-    K2("fast-noxcd",         "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64),
+    K2("fast-ww",            "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32),   // while-while schedule (the default before the single-step loop)
     K2("fast-exit0",         "k_bvh2_fast",          L_fast, 16, 0,  false, 64, 64, false, 32),
     K2("fast-exit16",        "k_bvh2_fast",          L_fast, 16, 16, false, 64, 64, false, 32),
     K2("fast-lds24",         "k_bvh2_fast",          L_fast, 24, 8,  false, 64, 64, false, 32),
     K2("fast-persistent",    "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 128),
-    K2("fast-xcd-g16",       "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 16),
-    K2("fast-xcd-g64",       "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 64),
+    K2("fast-noxcd",         "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 0,  false, false, true),
+    K2("fast-ww-noxcd",      "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64),
     //                                                       LDS_N PERSIST REFILL_IDLE CHUNK TRI_BIAS(x/4) PERMUTE
     K2("sched",              "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false),
     K2("sched-persistent",   "k_bvh2_sched",         L_sched, 16, true,  16, 64,  8, false),
@@ -792,7 +787,8 @@ const Variant2 kVariants2[] = {
     K2("stats-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, true),
     K2("trace-sched",        "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false, false, true),
     K2("trace-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, false, true),
-    K2("trace-fast",         "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32, true),
+    K2("trace-fast",         "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32, true,  false, true),
+    K2("trace-fast-ww",      "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32, true),
     //   static-stride persistent waves: one wave per resident slot, tickets b, b + grid, ... (no atomics)
     K2("fast-static-r64",    "k_bvh2_fast",          L_fast, 16, 8,  true,  64, 64, false, 32, false, true),
     K2("fast-static-r32",    "k_bvh2_fast",          L_fast, 16, 8,  true,  32, 64, false, 32, false, true),
