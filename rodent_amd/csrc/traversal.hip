@@ -172,6 +172,7 @@ __global__ __launch_bounds__(kWave) void k_bvh2_ww(const Node2* __restrict__ nod
 // Launch control block in device memory (zero between launches).
 struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; };
 
+
 // Per-lane stack of the fast / sched kernels: an LDS-only window of LDS_N entries behind an
 // address_space(3) pointer (plain ds_read / ds_write; LDS_N + 1 rows so the slot above the top
 // can always be written).  A ray that needs more is appended to the launch's "deep list" and
@@ -307,8 +308,45 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
     if (ray_id >= 0) store_hit(hits, ray_id, hit.id, hit.t, hit.u, hit.v);
 }
 
-template <bool ANY, int LDS_N, int NODE_EXIT, bool PERSIST, int REFILL_IDLE, int CHUNK, bool STATS = false, int XCD = 0, bool WIDE = false, bool TRACE = false,
-          bool STATIC = false, bool SINGLE = false>
+// BVH2 / Tri1, the default kernel: one 64-ray chunk per wave, single-step schedule (unified_chunk), XCD-aware chunk
+// mapping as in k_bvh2_fast.
+//
+// Measured and NOT kept -- adaptive launch order.  The kernel time of a 1 Mi-ray launch is (start of the last
+// expensive waves) + (their life); workgroups start in index order and the chip holds half of them at once, so on
+// the atrium, whose expensive rays end the stream, tracing the same rays in REVERSE stream order is 23 % faster
+// (0.179 vs 0.221 ms).  Costs are unknown before the launch; sampling them inside it (first dispatch round = every
+// other row of chunks, its waves report the rays still alive after 24 steps, the skipped rows are then started
+// most-expensive-first from a table sorted by the first workgroup that needs it) was built and was 12 % SLOWER:
+// half of the expensive rows cannot start before slots free up anyway, all expensive sampled rows running at once
+// take 1.6x longer each, the estimates are not in when the sort has to run (expensive waves report last), and the
+// waiting workgroups hold slots.  An age-based s_setprio for long-running waves was slower as well.
+template <bool ANY, int LDS_N, int XCD, bool TRACE = false>
+__global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                        const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                        Ctl* ctl, int* __restrict__ deep_list) {
+    __shared__ int lds_raw[(LDS_N + 1) * kWave];
+    lds_int* col = (lds_int*)lds_raw + threadIdx.x;
+    const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const int total_chunks = (n + kWave - 1) / kWave;
+    int chunk = blockIdx.x;
+    if (XCD > 0) {
+        const int span = 8 * XCD, full = (total_chunks / span) * span;        // region where the mapping is a bijection
+        if ((int)blockIdx.x < full) {
+            const int x = blockIdx.x % 8, l = blockIdx.x / 8;
+            chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
+        }
+    }
+    unified_chunk<ANY, LDS_N>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave);
+    if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
+        unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
+        tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
+        tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+        tr[3] = (unsigned long long)chunk;
+    }
+}
+
+template <bool ANY, int LDS_N, int NODE_EXIT, bool PERSIST, int REFILL_IDLE, int CHUNK, bool STATS = false, int XCD = 0, bool TRACE = false,
+          bool STATIC = false, bool WIDE = false>
 __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                       const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                       Ctl* ctl, int* __restrict__ deep_list) {
@@ -341,17 +379,6 @@ __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ n
     };
     int ticket = blockIdx.x;
     const int first_chunk = chunk_of(ticket);
-    if (SINGLE) {                                                     // single-step schedule: see unified_chunk
-        static_assert(!SINGLE || (!PERSIST && !STATS), "the single-step schedule is one chunk per wave");
-        unified_chunk<ANY, LDS_N>(nodes, tris, rays, hits, n, ctl, deep_list, col, first_chunk * kWave);
-        if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
-            unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
-            tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
-            tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
-            tr[3] = 0;
-        }
-        return;
-    }
     int pool_next = first_chunk * (PERSIST ? CHUNK : kWave);
     int pool_end = min(n, pool_next + (PERSIST ? CHUNK : kWave));
     bool exhausted = !PERSIST || (STATIC && ticket + (int)gridDim.x >= total_chunks);
@@ -728,15 +755,21 @@ template <bool ANY, int LDS_N> void L_lane(LAUNCH_ARGS) {
 template <bool ANY, int LDS_N, int NE> void L_ww(LAUNCH_ARGS) {
     hipLaunchKernelGGL((k_bvh2_ww<ANY, LDS_N, NE>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.scratch + 1);
 }
-template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false, int XCD = 0, bool TR = false, bool SC = false, bool SG = false> void L_fast(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false, int XCD = 0, bool TR = false, bool SC = false> void L_fast(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     const int per_block = P ? CH : kWave;
     int grid = (n + per_block - 1) / per_block;
     if (P) grid = std::min(grid, s.num_cus * (SC ? static_waves_per_cu() : persistent_waves_per_cu()));
     if (needs_wide_offsets(nodes, tris))
-        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, true, TR, SC, SG>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
+        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, TR, SC, true>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
     else
-        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, false, TR, SC, SG>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
+        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, TR, SC, false>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
+}
+
+template <bool ANY, int LDS_N, int XCD, bool TR = false> void L_single(LAUNCH_ARGS) {
+    ensure_deep_list(s, n);
+    hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
 }
 
@@ -767,7 +800,8 @@ const Variant2 kVariants2[] = {
     // 0 = default (used by the reference-named entry points).  All variants keep the reference's per-ray
     // visit order and are bit-identical; they differ in how a wavefront schedules its 64 rays.
     //                                                      LDS_N NODE_EXIT PERSIST REFILL_IDLE CHUNK STATS XCD_GROUP
-    K2("fast",               "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32, false, false, true),   // default: single-step schedule, XCD-aware 32-chunk groups
+    //                                                        LDS_N XCD_GROUP
+    K2("fast",               "k_bvh2_single",        L_single, 16, 32),                // default: single-step schedule, XCD-aware 32-chunk groups
     K2("lane",               "k_bvh2_lane",          L_lane, 24),                      // literal reference mapping
     K2("ww",                 "k_bvh2_ww",            L_ww, 24, 8),                     // while-while, LDS+scratch stack
     K2("fast-ww",            "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32),   // while-while schedule (the default before the single-step loop)
@@ -775,7 +809,7 @@ const Variant2 kVariants2[] = {
     K2("fast-exit16",        "k_bvh2_fast",          L_fast, 16, 16, false, 64, 64, false, 32),
     K2("fast-lds24",         "k_bvh2_fast",          L_fast, 24, 8,  false, 64, 64, false, 32),
     K2("fast-persistent",    "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 128),
-    K2("fast-noxcd",         "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 0,  false, false, true),
+    K2("fast-noxcd",         "k_bvh2_single",        L_single, 16, 0),
     K2("fast-ww-noxcd",      "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64),
     //                                                       LDS_N PERSIST REFILL_IDLE CHUNK TRI_BIAS(x/4) PERMUTE
     K2("sched",              "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false),
@@ -787,7 +821,7 @@ const Variant2 kVariants2[] = {
     K2("stats-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, true),
     K2("trace-sched",        "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false, false, true),
     K2("trace-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, false, true),
-    K2("trace-fast",         "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32, true,  false, true),
+    K2("trace-fast",         "k_bvh2_single",        L_single, 16, 32, true),
     K2("trace-fast-ww",      "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32, true),
     //   static-stride persistent waves: one wave per resident slot, tickets b, b + grid, ... (no atomics)
     K2("fast-static-r64",    "k_bvh2_fast",          L_fast, 16, 8,  true,  64, 64, false, 32, false, true),

@@ -86,6 +86,26 @@ def test_ragged_sizes(gpu, cornell, cornell_dev, width, n):
         assert got.tobytes() == exp.tobytes()
 
 
+@pytest.mark.parametrize("n", [8192 * 64 + 16384, 600_000, (1 << 20) + 12345, 3 << 20])
+def test_chunk_mapping_is_a_bijection(gpu, cornell, cornell_dev, n):
+    """The default kernel maps workgroups to ray chunks XCD-aware (k_bvh2_single): every chunk must be traced exactly
+    once at sizes with ragged tails and several dispatch rounds; the hit buffer starts as 0xFF."""
+    import torch
+    names = gpu.variants(2)
+    base = cornell.ray_sets["primary"]
+    rays = np.tile(base, (n + len(base) - 1) // len(base))[:n].copy()
+    rays["org"][:, 0] += (np.arange(n, dtype=np.float32) % 977) * 1e-4          # not all copies identical
+    rd = gpu.to_device(rays, 0)
+    out = {}
+    for name in ("fast", "fast-noxcd", "fast-ww"):
+        hd = torch.full((n * 16,), 0xFF, dtype=torch.uint8, device="cuda:0")
+        gpu.traverse_async(cornell_dev[2], rd, hd, n, False, names.index(name))
+        torch.cuda.synchronize()
+        out[name] = gpu.from_device(hd, F.HIT1)
+    assert out["fast"].tobytes() == out["fast-noxcd"].tobytes() == out["fast-ww"].tobytes()
+    assert (out["fast"]["tri_id"] >= -1).all() and (out["fast"]["tri_id"] < 64).all()
+
+
 def test_deep_stack_falls_back_to_global_stack(gpu, oracle):
     """Stacks deeper than the LDS window (16 entries) take the deep-ray epilogue / scratch spill;
     results must not change.  Mix deep and shallow rays in one wave and across waves."""
