@@ -86,8 +86,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(PrimaryStream p, int first_
 
 // ---------------------------------------------------------------------------------------------
 // K1 / K6: BVH2 traversal over an SoA ray stream.  Per-ray visit order = the reference kernel
-// (traversal/mapping_gpu.impala:94-178); wave scheduling = the "fast" mapping of traversal.hip
-// (while-while, branch-free node step).  Stack: 16-entry window in LDS, deeper entries in scratch.
+// (traversal/mapping_gpu.impala:94-178); wave scheduling = the single-step loop of traversal.hip
+// (branch-free node step).  Stack: 16-entry window in LDS, deeper entries in scratch.
 // ---------------------------------------------------------------------------------------------
 constexpr int kLdsStack = 16;
 struct StreamStack {
@@ -133,39 +133,45 @@ __device__ __forceinline__ void film_add_wave(float* film, int pixel, bool valid
     if (valid) { float* px = film + 3 * (size_t)pixel; unsafeAtomicAdd(px, r); unsafeAtomicAdd(px + 1, g); unsafeAtomicAdd(px + 2, b); }
 }
 
+// Single-step schedule, as k_bvh2_single / unified_chunk in traversal.hip: each lane advances by one node step or
+// one triangle test per wave iteration and the loads of both kinds are in flight together.
 template <bool ANY>
 __device__ __forceinline__ StreamHit trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, StreamStack& st) {
     StreamHit hit{-1, -1, ray.tmax, 0.0f, 0.0f};
     int ptr = 0, top = 1; st.put(0, 0);
-    while (top != 0) {
-        while (top > 0) {
-            const float4* p = reinterpret_cast<const float4*>(nodes + (top - 1));
-            const float4 b0 = p[0], b1 = p[1], b2 = p[2];
-            const int4 ch = *reinterpret_cast<const int4*>(p + 3);
+    const char* const node_base = reinterpret_cast<const char*>(nodes - 1);          // node ids are 1-based
+    const char* const tri_base = reinterpret_cast<const char*>(tris);
+    while (__ballot(top != 0)) {
+        if (top != 0) {
+            const bool is_node = top > 0;
+            const size_t off = is_node ? ((size_t)(unsigned)top << 6) : (size_t)(unsigned)(~top) * sizeof(Tri1);
+            const char* addr = (is_node ? node_base : tri_base) + off;
+            const float4* p = reinterpret_cast<const float4*>(addr);
+            float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            int2 ch = *reinterpret_cast<const int2*>(addr + (is_node ? 48 : 40));   // child ids / (triangle lanes) own last 8 bytes
             const int popped = st.get(ptr);
-            float te0, te1;
-            const bool h0 = slab(ray, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, te0) && ch.x != 0;
-            const bool h1 = slab(ray, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, te1) && ch.y != 0;
-            const bool c0first = te0 < te1, both = h0 && h1;
-            st.put(ptr + 1, c0first ? ch.y : ch.x);
-            top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
-            ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
-            if (__popcll(__ballot(top > 0)) < 8) break;
-        }
-        while (top < 0) {
-            int j = ~top; top = st.get(ptr); ptr--;
-            for (;;) {
-                const float4* p = reinterpret_cast<const float4*>(tris + j++);
-                const float4 a = p[0], b = p[1], c = p[2];
-                const int prim_id = __float_as_int(c.w);
-                const float nx = cross_x(b.x, b.y, b.z, c.x, c.y, c.z), ny = cross_y(b.x, b.y, b.z, c.x, c.y, c.z), nz = cross_z(b.x, b.y, b.z, c.x, c.y, c.z);
-                float t, u, v;
-                if (intersect_tri(ray, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, nx, ny, nz, t, u, v)) {
-                    hit.prim = prim_id & 0x7FFFFFFF; hit.geom = __float_as_int(b.w); hit.t = t; hit.u = u; hit.v = v;
-                    ray.tmax = t;
-                    if (ANY) return hit;
-                }
-                if (prim_id < 0) break;
+            // keep all four loads in flight together (see unified_chunk)
+            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
+                              "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(ch.x), "+v"(ch.y));
+            if (is_node) {
+                float te0, te1;
+                const bool h0 = slab(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
+                const bool h1 = slab(ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
+                const bool c0first = te0 < te1, both = h0 && h1;
+                st.put(ptr + 1, c0first ? ch.y : ch.x);
+                top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
+                ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
+            } else {
+                const int prim_id = __float_as_int(q2.w);
+                const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
+                float t = 0.0f, u = 0.0f, v = 0.0f;
+                const bool found = intersect_tri(ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v);
+                hit.prim = found ? (prim_id & 0x7FFFFFFF) : hit.prim; hit.geom = found ? __float_as_int(q1.w) : hit.geom;
+                hit.t = found ? t : hit.t; hit.u = found ? u : hit.u; hit.v = found ? v : hit.v;
+                ray.tmax = found ? t : ray.tmax;
+                const bool leave = prim_id < 0;                               // sentinel: the leaf is done
+                top = (ANY && found) ? 0 : (leave ? popped : top - 1);        // top - 1 == ~(j + 1)
+                ptr -= (leave && !(ANY && found)) ? 1 : 0;
             }
         }
     }
