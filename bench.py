@@ -176,7 +176,7 @@ def main():
                   "random_kernel_ms": {"mean": round(kr_mean, 5), "median": round(kr_med, 5), "min": round(kr_min, 5)},
                   "hit_counts_per_rank[primary,random]": counts_all},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         from oracle import binding as O      # checker / CPU baseline only: never on the measured path
         # (1) visit counts of the reference algorithm for THIS layout -> algorithmic bytes per ray
         if width == 2:
@@ -200,6 +200,7 @@ def main():
         if not same:
             ids_equal = float((hits[sample]["tri_id"] == ref_hits["tri_id"]).mean())
             out["extra"]["sample_id_match_fraction"] = ids_equal
+    if world == 1 and not args.no_cpu_baseline:
         # (2) CPU baseline: Rodent's CPU hybrid path (ray8 x bvh8 packets with single-ray fallback,
         #     mapping_cpu.impala:259-402) restated with AVX2 (oracle/hybrid_baseline.cpp), timed on this host:
         #     once on 1 core (the reference's bench loop is sequential) and once on all hardware threads.

@@ -319,7 +319,9 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
 // most-expensive-first from a table sorted by the first workgroup that needs it) was built and was 12 % SLOWER:
 // half of the expensive rows cannot start before slots free up anyway, all expensive sampled rows running at once
 // take 1.6x longer each, the estimates are not in when the sort has to run (expensive waves report last), and the
-// waiting workgroups hold slots.  An age-based s_setprio for long-running waves was slower as well.
+// waiting workgroups hold slots.  An age-based s_setprio for long-running waves was slower as well, and so was giving
+// every wave two chunks (b and b + grid/2) with idle lanes refilled from the second one (one dispatch round, all waves
+// start at t = 0: 0.247 vs 0.214 ms -- the second chunk's expensive rays still start late, inside the wave).
 template <bool ANY, int LDS_N, int XCD, bool TRACE = false>
 __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
