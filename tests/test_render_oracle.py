@@ -142,3 +142,12 @@ def test_converter_cli(native_build, tmp_path):
     assert r.returncode == 1 and "Unknown option" in r.stderr
     r = subprocess.run([rod, "--width"], capture_output=True, text=True)
     assert r.returncode == 1 and "expects 1 arguments" in r.stderr             # driver.cpp:164-167
+
+
+def test_cpu_render_bench_script(oracle, tmp_path):
+    """oracle/cpu_render_bench.py: prints the reference driver's Msamples/s line for the CPU path tracer."""
+    import subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_render_bench.py"), "--width", "64", "--height", "48", "--spp", "2",
+                        "--bench", "2", "--threads", "2"], capture_output=True, text=True, check=True)
+    assert "(min/med/max Msamples/s)" in r.stdout and "2 threads" in r.stdout
