@@ -39,9 +39,9 @@ HOST_FLAGS = ["-O2", "-std=c++17", "-Wall", "-fPIC", f"-I{ROOT / 'include'}"]
 ORACLE_FLAGS = ["-O2", "-std=c11", "-Wall", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma"]
 
 HIP_SOURCES = ["traversal.hip", "render.hip"]
-HOST_LIB_SOURCES = ["mesh.cpp", "bvh_build.cpp", "atrium.cpp", "scene.cpp"]
-HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png", "converter"]
-HIP_TOOLS = {"bench_traversal": [], "rodent": ["mesh.o", "bvh_build.o", "scene.o"]}   # tool -> host objects it links
+HOST_LIB_SOURCES = ["mesh.cpp", "bvh_build.cpp", "atrium.cpp", "scene.cpp", "image.cpp"]
+HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png", "converter", "tex_dump"]
+HIP_TOOLS = {"bench_traversal": [], "rodent": ["mesh.o", "bvh_build.o", "scene.o", "image.o"]}   # tool -> host objects it links
 
 
 def _newer(target: Path, *deps: Path) -> bool:
@@ -85,7 +85,7 @@ def build_host(force: bool = False) -> list[Path]:
             continue
         out = BIN_DIR / t
         if force or _newer(out, src, *objs, *_headers()):
-            _run([CXX, *HOST_FLAGS, src, *objs, "-pthread", "-o", out])
+            _run([CXX, *HOST_FLAGS, src, *objs, "-pthread", "-lz", "-o", out])
         outs.append(out)
     return outs
 
@@ -106,7 +106,7 @@ def build_hip_tools(force: bool = False) -> list[Path]:
             _run([CXX, "-O2", "-std=c++17", "-Wall", "-Wno-unused-result", "-D__HIP_PLATFORM_AMD__",
                   f"-I{ROOT / 'include'}", f"-I{ROCM / 'include'}", src, *objs,
                   f"-L{LIB_DIR}", "-lrodent_hip", f"-L{ROCM / 'lib'}", "-lamdhip64",
-                  "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{ROCM / 'lib'}", "-pthread", "-o", out])
+                  "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{ROCM / 'lib'}", "-pthread", "-lz", "-o", out])
         outs.append(out)
     return outs
 
