@@ -44,8 +44,12 @@ enum RodentBsdf { RODENT_BSDF_BLACK = 0, RODENT_BSDF_DIFFUSE = 1, RODENT_BSDF_PH
                   RODENT_BSDF_MIX = 3 /* diffuse (+) phong */, RODENT_BSDF_MIRROR = 4, RODENT_BSDF_GLASS = 5 };
 struct RodentMaterial {            /* 64 B; one per geometry id (converter.cpp:858-920) */
     float kd[3]; int32_t type; float ks[3]; float ns; float tf[3]; float ni;
-    float mix_k;                   /* lum(ks) / (lum(ks) + lum(kd)) (converter.cpp:900-906) */
-    int32_t emissive; int32_t pad[2];
+    float mix_k;                   /* lum(ks) / (lum(ks) + lum(kd)) (converter.cpp:900-906); recomputed per hit when textured */
+    int32_t emissive;
+    int32_t tex_kd, tex_ks;        /* 0: kd / ks are the constants above; else 1 + index of the map_Kd / map_Ks texture (converter.cpp:881-893) */
+};
+struct RodentTexture {             /* RGBA8 image, row 0 = bottom row of the file, gamma-corrected (src/driver/image.cpp:10-18,85) */
+    int32_t width, height; uint32_t offset /* first texel in the pool */; int32_t pad;
 };
 struct RodentLight {               /* 80 B; triangle area light (converter.cpp:831-851, light.impala:140-154) */
     float v0[4], v1[4], v2[4]; float n[3]; float inv_area; float color[4];
@@ -59,6 +63,10 @@ struct RodentSceneDesc {           /* HOST pointers; copied to HBM by rodent_hip
     const struct RodentMaterial* materials; const struct RodentLight* lights;
     const int32_t* light_ids;      /* per triangle: index into lights (0 if not a light) */
     int32_t num_vertices, num_tris, num_nodes, num_bvh_tris, num_materials, num_lights;
+    /* textures (src/render/image.impala:56-92: repeat border, bilinear filter); all three may be NULL when num_textures == 0 */
+    const float* texcoords;        /* float4 per vertex: u, v, 0, 0 (converter.cpp:408) */
+    const struct RodentTexture* textures; const uint32_t* texels;
+    int32_t num_textures; uint32_t num_texels;
 };
 
 void    rodent_hip_scene_create(int32_t dev, const struct RodentSceneDesc* desc);   /* replaces the device's current scene */

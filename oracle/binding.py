@@ -96,7 +96,8 @@ def brute_force(tris, rays):
 
 class _Scene(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")] + \
-               [("num_tris", C.c_int32), ("num_materials", C.c_int32), ("num_lights", C.c_int32), ("pad", C.c_int32)]
+               [("num_tris", C.c_int32), ("num_materials", C.c_int32), ("num_lights", C.c_int32), ("pad", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("texcoords", "textures", "texels")]
 
 
 class _Settings(C.Structure):
@@ -105,8 +106,9 @@ class _Settings(C.Structure):
 
 def _scene_struct(scene):
     keep = [np.ascontiguousarray(getattr(scene, n)) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")]
-    s = _Scene(*[_ptr(a) for a in keep], scene.num_tris, len(scene.materials), len(scene.lights), 0)
-    return s, keep
+    tex = [np.ascontiguousarray(getattr(scene, n)) for n in ("texcoords", "textures", "texels")]
+    s = _Scene(*[_ptr(a) for a in keep], scene.num_tris, len(scene.materials), len(scene.lights), 0, *[_ptr(a) for a in tex])
+    return s, keep + tex
 
 
 def render(scene, cam, iter_, spp, max_path_len, width, height, film=None, rows=None, threads=8):
@@ -132,6 +134,28 @@ def render(scene, cam, iter_, spp, max_path_len, width, height, film=None, rows=
     with cf.ThreadPoolExecutor(max(1, threads)) as ex:
         list(ex.map(work, range(len(bands) - 1)))
     return film, counts.sum(axis=0)
+
+
+def tex_lookup(scene, tex, uv):
+    """Bilinear / repeat lookup of texture `tex` at uv (n, 2) -> (n, 3) float32."""
+    l = lib()
+    s, keep = _scene_struct(scene)
+    uv = np.ascontiguousarray(uv, "<f4"); out = np.zeros((len(uv), 3), "<f4")
+    l.oracle_tex_lookup.restype = None
+    l.oracle_tex_lookup.argtypes = [C.POINTER(_Scene), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    l.oracle_tex_lookup(C.byref(s), int(tex), _ptr(uv), _ptr(out), len(uv))
+    return out
+
+
+def hit_material(scene, prim, u, v):
+    """The material table entry a hit on triangle `prim` at barycentrics (u, v) shades with (textures resolved)."""
+    l = lib()
+    s, keep = _scene_struct(scene)
+    out = np.zeros(1, scene.materials.dtype)
+    l.oracle_hit_material.restype = None
+    l.oracle_hit_material.argtypes = [C.POINTER(_Scene), C.c_int32, C.c_float, C.c_float, C.c_void_p]
+    l.oracle_hit_material(C.byref(s), int(prim), float(u), float(v), _ptr(out))
+    return out[0]
 
 
 def tonemap(film, iters):

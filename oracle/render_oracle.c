@@ -45,7 +45,8 @@ int oracle_bvh2_tri1(const struct Node2*, const struct Tri1*, const struct Ray1*
 
 /* Scene tables (same layout as include/rodent_render.h) */
 enum { MAT_BLACK = 0, MAT_DIFFUSE = 1, MAT_PHONG = 2, MAT_MIX = 3, MAT_MIRROR = 4, MAT_GLASS = 5 };
-struct Material { float kd[3]; int32_t type; float ks[3]; float ns; float tf[3]; float ni; float mix_k; int32_t emissive; int32_t pad[2]; };
+struct Material { float kd[3]; int32_t type; float ks[3]; float ns; float tf[3]; float ni; float mix_k; int32_t emissive; int32_t tex_kd, tex_ks; };
+struct Texture  { int32_t width, height; uint32_t offset; int32_t pad; };
 struct Light    { float v0[4], v1[4], v2[4]; float n[3]; float inv_area; float color[4]; };
 struct Scene {
     const float* vertices;      /* float4 per vertex */
@@ -55,6 +56,8 @@ struct Scene {
     const struct Node2* nodes; const struct Tri1* tris;
     const struct Material* materials; const struct Light* lights; const int32_t* light_ids;
     int32_t num_tris, num_materials, num_lights, pad;
+    const float* texcoords;     /* float4 per vertex: u, v, 0, 0 */
+    const struct Texture* textures; const uint32_t* texels;
 };
 struct Settings { float eye[3], dir[3], up[3], right[3]; float w, h; };
 
@@ -242,6 +245,39 @@ static Surf surface_element(const struct Scene* sc, v3 org, v3 dir, int32_t prim
     s.face_normal = s.entering ? fn : neg(fn); s.local = orthonormal(dot(dir, nrm) <= 0.0f ? nrm : neg(nrm)); return s;
 }
 
+/* image.impala:24-38 (RGBA8 -> colour), :48-54 (repeat border), :64-86 (bilinear filter) */
+static inline v3 texel(const struct Scene* sc, const struct Texture* t, int32_t x, int32_t y) {
+    const uint32_t p = sc->texels[t->offset + (uint32_t)y * (uint32_t)t->width + (uint32_t)x];
+    return V((float)(p & 0xFFu) * (1.0f / 255.0f), (float)((p >> 8) & 0xFFu) * (1.0f / 255.0f), (float)((p >> 16) & 0xFFu) * (1.0f / 255.0f));
+}
+static v3 tex_lookup(const struct Scene* sc, const struct Texture* t, float tu, float tv) {
+    const float ru = tu - floorf(tu), rv = tv - floorf(tv);
+    const float u = ru * (float)t->width, v = rv * (float)t->height;
+    const int32_t iu = (int32_t)u, iv = (int32_t)v;
+    const int32_t x0 = iu < t->width - 1 ? iu : t->width - 1, y0 = iv < t->height - 1 ? iv : t->height - 1;
+    const int32_t x1 = x0 + 1 < t->width - 1 ? x0 + 1 : t->width - 1, y1 = y0 + 1 < t->height - 1 ? y0 + 1 : t->height - 1;
+    const float kx = u - (float)iu, ky = v - (float)iv;
+    const v3 p00 = texel(sc, t, x0, y0), p10 = texel(sc, t, x1, y0), p01 = texel(sc, t, x0, y1), p11 = texel(sc, t, x1, y1);
+    return V(lerp1(lerp1(p00.x, p10.x, kx), lerp1(p01.x, p11.x, kx), ky), lerp1(lerp1(p00.y, p10.y, kx), lerp1(p01.y, p11.y, kx), ky),
+             lerp1(lerp1(p00.z, p10.z, kx), lerp1(p01.z, p11.z, kx), ky));
+}
+/* The material of a hit: map_Kd / map_Ks replace kd / ks with texture lookups at the interpolated texture coordinates,
+ * and the diffuse/Phong mix weight follows the looked-up colours (converter.cpp:881-906, geometry.impala:30-40). */
+static const struct Material* resolve_material(const struct Scene* sc, const struct Material* m, struct Material* tmp, int32_t prim, float u, float v) {
+    if (!(m->tex_kd | m->tex_ks)) return m;
+    const int32_t* idx = sc->indices + 4 * prim;
+    const float* t0 = sc->texcoords + 4 * idx[0]; const float* t1 = sc->texcoords + 4 * idx[1]; const float* t2 = sc->texcoords + 4 * idx[2];
+    const float tu = lerp2(t0[0], t1[0], t2[0], u, v), tv = lerp2(t0[1], t1[1], t2[1], u, v);
+    *tmp = *m;
+    if (m->tex_kd) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_kd - 1), tu, tv); tmp->kd[0] = c.x; tmp->kd[1] = c.y; tmp->kd[2] = c.z; }
+    if (m->tex_ks) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_ks - 1), tu, tv); tmp->ks[0] = c.x; tmp->ks[1] = c.y; tmp->ks[2] = c.z; }
+    if (m->type == MAT_MIX) {
+        const float ls = luminance(LD3(tmp->ks)), ld = luminance(LD3(tmp->kd));
+        tmp->mix_k = (ls + ld == 0.0f) ? 0.0f : ls / (ls + ld);
+    }
+    return tmp;
+}
+
 static inline v3 sample_triangle(float u, float v, v3 v0, v3 v1, v3 v2) {              /* random.impala:49-60 */
     if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
     return add(add(mulf(v0, 1.0f - v - u), mulf(v1, u)), mulf(v2, v));
@@ -274,7 +310,8 @@ void oracle_render(const struct Scene* sc, const struct Settings* st, int32_t it
             struct Hit1 h; n_primary++;
             if (!trace(sc, org, dir, tmin, tmax, 0, &h)) break;                          /* miss: dropped (mapping_gpu.impala:347-357) */
             const int32_t prim = h.tri_id;
-            const struct Material* m = sc->materials + sc->indices[4 * prim + 3];
+            struct Material textured;
+            const struct Material* m = resolve_material(sc, sc->materials + sc->indices[4 * prim + 3], &textured, prim, h.u, h.v);
             const Surf s = surface_element(sc, org, dir, prim, h.t, h.u, h.v);
             const v3 out_dir = neg(dir);
             /* on_hit (renderer.impala:113-128) */
@@ -330,6 +367,13 @@ void oracle_render(const struct Scene* sc, const struct Settings* st, int32_t it
 
 /* Single-function probes for property tests */
 void oracle_sincos_2pi(const float* u, float* c, float* s, int32_t n) { for (int32_t i = 0; i < n; i++) sincos_2pi(u[i], &c[i], &s[i]); }
+/* probes for the tests: texture lookup and the per-hit material of a textured scene */
+void oracle_tex_lookup(const struct Scene* sc, int32_t tex, const float* uv, float* rgb, int32_t n) {
+    for (int32_t i = 0; i < n; i++) { const v3 c = tex_lookup(sc, sc->textures + tex, uv[2 * i], uv[2 * i + 1]); rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z; }
+}
+void oracle_hit_material(const struct Scene* sc, int32_t prim, float u, float v, struct Material* out) {
+    struct Material tmp; *out = *resolve_material(sc, sc->materials + sc->indices[4 * prim + 3], &tmp, prim, u, v);
+}
 void oracle_fastpow(const float* x, const float* p, float* out, int32_t n) { for (int32_t i = 0; i < n; i++) out[i] = fastpow(x[i], p[i]); }
 void oracle_randf(uint32_t seed, float* out, int32_t n) { for (int32_t i = 0; i < n; i++) out[i] = randf(&seed); }
 uint32_t oracle_seed(int32_t sample, int32_t iter, int32_t x, int32_t y) {

@@ -243,7 +243,8 @@ __device__ __forceinline__ ShadeOut shade_vertex(const SceneDev& sc, const PathV
     ShadeOut o;
     const float pdf_lightpick = 1.0f / (float)sc.num_lights;
     uint32_t rnd = pv.rnd;
-    const RodentMaterial* m = sc.materials + pv.geom;
+    RodentMaterial textured;
+    const RodentMaterial* m = resolve_material(&sc, sc.materials + pv.geom, &textured, pv.prim, pv.u, pv.v);
     const Surf sf = surface_element(&sc, pv.org, pv.dir, pv.prim, pv.t, pv.u, pv.v);
     const v3 out_dir = neg(pv.dir);
 
@@ -730,6 +731,15 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
     s.dev.materials = upload(s, d->materials, (size_t)d->num_materials);
     s.dev.lights = upload(s, d->lights, (size_t)d->num_lights);
     s.dev.light_ids = upload(s, d->light_ids, (size_t)d->num_tris);
+    const bool textured = d->num_textures > 0;
+    if (textured && (!d->texcoords || !d->textures || !d->texels)) { fprintf(stderr, "rodent_hip: scene with textures but without texture data\n"); abort(); }
+    s.dev.texcoords = upload(s, d->texcoords, textured ? 4 * (size_t)d->num_vertices : 0);
+    s.dev.textures = upload(s, d->textures, textured ? (size_t)d->num_textures : 0);
+    s.dev.texels = upload(s, d->texels, textured ? (size_t)d->num_texels : 0);
+    for (int32_t k = 0; k < d->num_materials; k++)
+        if (d->materials[k].tex_kd < 0 || d->materials[k].tex_kd > d->num_textures || d->materials[k].tex_ks < 0 || d->materials[k].tex_ks > d->num_textures) {
+            fprintf(stderr, "rodent_hip: material %d refers to a texture that does not exist\n", k); abort();
+        }
     s.dev.num_tris = d->num_tris; s.dev.num_materials = d->num_materials; s.dev.num_lights = d->num_lights;
     s.loaded = true;
 }

@@ -18,6 +18,7 @@ struct SceneDev {                 // device pointers (uploaded by rodent_hip_sce
     const Node2* nodes; const Tri1* tris;
     const RodentMaterial* materials; const RodentLight* lights; const int32_t* light_ids;
     int32_t num_tris, num_materials, num_lights, pad;
+    const float* texcoords; const RodentTexture* textures; const uint32_t* texels;
 };
 
 #define FLT_MAX_REF 3.4028234664e+38f
@@ -202,6 +203,39 @@ RD_FN Surf surface_element(const SceneDev* sc, v3 org, v3 dir, int32_t prim, flo
     const v3 nrm = normalize(V(lerp2(n0[0], n1[0], n2[0], u, v), lerp2(n0[1], n1[1], n2[1], u, v), lerp2(n0[2], n1[2], n2[2], u, v)));
     Surf s; s.entering = dot(dir, fn) <= 0.0f; s.point = add(org, mulf(dir, t));
     s.face_normal = s.entering ? fn : neg(fn); s.local = orthonormal(dot(dir, nrm) <= 0.0f ? nrm : neg(nrm)); return s;
+}
+
+/* image.impala:24-38 (RGBA8 -> colour), :48-54 (repeat border), :64-86 (bilinear filter) */
+RD_FN v3 texel(const SceneDev* sc, const RodentTexture* t, int32_t x, int32_t y) {
+    const uint32_t p = sc->texels[t->offset + (uint32_t)y * (uint32_t)t->width + (uint32_t)x];
+    return V((float)(p & 0xFFu) * (1.0f / 255.0f), (float)((p >> 8) & 0xFFu) * (1.0f / 255.0f), (float)((p >> 16) & 0xFFu) * (1.0f / 255.0f));
+}
+RD_FN v3 tex_lookup(const SceneDev* sc, const RodentTexture* t, float tu, float tv) {
+    const float ru = tu - floorf(tu), rv = tv - floorf(tv);
+    const float u = ru * (float)t->width, v = rv * (float)t->height;
+    const int32_t iu = (int32_t)u, iv = (int32_t)v;
+    const int32_t x0 = iu < t->width - 1 ? iu : t->width - 1, y0 = iv < t->height - 1 ? iv : t->height - 1;
+    const int32_t x1 = x0 + 1 < t->width - 1 ? x0 + 1 : t->width - 1, y1 = y0 + 1 < t->height - 1 ? y0 + 1 : t->height - 1;
+    const float kx = u - (float)iu, ky = v - (float)iv;
+    const v3 p00 = texel(sc, t, x0, y0), p10 = texel(sc, t, x1, y0), p01 = texel(sc, t, x0, y1), p11 = texel(sc, t, x1, y1);
+    return V(lerp1(lerp1(p00.x, p10.x, kx), lerp1(p01.x, p11.x, kx), ky), lerp1(lerp1(p00.y, p10.y, kx), lerp1(p01.y, p11.y, kx), ky),
+             lerp1(lerp1(p00.z, p10.z, kx), lerp1(p01.z, p11.z, kx), ky));
+}
+/* The material of a hit: map_Kd / map_Ks replace kd / ks with texture lookups at the interpolated texture coordinates,
+ * and the diffuse/Phong mix weight follows the looked-up colours (converter.cpp:881-906, geometry.impala:30-40). */
+RD_FN const RodentMaterial* resolve_material(const SceneDev* sc, const RodentMaterial* m, RodentMaterial* tmp, int32_t prim, float u, float v) {
+    if (!(m->tex_kd | m->tex_ks)) return m;
+    const int32_t* idx = sc->indices + 4 * prim;
+    const float* t0 = sc->texcoords + 4 * idx[0]; const float* t1 = sc->texcoords + 4 * idx[1]; const float* t2 = sc->texcoords + 4 * idx[2];
+    const float tu = lerp2(t0[0], t1[0], t2[0], u, v), tv = lerp2(t0[1], t1[1], t2[1], u, v);
+    *tmp = *m;
+    if (m->tex_kd) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_kd - 1), tu, tv); tmp->kd[0] = c.x; tmp->kd[1] = c.y; tmp->kd[2] = c.z; }
+    if (m->tex_ks) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_ks - 1), tu, tv); tmp->ks[0] = c.x; tmp->ks[1] = c.y; tmp->ks[2] = c.z; }
+    if (m->type == RODENT_BSDF_MIX) {
+        const float ls = luminance(LD3(tmp->ks)), ld = luminance(LD3(tmp->kd));
+        tmp->mix_k = (ls + ld == 0.0f) ? 0.0f : ls / (ls + ld);
+    }
+    return tmp;
 }
 
 RD_FN v3 sample_triangle(float u, float v, v3 v0, v3 v1, v3 v2) {              /* random.impala:49-60 */

@@ -7,6 +7,7 @@
 #include <unordered_set>
 
 #include "bvh_build.h"
+#include "image.h"
 
 namespace rodent {
 namespace {
@@ -29,7 +30,7 @@ RodentMaterial to_table(const Material& m) {                           // conver
     if (m.illum == 5) r.type = RODENT_BSDF_MIRROR;
     else if (m.illum == 7) r.type = RODENT_BSDF_GLASS;
     else {
-        const bool diffuse = !zero(m.kd), specular = !zero(m.ks);
+        const bool diffuse = !zero(m.kd) || !m.map_kd.empty(), specular = !zero(m.ks) || !m.map_ks.empty();   // converter.cpp:875-876
         if (diffuse && specular) {
             const float ls = lum(m.ks), ld = lum(m.kd);
             r.type = RODENT_BSDF_MIX; r.mix_k = (ls + ld == 0.0f) ? 0.0f : ls / (ls + ld);
@@ -49,6 +50,8 @@ RodentSceneDesc SceneData::desc() const {
     d.nodes = nodes.data(); d.tris = tris.data(); d.materials = materials.data(); d.lights = lights.data(); d.light_ids = light_ids.data();
     d.num_vertices = (int32_t)(vertices.size() / 4); d.num_tris = (int32_t)num_tris(); d.num_nodes = (int32_t)nodes.size();
     d.num_bvh_tris = (int32_t)tris.size(); d.num_materials = (int32_t)materials.size(); d.num_lights = (int32_t)lights.size();
+    d.texcoords = texcoords.data(); d.textures = textures.data(); d.texels = texels.data();
+    d.num_textures = (int32_t)textures.size(); d.num_texels = (uint32_t)texels.size();
     return d;
 }
 
@@ -76,10 +79,36 @@ bool build_scene_from_obj(const std::string& obj_path, SceneData& scene) {
     std::vector<int> used(names.size(), 0);
     for (size_t t = 0; t < nt; t++) used[canon[mesh.indices[4 * t + 3]]] = 1;
     std::vector<int> new_id(names.size(), -1);
+    // textures: one pool entry per distinct file (converter.cpp:595-610); a file that cannot be decoded becomes the
+    // reference's 1x1 black dummy image (converter.cpp:752,766) with a warning
+    const size_t slash = obj_path.find_last_of("/\\");
+    const std::string base = slash == std::string::npos ? std::string(".") : obj_path.substr(0, slash);
+    std::unordered_map<std::string, int> tex_ids;
+    auto texture_of = [&](std::string name) -> int {
+        if (name.empty()) return 0;
+        std::replace(name.begin(), name.end(), '\\', '/');                          // fix_file
+        auto it = tex_ids.find(name);
+        if (it != tex_ids.end()) return it->second;
+        ImageRgba8 img; std::string err;
+        if (!load_image(base + "/" + name, img, &err)) {
+            std::clog << "Cannot load texture '" << name << "' (" << err << "). Replaced by a black image." << std::endl;
+            img.width = img.height = 1; img.pixels.assign(4, 0);
+        }
+        RodentTexture t; t.width = img.width; t.height = img.height; t.offset = (uint32_t)scene.texels.size(); t.pad = 0;
+        const size_t count = (size_t)img.width * img.height;
+        scene.texels.resize(scene.texels.size() + count);
+        std::memcpy(scene.texels.data() + t.offset, img.pixels.data(), count * 4);
+        scene.textures.push_back(t); scene.texture_names.push_back(name);
+        return tex_ids[name] = (int)scene.textures.size();                           // 1 + index
+    };
     for (size_t i = 0; i < names.size(); i++)
         if (canon[i] == (int)i && used[i]) {
             new_id[i] = (int)scene.materials.size();
-            scene.materials.push_back(to_table(lib[names[i]]));
+            RodentMaterial rm = to_table(lib[names[i]]);
+            if (rm.type == RODENT_BSDF_DIFFUSE || rm.type == RODENT_BSDF_PHONG || rm.type == RODENT_BSDF_MIX) {
+                rm.tex_kd = texture_of(lib[names[i]].map_kd); rm.tex_ks = texture_of(lib[names[i]].map_ks);
+            }
+            scene.materials.push_back(rm);
             scene.material_names.push_back(names[i]);
         }
     for (size_t t = 0; t < nt; t++) mesh.indices[4 * t + 3] = (uint32_t)new_id[canon[mesh.indices[4 * t + 3]]];
@@ -88,6 +117,8 @@ bool build_scene_from_obj(const std::string& obj_path, SceneData& scene) {
     auto pad4 = [](const std::vector<V3>& v) { std::vector<float> o(v.size() * 4, 0.0f); for (size_t i = 0; i < v.size(); i++) { o[4 * i] = v[i].x; o[4 * i + 1] = v[i].y; o[4 * i + 2] = v[i].z; } return o; };
     scene.vertices = pad4(mesh.vertices); scene.normals = pad4(mesh.normals); scene.face_normals = pad4(mesh.face_normals);
     scene.indices.assign(mesh.indices.begin(), mesh.indices.end());
+    scene.texcoords.assign(mesh.vertices.size() * 4, 0.0f);
+    for (size_t i = 0; i < mesh.texcoords.size() && i < mesh.vertices.size(); i++) { scene.texcoords[4 * i] = mesh.texcoords[i].x; scene.texcoords[4 * i + 1] = mesh.texcoords[i].y; }
 
     // lights (converter.cpp:770-851): one per emissive triangle
     scene.light_ids.assign(nt, 0);
@@ -116,22 +147,25 @@ bool build_scene_from_obj(const std::string& obj_path, SceneData& scene) {
     return true;
 }
 
-// ---- .rscene: magic, version, defaults, counts, then the arrays in declaration order ----
-namespace { const uint32_t kMagic = 0x43534452u /* "RDSC" */, kVersion = 1; }
+// ---- .rscene (version 2): magic, version, defaults, counts, then the arrays in declaration order ----
+namespace { const uint32_t kMagic = 0x43534452u /* "RDSC" */, kVersion = 2; }
 
 bool save_scene(const std::string& path, const SceneData& s) {
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) return false;
-    const uint32_t hdr[10] = {kMagic, kVersion, (uint32_t)s.default_spp, (uint32_t)s.default_max_path_len,
+    const uint32_t hdr[12] = {kMagic, kVersion, (uint32_t)s.default_spp, (uint32_t)s.default_max_path_len,
                               (uint32_t)(s.vertices.size() / 4), (uint32_t)s.num_tris(), (uint32_t)s.nodes.size(),
-                              (uint32_t)s.tris.size(), (uint32_t)s.materials.size(), (uint32_t)s.lights.size()};
-    bool ok = fwrite(hdr, 4, 10, f) == 10;
+                              (uint32_t)s.tris.size(), (uint32_t)s.materials.size(), (uint32_t)s.lights.size(),
+                              (uint32_t)s.textures.size(), (uint32_t)s.texels.size()};
+    bool ok = fwrite(hdr, 4, 12, f) == 12;
     auto put = [&](const void* p, size_t bytes) { ok = ok && (bytes == 0 || fwrite(p, 1, bytes, f) == bytes); };
     put(s.vertices.data(), s.vertices.size() * 4); put(s.normals.data(), s.normals.size() * 4);
     put(s.face_normals.data(), s.face_normals.size() * 4); put(s.indices.data(), s.indices.size() * 4);
     put(s.nodes.data(), s.nodes.size() * sizeof(Node2)); put(s.tris.data(), s.tris.size() * sizeof(Tri1));
     put(s.materials.data(), s.materials.size() * sizeof(RodentMaterial)); put(s.lights.data(), s.lights.size() * sizeof(RodentLight));
     put(s.light_ids.data(), s.light_ids.size() * 4);
+    put(s.texcoords.data(), s.texcoords.size() * 4); put(s.textures.data(), s.textures.size() * sizeof(RodentTexture));
+    put(s.texels.data(), s.texels.size() * 4);
     fclose(f);
     return ok;
 }
@@ -139,13 +173,14 @@ bool save_scene(const std::string& path, const SceneData& s) {
 bool load_scene(const std::string& path, SceneData& s) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
-    uint32_t hdr[10];
-    bool ok = fread(hdr, 4, 10, f) == 10 && hdr[0] == kMagic && hdr[1] == kVersion;
+    uint32_t hdr[12];
+    bool ok = fread(hdr, 4, 12, f) == 12 && hdr[0] == kMagic && hdr[1] == kVersion;
     if (ok) {
         s.default_spp = (int32_t)hdr[2]; s.default_max_path_len = (int32_t)hdr[3];
         auto get = [&](auto& vec, size_t count) { vec.resize(count); ok = ok && (count == 0 || fread(vec.data(), sizeof(vec[0]), count, f) == count); };
         get(s.vertices, 4ull * hdr[4]); get(s.normals, 4ull * hdr[4]); get(s.face_normals, 4ull * hdr[5]); get(s.indices, 4ull * hdr[5]);
         get(s.nodes, hdr[6]); get(s.tris, hdr[7]); get(s.materials, hdr[8]); get(s.lights, hdr[9]); get(s.light_ids, hdr[5]);
+        get(s.texcoords, 4ull * hdr[4]); get(s.textures, hdr[10]); get(s.texels, hdr[11]);
     }
     fclose(f);
     return ok;

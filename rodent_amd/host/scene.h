@@ -8,7 +8,8 @@
 //   triangle lights with precomputed normal / inverse area                    converter.cpp:770-851
 //   mesh buffers padded to float4 / int4 like the GPU targets                 converter.cpp:629-632,403-426
 //   BVH2/Tri1 with geom_id = material id                                      converter.cpp:262-383,713-720
-// Textures (map_Kd/Ks/Ke) are not supported yet: such materials fall back to their constant colours.
+//   map_Kd / map_Ks textures (PNG, JPEG, TGA next to the OBJ) loaded into one RGBA8 pool        converter.cpp:595-610,749-768
+// map_Ke (textured emitters) is not supported: such lights use their constant Ke.
 #pragma once
 #include <string>
 #include <vector>
@@ -25,7 +26,10 @@ struct SceneData {
     std::vector<RodentMaterial> materials;
     std::vector<RodentLight>    lights;
     std::vector<int32_t> light_ids;
-    std::vector<std::string> material_names;
+    std::vector<float>   texcoords;                          // float4 per vertex (u, v, 0, 0)
+    std::vector<RodentTexture> textures;
+    std::vector<uint32_t> texels;                            // RGBA8 pool
+    std::vector<std::string> material_names, texture_names;
     int32_t default_spp = 4, default_max_path_len = 64;      // converter.cpp:1007-1012
 
     size_t num_tris() const { return indices.size() / 4; }

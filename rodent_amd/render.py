@@ -23,7 +23,8 @@ class Settings(C.Structure):
 
 class SceneDesc(C.Structure):
     _fields_ = [(n, vp) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")] + \
-               [(n, i32) for n in ("num_vertices", "num_tris", "num_nodes", "num_bvh_tris", "num_materials", "num_lights")]
+               [(n, i32) for n in ("num_vertices", "num_tris", "num_nodes", "num_bvh_tris", "num_materials", "num_lights")] + \
+               [(n, vp) for n in ("texcoords", "textures", "texels")] + [("num_textures", i32), ("num_texels", C.c_uint32)]
 
 
 RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "get_spp", "render",
@@ -75,8 +76,9 @@ class Renderer:
         self.dev, self.width, self.height, self.spp = dev, width, height, spp
         l = lib()
         keep = [np.ascontiguousarray(getattr(scene, n)) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")]
+        tex = [np.ascontiguousarray(getattr(scene, n)) for n in ("texcoords", "textures", "texels")]
         desc = SceneDesc(*[a.ctypes.data_as(vp) for a in keep], len(scene.vertices), scene.num_tris, len(scene.nodes), len(scene.tris),
-                         len(scene.materials), len(scene.lights))
+                         len(scene.materials), len(scene.lights), *[a.ctypes.data_as(vp) for a in tex], len(scene.textures), len(scene.texels))
         l.rodent_hip_set_device(dev)
         l.rodent_hip_scene_create(dev, C.byref(desc))
         l.rodent_hip_render_config(dev, spp, max_path_len)

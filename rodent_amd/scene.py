@@ -11,7 +11,8 @@ import numpy as np
 from . import build, formats as F
 
 MATERIAL = np.dtype([("kd", "<f4", (3,)), ("type", "<i4"), ("ks", "<f4", (3,)), ("ns", "<f4"), ("tf", "<f4", (3,)), ("ni", "<f4"),
-                     ("mix_k", "<f4"), ("emissive", "<i4"), ("pad", "<i4", (2,))])
+                     ("mix_k", "<f4"), ("emissive", "<i4"), ("tex_kd", "<i4"), ("tex_ks", "<i4")])
+TEXTURE = np.dtype([("width", "<i4"), ("height", "<i4"), ("offset", "<u4"), ("pad", "<i4")])
 LIGHT = np.dtype([("v0", "<f4", (4,)), ("v1", "<f4", (4,)), ("v2", "<f4", (4,)), ("n", "<f4", (3,)), ("inv_area", "<f4"), ("color", "<f4", (4,))])
 assert MATERIAL.itemsize == 64 and LIGHT.itemsize == 80
 MAGIC = 0x43534452
@@ -22,12 +23,12 @@ class Scene:
 
     def __init__(self, path):
         data = Path(path).read_bytes()
-        hdr = struct.unpack_from("<10I", data, 0)
-        if hdr[0] != MAGIC or hdr[1] != 1:
-            raise ValueError(f"{path}: not a .rscene file")
+        hdr = struct.unpack_from("<12I", data, 0)
+        if hdr[0] != MAGIC or hdr[1] != 2:
+            raise ValueError(f"{path}: not a .rscene file (version 2)")
         self.default_spp, self.default_max_path_len = hdr[2], hdr[3]
-        nv, nt, nn, nbt, nm, nl = hdr[4:10]
-        pos = 40
+        nv, nt, nn, nbt, nm, nl, ntex, ntexels = hdr[4:12]
+        pos = 48
 
         def take(dtype, count):
             nonlocal pos
@@ -43,6 +44,9 @@ class Scene:
         self.materials = take(MATERIAL, nm)
         self.lights = take(LIGHT, nl)
         self.light_ids = take("<i4", nt)
+        self.texcoords = take("<f4", 4 * nv).reshape(-1, 4)
+        self.textures = take(TEXTURE, ntex)
+        self.texels = take("<u4", ntexels)
         if pos != len(data):
             raise ValueError(f"{path}: trailing bytes")
 

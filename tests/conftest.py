@@ -77,3 +77,47 @@ def chain_bvh2(depth, z0=200.0):
         nodes[i]["bounds"] = inner + leaf
         nodes[i]["child"] = [(i + 2) if not last else ~depth, ~i]
     return nodes, tris
+
+
+def write_textured_scene(d):
+    """A small textured room for the texture tests: floor with a PNG checker map_Kd, back wall with a JPEG map_Kd AND a
+    TGA map_Ks (diffuse/Phong mix whose weight varies per texel), a plain red side wall and a ceiling light.  Texture
+    coordinates exceed [0, 1] (repeat border) and are flipped on one quad."""
+    import numpy as np
+    from PIL import Image
+    d.mkdir(parents=True, exist_ok=True)
+    yy, xx = np.mgrid[0:32, 0:32]
+    checker = np.where(((xx // 4 + yy // 4) % 2)[..., None] == 0, np.array([230, 230, 40], np.uint8), np.array([30, 60, 200], np.uint8)).astype(np.uint8)
+    checker[:4, :4] = (255, 0, 0)                                     # orientation marker: top-left of the file
+    Image.fromarray(checker, "RGB").save(d / "checker.png")
+    grad = np.stack([xx * 8, yy * 8, 255 - xx * 4], -1).astype(np.uint8)
+    Image.fromarray(grad, "RGB").resize((48, 24), Image.BILINEAR).save(d / "grad.jpg", quality=95, subsampling=0)
+    spec = ((xx % 8 < 4) * 200).astype(np.uint8)
+    Image.fromarray(np.stack([spec, spec, spec], -1), "RGB").save(d / "spec.tga")
+    (d / "room.mtl").write_text(
+        "newmtl floor\nKd 1 1 1\nmap_Kd checker.png\n"
+        "newmtl back\nKd 0.5 0.5 0.5\nKs 0.3 0.3 0.3\nNs 40\nmap_Kd grad.jpg\nmap_Ks spec.tga\n"
+        "newmtl side\nKd 0.8 0.1 0.1\n"
+        "newmtl lamp\nKd 0 0 0\nKe 12 12 12\n")
+    (d / "room.obj").write_text(
+        "mtllib room.mtl\n"
+        "v -1 0 1\nv 1 0 1\nv 1 0 -1\nv -1 0 -1\n"            # floor 1-4
+        "v -1 0 -1\nv 1 0 -1\nv 1 2 -1\nv -1 2 -1\n"          # back 5-8
+        "v -1 0 1\nv -1 0 -1\nv -1 2 -1\nv -1 2 1\n"          # side 9-12
+        "v -0.4 1.98 0.4\nv 0.4 1.98 0.4\nv 0.4 1.98 -0.4\nv -0.4 1.98 -0.4\n"   # lamp 13-16
+        "vt 0 0\nvt 2.5 0\nvt 2.5 2.5\nvt 0 2.5\n"            # floor: repeats 2.5 times
+        "vt 1 0\nvt 0 0\nvt 0 1\nvt 1 1\n"                    # back: mirrored in u
+        "vt -0.25 -0.25\n"
+        "usemtl floor\nf 1/1 2/2 3/3\nf 1/1 3/3 4/4\n"
+        "usemtl back\nf 5/5 6/6 7/7\nf 5/5 7/7 8/8\n"
+        "usemtl side\nf 9/9 10/9 11/9\nf 9/9 11/9 12/9\n"
+        "usemtl lamp\nf 13/9 15/9 14/9\nf 13/9 16/9 15/9\n")
+    return d / "room.obj"
+
+
+@pytest.fixture(scope="session")
+def textured_scene(native_build, tmp_path_factory):
+    from rodent_amd import scene as S
+    d = tmp_path_factory.mktemp("textured")
+    obj = write_textured_scene(d)
+    return S.convert(obj, d / "room.rscene"), d

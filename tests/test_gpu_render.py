@@ -196,3 +196,35 @@ def test_rodent_cli_megakernel_target(native_build, tmp_path):
     assert imgs["amdgpu-megakernel"].mean() > 40
     bad = subprocess.run(cmd[:-4] + ["--target", "nvvm-streaming"], capture_output=True, text=True)
     assert bad.returncode != 0 and "Unknown target" in bad.stderr
+
+
+@pytest.mark.parametrize("mapping", ["streaming", "megakernel"])
+def test_textured_scene_matches_oracle(R, oracle, textured_scene, mapping):
+    """Textures: map_Kd (PNG, JPEG), map_Ks (TGA) with the per-texel diffuse/Phong mix, repeat border,
+    bilinear filter -- same paths as the CPU oracle: ray counts exact, film within the usual tolerance."""
+    sc, _ = textured_scene
+    W, H = 160, 100
+    cam = S.camera_settings((0.3, 1.0, 3.2), (-0.1, -0.25, -1), (0, 1, 0), 50, W, H)
+    r = R.Renderer(sc, W, H, 4, 8, mapping=mapping)
+    film_o = None
+    for it in range(2):
+        r.render(cam, it)
+        c = r.counters()
+        film_o, counts = oracle.render(sc, cam, it, 4, 8, W, H, film_o)
+        assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1])
+    film_g = r.film()
+    r.close()
+    assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
+    floor = film_g[70:98, 30:130] / 2
+    assert (floor[..., 0] > 1.5 * floor[..., 2]).mean() > 0.1 and (floor[..., 2] > 1.5 * floor[..., 0]).mean() > 0.05
+
+
+def test_rodent_cli_renders_textured_obj(native_build, textured_scene, tmp_path):
+    _, d = textured_scene
+    out = tmp_path / "room.png"
+    subprocess.run([native_build.BIN_DIR / "rodent", "--scene", d / "room.obj", "--eye", "0.3", "1.0", "3.2", "--dir", "-0.1", "-0.25", "-1",
+                    "--up", "0", "1", "0", "--fov", "50", "--width", "240", "--height", "160", "--spp", "8", "--bench", "4", "-o", out],
+                   capture_output=True, text=True, check=True)
+    im = np.asarray(Image.open(out).convert("RGB"), dtype=np.float32)
+    floor = im[115:155, 40:200]
+    assert (floor[..., 0] > 1.3 * floor[..., 2]).mean() > 0.1 and (floor[..., 2] > 1.3 * floor[..., 0]).mean() > 0.05
