@@ -90,18 +90,36 @@ __global__ __launch_bounds__(kBlock) void k_generate(PrimaryStream p, int first_
 // (branch-free node step).  Stack: 16-entry window in LDS, deeper entries in scratch.
 // ---------------------------------------------------------------------------------------------
 constexpr int kLdsStack = 16;
-struct StreamStack {
-    lds_int* col; int spill[kStackCap - kLdsStack]; int* err;
+constexpr int kSpillEntries = kStackCap - kLdsStack;
+// Entries beyond the LDS window: the stream kernels keep them in a slab in HBM ([wave][entry][lane], 12 KiB per wave,
+// 192 MiB for a full stream -- nothing on a 288 GB part) so that the kernels need no scratch segment; the megakernel,
+// whose grid is one workgroup per film tile, keeps them in scratch.
+template <bool GLOBAL_SPILL>
+struct StreamStackT {
+    lds_int* col; int* err;
+    int* slab;                                     // GLOBAL_SPILL: this lane's column of the wave's slab
+    int local[GLOBAL_SPILL ? 1 : kSpillEntries];
     __device__ __forceinline__ int get(int e) const {
         if (__builtin_expect(e < kLdsStack, 1)) return col[e * kWave];
-        return spill[(e < kStackCap ? e : kStackCap - 1) - kLdsStack];
+        const int k = (e < kStackCap ? e : kStackCap - 1) - kLdsStack;
+        return GLOBAL_SPILL ? slab[k * kWave] : local[k];
     }
     __device__ __forceinline__ void put(int e, int v) {
         if (__builtin_expect(e < kLdsStack, 1)) col[e * kWave] = v;
-        else if (e < kStackCap) spill[e - kLdsStack] = v;
+        else if (e < kStackCap) { if (GLOBAL_SPILL) slab[(e - kLdsStack) * kWave] = v; else local[e - kLdsStack] = v; }
         else *err = 1;
     }
 };
+using StreamStack = StreamStackT<false>;
+
+// XCD-aware wave -> chunk mapping of traversal.hip (k_bvh2_single): groups of 32 consecutive 64-ray chunks per XCD.
+__device__ __forceinline__ int xcd_chunk(int block, int total_chunks) {
+    constexpr int G = 32;
+    const int span = 8 * G, full = (total_chunks / span) * span;
+    if (block >= full) return block;
+    const int x = block % 8, l = block / 8;
+    return ((l / G) * 8 + x) * G + l % G;
+}
 
 struct StreamHit { int prim, geom; float t, u, v; };
 
@@ -135,8 +153,8 @@ __device__ __forceinline__ void film_add_wave(float* film, int pixel, bool valid
 
 // Single-step schedule, as k_bvh2_single / unified_chunk in traversal.hip: each lane advances by one node step or
 // one triangle test per wave iteration and the loads of both kinds are in flight together.
-template <bool ANY>
-__device__ __forceinline__ StreamHit trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, StreamStack& st) {
+template <bool ANY, typename Stack>
+__device__ __forceinline__ StreamHit trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, Stack& st) {
     StreamHit hit{-1, -1, ray.tmax, 0.0f, 0.0f};
     int ptr = 0, top = 1; st.put(0, 0);
     const char* const node_base = reinterpret_cast<const char*>(nodes - 1);          // node ids are 1-based
@@ -190,13 +208,15 @@ __device__ __forceinline__ RayX load_stream_ray(const RayStream& r, int i) {   /
 }
 
 // primary: writes geom_id (num_geometries on a miss, driver.impala:106-115), prim_id, t, u, v
-__global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStream p, const int* size_ptr, int n_value, int* err, unsigned long long* counters) {
+__global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStream p, const int* size_ptr, int n_value, int* err, unsigned long long* counters,
+                                                         int* spill) {
     __shared__ int lds[kLdsStack * kWave];
     const int n = stream_size(size_ptr, n_value);
-    const int i = blockIdx.x * kWave + threadIdx.x;
-    if (blockIdx.x * kWave >= n) return;
+    const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+    const int i = chunk * kWave + threadIdx.x;
+    if (chunk * kWave >= n) return;
     if (i >= n) return;
-    StreamStack st; st.col = (lds_int*)lds + threadIdx.x; st.err = err;
+    StreamStackT<true> st; st.col = (lds_int*)lds + threadIdx.x; st.err = err; st.slab = spill + (size_t)blockIdx.x * kSpillEntries * kWave + threadIdx.x;
     const StreamHit h = trace_one<false>(sc.nodes, sc.tris, load_stream_ray(p.rays, i), st);
     p.geom_id[i] = h.prim >= 0 ? h.geom : sc.num_materials;
     p.prim_id[i] = h.prim; p.t[i] = h.t; p.u[i] = h.u; p.v[i] = h.v;
@@ -205,18 +225,19 @@ __global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStr
 
 // secondary: any-hit; unoccluded rays add their colour to the film (mapping_gpu.impala:32-45,47-80)
 __global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
-                                                           int* err, unsigned long long* counters) {
+                                                           int* err, unsigned long long* counters, int* spill) {
     __shared__ int lds[kLdsStack * kWave];
     const int n = stream_size(size_ptr, n_value);
-    const int i = blockIdx.x * kWave + threadIdx.x;
-    if (blockIdx.x * kWave >= n) return;
+    const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+    const int i = chunk * kWave + threadIdx.x;
+    if (chunk * kWave >= n) return;
     const int pixel = i < n ? s.rays.id[i] : -1;
     const unsigned long long live = __ballot(pixel >= 0);
     // striped over 64 words: one counter word saturates near 88 atomics/us and made this kernel 3x slower
     if (threadIdx.x == 0 && live) atomicAdd(&counters[4 + (blockIdx.x & 63)], (unsigned long long)__popcll(live));
     bool lit = false;
     if (pixel >= 0) {
-        StreamStack st; st.col = (lds_int*)lds + threadIdx.x; st.err = err;
+        StreamStackT<true> st; st.col = (lds_int*)lds + threadIdx.x; st.err = err; st.slab = spill + (size_t)blockIdx.x * kSpillEntries * kWave + threadIdx.x;
         lit = trace_one<true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st).prim < 0;
     }
     film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
@@ -507,6 +528,7 @@ struct RenderDevice {
     float* film = nullptr; int film_w = 0, film_h = 0;
     float* slab[3] = {nullptr, nullptr, nullptr}; int slab_cap[3] = {0, 0, 0};       // first primary, second primary, secondary
     int* tmp = nullptr; int tmp_cap = 0;
+    int* spill = nullptr; int spill_waves = 0;     // stack entries beyond the LDS window of the stream traversal kernels
     int* hist = nullptr; size_t hist_cap = 0;
     int* ctl = nullptr;       // [0] primary size, [1] secondary size, [2] error flag, [8..] bin_total, bin_begin, bin_end (kMaxBins each)
     unsigned long long* counters = nullptr;    // [0] primary rays, [1] unused, [2] iterations, [3] generated, [4..67] shadow rays (striped)
@@ -567,6 +589,16 @@ void carve_primary(PrimaryStream& p, float* ptr, size_t cap) {               // 
 void carve_secondary(SecondaryStream& s, float* ptr, size_t cap) {           // interface.cpp:556-563
     carve_rays(s.rays, ptr, cap);
     s.prim_id = (int32_t*)ptr + 9 * cap; s.color_r = ptr + 10 * cap; s.color_g = ptr + 11 * cap; s.color_b = ptr + 12 * cap; s.size = 0; s.pad = 0;
+}
+
+int* ensure_spill(RenderDevice& r, int waves) {
+    if (r.spill_waves < waves) {
+        HIP_CHECK(hipSetDevice(r.dev));
+        if (r.spill) HIP_CHECK(hipFree(r.spill));
+        HIP_CHECK(hipMalloc(&r.spill, sizeof(int) * (size_t)waves * kSpillEntries * kWave));
+        r.spill_waves = waves;
+    }
+    return r.spill;
 }
 
 void ensure_hist(RenderDevice& r, size_t ints) {
@@ -639,6 +671,7 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 3, stream));
     HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * kNumCounters, stream));
     unsigned long long iterations = 0, generated = 0;
+    int* spill = ensure_spill(r, kCapacity / kWave);
     const int* d_valid = bin_end(r, 0) + (G - 1);      // rays that hit something = exclusive end of the last geometry bin (:347-357)
     while (id < num_rays || size > 0) {
         if (size < kCapacity && id < num_rays) {                                         // regenerate (mapping_gpu.impala:332-336)
@@ -648,11 +681,11 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
             id += n; size += n; generated += n;
         }
         const int waves = (size + kWave - 1) / kWave, blocks = (size + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_trace_primary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, *primary, (const int*)nullptr, size, err, r.counters);
+        hipLaunchKernelGGL(k_trace_primary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, *primary, (const int*)nullptr, size, err, r.counters, spill);
         bin_stream(r, 0, *primary, *other, nullptr, size, KEY_GEOM, G + 1, 1, G, stream);    // misses (bin G) are dropped (:347-357)
         std::swap(primary, other);
         hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, d_valid, 0, r.film, inv_spp, r.max_path_len);
-        hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, sec, d_valid, 0, r.film, inv_spp, err, r.counters);
+        hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, sec, d_valid, 0, r.film, inv_spp, err, r.counters, spill);
         bin_stream(r, 1, *primary, *other, d_valid, size, KEY_ALIVE, 2, 0, 1, stream);       // compaction (:267-300)
         std::swap(primary, other);
         HIP_CHECK(hipMemcpyAsync(r.host_pinned, bin_end(r, 1), sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -825,7 +858,9 @@ void hip_generate_rays(int32_t dev, PrimaryStream* primary, int32_t capacity, in
 void hip_traverse_primary(int32_t dev, PrimaryStream* primary, void* stream) {
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
     if (primary->size <= 0) return;
-    hipLaunchKernelGGL(k_trace_primary, dim3((primary->size + kWave - 1) / kWave), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *primary, (const int*)nullptr, primary->size, r.ctl + 2, r.counters);
+    const int waves = (primary->size + kWave - 1) / kWave;
+    hipLaunchKernelGGL(k_trace_primary, dim3(waves), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *primary, (const int*)nullptr, primary->size, r.ctl + 2, r.counters,
+                       ensure_spill(r, waves));
     HIP_CHECK(hipGetLastError());
 }
 
@@ -851,8 +886,9 @@ void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, 
 void hip_traverse_secondary(int32_t dev, SecondaryStream* secondary, void* stream) {
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
     if (secondary->size <= 0) return;
-    hipLaunchKernelGGL(k_trace_secondary, dim3((secondary->size + kWave - 1) / kWave), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *secondary, (const int*)nullptr, secondary->size,
-                       r.film, 1.0f / (float)r.spp, r.ctl + 2, r.counters);
+    const int waves = (secondary->size + kWave - 1) / kWave;
+    hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *secondary, (const int*)nullptr, secondary->size,
+                       r.film, 1.0f / (float)r.spp, r.ctl + 2, r.counters, ensure_spill(r, waves));
     HIP_CHECK(hipGetLastError());
 }
 
