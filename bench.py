@@ -61,6 +61,25 @@ def measured_traffic(kernel):
     return best
 
 
+def measured_issue(kernel, kernel_ms):
+    """VALU occupancy of `kernel` on the primary pass from the committed SQ counter pass (profiles/rNN_traffic.json):
+    fraction of the launch during which the 1024 SIMDs issue VALU instructions (4 cycles per wave64 instruction at
+    2.4 GHz) and the fraction of lanes active in them.  None if no profile of this kernel has been recorded."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_traffic.json")):
+        try:
+            data = json.loads(f.read_text())
+        except ValueError:
+            continue
+        for name, t in data.items():
+            if name.replace(" ", "").startswith(kernel.replace(" ", "").rstrip(">")) and "SQ_ACTIVE_INST_VALU" in t and "SQ_THREAD_CYCLES_VALU" in t:
+                best = {"valu_instructions_per_launch": int(t.get("SQ_INSTS_VALU", 0)),
+                        "valu_busy_frac": round(4.0 * t["SQ_ACTIVE_INST_VALU"] / (kernel_ms * 1e-3 * 2.4e9 * 1024), 4),
+                        "lane_utilisation": round(t["SQ_THREAD_CYCLES_VALU"] / (64.0 * t["SQ_ACTIVE_INST_VALU"]), 4),
+                        "source": f.name}
+    return best
+
+
 def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, dist, any_hit=False):
     """W untimed + K timed launches.  Returns (wall seconds for K steps [max over ranks is taken by
     the caller], mean kernel ms from HIP events recorded on the launch stream)."""
@@ -193,7 +212,8 @@ def main():
                            "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": measured_traffic(abi.kernel_name(width, variant)),
                            "bytes_per_ray": round(bytes_per_ray, 2),
                            "visits_per_ray": {"inner": round(st["inner_per_ray"], 3), "prim": round(st["prims_per_ray"], 3)},
-                           "compulsory_bytes_per_ray": 48, "kernel_ms": round(k_mean, 5)}
+                           "compulsory_bytes_per_ray": 48, "kernel_ms": round(k_mean, 5),
+                           "issue": measured_issue(abi.kernel_name(width, variant), k_mean)}
         # parity spot check on the sample (bit-exact for the order-preserving kernels)
         same = hits[sample].tobytes() == ref_hits.tobytes()
         out["extra"]["sample_bit_exact_vs_oracle"] = bool(same)
