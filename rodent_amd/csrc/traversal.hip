@@ -254,29 +254,38 @@ struct ChunkPerm {
 template <bool ANY, int LDS_N>
 __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, const Ray1* __restrict__ rays,
                                               Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray) {
-    int ray_id = first_ray + (int)threadIdx.x;
-    if (ray_id >= n) ray_id = -1;
+    const int lane_ray = first_ray + (int)threadIdx.x;
+    const int ray_id = lane_ray < n ? lane_ray : -1;
     RayX ray = load_ray(rays, ray_id >= 0 ? ray_id : first_ray);
-    HitAcc hit{-1, ray.tmax, 0.0f, 0.0f};
+    // The hit record lives in memory, not in registers: the miss record is written up front and every accepted
+    // triangle overwrites it (2-3 sixteen-byte stores per ray, off the critical path; same-address stores of one lane
+    // stay in order).  That leaves top, ptr and tmax as the only per-lane state carried around the loop -- with the
+    // record in registers the compiler shuffled it between two register sets every iteration (a fifth of the loop's
+    // VALU instructions were v_mov).
+    if (ray_id >= 0) store_hit(hits, ray_id, -1, ray.tmax, 0.0f, 0.0f);
     int top = ray_id >= 0 ? 1 : 0, ptr = 0;
     col[0] = 0;
-    const char* const node_base = reinterpret_cast<const char*>(nodes - 1);          // node ids are 1-based
-    const char* const tri_base = reinterpret_cast<const char*>(tris);
+    const char* node_base = reinterpret_cast<const char*>(nodes - 1);                // node ids are 1-based
+    const char* tri_base = reinterpret_cast<const char*>(tris);
+    asm volatile("" : "+v"(node_base), "+v"(tri_base));    // keep both bases in VGPRs: the per-lane select below would copy them from SGPRs every iteration
     while (__ballot(top != 0)) {
         if (top != 0) {
             const bool is_node = top > 0;
-            // one address for both kinds, by selects (no divergent address code)
-            const size_t off = is_node ? ((size_t)(unsigned)top << 6) : (size_t)(unsigned)(~top) * sizeof(Tri1);
-            const char* addr = (is_node ? node_base : tri_base) + off;
-            const float4* p = reinterpret_cast<const float4*>(addr);
-            float4 q0 = p[0], q1 = p[1], q2 = p[2];
-            // child ids of a node; a triangle lane re-reads its own last 8 bytes so that the load stays inside the array
-            int2 ch = *reinterpret_cast<const int2*>(addr + (is_node ? 48 : 40));
+            // one address for both kinds: base + index * stride with per-lane selected operands (straight-line code)
+            const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
+            const char* addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            typedef int i32x2 __attribute__((ext_vector_type(2)));
+            const f32x4* p = reinterpret_cast<const f32x4*>(addr);
+            f32x4 q0 = p[0], q1 = p[1], q2 = p[2];
+            // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
+            // inside the array
+            i32x2 ch = *reinterpret_cast<const i32x2*>(addr + (is_node ? 48u : 40u));
             const int popped = col[ptr * kWave];
             // All four loads must be in flight together: without this barrier the compiler narrows the shared loads to
             // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
-            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
-                              "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(ch.x), "+v"(ch.y));
+            // (Whole-vector operands: the loaded register quads stay where the loads put them.)
+            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
             if (is_node) {
                 float te0, te1;
                 const bool h0 = slab(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
@@ -285,27 +294,27 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
                 col[(ptr + 1) * kWave] = c0first ? ch.y : ch.x;
                 top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
                 ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
-                if (ptr >= LDS_N) {
+                if (ptr >= LDS_N) {                                           // deeper than the LDS window: k_bvh2_finish redoes this ray
                     deep_list[atomicAdd(&ctl->deep_count, 1)] = ray_id;
-                    ray_id = -1; top = 0;
+                    top = 0;
                 }
             } else {
                 const int prim_id = __float_as_int(q2.w);
                 const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
                 const float ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
                 const float nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
-                float t = 0.0f, u = 0.0f, v = 0.0f;
-                const bool found = intersect_tri(ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v);
-                hit.id = found ? (prim_id & 0x7FFFFFFF) : hit.id;
-                hit.t = found ? t : hit.t; hit.u = found ? u : hit.u; hit.v = found ? v : hit.v;
-                ray.tmax = found ? t : ray.tmax;
+                float t, u, v;
+                bool found = false;
+                if (intersect_tri(ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v)) {
+                    store_hit(hits, ray_id, prim_id & 0x7FFFFFFF, t, u, v);
+                    ray.tmax = t; found = true;
+                }
                 const bool leave = prim_id < 0;                               // sentinel: the leaf is done
                 top = (ANY && found) ? 0 : (leave ? popped : top - 1);        // top - 1 == ~(j + 1)
                 ptr -= (leave && !(ANY && found)) ? 1 : 0;
             }
         }
     }
-    if (ray_id >= 0) store_hit(hits, ray_id, hit.id, hit.t, hit.u, hit.v);
 }
 
 // BVH2 / Tri1, the default kernel: one 64-ray chunk per wave, single-step schedule (unified_chunk), XCD-aware chunk
