@@ -153,24 +153,28 @@ __device__ __forceinline__ void film_add_wave(float* film, int pixel, bool valid
 
 // Single-step schedule, as k_bvh2_single / unified_chunk in traversal.hip: each lane advances by one node step or
 // one triangle test per wave iteration and the loads of both kinds are in flight together.
-template <bool ANY, typename Stack>
-__device__ __forceinline__ StreamHit trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, Stack& st) {
-    StreamHit hit{-1, -1, ray.tmax, 0.0f, 0.0f};
+// on_hit(prim, geom, t, u, v) is called for every accepted triangle (the last call is the closest hit); returns whether
+// anything was hit.  The stream kernels store from on_hit instead of carrying a hit record in registers.
+template <bool ANY, typename Stack, typename OnHit>
+__device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, Stack& st, OnHit on_hit) {
+    bool any_found = false;
     int ptr = 0, top = 1; st.put(0, 0);
-    const char* const node_base = reinterpret_cast<const char*>(nodes - 1);          // node ids are 1-based
-    const char* const tri_base = reinterpret_cast<const char*>(tris);
+    const char* node_base = reinterpret_cast<const char*>(nodes - 1);                // node ids are 1-based
+    const char* tri_base = reinterpret_cast<const char*>(tris);
+    asm volatile("" : "+v"(node_base), "+v"(tri_base));    // both bases in VGPRs for the per-lane select (see unified_chunk)
     while (__ballot(top != 0)) {
         if (top != 0) {
             const bool is_node = top > 0;
-            const size_t off = is_node ? ((size_t)(unsigned)top << 6) : (size_t)(unsigned)(~top) * sizeof(Tri1);
-            const char* addr = (is_node ? node_base : tri_base) + off;
-            const float4* p = reinterpret_cast<const float4*>(addr);
-            float4 q0 = p[0], q1 = p[1], q2 = p[2];
-            int2 ch = *reinterpret_cast<const int2*>(addr + (is_node ? 48 : 40));   // child ids / (triangle lanes) own last 8 bytes
+            const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
+            const char* addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            typedef int i32x2 __attribute__((ext_vector_type(2)));
+            const f32x4* p = reinterpret_cast<const f32x4*>(addr);
+            f32x4 q0 = p[0], q1 = p[1], q2 = p[2];
+            i32x2 ch = *reinterpret_cast<const i32x2*>(addr + (is_node ? 48u : 40u));   // child ids / (triangle lanes) own last 8 bytes
             const int popped = st.get(ptr);
             // keep all four loads in flight together (see unified_chunk)
-            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
-                              "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(ch.x), "+v"(ch.y));
+            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
             if (is_node) {
                 float te0, te1;
                 const bool h0 = slab(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
@@ -182,18 +186,19 @@ __device__ __forceinline__ StreamHit trace_one(const Node2* __restrict__ nodes, 
             } else {
                 const int prim_id = __float_as_int(q2.w);
                 const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
-                float t = 0.0f, u = 0.0f, v = 0.0f;
-                const bool found = intersect_tri(ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v);
-                hit.prim = found ? (prim_id & 0x7FFFFFFF) : hit.prim; hit.geom = found ? __float_as_int(q1.w) : hit.geom;
-                hit.t = found ? t : hit.t; hit.u = found ? u : hit.u; hit.v = found ? v : hit.v;
-                ray.tmax = found ? t : ray.tmax;
+                float t, u, v;
+                bool found = false;
+                if (intersect_tri(ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v)) {
+                    on_hit(prim_id & 0x7FFFFFFF, __float_as_int(q1.w), t, u, v);
+                    ray.tmax = t; found = true; any_found = true;
+                }
                 const bool leave = prim_id < 0;                               // sentinel: the leaf is done
                 top = (ANY && found) ? 0 : (leave ? popped : top - 1);        // top - 1 == ~(j + 1)
                 ptr -= (leave && !(ANY && found)) ? 1 : 0;
             }
         }
     }
-    return hit;
+    return any_found;
 }
 
 __device__ __forceinline__ RayX make_rayx(float ox, float oy, float oz, float dx, float dy, float dz, float tmin, float tmax) {   // intersection.impala:88-99
@@ -217,9 +222,13 @@ __global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStr
     if (chunk * kWave >= n) return;
     if (i >= n) return;
     StreamStackT<true> st; st.col = (lds_int*)lds + threadIdx.x; st.err = err; st.slab = spill + (size_t)blockIdx.x * kSpillEntries * kWave + threadIdx.x;
-    const StreamHit h = trace_one<false>(sc.nodes, sc.tris, load_stream_ray(p.rays, i), st);
-    p.geom_id[i] = h.prim >= 0 ? h.geom : sc.num_materials;
-    p.prim_id[i] = h.prim; p.t[i] = h.t; p.u[i] = h.u; p.v[i] = h.v;
+    const RayX ray = load_stream_ray(p.rays, i);
+    p.geom_id[i] = sc.num_materials; p.prim_id[i] = -1; p.t[i] = ray.tmax; p.u[i] = 0.0f; p.v[i] = 0.0f;     // the miss record; hits overwrite it
+    trace_one<false>(sc.nodes, sc.tris, ray, st, [&](int prim, int geom, float t, float u, float v) {
+        unsigned k = (unsigned)i;
+        asm volatile("" : "+v"(k));                  // opaque index: SGPR bases + one VGPR offset here, instead of five 64-bit addresses held across the loop
+        p.geom_id[k] = geom; p.prim_id[k] = prim; p.t[k] = t; p.u[k] = u; p.v[k] = v;
+    });
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)n);
 }
 
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, Secondar
     bool lit = false;
     if (pixel >= 0) {
         StreamStackT<true> st; st.col = (lds_int*)lds + threadIdx.x; st.err = err; st.slab = spill + (size_t)blockIdx.x * kSpillEntries * kWave + threadIdx.x;
-        lit = trace_one<true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st).prim < 0;
+        lit = !trace_one<true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {});
     }
     film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
 }
@@ -399,10 +408,10 @@ __global__ __launch_bounds__(kWave) void k_mega(SceneDev sc, CameraDev cam, floa
         ShadeOut o; o.shadow = false; o.s_org = V(0, 0, 0); o.s_dir = V(0, 0, 1); o.s_color = V(0, 0, 0);
         if (has_path) {
             n_primary++;
-            const StreamHit h = trace_one<false>(sc.nodes, sc.tris, make_rayx(pv.org.x, pv.org.y, pv.org.z, pv.dir.x, pv.dir.y, pv.dir.z, tmin, FLT_MAX_REF), st);
-            if (h.prim < 0) done = true;
+            const bool hit_any = trace_one<false>(sc.nodes, sc.tris, make_rayx(pv.org.x, pv.org.y, pv.org.z, pv.dir.x, pv.dir.y, pv.dir.z, tmin, FLT_MAX_REF), st,
+                                                  [&](int prim, int geom, float t, float u, float v) { pv.prim = prim; pv.geom = geom; pv.t = t; pv.u = u; pv.v = v; });
+            if (!hit_any) done = true;
             else {
-                pv.prim = h.prim; pv.geom = h.geom; pv.t = h.t; pv.u = h.u; pv.v = h.v;
                 o = shade_vertex(sc, pv, max_path_len);
                 if (o.emits) final_color = add(final_color, o.emitted);
                 if (o.bounce) { pv.org = o.b_org; pv.dir = o.b_dir; pv.rnd = o.rnd; pv.mis = o.mis; pv.contrib = o.contrib; pv.depth++; tmin = kRayOffset; }
@@ -411,7 +420,8 @@ __global__ __launch_bounds__(kWave) void k_mega(SceneDev sc, CameraDev cam, floa
         }
         if (o.shadow) {
             n_shadow++;
-            const bool lit = trace_one<true>(sc.nodes, sc.tris, make_rayx(o.s_org.x, o.s_org.y, o.s_org.z, o.s_dir.x, o.s_dir.y, o.s_dir.z, kRayOffset, 1.0f - kRayOffset), st).prim < 0;
+            const bool lit = !trace_one<true>(sc.nodes, sc.tris, make_rayx(o.s_org.x, o.s_org.y, o.s_org.z, o.s_dir.x, o.s_dir.y, o.s_dir.z, kRayOffset, 1.0f - kRayOffset), st,
+                                              [](int, int, float, float, float) {});
             if (lit) final_color = add(final_color, o.s_color);
         }
         film_add_wave(film, pv.pixel, done, final_color.x * inv_spp, final_color.y * inv_spp, final_color.z * inv_spp);
