@@ -263,6 +263,7 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
     // record in registers the compiler shuffled it between two register sets every iteration (a fifth of the loop's
     // VALU instructions were v_mov).
     if (ray_id >= 0) store_hit(hits, ray_id, -1, ray.tmax, 0.0f, 0.0f);
+    ray.tmin = canonical(ray.tmin); ray.tmax = canonical(ray.tmax);      // see slab_canonical (after the miss record: it keeps the file's bits)
     int top = ray_id >= 0 ? 1 : 0, ptr = 0;
     col[0] = 0;
     const char* node_base = reinterpret_cast<const char*>(nodes - 1);                // node ids are 1-based
@@ -288,8 +289,8 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
             asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
             if (is_node) {
                 float te0, te1;
-                const bool h0 = slab(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
-                const bool h1 = slab(ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
+                const bool h0 = slab_canonical(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
+                const bool h1 = slab_canonical(ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
                 const bool c0first = te0 < te1, both = h0 && h1;
                 col[(ptr + 1) * kWave] = c0first ? ch.y : ch.x;
                 top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));

@@ -63,6 +63,24 @@ __device__ __forceinline__ bool slab(const RayX& r, float lox, float hix, float 
     return tentry <= texit;
 }
 
+// slab() for loops that keep r.tmin / r.tmax CANONICAL (quieted once with canonical() when the ray is loaded; later
+// tmax values are results of a division).  fmaxf / fminf must quiet a signalling NaN operand first, and the compiler
+// cannot see across loop iterations that these two already are: it re-canonicalises both in every iteration (two
+// v_max_f32 x, x).  The two operations that touch them are therefore issued as plain v_max_f32 / v_min_f32, which on
+// canonical operands compute exactly fmaxf / fminf.
+__device__ __forceinline__ float canonical(float x) { return __builtin_canonicalizef(x); }
+__device__ __forceinline__ bool slab_canonical(const RayX& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float& tentry) {
+    const f32x2 tx = __builtin_elementwise_fma((f32x2){r.idx, r.idx}, (f32x2){lox, hix}, (f32x2){r.iox, r.iox});
+    const f32x2 ty = __builtin_elementwise_fma((f32x2){r.idy, r.idy}, (f32x2){loy, hiy}, (f32x2){r.ioy, r.ioy});
+    const f32x2 tz = __builtin_elementwise_fma((f32x2){r.idz, r.idz}, (f32x2){loz, hiz}, (f32x2){r.ioz, r.ioz});
+    float nz, fz;
+    asm("v_max_f32 %0, %1, %2" : "=v"(nz) : "v"(fminf(tz.x, tz.y)), "v"(r.tmin));
+    asm("v_min_f32 %0, %1, %2" : "=v"(fz) : "v"(fmaxf(tz.x, tz.y)), "v"(r.tmax));
+    tentry = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), nz);
+    const float texit = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fz);
+    return tentry <= texit;
+}
+
 // intersection.impala:164-192, no back-face culling
 __device__ __forceinline__ bool intersect_tri(const RayX& r,
                                               float v0x, float v0y, float v0z, float e1x, float e1y, float e1z,
