@@ -106,6 +106,27 @@ def test_chunk_mapping_is_a_bijection(gpu, cornell, cornell_dev, n):
     assert (out["fast"]["tri_id"] >= -1).all() and (out["fast"]["tri_id"] < 64).all()
 
 
+def test_special_tmin_tmax_values(gpu, oracle, cornell, cornell_dev):
+    """tmin / tmax taken from {0, -0, denormal, +-inf, quiet NaN, signalling NaN, ...}: the reference's fminf / fmaxf box test
+    ignores a NaN bound, the triangle test's comparisons reject it; every variant must reproduce the oracle bit for bit,
+    the NaN payload of a miss record included (the default kernel issues raw v_max/v_min on canonicalised bounds)."""
+    specials = np.array([0x00000000, 0x80000000, 0x00000001, 0x7F800000, 0xFF800000, 0x7FC00000, 0x7FA00001, 0xFFC12345,
+                         0x40A00000, 0xBF800000, 0x3C23D70A, 0x7F7FFFFF], dtype="<u4").view("<f4")
+    base = cornell.ray_sets["primary"][:len(specials) ** 2 * 4].copy()
+    k = np.arange(len(base))
+    base["tmin"] = specials[k % len(specials)]
+    base["tmax"] = specials[(k // len(specials)) % len(specials)]
+    nodes, tris = F.read_bvh(cornell.bvh_path, F.BVH2_TRI1)
+    for any_hit in (False, True):
+        exp, _ = oracle.traverse(2, nodes, tris, base, any_hit=any_hit)
+        for v in variants(gpu, 2):
+            got = gpu.traverse(cornell_dev[2], base, any_hit=any_hit, variant=v)
+            if any_hit:
+                assert np.array_equal(got["tri_id"] >= 0, exp["tri_id"] >= 0), gpu.variants(2)[v]
+            else:
+                assert got.tobytes() == exp.tobytes(), gpu.variants(2)[v]
+
+
 def test_deep_stack_falls_back_to_global_stack(gpu, oracle):
     """Stacks deeper than the LDS window (16 entries) take the deep-ray epilogue / scratch spill;
     results must not change.  Mix deep and shallow rays in one wave and across waves."""
