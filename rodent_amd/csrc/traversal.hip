@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kWave) void k_bvh2_finish(const Node2* __restrict__
             store_hit(hits, i, hit.id, hit.t, hit.u, hit.v);
         }
     }
-    if (threadIdx.x == 0) { ctl->counter = 0; ctl->deep_count = 0; }      // ready for the next launch
+    if (threadIdx.x == 0) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; }   // stats[7]: rays handed over (read by the tests); ready for the next launch
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -264,7 +264,9 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
     // VALU instructions were v_mov).
     if (ray_id >= 0) store_hit(hits, ray_id, -1, ray.tmax, 0.0f, 0.0f);
     ray.tmin = canonical(ray.tmin); ray.tmax = canonical(ray.tmax);      // see slab_canonical (after the miss record: it keeps the file's bits)
-    int top = ray_id >= 0 ? 1 : 0, ptr = 0;
+    int top = ray_id >= 0 ? 1 : 0;
+    lds_int* sp = col;                             // the stack entry under the top (entry `ptr` of the other kernels)
+    lds_int* const sp_limit = col + LDS_N * kWave;
     col[0] = 0;
     const char* node_base = reinterpret_cast<const char*>(nodes - 1);                // node ids are 1-based
     const char* tri_base = reinterpret_cast<const char*>(tris);
@@ -282,7 +284,7 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
             // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
             // inside the array
             i32x2 ch = *reinterpret_cast<const i32x2*>(addr + (is_node ? 48u : 40u));
-            const int popped = col[ptr * kWave];
+            const int popped = *sp;
             // All four loads must be in flight together: without this barrier the compiler narrows the shared loads to
             // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
             // (Whole-vector operands: the loaded register quads stay where the loads put them.)
@@ -292,10 +294,10 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
                 const bool h0 = slab_canonical(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
                 const bool h1 = slab_canonical(ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
                 const bool c0first = te0 < te1, both = h0 && h1;
-                col[(ptr + 1) * kWave] = c0first ? ch.y : ch.x;
+                sp[kWave] = c0first ? ch.y : ch.x;
                 top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
-                ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
-                if (ptr >= LDS_N) {                                           // deeper than the LDS window: k_bvh2_finish redoes this ray
+                sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
+                if (both && sp >= sp_limit) {                                 // (`both`: popping the sentinel moves sp below col, which wraps)                                           // deeper than the LDS window: k_bvh2_finish redoes this ray
                     deep_list[atomicAdd(&ctl->deep_count, 1)] = ray_id;
                     top = 0;
                 }
@@ -312,7 +314,7 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
                 }
                 const bool leave = prim_id < 0;                               // sentinel: the leaf is done
                 top = (ANY && found) ? 0 : (leave ? popped : top - 1);        // top - 1 == ~(j + 1)
-                ptr -= (leave && !(ANY && found)) ? 1 : 0;
+                sp -= (leave && !(ANY && found)) ? kWave : 0;
             }
         }
     }

@@ -9,7 +9,12 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ambiguous_mask
+from conftest import GOLDEN as GOLDEN_DIR, ambiguous_mask
+
+
+def cornell_bvh_path():
+    return GOLDEN_DIR / "cornell.bvh"
+
 from rodent_amd import formats as F
 
 pytestmark = pytest.mark.gpu
@@ -146,6 +151,15 @@ def test_deep_stack_falls_back_to_global_stack(gpu, oracle):
             assert got.tobytes() == ref.tobytes(), f"variant {v} any={any_hit}"
         # and again: the launch counters must have been reset by the epilogue
         assert gpu.traverse(bvh, rays, any_hit=any_hit, variant=0).tobytes() == ref.tobytes()
+    # the follow-up kernel is for the deep rays only: it traces one wave at a time, so a kernel that hands over rays it
+    # could finish itself stays correct and gets 1000x slower (stats word 7 = rays handed over, summed by k_bvh2_finish)
+    gpu.read_stats()
+    gpu.traverse(bvh, rays, variant=0)
+    deep = gpu.read_stats()[7]
+    assert 0 < deep <= int((ref["tri_id"] >= 0).sum())           # only rays that enter the 40-deep chain
+    cb = gpu.DeviceBvh.load(cornell_bvh_path(), 2, 0)
+    gpu.traverse(cb, F.read_rays(GOLDEN_DIR / "cornell-primary-64x64.rays", 0.0, 100.0), variant=0)
+    assert gpu.read_stats()[7] == 0
 
 
 @pytest.mark.parametrize("width", [2, 8])
