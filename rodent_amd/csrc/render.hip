@@ -159,19 +159,21 @@ template <bool ANY, typename Stack, typename OnHit>
 __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, Stack& st, OnHit on_hit) {
     bool any_found = false;
     int ptr = 0, top = 1; st.put(0, 0);
-    const char* node_base = reinterpret_cast<const char*>(nodes - 1);                // node ids are 1-based
-    const char* tri_base = reinterpret_cast<const char*>(tris);
-    asm volatile("" : "+v"(node_base), "+v"(tri_base));    // both bases in VGPRs for the per-lane select (see unified_chunk)
+    // both bases as integers in VGPRs for the per-lane select, then GLOBAL pointers again (see unified_chunk)
+    typedef const __attribute__((address_space(1))) char* gptr;
+    unsigned long long node_bits = reinterpret_cast<unsigned long long>(nodes - 1), tri_bits = reinterpret_cast<unsigned long long>(tris);   // node ids are 1-based
+    asm volatile("" : "+v"(node_bits), "+v"(tri_bits));
+    const gptr node_base = (gptr)node_bits, tri_base = (gptr)tri_bits;
     while (__ballot(top != 0)) {
         if (top != 0) {
             const bool is_node = top > 0;
             const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
-            const char* addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
+            const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             typedef int i32x2 __attribute__((ext_vector_type(2)));
-            const f32x4* p = reinterpret_cast<const f32x4*>(addr);
+            const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
             f32x4 q0 = p[0], q1 = p[1], q2 = p[2];
-            i32x2 ch = *reinterpret_cast<const i32x2*>(addr + (is_node ? 48u : 40u));   // child ids / (triangle lanes) own last 8 bytes
+            i32x2 ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));   // child ids / (triangle lanes) own last 8 bytes
             const int popped = st.get(ptr);
             // keep all four loads in flight together (see unified_chunk)
             asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));

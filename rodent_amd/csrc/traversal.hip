@@ -268,22 +268,27 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
     lds_int* sp = col;                             // the stack entry under the top (entry `ptr` of the other kernels)
     lds_int* const sp_limit = col + LDS_N * kWave;
     col[0] = 0;
-    const char* node_base = reinterpret_cast<const char*>(nodes - 1);                // node ids are 1-based
-    const char* tri_base = reinterpret_cast<const char*>(tris);
-    asm volatile("" : "+v"(node_base), "+v"(tri_base));    // keep both bases in VGPRs: the per-lane select below would copy them from SGPRs every iteration
+    // Both bases as 64-bit integers in VGPRs (the per-lane select below would otherwise copy them from SGPRs in every
+    // iteration), turned back into GLOBAL pointers: laundering the pointers themselves leaves generic ones and flat loads.
+    typedef const __attribute__((address_space(1))) char* gptr;
+    unsigned long long node_bits = reinterpret_cast<unsigned long long>(nodes - 1), tri_bits = reinterpret_cast<unsigned long long>(tris);   // node ids are 1-based
+    asm volatile("" : "+v"(node_bits), "+v"(tri_bits));
+    const gptr node_base = (gptr)node_bits, tri_base = (gptr)tri_bits;
     while (__ballot(top != 0)) {
         if (top != 0) {
             const bool is_node = top > 0;
             // one address for both kinds: base + index * stride with per-lane selected operands (straight-line code)
             const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
-            const char* addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
+            const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             typedef int i32x2 __attribute__((ext_vector_type(2)));
-            const f32x4* p = reinterpret_cast<const f32x4*>(addr);
+            const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
             f32x4 q0 = p[0], q1 = p[1], q2 = p[2];
             // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
             // inside the array
-            i32x2 ch = *reinterpret_cast<const i32x2*>(addr + (is_node ? 48u : 40u));
+            i32x2 ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
+            // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
+            // inside the array
             const int popped = *sp;
             // All four loads must be in flight together: without this barrier the compiler narrows the shared loads to
             // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
