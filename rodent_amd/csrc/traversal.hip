@@ -287,8 +287,6 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
             // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
             // inside the array
             i32x2 ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
-            // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
-            // inside the array
             const int popped = *sp;
             // All four loads must be in flight together: without this barrier the compiler narrows the shared loads to
             // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
