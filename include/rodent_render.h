@@ -77,6 +77,9 @@ void    rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len)
  * amdgpu-megakernel / nvvm-megakernel, converter.cpp:30-35,1032-1037; `rodent --target amdgpu-megakernel` here).
  * The initial value can also be set with the environment variable RODENT_HIP_MAPPING=streaming|mega. */
 void    rodent_hip_render_mapping(int32_t dev, int32_t mapping);
+/* Rays per ray stream of the streaming mapping: the reference's constant 1 Mi (mapping_gpu.impala:319) is 8 Mi here
+ * by default (larger launches amortise their fill and drain on a 256-CU chip; 0 restores the default). */
+void    rodent_hip_render_capacity(int32_t dev, int32_t rays);
 
 /* ---- the reference's renderer ABI ---- */
 int32_t get_spp(void);

@@ -63,11 +63,13 @@ def test_row_bands_reproduce_the_frame(R, oracle, cornell_scene):
     assert np.allclose(full, ref, rtol=FILM_RTOL, atol=FILM_ATOL)
 
 
-def test_capacity_regeneration(R, oracle, cornell_scene):
-    """More than 1 Mi paths per frame: the stream is refilled while it drains (mapping_gpu.impala:332-336)."""
-    W, H, SPP = 640, 480, 5                       # 1 536 000 paths > capacity
+@pytest.mark.parametrize("capacity", [1 << 20, 100_000, 4096])
+def test_capacity_regeneration(R, oracle, cornell_scene, capacity):
+    """More paths per frame than a stream holds: the stream is refilled while it drains (mapping_gpu.impala:332-336).
+    The reference's capacity (1 Mi), an odd one and a tiny one; the default (8 Mi) is what the other tests run with."""
+    W, H, SPP = (640, 480, 5) if capacity == 1 << 20 else (200, 150, 3)       # 1 536 000 / 90 000 paths > capacity
     cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
-    r = R.Renderer(cornell_scene, W, H, SPP, 6)
+    r = R.Renderer(cornell_scene, W, H, SPP, 6, capacity=capacity)
     r.render(cam, 0)
     c = r.counters(); film_g = r.film(); r.close()
     film_o, counts = oracle.render(cornell_scene, cam, 0, SPP, 6, W, H)
