@@ -9,7 +9,8 @@
 //   mesh buffers padded to float4 / int4 like the GPU targets                 converter.cpp:629-632,403-426
 //   BVH2/Tri1 with geom_id = material id                                      converter.cpp:262-383,713-720
 //   map_Kd / map_Ks textures (PNG, JPEG, TGA next to the OBJ) loaded into one RGBA8 pool        converter.cpp:595-610,749-768
-// map_Ke (textured emitters) is not supported: such lights use their constant Ke.
+// map_Ke (textured emitters): such lights use their constant Ke.  (The reference emits `make_triangle_light(math, v0, v1, v2,
+// make_texture(...))` for it, converter.cpp:795-803, which passes a Texture where light.impala:140 takes a Color -- it cannot compile.)
 #pragma once
 #include <string>
 #include <vector>
