@@ -80,6 +80,10 @@ void    rodent_hip_render_mapping(int32_t dev, int32_t mapping);
 /* Rays per ray stream of the streaming mapping: the reference's constant 1 Mi (mapping_gpu.impala:319) is 8 Mi here
  * by default (larger launches amortise their fill and drain on a 256-CU chip; 0 restores the default). */
 void    rodent_hip_render_capacity(int32_t dev, int32_t rays);
+/* 1 (default): hit rays are sorted by material before shading and misses dropped, as in the reference
+ * (mapping_gpu.impala:166-221,347-357).  0: no sort -- the table-driven shader runs in stream order and ends the rays that
+ * missed; one stream copy less per bounce.  Same paths, same ray counts; RODENT_HIP_SORT=0|1 sets the initial value. */
+void    rodent_hip_render_sort(int32_t dev, int32_t enable);
 
 /* ---- the reference's renderer ABI ---- */
 int32_t get_spp(void);

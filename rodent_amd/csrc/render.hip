@@ -342,21 +342,28 @@ __device__ __forceinline__ ShadeOut shade_vertex(const SceneDev& sc, const PathV
 }
 
 __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, SecondaryStream s, const int* size_ptr, int n_value, float* film,
-                                                   float inv_spp, int max_path_len) {
+                                                   float inv_spp, int max_path_len, int unsorted) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int n_valid = stream_size(size_ptr, n_value);
     if ((int)(blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave) >= n_valid) return;     // whole wave beyond the stream
-    if (i >= n_valid) { film_add_wave(film, -1, false, 0.0f, 0.0f, 0.0f); return; }
-    PathVertex pv;
-    pv.pixel = p.rays.id[i];
-    pv.org = V(p.rays.org_x[i], p.rays.org_y[i], p.rays.org_z[i]); pv.dir = V(p.rays.dir_x[i], p.rays.dir_y[i], p.rays.dir_z[i]);
-    pv.prim = p.prim_id[i]; pv.geom = p.geom_id[i]; pv.t = p.t[i]; pv.u = p.u[i]; pv.v = p.v[i];
-    pv.rnd = p.rnd[i]; pv.mis = p.mis[i];
-    pv.contrib = V(p.contrib_r[i], p.contrib_g[i], p.contrib_b[i]);
-    pv.depth = p.depth[i];
-    const ShadeOut o = shade_vertex(sc, pv, max_path_len);
-
-    film_add_wave(film, pv.pixel, o.emits, o.emitted.x * inv_spp, o.emitted.y * inv_spp, o.emitted.z * inv_spp);
+    // Every lane of the wave reaches the ONE film_add_wave call below (it reduces across lanes with shuffles, which must
+    // not read lanes that took another path): lanes beyond the stream and rays that missed take part with nothing to add.
+    const bool in_range = i < n_valid;
+    const bool live = in_range && !(unsorted && p.geom_id[i] >= sc.num_materials);
+    if (in_range && !live) { p.rays.id[i] = -1; s.rays.id[i] = -1; }                       // unsorted stream: a ray that missed ends here
+    PathVertex pv; pv.pixel = -1; pv.depth = 0;
+    ShadeOut o; o.emits = false; o.shadow = false; o.bounce = false; o.emitted = V(0, 0, 0);
+    if (live) {
+        pv.pixel = p.rays.id[i];
+        pv.org = V(p.rays.org_x[i], p.rays.org_y[i], p.rays.org_z[i]); pv.dir = V(p.rays.dir_x[i], p.rays.dir_y[i], p.rays.dir_z[i]);
+        pv.prim = p.prim_id[i]; pv.geom = p.geom_id[i]; pv.t = p.t[i]; pv.u = p.u[i]; pv.v = p.v[i];
+        pv.rnd = p.rnd[i]; pv.mis = p.mis[i];
+        pv.contrib = V(p.contrib_r[i], p.contrib_g[i], p.contrib_b[i]);
+        pv.depth = p.depth[i];
+        o = shade_vertex(sc, pv, max_path_len);
+    }
+    film_add_wave(film, pv.pixel, live && o.emits, o.emitted.x * inv_spp, o.emitted.y * inv_spp, o.emitted.z * inv_spp);
+    if (!live) return;
 
     // the secondary ray is written at the SAME index (mapping_gpu.impala:111-115)
     if (o.shadow) {
@@ -546,6 +553,7 @@ struct RenderDevice {
     DevScene scene;
     int spp = 4, max_path_len = 64;
     int capacity = 0;                          // rays per stream; 0 = default (env_capacity())
+    int sort = 1;                              // 1 = sort hit rays by material before shading (mapping_gpu.impala:166-221), 0 = shade in stream order
     int mapping = 0;                           // 0 = streaming wavefront (mapping_gpu.impala:308-369), 1 = megakernel (:371-474)
     float* film = nullptr; int film_w = 0, film_h = 0;
     float* slab[3] = {nullptr, nullptr, nullptr}; int slab_cap[3] = {0, 0, 0};       // first primary, second primary, secondary
@@ -575,6 +583,7 @@ RenderDevice& rdev(int dev) {
         HIP_CHECK(hipMalloc(&r.counters, sizeof(unsigned long long) * kNumCounters));
         HIP_CHECK(hipMemset(r.counters, 0, sizeof(unsigned long long) * kNumCounters));
         HIP_CHECK(hipHostMalloc(&r.host_pinned, sizeof(int) * (8 + kMaxBins)));
+        if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
         if (const char* m = getenv("RODENT_HIP_MAPPING")) {
             if (!strcmp(m, "mega") || !strcmp(m, "megakernel") || !strcmp(m, "1")) r.mapping = 1;
             else if (strcmp(m, "streaming") && strcmp(m, "0")) { fprintf(stderr, "rodent_hip: RODENT_HIP_MAPPING must be 'streaming' or 'mega'\n"); abort(); }
@@ -705,11 +714,17 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
         }
         const int waves = (size + kWave - 1) / kWave, blocks = (size + kBlock - 1) / kBlock;
         hipLaunchKernelGGL(k_trace_primary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, *primary, (const int*)nullptr, size, err, r.counters, spill);
-        bin_stream(r, 0, *primary, *other, nullptr, size, KEY_GEOM, G + 1, 1, G, stream);    // misses (bin G) are dropped (:347-357)
-        std::swap(primary, other);
-        hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, d_valid, 0, r.film, inv_spp, r.max_path_len);
-        hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, sec, d_valid, 0, r.film, inv_spp, err, r.counters, spill);
-        bin_stream(r, 1, *primary, *other, d_valid, size, KEY_ALIVE, 2, 0, 1, stream);       // compaction (:267-300)
+        if (r.sort) {
+            bin_stream(r, 0, *primary, *other, nullptr, size, KEY_GEOM, G + 1, 1, G, stream);    // misses (bin G) are dropped (:347-357)
+            std::swap(primary, other);
+            hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, d_valid, 0, r.film, inv_spp, r.max_path_len, 0);
+            hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, sec, d_valid, 0, r.film, inv_spp, err, r.counters, spill);
+            bin_stream(r, 1, *primary, *other, d_valid, size, KEY_ALIVE, 2, 0, 1, stream);       // compaction (:267-300)
+        } else {                                     // option: no sort by material -- shade in stream order, misses end in the shader
+            hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, (const int*)nullptr, size, r.film, inv_spp, r.max_path_len, 1);
+            hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, sec, (const int*)nullptr, size, r.film, inv_spp, err, r.counters, spill);
+            bin_stream(r, 1, *primary, *other, nullptr, size, KEY_ALIVE, 2, 0, 1, stream);
+        }
         std::swap(primary, other);
         HIP_CHECK(hipMemcpyAsync(r.host_pinned, bin_end(r, 1), sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -804,6 +819,8 @@ void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
     if (spp < 1 || max_path_len < 0) { fprintf(stderr, "rodent_hip: invalid render configuration\n"); abort(); }
     RenderDevice& r = rdev(dev); r.spp = spp; r.max_path_len = max_path_len;
 }
+
+void rodent_hip_render_sort(int32_t dev, int32_t enable) { rdev(dev).sort = enable ? 1 : 0; }
 
 void rodent_hip_render_capacity(int32_t dev, int32_t rays) {
     if (rays != 0 && (rays < 64 || rays > kMaxCapacity)) { fprintf(stderr, "rodent_hip: stream capacity must be 0 (default) or 64 .. %ld rays\n", kMaxCapacity); abort(); }
@@ -907,7 +924,7 @@ void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, 
     primary->size = num_rays; secondary->size = num_rays;
     if (num_rays <= 0) return;
     hipLaunchKernelGGL(k_shade, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, r.scene.dev, *primary, *secondary, (const int*)nullptr, num_rays, r.film,
-                       1.0f / (float)r.spp, r.max_path_len);
+                       1.0f / (float)r.spp, r.max_path_len, 0);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -9,6 +9,7 @@
 //   --max-path-len n    maximum path length                (default: the scene file's, 64)
 //   -dev n              HIP device                          (default 0)
 //   --target t          amdgpu-streaming (default) or amdgpu-megakernel (converter.cpp:30-35,1032-1037)
+//   --no-sort           streaming target: shade in stream order instead of sorting hit rays by material first
 // Without --bench the reference opens an SDL window and renders until it is closed; this build is
 // headless (DISABLE_GUI, driver.cpp:236-242), so --bench or -o is required.
 #include <algorithm>
@@ -32,6 +33,7 @@ static void usage() {
               << "   --max-path-len n    Maximum path length\n"
               << "   -dev     n          GPU device index\n"
               << "   --target t          amdgpu-streaming (default) or amdgpu-megakernel\n"
+              << "   --no-sort           Do not sort rays by material before shading (streaming target)\n"
               << "   --width  pixels     Sets the viewport horizontal dimension (in pixels)\n"
               << "   --height pixels     Sets the viewport vertical dimension (in pixels)\n"
               << "   --eye    x y z      Sets the position of the camera\n"
@@ -50,6 +52,7 @@ int main(int argc, char** argv) {
     float fov = 60.0f;
     V3 eye(0.0f), dir(0.0f, 0.0f, 1.0f), up(0.0f, 1.0f, 0.0f);
     int spp = 0, max_path_len = -1, dev = 0, mapping = -1;
+    bool no_sort = false;
 
     for (int i = 1; i < argc; ++i) {
         if (argv[i][0] != '-') fail(std::string("Unexpected argument '") + argv[i] + "'");
@@ -66,6 +69,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--spp")) { need(1); spp = strtol(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "--max-path-len")) { need(1); max_path_len = strtol(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "-dev")) { need(1); dev = strtol(argv[++i], nullptr, 10); }
+        else if (!strcmp(argv[i], "--no-sort")) no_sort = true;
         else if (!strcmp(argv[i], "--target")) {
             need(1); ++i;
             if (!strcmp(argv[i], "amdgpu-streaming") || !strcmp(argv[i], "amdgpu")) mapping = 0;
@@ -96,6 +100,7 @@ int main(int argc, char** argv) {
     rodent_hip_scene_create(dev, &desc);
     rodent_hip_render_config(dev, spp, max_path_len);
     if (mapping >= 0) rodent_hip_render_mapping(dev, mapping);
+    if (no_sort) rodent_hip_render_sort(dev, 0);
     setup_interface(width, height);
     clear_pixels();
 

@@ -46,6 +46,25 @@ def test_film_matches_oracle(R, oracle, cornell_scene, spp, max_len, iters):
     assert film_g.mean() > 0.02
 
 
+@pytest.mark.parametrize("scene_name", ["cornell", "textured"])
+def test_unsorted_shading_traces_the_same_paths(R, oracle, cornell_scene, textured_scene, scene_name):
+    """rodent_hip_render_sort(0): no sort by material, the shader ends the rays that missed -- same paths as the oracle."""
+    sc = cornell_scene if scene_name == "cornell" else textured_scene[0]
+    eye, d = ((0, 1, 2.7), (0, 0, -1)) if scene_name == "cornell" else ((0.3, 1.0, 3.2), (-0.1, -0.25, -1))
+    W, H = 180, 110
+    cam = S.camera_settings(eye, d, (0, 1, 0), 55, W, H)
+    r = R.Renderer(sc, W, H, 3, 7, sort=False, capacity=20000)
+    film_o = None
+    for it in range(2):
+        r.render(cam, it)
+        c = r.counters()
+        film_o, counts = oracle.render(sc, cam, it, 3, 7, W, H, film_o)
+        assert (c["primary_rays"], c["shadow_rays"], c["generated"]) == (counts[0], counts[1], W * H * 3)
+    film_g = r.film()
+    r.close()
+    assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
+
+
 def test_row_bands_reproduce_the_frame(R, oracle, cornell_scene):
     """Tile sharding (multi-GPU path): bands rendered separately sum to the full frame."""
     W, H = 160, 96
