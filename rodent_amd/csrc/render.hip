@@ -96,30 +96,43 @@ __global__ __launch_bounds__(kBlock) void k_generate(PrimaryStream p, int first_
 // ---------------------------------------------------------------------------------------------
 // K1 / K6: BVH2 traversal over an SoA ray stream.  Per-ray visit order = the reference kernel
 // (traversal/mapping_gpu.impala:94-178); wave scheduling = the single-step loop of traversal.hip
-// (branch-free node step).  Stack: 16-entry window in LDS, deeper entries in scratch.
+// (branch-free node step).  Stack: 16-entry window in LDS; deeper rays go to k_trace_deep (stream kernels) / scratch (megakernel).
 // ---------------------------------------------------------------------------------------------
 constexpr int kLdsStack = 16;
 constexpr int kSpillEntries = kStackCap - kLdsStack;
-// Entries beyond the LDS window: the stream kernels keep them in a slab in HBM ([wave][entry][lane], 12 KiB per wave,
-// 192 MiB for a full stream -- nothing on a 288 GB part) so that the kernels need no scratch segment; the megakernel,
-// whose grid is one workgroup per film tile, keeps them in scratch.
-template <bool GLOBAL_SPILL>
+// Stack of the megakernel (one workgroup per film tile): 16-entry window in LDS, deeper entries in scratch.
+template <bool UNUSED>
 struct StreamStackT {
     lds_int* col; int* err;
-    int* slab;                                     // GLOBAL_SPILL: this lane's column of the wave's slab
-    int local[GLOBAL_SPILL ? 1 : kSpillEntries];
+    int local[kSpillEntries];
     __device__ __forceinline__ int get(int e) const {
         if (__builtin_expect(e < kLdsStack, 1)) return col[e * kWave];
-        const int k = (e < kStackCap ? e : kStackCap - 1) - kLdsStack;
-        return GLOBAL_SPILL ? slab[k * kWave] : local[k];
+        return local[(e < kStackCap ? e : kStackCap - 1) - kLdsStack];
     }
     __device__ __forceinline__ void put(int e, int v) {
         if (__builtin_expect(e < kLdsStack, 1)) col[e * kWave] = v;
-        else if (e < kStackCap) { if (GLOBAL_SPILL) slab[(e - kLdsStack) * kWave] = v; else local[e - kLdsStack] = v; }
+        else if (e < kStackCap) local[e - kLdsStack] = v;
         else *err = 1;
     }
 };
 using StreamStack = StreamStackT<false>;
+
+// LDS-only stack of the stream traversal kernels, kept as a cursor (pointer to the entry under the top).  A ray whose
+// stack outgrows the 16-entry window is abandoned (overflow = true) and traced again by k_trace_deep with the
+// 64-entry stack in global memory -- the arrangement of traversal.hip (k_bvh2_single / k_bvh2_finish): no overflow
+// handling inside the hot loop.
+struct CursorStack {
+    lds_int* sp; lds_int* limit; bool overflow;
+    __device__ __forceinline__ void init(lds_int* col) { sp = col; limit = col + kLdsStack * kWave; overflow = false; col[0] = 0; }
+};
+// 64 entries in global memory ([entry][lane]), the reference's capacity (stack.impala:53); used by k_trace_deep only.
+struct DeepStack {
+    int* base; int* err;
+    __device__ __forceinline__ int get(int e) const { return base[(e < kStackCap ? e : kStackCap - 1) * kWave]; }
+    __device__ __forceinline__ void put(int e, int v) { if (e < kStackCap) base[e * kWave] = v; else *err = 1; }
+};
+template <typename T> struct is_cursor { static constexpr bool value = false; };
+template <> struct is_cursor<CursorStack> { static constexpr bool value = true; };
 
 // XCD-aware wave -> chunk mapping of traversal.hip (k_bvh2_single): groups of 32 consecutive 64-ray chunks per XCD.
 __device__ __forceinline__ int xcd_chunk(int block, int total_chunks) {
@@ -166,8 +179,11 @@ __device__ __forceinline__ void film_add_wave(float* film, int pixel, bool valid
 // anything was hit.  The stream kernels store from on_hit instead of carrying a hit record in registers.
 template <bool ANY, typename Stack, typename OnHit>
 __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, Stack& st, OnHit on_hit) {
+    constexpr bool kCursor = is_cursor<Stack>::value;
     bool any_found = false;
-    int ptr = 0, top = 1; st.put(0, 0);
+    int ptr = 0, top = 1;
+    if constexpr (!kCursor) st.put(0, 0);
+    ray.tmin = canonical(ray.tmin); ray.tmax = canonical(ray.tmax);           // see slab_canonical (traversal_device.h)
     // both bases as integers in VGPRs for the per-lane select, then GLOBAL pointers again (see unified_chunk)
     typedef const __attribute__((address_space(1))) char* gptr;
     unsigned long long node_bits = reinterpret_cast<unsigned long long>(nodes - 1), tri_bits = reinterpret_cast<unsigned long long>(tris);   // node ids are 1-based
@@ -183,17 +199,24 @@ __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const
             const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
             f32x4 q0 = p[0], q1 = p[1], q2 = p[2];
             i32x2 ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));   // child ids / (triangle lanes) own last 8 bytes
-            const int popped = st.get(ptr);
+            int popped;
+            if constexpr (kCursor) popped = *st.sp; else popped = st.get(ptr);
             // keep all four loads in flight together (see unified_chunk)
             asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
             if (is_node) {
                 float te0, te1;
-                const bool h0 = slab(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
-                const bool h1 = slab(ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
+                const bool h0 = slab_canonical(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
+                const bool h1 = slab_canonical(ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
                 const bool c0first = te0 < te1, both = h0 && h1;
-                st.put(ptr + 1, c0first ? ch.y : ch.x);
                 top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
-                ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
+                if constexpr (kCursor) {
+                    st.sp[kWave] = c0first ? ch.y : ch.x;
+                    st.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
+                    if (both && st.sp >= st.limit) { st.overflow = true; top = 0; }      // (`both`: popping the sentinel moves sp below its column)
+                } else {
+                    st.put(ptr + 1, c0first ? ch.y : ch.x);
+                    ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
+                }
             } else {
                 const int prim_id = __float_as_int(q2.w);
                 const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
@@ -205,7 +228,8 @@ __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const
                 }
                 const bool leave = prim_id < 0;                               // sentinel: the leaf is done
                 top = (ANY && found) ? 0 : (leave ? popped : top - 1);        // top - 1 == ~(j + 1)
-                ptr -= (leave && !(ANY && found)) ? 1 : 0;
+                if constexpr (kCursor) st.sp -= (leave && !(ANY && found)) ? kWave : 0;
+                else ptr -= (leave && !(ANY && found)) ? 1 : 0;
             }
         }
     }
@@ -224,29 +248,36 @@ __device__ __forceinline__ RayX load_stream_ray(const RayStream& r, int i) {   /
 }
 
 // primary: writes geom_id (num_geometries on a miss, driver.impala:106-115), prim_id, t, u, v
-__global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStream p, const int* size_ptr, int n_value, int* err, unsigned long long* counters,
-                                                         int* spill) {
-    __shared__ int lds[kLdsStack * kWave];
+__device__ __forceinline__ void trace_primary_ray(const SceneDev& sc, const PrimaryStream& p, int i, CursorStack* cursor, DeepStack* deep) {
+    const RayX ray = load_stream_ray(p.rays, i);
+    p.geom_id[i] = sc.num_materials; p.prim_id[i] = -1; p.t[i] = ray.tmax; p.u[i] = 0.0f; p.v[i] = 0.0f;     // the miss record; hits overwrite it
+    auto on_hit = [&](int prim, int geom, float t, float u, float v) {
+        unsigned k = (unsigned)i;
+        asm volatile("" : "+v"(k));                  // opaque index: SGPR bases + one VGPR offset here, instead of five 64-bit addresses held across the loop
+        p.geom_id[k] = geom; p.prim_id[k] = prim; p.t[k] = t; p.u[k] = u; p.v[k] = v;
+    };
+    if (cursor) trace_one<false>(sc.nodes, sc.tris, ray, *cursor, on_hit);
+    else trace_one<false>(sc.nodes, sc.tris, ray, *deep, on_hit);
+}
+
+__global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStream p, const int* size_ptr, int n_value, int* ctl, unsigned long long* counters,
+                                                         int* deep_list) {
+    __shared__ int lds[(kLdsStack + 1) * kWave];
     const int n = stream_size(size_ptr, n_value);
     const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
     const int i = chunk * kWave + threadIdx.x;
     if (chunk * kWave >= n) return;
     if (i >= n) return;
-    StreamStackT<true> st; st.col = (lds_int*)lds + threadIdx.x; st.err = err; st.slab = spill + (size_t)blockIdx.x * kSpillEntries * kWave + threadIdx.x;
-    const RayX ray = load_stream_ray(p.rays, i);
-    p.geom_id[i] = sc.num_materials; p.prim_id[i] = -1; p.t[i] = ray.tmax; p.u[i] = 0.0f; p.v[i] = 0.0f;     // the miss record; hits overwrite it
-    trace_one<false>(sc.nodes, sc.tris, ray, st, [&](int prim, int geom, float t, float u, float v) {
-        unsigned k = (unsigned)i;
-        asm volatile("" : "+v"(k));                  // opaque index: SGPR bases + one VGPR offset here, instead of five 64-bit addresses held across the loop
-        p.geom_id[k] = geom; p.prim_id[k] = prim; p.t[k] = t; p.u[k] = u; p.v[k] = v;
-    });
+    CursorStack st; st.init((lds_int*)lds + threadIdx.x);
+    trace_primary_ray(sc, p, i, &st, nullptr);
+    if (st.overflow) deep_list[atomicAdd(&ctl[3], 1)] = i;
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)n);
 }
 
 // secondary: any-hit; unoccluded rays add their colour to the film (mapping_gpu.impala:32-45,47-80)
 __global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
-                                                           int* err, unsigned long long* counters, int* spill) {
-    __shared__ int lds[kLdsStack * kWave];
+                                                           int* ctl, unsigned long long* counters, int* deep_list) {
+    __shared__ int lds[(kLdsStack + 1) * kWave];
     const int n = stream_size(size_ptr, n_value);
     const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
     const int i = chunk * kWave + threadIdx.x;
@@ -257,10 +288,34 @@ __global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, Secondar
     if (threadIdx.x == 0 && live) atomicAdd(&counters[4 + (blockIdx.x & 63)], (unsigned long long)__popcll(live));
     bool lit = false;
     if (pixel >= 0) {
-        StreamStackT<true> st; st.col = (lds_int*)lds + threadIdx.x; st.err = err; st.slab = spill + (size_t)blockIdx.x * kSpillEntries * kWave + threadIdx.x;
+        CursorStack st; st.init((lds_int*)lds + threadIdx.x);
         lit = !trace_one<true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {});
+        if (st.overflow) { deep_list[atomicAdd(&ctl[3], 1)] = i; lit = false; }       // k_trace_deep decides
     }
     film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
+}
+
+// The rays the two kernels above abandoned (stack deeper than the LDS window), traced again from the root with the
+// 64-entry stack in global memory; one wave, enqueued behind every stream traversal launch; resets the list.
+template <bool SECONDARY>
+__global__ __launch_bounds__(kWave) void k_trace_deep(SceneDev sc, PrimaryStream p, SecondaryStream s, float* film, float inv_spp, int* ctl,
+                                                      const int* deep_list, int* deep_stack) {
+    const int count = ctl[3];
+    DeepStack st{deep_stack + threadIdx.x, ctl + 2};
+    for (int k = threadIdx.x; k < count; k += kWave) {
+        const int i = deep_list[k];
+        if (SECONDARY) {
+            const bool lit = !trace_one<true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {});
+            if (lit) {
+                float* px = film + 3 * (size_t)s.rays.id[i];
+                unsafeAtomicAdd(px, s.color_r[i] * inv_spp); unsafeAtomicAdd(px + 1, s.color_g[i] * inv_spp); unsafeAtomicAdd(px + 2, s.color_b[i] * inv_spp);
+            }
+        } else {
+            trace_primary_ray(sc, p, i, nullptr, &st);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ctl[3] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -558,7 +613,8 @@ struct RenderDevice {
     float* film = nullptr; int film_w = 0, film_h = 0;
     float* slab[3] = {nullptr, nullptr, nullptr}; int slab_cap[3] = {0, 0, 0};       // first primary, second primary, secondary
     int* tmp = nullptr; int tmp_cap = 0;
-    int* spill = nullptr; int spill_waves = 0;     // stack entries beyond the LDS window of the stream traversal kernels
+    int* deep_list = nullptr; int deep_cap = 0;    // rays the stream traversal kernels hand to k_trace_deep
+    int* deep_stack = nullptr;                     // its 64 x 64-entry stack
     int* hist = nullptr; size_t hist_cap = 0;
     int* ctl = nullptr;       // [0] primary size, [1] secondary size, [2] error flag, [8..] bin_total, bin_begin, bin_end (kMaxBins each)
     unsigned long long* counters = nullptr;    // [0] primary rays, [1] unused, [2] iterations, [3] generated, [4..67] shadow rays (striped)
@@ -622,14 +678,26 @@ void carve_secondary(SecondaryStream& s, float* ptr, size_t cap) {           // 
     s.prim_id = (int32_t*)ptr + 9 * cap; s.color_r = ptr + 10 * cap; s.color_g = ptr + 11 * cap; s.color_b = ptr + 12 * cap; s.size = 0; s.pad = 0;
 }
 
-int* ensure_spill(RenderDevice& r, int waves) {
-    if (r.spill_waves < waves) {
+void ensure_deep(RenderDevice& r, int rays) {
+    if (r.deep_cap < rays) {
         HIP_CHECK(hipSetDevice(r.dev));
-        if (r.spill) HIP_CHECK(hipFree(r.spill));
-        HIP_CHECK(hipMalloc(&r.spill, sizeof(int) * (size_t)waves * kSpillEntries * kWave));
-        r.spill_waves = waves;
+        if (r.deep_list) HIP_CHECK(hipFree(r.deep_list));
+        HIP_CHECK(hipMalloc(&r.deep_list, sizeof(int) * (size_t)rays));
+        r.deep_cap = rays;
     }
-    return r.spill;
+    if (!r.deep_stack) HIP_CHECK(hipMalloc(&r.deep_stack, sizeof(int) * kStackCap * kWave));
+}
+
+// Stream traversal launches: the main kernel, then the one-wave kernel for the rays it abandoned.
+void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n) {
+    ensure_deep(r, n);
+    hipLaunchKernelGGL(k_trace_primary, dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl, r.counters, r.deep_list);
+    hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl, r.deep_list, r.deep_stack);
+}
+void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const SecondaryStream& s, const int* size_ptr, int max_n, float inv_spp) {
+    ensure_deep(r, max_n);
+    hipLaunchKernelGGL(k_trace_secondary, dim3((max_n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl, r.counters, r.deep_list);
+    hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl, r.deep_list, r.deep_stack);
 }
 
 void ensure_hist(RenderDevice& r, size_t ints) {
@@ -703,7 +771,6 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 3, stream));
     HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * kNumCounters, stream));
     unsigned long long iterations = 0, generated = 0;
-    int* spill = ensure_spill(r, kCapacity / kWave);
     const int* d_valid = bin_end(r, 0) + (G - 1);      // rays that hit something = exclusive end of the last geometry bin (:347-357)
     while (id < num_rays || size > 0) {
         if (size < kCapacity && id < num_rays) {                                         // regenerate (mapping_gpu.impala:332-336)
@@ -712,17 +779,17 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
                                r.film_w, r.film_h, first_pixel, r.spp);
             id += n; size += n; generated += n;
         }
-        const int waves = (size + kWave - 1) / kWave, blocks = (size + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_trace_primary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, *primary, (const int*)nullptr, size, err, r.counters, spill);
+        const int blocks = (size + kBlock - 1) / kBlock;
+        launch_trace_primary(r, stream, *primary, size);
         if (r.sort) {
             bin_stream(r, 0, *primary, *other, nullptr, size, KEY_GEOM, G + 1, 1, G, stream);    // misses (bin G) are dropped (:347-357)
             std::swap(primary, other);
             hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, d_valid, 0, r.film, inv_spp, r.max_path_len, 0);
-            hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, sec, d_valid, 0, r.film, inv_spp, err, r.counters, spill);
+            launch_trace_secondary(r, stream, sec, d_valid, size, inv_spp);
             bin_stream(r, 1, *primary, *other, d_valid, size, KEY_ALIVE, 2, 0, 1, stream);       // compaction (:267-300)
         } else {                                     // option: no sort by material -- shade in stream order, misses end in the shader
             hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, (const int*)nullptr, size, r.film, inv_spp, r.max_path_len, 1);
-            hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, stream, r.scene.dev, sec, (const int*)nullptr, size, r.film, inv_spp, err, r.counters, spill);
+            launch_trace_secondary(r, stream, sec, nullptr, size, inv_spp);
             bin_stream(r, 1, *primary, *other, nullptr, size, KEY_ALIVE, 2, 0, 1, stream);
         }
         std::swap(primary, other);
@@ -901,16 +968,14 @@ void hip_generate_rays(int32_t dev, PrimaryStream* primary, int32_t capacity, in
 }
 
 void hip_traverse_primary(int32_t dev, PrimaryStream* primary, void* stream) {
-    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
+    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); ensure_film(r); require_scene(r);
     if (primary->size <= 0) return;
-    const int waves = (primary->size + kWave - 1) / kWave;
-    hipLaunchKernelGGL(k_trace_primary, dim3(waves), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *primary, (const int*)nullptr, primary->size, r.ctl + 2, r.counters,
-                       ensure_spill(r, waves));
+    launch_trace_primary(r, (hipStream_t)stream, *primary, primary->size);
     HIP_CHECK(hipGetLastError());
 }
 
 void hip_sort_primary(int32_t dev, PrimaryStream* primary, PrimaryStream* other, int32_t* ray_ends, void* stream) {
-    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
+    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); ensure_film(r); require_scene(r);
     const int G = r.scene.dev.num_materials;
     bin_stream(r, 0, *primary, *other, nullptr, primary->size, KEY_GEOM, G + 1, 1, G + 1, (hipStream_t)stream);
     HIP_CHECK(hipMemcpyAsync(r.host_pinned + 8, bin_end(r, 0), sizeof(int) * (G + 1), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -920,7 +985,7 @@ void hip_sort_primary(int32_t dev, PrimaryStream* primary, PrimaryStream* other,
 }
 
 void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, int32_t num_rays, void* stream) {
-    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
+    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); ensure_film(r); require_scene(r);
     primary->size = num_rays; secondary->size = num_rays;
     if (num_rays <= 0) return;
     hipLaunchKernelGGL(k_shade, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, r.scene.dev, *primary, *secondary, (const int*)nullptr, num_rays, r.film,
@@ -929,11 +994,9 @@ void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, 
 }
 
 void hip_traverse_secondary(int32_t dev, SecondaryStream* secondary, void* stream) {
-    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); require_scene(r);
+    RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); ensure_film(r); require_scene(r);
     if (secondary->size <= 0) return;
-    const int waves = (secondary->size + kWave - 1) / kWave;
-    hipLaunchKernelGGL(k_trace_secondary, dim3(waves), dim3(kWave), 0, (hipStream_t)stream, r.scene.dev, *secondary, (const int*)nullptr, secondary->size,
-                       r.film, 1.0f / (float)r.spp, r.ctl + 2, r.counters, ensure_spill(r, waves));
+    launch_trace_secondary(r, (hipStream_t)stream, *secondary, nullptr, secondary->size, 1.0f / (float)r.spp);
     HIP_CHECK(hipGetLastError());
 }
 

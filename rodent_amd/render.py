@@ -151,6 +151,19 @@ def stage_lib():
     return l
 
 
+def write_stream_array(ptr, values):
+    """Copies a host array of 4-byte words into one stream array (device pointer)."""
+    import torch
+    a = np.ascontiguousarray(values)
+    assert a.dtype.itemsize == 4
+    if a.size == 0:
+        return
+    t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).cuda()
+    abi.lib()
+    C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(ptr), C.c_void_p(t.data_ptr()), C.c_size_t(a.nbytes), 3)
+    torch.cuda.synchronize()
+
+
 def read_stream_array(ptr, count, dtype):
     """Copies `count` words of one stream array (device pointer) to the host."""
     import torch

@@ -249,3 +249,60 @@ def test_rodent_cli_renders_textured_obj(native_build, textured_scene, tmp_path)
     im = np.asarray(Image.open(out).convert("RGB"), dtype=np.float32)
     floor = im[115:155, 40:200]
     assert (floor[..., 0] > 1.3 * floor[..., 2]).mean() > 0.1 and (floor[..., 2] > 1.3 * floor[..., 0]).mean() > 0.05
+
+
+def test_stream_traversal_hands_deep_rays_to_the_follow_up_kernel(R, oracle):
+    """Stacks deeper than the 16-entry LDS window: k_trace_primary / k_trace_secondary abandon the ray and k_trace_deep
+    traces it again with the 64-entry stack in global memory.  A 40-deep chain BVH (stack reaches 40) as the scene of
+    the stage-level entry points, deep and shallow rays mixed in one wave: hit fields bit-exact against the oracle,
+    and the film gets exactly the unoccluded shadow rays' colours."""
+    import ctypes as C
+    from types import SimpleNamespace
+    from conftest import chain_bvh2
+    from rodent_amd import formats as F
+    nodes, tris = chain_bvh2(40)
+    ntri = len(tris)
+    mat = np.zeros(1, S.MATERIAL); mat["kd"] = 0.5; mat["type"] = 1
+    light = np.zeros(1, S.LIGHT); light["inv_area"] = 1.0
+    scene = SimpleNamespace(vertices=np.zeros((3 * ntri, 4), "<f4"), normals=np.zeros((3 * ntri, 4), "<f4"), face_normals=np.zeros((ntri, 4), "<f4"),
+                            indices=np.zeros((ntri, 4), "<i4"), nodes=nodes, tris=tris, materials=mat, lights=light, light_ids=np.zeros(ntri, "<i4"),
+                            texcoords=np.zeros((0, 4), "<f4"), textures=np.zeros(0, S.TEXTURE), texels=np.zeros(0, "<u4"), num_tris=ntri)
+    n = 1000
+    rng = np.random.default_rng(3)
+    org = np.zeros((n, 3), "<f4"); org[:, :2] = rng.uniform(-4, 4, (n, 2)); org[::3, 0] += 50.0          # every 3rd ray misses everything
+    d = np.tile(np.float32([0.001, 0.002, 1.0]), (n, 1))
+    rays = F.make_rays(org, d, 0.0, 1000.0)
+    W, H = 40, 25                                                 # film of n pixels: ray k is pixel k
+    r = R.Renderer(scene, W, H, 1, 4)
+    l = R.stage_lib()
+    p, s = R.PrimaryStream(), R.SecondaryStream()
+    l.rodent_gpu_get_first_primary_stream(0, C.byref(p), n)
+    l.rodent_gpu_get_secondary_stream(0, C.byref(s), n)
+    for stream_rays in (p.rays, s.rays):
+        R.write_stream_array(stream_rays.id, np.arange(n, dtype="<i4"))
+        for k, name in enumerate(("org_x", "org_y", "org_z")):
+            R.write_stream_array(getattr(stream_rays, name), rays["org"][:, k])
+        for k, name in enumerate(("dir_x", "dir_y", "dir_z")):
+            R.write_stream_array(getattr(stream_rays, name), rays["dir"][:, k])
+        R.write_stream_array(stream_rays.tmin, rays["tmin"]); R.write_stream_array(stream_rays.tmax, rays["tmax"])
+    color = rng.uniform(0.1, 1.0, (n, 3)).astype("<f4")
+    for k, name in enumerate(("color_r", "color_g", "color_b")):
+        R.write_stream_array(getattr(s, name), color[:, k])
+    p.size = n; s.size = n
+    ref, st = oracle.traverse(2, nodes, tris, rays)
+    assert st["max_stack"] == 40 and (ref["tri_id"] >= 0).sum() > 600
+    l.hip_traverse_primary(0, C.byref(p), None)
+    got_prim = R.read_stream_array(p.prim_id, n, "<i4")
+    assert np.array_equal(got_prim, ref["tri_id"])
+    for name in ("t", "u", "v"):
+        got = R.read_stream_array(getattr(p, name), n, "<f4")
+        hit = ref["tri_id"] >= 0
+        assert got[hit].tobytes() == ref[name][hit].tobytes() and (name != "t" or got[~hit].tobytes() == ref["t"][~hit].tobytes())
+    assert np.array_equal(R.read_stream_array(p.geom_id, n, "<i4"), np.where(ref["tri_id"] >= 0, 0, 1))
+    r.clear()
+    l.hip_traverse_secondary(0, C.byref(s), None)
+    film = r.film().reshape(-1, 3)
+    occluded, _ = oracle.traverse(2, nodes, tris, rays, any_hit=True)
+    expect = np.where((occluded["tri_id"] < 0)[:, None], color, 0.0).astype("<f4")
+    assert np.array_equal(film, expect)
+    r.close()
