@@ -158,6 +158,21 @@ def main():
     steps_r, warm_r = (args.steps, args.warmup) if args.only != "primary" else (1, 0)
     wall, k_mean, k_med, k_min = time_passes(abi, torch, bvh, prim_dev, hits_dev, n, variant, steps_p, warm_p, dist)
     wall_r, kr_mean, kr_med, kr_min = time_passes(abi, torch, bvh, rnd_dev, hits_rnd_dev, len(rnd), variant, steps_r, warm_r, dist)
+    # for information only (never `value`): independent batches in flight on two streams -- the fill of one launch
+    # overlaps the drain of the other (every (device, stream) has its own launch state)
+    overlapped = None
+    if args.only is None and not args.no_cpu_baseline:           # not in the profiling runs: their per-kernel averages are the serial launches
+        s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+        h2 = [hits_dev, torch.zeros_like(hits_dev)]
+        for k in range(2):
+            abi.traverse_async(bvh, prim_dev, h2[k], n, False, variant, s2[k])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(1, args.steps // 2)):
+            for k in range(2):
+                abi.traverse_async(bvh, prim_dev, h2[k], n, False, variant, s2[k])
+        torch.cuda.synchronize()
+        overlapped = 2 * max(1, args.steps // 2) * n / (time.perf_counter() - t0) / 1e6
     abi.lib()  # keep the handle alive
     if dist is not None:
         t = torch.tensor([wall, wall_r], dtype=torch.float64, device=f"cuda:{dev}")
@@ -193,7 +208,8 @@ def main():
         "extra": {"random_Mrays_s": round(value_rnd, 3), "random_ms_per_step": round(1e3 * wall_r / steps_r, 5),
                   "primary_kernel_ms": {"mean": round(k_mean, 5), "median": round(k_med, 5), "min": round(k_min, 5)},
                   "random_kernel_ms": {"mean": round(kr_mean, 5), "median": round(kr_med, 5), "min": round(kr_min, 5)},
-                  "hit_counts_per_rank[primary,random]": counts_all},
+                  "hit_counts_per_rank[primary,random]": counts_all,
+                  "two_streams_Mrays_s_per_gpu": None if overlapped is None else round(overlapped, 3)},
     }
     if not args.no_cpu_baseline:
         from oracle import binding as O      # checker / CPU baseline only: never on the measured path

@@ -100,9 +100,9 @@ void hip_occluded_single_ray1_bvh8_tri4(int32_t dev,
  * NULL = the device's null stream) and return without synchronising, so a
  * caller can bracket launches with its own HIP events.  `variant` selects the
  * kernel mapping (see rodent_hip_variant_name); 0 is the default shipped one.
- * BVH2 launches of one device share that device's deep-ray list and counters (rays whose stack outgrows the LDS
- * window are finished by a follow-up kernel enqueued behind each launch): enqueue them on ONE stream at a time, or
- * order the streams with events; launches on different devices are independent. */
+ * Every (device, stream) pair has its own control words and deep-ray list (rays whose stack outgrows the LDS window
+ * are finished by a follow-up kernel enqueued behind each launch), so launches on different streams may overlap;
+ * up to 64 streams per device. */
 void hip_traverse_bvh2_tri1_async(int32_t dev,
         const struct Node2* nodes, const struct Tri1* tris,
         const struct Ray1* rays, struct Hit1* hits, int32_t num_rays,

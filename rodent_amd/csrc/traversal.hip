@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
 
 #include "rodent_traversal.h"
@@ -698,28 +699,43 @@ struct DeviceState {
     unsigned long long* trace = nullptr;   // debug: 16384 x 4 words (instrumented variants)
     Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
 };
-DeviceState g_dev[16];
+// One DeviceState per (device, stream): launches enqueued on different streams of a device may overlap, so each
+// stream gets its own control words, deep-ray list and follow-up stack.
+struct DeviceStreams { std::vector<std::pair<hipStream_t, std::unique_ptr<DeviceState>>> ctx; DeviceState* last = nullptr; };
+DeviceStreams g_dev[16];
 std::mutex  g_mutex;
+constexpr size_t kMaxStreamContexts = 64;
 
-DeviceState& device_state(int dev) {
+DeviceState& device_state(int dev, hipStream_t stream) {
     if (dev < 0 || dev >= 16) { fprintf(stderr, "rodent_hip: invalid device index %d\n", dev); abort(); }
     std::lock_guard<std::mutex> lock(g_mutex);
-    DeviceState& s = g_dev[dev];
-    if (!s.init) {
-        int count = 0;
-        if (hipGetDeviceCount(&count) != hipSuccess || dev >= count) {
-            fprintf(stderr, "rodent_hip: no HIP device %d (%d visible)\n", dev, count); abort();
-        }
-        HIP_CHECK(hipSetDevice(dev));
-        hipDeviceProp_t prop;
-        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        s.num_cus = prop.multiProcessorCount;
-        HIP_CHECK(hipMalloc(&s.scratch, 64 * sizeof(int)));
-        HIP_CHECK(hipMemset(s.scratch, 0, 64 * sizeof(int)));
-        HIP_CHECK(hipMalloc(&s.deep_stack, kStackCap * kWave * sizeof(int)));
-        s.init = true;
+    DeviceStreams& d = g_dev[dev];
+    for (auto& c : d.ctx) if (c.first == stream) { d.last = c.second.get(); return *c.second; }
+    if (d.ctx.size() >= kMaxStreamContexts) { fprintf(stderr, "rodent_hip: more than %zu streams used on device %d\n", kMaxStreamContexts, dev); abort(); }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || dev >= count) {
+        fprintf(stderr, "rodent_hip: no HIP device %d (%d visible)\n", dev, count); abort();
     }
-    return s;
+    HIP_CHECK(hipSetDevice(dev));
+    auto s = std::make_unique<DeviceState>();
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    s->num_cus = prop.multiProcessorCount;
+    HIP_CHECK(hipMalloc(&s->scratch, 64 * sizeof(int)));
+    HIP_CHECK(hipMemset(s->scratch, 0, 64 * sizeof(int)));
+    HIP_CHECK(hipMalloc(&s->deep_stack, kStackCap * kWave * sizeof(int)));
+    s->init = true;
+    d.ctx.emplace_back(stream, std::move(s));
+    d.last = d.ctx.back().second.get();
+    return *d.last;
+}
+// the context of the stream used last on this device (the debug read-outs and the synchronous entry points)
+DeviceState& device_state(int dev) {
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (dev >= 0 && dev < 16 && g_dev[dev].last) return *g_dev[dev].last;
+    }
+    return device_state(dev, nullptr);
 }
 
 void ensure_deep_list(DeviceState& s, int n) {
@@ -886,7 +902,7 @@ extern "C" {
 
 void hip_traverse_bvh2_tri1_async(int32_t dev, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits,
                                   int32_t num_rays, int32_t any_hit, int32_t variant, void* stream) {
-    DeviceState& s = device_state(dev);
+    DeviceState& s = device_state(dev, (hipStream_t)stream);
     HIP_CHECK(hipSetDevice(dev));
     if (any_hit) launch_bvh2<true>(s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
     else         launch_bvh2<false>(s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
@@ -894,7 +910,7 @@ void hip_traverse_bvh2_tri1_async(int32_t dev, const Node2* nodes, const Tri1* t
 
 void hip_traverse_bvh8_tri4_async(int32_t dev, const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits,
                                   int32_t num_rays, int32_t any_hit, int32_t variant, void* stream) {
-    DeviceState& s = device_state(dev);
+    DeviceState& s = device_state(dev, (hipStream_t)stream);
     HIP_CHECK(hipSetDevice(dev));
     if (any_hit) launch_bvh8<true>(s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
     else         launch_bvh8<false>(s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
@@ -902,19 +918,19 @@ void hip_traverse_bvh8_tri4_async(int32_t dev, const Node8* nodes, const Tri4* t
 
 void amdgpu_intersect_single_ray1_bvh2_tri1(int32_t dev, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
     hip_traverse_bvh2_tri1_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(2), nullptr);
-    check_error_flag(device_state(dev), nullptr);
+    check_error_flag(device_state(dev, nullptr), nullptr);
 }
 void amdgpu_occluded_single_ray1_bvh2_tri1(int32_t dev, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
     hip_traverse_bvh2_tri1_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(2), nullptr);
-    check_error_flag(device_state(dev), nullptr);
+    check_error_flag(device_state(dev, nullptr), nullptr);
 }
 void hip_intersect_single_ray1_bvh8_tri4(int32_t dev, const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
     hip_traverse_bvh8_tri4_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(8), nullptr);
-    check_error_flag(device_state(dev), nullptr);
+    check_error_flag(device_state(dev, nullptr), nullptr);
 }
 void hip_occluded_single_ray1_bvh8_tri4(int32_t dev, const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
     hip_traverse_bvh8_tri4_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(8), nullptr);
-    check_error_flag(device_state(dev), nullptr);
+    check_error_flag(device_state(dev, nullptr), nullptr);
 }
 
 int32_t rodent_hip_device_count(void) {

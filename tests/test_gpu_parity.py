@@ -111,6 +111,33 @@ def test_chunk_mapping_is_a_bijection(gpu, cornell, cornell_dev, n):
     assert (out["fast"]["tri_id"] >= -1).all() and (out["fast"]["tri_id"] < 64).all()
 
 
+def test_launches_on_several_streams_may_overlap(gpu, oracle):
+    """Every (device, stream) has its own control words and deep-ray list: four streams trace different ray sets of the
+    deep-chain scene (every launch hands rays to its follow-up kernel) at the same time, repeatedly; all results exact."""
+    import torch
+    from conftest import chain_bvh2
+    nodes, tris = chain_bvh2(40)
+    bvh = gpu.DeviceBvh(2, nodes, tris, 0)
+    rng = np.random.default_rng(11)
+    sets = []
+    for k in range(4):
+        n = 20000 + 777 * k
+        org = np.zeros((n, 3), "<f4"); org[:, :2] = rng.uniform(-4, 4, (n, 2)); org[k::3, 0] += 50.0
+        rays = F.make_rays(org, np.tile(np.float32([0.001, 0.002, 1.0]), (n, 1)), 0.0, 1000.0)
+        ref, _ = oracle.traverse(2, nodes, tris, rays)
+        sets.append((rays, ref, gpu.to_device(rays, 0), torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0"), torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    for rep in range(5):
+        for rays, ref, rd, hd, st in sets:
+            hd.fill_(0xFF)
+        torch.cuda.synchronize()
+        for rays, ref, rd, hd, st in sets:
+            gpu.traverse_async(bvh, rd, hd, len(rays), False, 0, st)
+        torch.cuda.synchronize()
+        for rays, ref, rd, hd, st in sets:
+            assert gpu.from_device(hd, F.HIT1).tobytes() == ref.tobytes()
+
+
 def test_special_tmin_tmax_values(gpu, oracle, cornell, cornell_dev):
     """tmin / tmax taken from {0, -0, denormal, +-inf, quiet NaN, signalling NaN, ...}: the reference's fminf / fmaxf box test
     ignores a NaN bound, the triangle test's comparisons reject it; every variant must reproduce the oracle bit for bit,
