@@ -189,6 +189,49 @@ def test_deep_stack_falls_back_to_global_stack(gpu, oracle):
     assert gpu.read_stats()[7] == 0
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_triangle_soups_bit_exact(gpu, oracle, native_build, tmp_path, seed):
+    """Unstructured input through the whole tool chain (OBJ -> bvh_extractor -> .bvh -> HIP): a soup of random triangles with
+    zero-area, needle, duplicated, shared-edge and huge-coordinate members; random, axis-parallel, grazing and
+    vertex-aimed rays; every BVH2 variant and the BVH8 kernel bit for bit against the oracle, closest and any hit."""
+    rng = np.random.default_rng(seed)
+    nt = 700
+    c = rng.uniform(-10, 10, (nt, 1, 3)); tri = c + rng.normal(0, [0.3, 1.5, 0.05][seed - 1], (nt, 3, 3))
+    tri[:20, 2] = tri[:20, 1]                                   # zero area (two equal vertices)
+    tri[20:40, 2] = tri[20:40, 0] + 1e3 * (tri[20:40, 1] - tri[20:40, 0])       # needles
+    tri[40:60] = tri[60:80]                                     # exact duplicates (ties)
+    tri[80:100, 0] = tri[100:120, 0]; tri[80:100, 1] = tri[100:120, 1]            # shared edges
+    tri[120:125] *= 1e4                                         # huge coordinates
+    tri = tri.astype(np.float32)
+    with open(tmp_path / "soup.obj", "w") as f:
+        for v in tri.reshape(-1, 3):
+            f.write("v %.9g %.9g %.9g\n" % tuple(v))
+        for k in range(nt):
+            f.write("f %d %d %d\n" % (3 * k + 1, 3 * k + 2, 3 * k + 3))
+    subprocess.run([native_build.BIN_DIR / "bvh_extractor", "-obj", tmp_path / "soup.obj", "-o", tmp_path / "soup.bvh"], check=True, stdout=subprocess.DEVNULL)
+    n = 6000
+    org = rng.uniform(-14, 14, (n, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    d[:500, rng.integers(0, 3, 500)] *= 1.0                     # (general rays)
+    d[500:800] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 300)] * rng.choice([-1, 1], (300, 1))   # axis-parallel: the reference's slab test culls them
+    aim = tri.reshape(-1, 3)[rng.integers(0, 3 * nt, 1500)]
+    d[800:2300] = aim - org[800:2300]                           # aimed at vertices (ties between neighbours)
+    mid = 0.5 * (tri[rng.integers(0, nt, 700), 0] + tri[rng.integers(0, nt, 700), 1])
+    d[2300:3000] = mid - org[2300:3000]
+    rays = F.make_rays(org, d, 0.0, 3.0)                        # dir is not normalised: t in units of |dir|
+    rays["tmin"][3000:3500] = 0.5; rays["tmax"][3500:4000] = 0.7
+    for width in (2, 8):
+        name, algo = LAYOUTS[width]
+        nodes, prims = F.read_bvh(tmp_path / "soup.bvh", F.BVH2_TRI1 if width == 2 else F.BVH8_TRI4)
+        bvh = gpu.DeviceBvh(width, nodes, prims, 0)
+        for any_hit in (False, True):
+            ref, _ = oracle.traverse(width, nodes, prims, rays, any_hit=any_hit, algo=algo)
+            assert (ref["tri_id"] >= 0).sum() > 100
+            for v in variants(gpu, width):
+                got = gpu.traverse(bvh, rays, any_hit=any_hit, variant=v)
+                assert got.tobytes() == ref.tobytes(), f"BVH{width} variant {gpu.variants(width)[v]} any={any_hit}"
+
+
 @pytest.mark.parametrize("width", [2, 8])
 @pytest.mark.parametrize("kind", ["primary", "random"])
 def test_atrium_sample_bit_exact_vs_oracle(gpu, oracle, atrium, width, kind):
