@@ -121,3 +121,48 @@ def textured_scene(native_build, tmp_path_factory):
     d = tmp_path_factory.mktemp("textured")
     obj = write_textured_scene(d)
     return S.convert(obj, d / "room.rscene"), d
+
+
+def write_materials_scene(d):
+    """A closed room whose walls exercise every BSDF of the MTL mapping (converter.cpp:858-920): diffuse, Phong only
+    (Kd 0), diffuse + Phong mix, mirror (illum 5), glass (illum 7, Ni 1.5, Tf), black (Kd = Ks = 0), and an emitter."""
+    d.mkdir(parents=True, exist_ok=True)
+    (d / "mats.mtl").write_text(
+        "newmtl diffuse\nKd 0.7 0.7 0.6\n"
+        "newmtl phong\nKd 0 0 0\nKs 0.8 0.8 0.8\nNs 60\n"
+        "newmtl mix\nKd 0.5 0.2 0.2\nKs 0.4 0.4 0.4\nNs 20\n"
+        "newmtl mirror\nKs 0.9 0.9 0.9\nillum 5\n"
+        "newmtl glass\nKs 1 1 1\nTf 0.9 0.95 0.9\nNi 1.5\nillum 7\n"
+        "newmtl black\nKd 0 0 0\nKs 0 0 0\n"
+        "newmtl lamp\nKd 0 0 0\nKe 15 15 13\n")
+    quads = {                                    # name: four corners, counter-clockwise seen from inside the room
+        "diffuse": [(-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1)],              # floor
+        "phong":   [(-1, 0, -1), (1, 0, -1), (1, 2, -1), (-1, 2, -1)],            # back
+        "mix":     [(-1, 0, 1), (-1, 0, -1), (-1, 2, -1), (-1, 2, 1)],            # left
+        "mirror":  [(1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1)],                # right
+        "black":   [(-1, 2, -1), (1, 2, -1), (1, 2, 1), (-1, 2, 1)],              # ceiling
+        "lamp":    [(-0.4, 1.99, -0.4), (0.4, 1.99, -0.4), (0.4, 1.99, 0.4), (-0.4, 1.99, 0.4)],
+    }
+    lines, nv = ["mtllib mats.mtl"], 0
+    for name, q in quads.items():
+        for v in q:
+            lines.append("v %g %g %g" % v)
+        lines += [f"usemtl {name}", f"f {nv + 1} {nv + 2} {nv + 3}", f"f {nv + 1} {nv + 3} {nv + 4}"]
+        nv += 4
+    # a glass slab standing in the room (two-sided box: six quads)
+    x0, x1, y0, y1, z0, z1 = -0.5, 0.2, 0.0, 1.1, -0.2, 0.1
+    c = [(x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)]
+    for v in c:
+        lines.append("v %g %g %g" % v)
+    lines.append("usemtl glass")
+    for a, b, cc, dd in ((0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (2, 3, 7, 6), (1, 2, 6, 5), (0, 4, 7, 3)):
+        lines += [f"f {nv + a + 1} {nv + b + 1} {nv + cc + 1}", f"f {nv + a + 1} {nv + cc + 1} {nv + dd + 1}"]
+    (d / "mats.obj").write_text("\n".join(lines) + "\n")
+    return d / "mats.obj"
+
+
+@pytest.fixture(scope="session")
+def materials_scene(native_build, tmp_path_factory):
+    from rodent_amd import scene as S
+    d = tmp_path_factory.mktemp("materials")
+    return S.convert(write_materials_scene(d), d / "mats.rscene")

@@ -306,3 +306,21 @@ def test_stream_traversal_hands_deep_rays_to_the_follow_up_kernel(R, oracle):
     expect = np.where((occluded["tri_id"] < 0)[:, None], color, 0.0).astype("<f4")
     assert np.array_equal(film, expect)
     r.close()
+
+
+@pytest.mark.parametrize("mapping,sort", [("streaming", True), ("streaming", False), ("megakernel", True)])
+def test_every_bsdf_matches_oracle(R, oracle, materials_scene, mapping, sort):
+    """Diffuse, Phong, mix, mirror, glass (refraction and total internal reflection inside a slab), black and an emitter in
+    one room: the GPU shader takes the same paths as the oracle -- ray counts exact, film within tolerance."""
+    W, H = 150, 100
+    cam = S.camera_settings((0, 1, 2.6), (0, -0.05, -1), (0, 1, 0), 60, W, H)
+    r = R.Renderer(materials_scene, W, H, 4, 12, mapping=mapping, sort=sort)
+    film_o = None
+    for it in range(2):
+        r.render(cam, it)
+        c = r.counters()
+        film_o, counts = oracle.render(materials_scene, cam, it, 4, 12, W, H, film_o)
+        assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1])
+    film_g = r.film()
+    r.close()
+    assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)

@@ -151,3 +151,15 @@ def test_cpu_render_bench_script(oracle, tmp_path):
     r = subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_render_bench.py"), "--width", "64", "--height", "48", "--spp", "2",
                         "--bench", "2", "--threads", "2"], capture_output=True, text=True, check=True)
     assert "(min/med/max Msamples/s)" in r.stdout and "2 threads" in r.stdout
+
+
+def test_materials_scene_covers_every_bsdf(oracle, materials_scene):
+    """The MTL -> BSDF mapping of the converter on a room with one wall per BSDF (converter.cpp:858-920), and a CPU render."""
+    from rodent_amd import scene as S
+    types = sorted(materials_scene.materials["type"].tolist())
+    assert types == [0, 0, 1, 2, 3, 4, 5]                         # black (ceiling) + black emitter, diffuse, phong, mix, mirror, glass
+    assert materials_scene.materials["emissive"].sum() == 1 and len(materials_scene.lights) == 2
+    W, H = 64, 48
+    cam = S.camera_settings((0, 1, 2.6), (0, -0.05, -1), (0, 1, 0), 60, W, H)
+    film, counts = oracle.render(materials_scene, cam, 0, 4, 10, W, H)
+    assert np.isfinite(film).all() and film.mean() > 0.02 and counts[0] > 4 * W * H * 2
