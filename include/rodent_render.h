@@ -84,6 +84,9 @@ void    rodent_hip_render_capacity(int32_t dev, int32_t rays);
  * (mapping_gpu.impala:166-221,347-357).  0: no sort -- the table-driven shader runs in stream order and ends the rays that
  * missed; one stream copy less per bounce.  Same paths, same ray counts; RODENT_HIP_SORT=0|1 sets the initial value. */
 void    rodent_hip_render_sort(int32_t dev, int32_t enable);
+/* 1 (default): the shadow rays of a bounce are traced on a second HIP stream beside the compaction, regeneration and the
+ * next closest-hit pass; 0: one stream.  Same film up to the order of the atomic adds.  RODENT_HIP_OVERLAP=0|1. */
+void    rodent_hip_render_overlap(int32_t dev, int32_t enable);
 
 /* ---- the reference's renderer ABI ---- */
 int32_t get_spp(void);

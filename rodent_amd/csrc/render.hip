@@ -260,7 +260,7 @@ __device__ __forceinline__ void trace_primary_ray(const SceneDev& sc, const Prim
     else trace_one<false>(sc.nodes, sc.tris, ray, *deep, on_hit);
 }
 
-__global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStream p, const int* size_ptr, int n_value, int* ctl, unsigned long long* counters,
+__global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStream p, const int* size_ptr, int n_value, int* deep_count, unsigned long long* counters,
                                                          int* deep_list) {
     __shared__ int lds[(kLdsStack + 1) * kWave];
     const int n = stream_size(size_ptr, n_value);
@@ -270,13 +270,13 @@ __global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStr
     if (i >= n) return;
     CursorStack st; st.init((lds_int*)lds + threadIdx.x);
     trace_primary_ray(sc, p, i, &st, nullptr);
-    if (st.overflow) deep_list[atomicAdd(&ctl[3], 1)] = i;
+    if (st.overflow) deep_list[atomicAdd(deep_count, 1)] = i;
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)n);
 }
 
 // secondary: any-hit; unoccluded rays add their colour to the film (mapping_gpu.impala:32-45,47-80)
 __global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
-                                                           int* ctl, unsigned long long* counters, int* deep_list) {
+                                                           int* deep_count, unsigned long long* counters, int* deep_list) {
     __shared__ int lds[(kLdsStack + 1) * kWave];
     const int n = stream_size(size_ptr, n_value);
     const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, Secondar
     if (pixel >= 0) {
         CursorStack st; st.init((lds_int*)lds + threadIdx.x);
         lit = !trace_one<true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {});
-        if (st.overflow) { deep_list[atomicAdd(&ctl[3], 1)] = i; lit = false; }       // k_trace_deep decides
+        if (st.overflow) { deep_list[atomicAdd(deep_count, 1)] = i; lit = false; }      // k_trace_deep decides
     }
     film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
 }
@@ -298,10 +298,10 @@ __global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, Secondar
 // The rays the two kernels above abandoned (stack deeper than the LDS window), traced again from the root with the
 // 64-entry stack in global memory; one wave, enqueued behind every stream traversal launch; resets the list.
 template <bool SECONDARY>
-__global__ __launch_bounds__(kWave) void k_trace_deep(SceneDev sc, PrimaryStream p, SecondaryStream s, float* film, float inv_spp, int* ctl,
+__global__ __launch_bounds__(kWave) void k_trace_deep(SceneDev sc, PrimaryStream p, SecondaryStream s, float* film, float inv_spp, int* err, int* deep_count,
                                                       const int* deep_list, int* deep_stack) {
-    const int count = ctl[3];
-    DeepStack st{deep_stack + threadIdx.x, ctl + 2};
+    const int count = *deep_count;
+    DeepStack st{deep_stack + threadIdx.x, err};
     for (int k = threadIdx.x; k < count; k += kWave) {
         const int i = deep_list[k];
         if (SECONDARY) {
@@ -315,8 +315,10 @@ __global__ __launch_bounds__(kWave) void k_trace_deep(SceneDev sc, PrimaryStream
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) ctl[3] = 0;
+    if (threadIdx.x == 0) *deep_count = 0;
 }
+
+__global__ void k_copy_int(const int* src, int* dst) { *dst = *src; }
 
 // ---------------------------------------------------------------------------------------------
 // K5: shading (mapping_gpu.impala:82-134; renderer.impala:69-152).  One launch over the sorted,
@@ -613,8 +615,11 @@ struct RenderDevice {
     float* film = nullptr; int film_w = 0, film_h = 0;
     float* slab[3] = {nullptr, nullptr, nullptr}; int slab_cap[3] = {0, 0, 0};       // first primary, second primary, secondary
     int* tmp = nullptr; int tmp_cap = 0;
-    int* deep_list = nullptr; int deep_cap = 0;    // rays the stream traversal kernels hand to k_trace_deep
-    int* deep_stack = nullptr;                     // its 64 x 64-entry stack
+    int* deep_list[2] = {nullptr, nullptr}; int deep_cap[2] = {0, 0};   // rays handed to k_trace_deep: [0] primary, [1] secondary (may run at the same time)
+    int* deep_stack[2] = {nullptr, nullptr};       // their 64 x 64-entry stacks
+    hipStream_t aux = nullptr;                     // shadow-ray traversal runs here, beside the compaction / next primary pass
+    hipEvent_t ev_shade = nullptr, ev_sec = nullptr, ev_copy = nullptr;
+    int overlap = 1;                               // 0: everything on the caller's stream
     int* hist = nullptr; size_t hist_cap = 0;
     int* ctl = nullptr;       // [0] primary size, [1] secondary size, [2] error flag, [8..] bin_total, bin_begin, bin_end (kMaxBins each)
     unsigned long long* counters = nullptr;    // [0] primary rays, [1] unused, [2] iterations, [3] generated, [4..67] shadow rays (striped)
@@ -640,6 +645,7 @@ RenderDevice& rdev(int dev) {
         HIP_CHECK(hipMemset(r.counters, 0, sizeof(unsigned long long) * kNumCounters));
         HIP_CHECK(hipHostMalloc(&r.host_pinned, sizeof(int) * (8 + kMaxBins)));
         if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
+        if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
         if (const char* m = getenv("RODENT_HIP_MAPPING")) {
             if (!strcmp(m, "mega") || !strcmp(m, "megakernel") || !strcmp(m, "1")) r.mapping = 1;
             else if (strcmp(m, "streaming") && strcmp(m, "0")) { fprintf(stderr, "rodent_hip: RODENT_HIP_MAPPING must be 'streaming' or 'mega'\n"); abort(); }
@@ -678,26 +684,28 @@ void carve_secondary(SecondaryStream& s, float* ptr, size_t cap) {           // 
     s.prim_id = (int32_t*)ptr + 9 * cap; s.color_r = ptr + 10 * cap; s.color_g = ptr + 11 * cap; s.color_b = ptr + 12 * cap; s.size = 0; s.pad = 0;
 }
 
-void ensure_deep(RenderDevice& r, int rays) {
-    if (r.deep_cap < rays) {
+void ensure_deep(RenderDevice& r, int which, int rays) {
+    if (r.deep_cap[which] < rays) {
         HIP_CHECK(hipSetDevice(r.dev));
-        if (r.deep_list) HIP_CHECK(hipFree(r.deep_list));
-        HIP_CHECK(hipMalloc(&r.deep_list, sizeof(int) * (size_t)rays));
-        r.deep_cap = rays;
+        HIP_CHECK(hipDeviceSynchronize());
+        if (r.deep_list[which]) HIP_CHECK(hipFree(r.deep_list[which]));
+        HIP_CHECK(hipMalloc(&r.deep_list[which], sizeof(int) * (size_t)rays));
+        r.deep_cap[which] = rays;
     }
-    if (!r.deep_stack) HIP_CHECK(hipMalloc(&r.deep_stack, sizeof(int) * kStackCap * kWave));
+    if (!r.deep_stack[which]) HIP_CHECK(hipMalloc(&r.deep_stack[which], sizeof(int) * kStackCap * kWave));
 }
 
 // Stream traversal launches: the main kernel, then the one-wave kernel for the rays it abandoned.
+// ctl words: [2] error flag, [3] primary deep count, [4] secondary deep count, [5] secondary stream size (copy for the aux stream)
 void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n) {
-    ensure_deep(r, n);
-    hipLaunchKernelGGL(k_trace_primary, dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl, r.counters, r.deep_list);
-    hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl, r.deep_list, r.deep_stack);
+    ensure_deep(r, 0, n);
+    hipLaunchKernelGGL(k_trace_primary, dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
+    hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_stack[0]);
 }
 void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const SecondaryStream& s, const int* size_ptr, int max_n, float inv_spp) {
-    ensure_deep(r, max_n);
-    hipLaunchKernelGGL(k_trace_secondary, dim3((max_n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl, r.counters, r.deep_list);
-    hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl, r.deep_list, r.deep_stack);
+    ensure_deep(r, 1, max_n);
+    hipLaunchKernelGGL(k_trace_secondary, dim3((max_n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
+    hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_stack[1]);
 }
 
 void ensure_hist(RenderDevice& r, size_t ints) {
@@ -768,10 +776,21 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     const long long num_rays = (long long)r.spp * r.film_w * (y1 - y0);
     const int first_pixel = y0 * r.film_w;
     long long id = 0; int size = 0;
-    HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 3, stream));
+    HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 8, stream));
     HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * kNumCounters, stream));
     unsigned long long iterations = 0, generated = 0;
     const int* d_valid = bin_end(r, 0) + (G - 1);      // rays that hit something = exclusive end of the last geometry bin (:347-357)
+    // Shadow rays are independent of what follows the shader on the primary stream (compaction, regeneration, the next
+    // closest-hit pass and sort): they are traced on a second HIP stream and joined again before the next shader run
+    // overwrites the secondary stream.  The latency-bound traversal then shares the chip with the HBM-bound stream copies.
+    const bool overlap = r.overlap != 0;
+    if (overlap && !r.aux) {
+        HIP_CHECK(hipStreamCreateWithFlags(&r.aux, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&r.ev_shade, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&r.ev_sec, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&r.ev_copy, hipEventDisableTiming));
+    }
+    ensure_deep(r, 0, kCapacity); ensure_deep(r, 1, kCapacity);       // before the loop: growing them synchronises the device
+    hipStream_t sstream = overlap ? r.aux : stream;
     while (id < num_rays || size > 0) {
         if (size < kCapacity && id < num_rays) {                                         // regenerate (mapping_gpu.impala:332-336)
             const int n = (int)std::min<long long>(num_rays - id, kCapacity - size);
@@ -782,14 +801,29 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
         const int blocks = (size + kBlock - 1) / kBlock;
         launch_trace_primary(r, stream, *primary, size);
         if (r.sort) {
+            if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_copy, 0));      // the aux stream has its copy of the previous valid count
             bin_stream(r, 0, *primary, *other, nullptr, size, KEY_GEOM, G + 1, 1, G, stream);    // misses (bin G) are dropped (:347-357)
             std::swap(primary, other);
+            if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));       // the previous shadow rays have been traced
             hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, d_valid, 0, r.film, inv_spp, r.max_path_len, 0);
-            launch_trace_secondary(r, stream, sec, d_valid, size, inv_spp);
+            if (overlap) {
+                HIP_CHECK(hipEventRecord(r.ev_shade, stream));
+                HIP_CHECK(hipStreamWaitEvent(r.aux, r.ev_shade, 0));
+                hipLaunchKernelGGL(k_copy_int, dim3(1), dim3(1), 0, r.aux, d_valid, r.ctl + 5);
+                HIP_CHECK(hipEventRecord(r.ev_copy, r.aux));
+                launch_trace_secondary(r, r.aux, sec, r.ctl + 5, size, inv_spp);
+                HIP_CHECK(hipEventRecord(r.ev_sec, r.aux));
+            } else launch_trace_secondary(r, stream, sec, d_valid, size, inv_spp);
             bin_stream(r, 1, *primary, *other, d_valid, size, KEY_ALIVE, 2, 0, 1, stream);       // compaction (:267-300)
         } else {                                     // option: no sort by material -- shade in stream order, misses end in the shader
+            if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));
             hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, (const int*)nullptr, size, r.film, inv_spp, r.max_path_len, 1);
-            launch_trace_secondary(r, stream, sec, nullptr, size, inv_spp);
+            if (overlap) {
+                HIP_CHECK(hipEventRecord(r.ev_shade, stream));
+                HIP_CHECK(hipStreamWaitEvent(r.aux, r.ev_shade, 0));
+            }
+            launch_trace_secondary(r, sstream, sec, nullptr, size, inv_spp);
+            if (overlap) HIP_CHECK(hipEventRecord(r.ev_sec, r.aux));
             bin_stream(r, 1, *primary, *other, nullptr, size, KEY_ALIVE, 2, 0, 1, stream);
         }
         std::swap(primary, other);
@@ -798,6 +832,7 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
         size = r.host_pinned[0];
         iterations++;
     }
+    if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));           // the last shadow rays belong to this call
     const unsigned long long host_counts[2] = {iterations, generated};
     HIP_CHECK(hipMemcpyAsync(r.counters + 2, host_counts, sizeof(host_counts), hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(r.host_pinned + 2, err, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -888,6 +923,7 @@ void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
 }
 
 void rodent_hip_render_sort(int32_t dev, int32_t enable) { rdev(dev).sort = enable ? 1 : 0; }
+void rodent_hip_render_overlap(int32_t dev, int32_t enable) { rdev(dev).overlap = enable ? 1 : 0; }
 
 void rodent_hip_render_capacity(int32_t dev, int32_t rays) {
     if (rays != 0 && (rays < 64 || rays > kMaxCapacity)) { fprintf(stderr, "rodent_hip: stream capacity must be 0 (default) or 64 .. %ld rays\n", kMaxCapacity); abort(); }

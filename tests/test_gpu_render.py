@@ -308,13 +308,14 @@ def test_stream_traversal_hands_deep_rays_to_the_follow_up_kernel(R, oracle):
     r.close()
 
 
-@pytest.mark.parametrize("mapping,sort", [("streaming", True), ("streaming", False), ("megakernel", True)])
-def test_every_bsdf_matches_oracle(R, oracle, materials_scene, mapping, sort):
+@pytest.mark.parametrize("mapping,sort,overlap", [("streaming", True, True), ("streaming", False, True), ("streaming", True, False),
+                                                  ("streaming", False, False), ("megakernel", True, True)])
+def test_every_bsdf_matches_oracle(R, oracle, materials_scene, mapping, sort, overlap):
     """Diffuse, Phong, mix, mirror, glass (refraction and total internal reflection inside a slab), black and an emitter in
     one room: the GPU shader takes the same paths as the oracle -- ray counts exact, film within tolerance."""
     W, H = 150, 100
     cam = S.camera_settings((0, 1, 2.6), (0, -0.05, -1), (0, 1, 0), 60, W, H)
-    r = R.Renderer(materials_scene, W, H, 4, 12, mapping=mapping, sort=sort)
+    r = R.Renderer(materials_scene, W, H, 4, 12, mapping=mapping, sort=sort, overlap=overlap, capacity=30000)     # 60 000 paths: refills too
     film_o = None
     for it in range(2):
         r.render(cam, it)
