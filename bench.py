@@ -108,6 +108,11 @@ def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher the contract describes (one rank per GPU)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29517"), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     import torch
     from rodent_amd import abi, formats as F, raygen, scenes
 
