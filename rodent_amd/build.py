@@ -40,7 +40,7 @@ ORACLE_FLAGS = ["-O2", "-std=c11", "-Wall", "-fPIC", "-ffp-contract=off", "-fno-
 
 HIP_SOURCES = ["traversal.hip", "render.hip"]
 HOST_LIB_SOURCES = ["mesh.cpp", "bvh_build.cpp", "atrium.cpp", "scene.cpp", "image.cpp"]
-HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png", "converter", "tex_dump"]
+HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png", "converter", "tex_dump", "buffer_tool"]
 HIP_TOOLS = {"bench_traversal": [], "rodent": ["mesh.o", "bvh_build.o", "scene.o", "image.o"]}   # tool -> host objects it links
 
 

@@ -102,3 +102,67 @@ def write_fbuf(path, hits):
 
 def read_fbuf(path):
     return np.fromfile(path, "<f4")
+
+
+# ---- the reference's LZ4 buffer files (src/driver/buffer.h): [u32 size][u32 compressed size][LZ4 block] -------------
+# Python side of the data/*.bin compatibility: liblz4 through ctypes (the C++ side carries its own block codec,
+# rodent_amd/host/lz4_block.h, because lz4.h is not in this image); the tests play the two against each other.
+_lz4 = None
+
+
+def _liblz4():
+    global _lz4
+    if _lz4 is None:
+        import ctypes as C
+        _lz4 = C.CDLL("liblz4.so.1")
+        _lz4.LZ4_compressBound.restype = C.c_int; _lz4.LZ4_compressBound.argtypes = [C.c_int]
+        _lz4.LZ4_compress_default.restype = C.c_int; _lz4.LZ4_compress_default.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        _lz4.LZ4_decompress_safe.restype = C.c_int; _lz4.LZ4_decompress_safe.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    return _lz4
+
+
+def _read_buffer(data, pos):
+    import ctypes as C
+    size, csize = struct.unpack_from("<II", data, pos)
+    out = C.create_string_buffer(max(size, 1))
+    n = _liblz4().LZ4_decompress_safe(data[pos + 8: pos + 8 + csize], out, csize, size)
+    if n != size:
+        raise ValueError("corrupt LZ4 buffer")
+    return out.raw[:size], pos + 8 + csize
+
+
+def _pack_buffer(raw):
+    import ctypes as C
+    bound = _liblz4().LZ4_compressBound(len(raw))
+    out = C.create_string_buffer(max(bound, 1))
+    n = _liblz4().LZ4_compress_default(raw, out, len(raw), bound)
+    return struct.pack("<II", len(raw), n) + out.raw[:n]
+
+
+def read_buffer_file(path, dtype=np.uint8):
+    raw, _ = _read_buffer(Path(path).read_bytes(), 0)
+    return np.frombuffer(raw, dtype).copy()
+
+
+def write_buffer_file(path, array):
+    Path(path).write_bytes(_pack_buffer(np.ascontiguousarray(array).tobytes()))
+
+
+def read_bvh_bin(path, node_dtype=None, tri_dtype=None):
+    """data/bvh.bin (converter.cpp:428-437): the layout whose element sizes match (default: BVH2/Tri1) -> (nodes, tris)."""
+    node_dtype = node_dtype or NODE2; tri_dtype = tri_dtype or TRI1
+    data = Path(path).read_bytes()
+    pos = 0
+    while pos + 8 <= len(data):
+        ns, ts = struct.unpack_from("<II", data, pos)
+        pos += 8
+        nodes, pos = _read_buffer(data, pos)
+        tris, pos = _read_buffer(data, pos)
+        if (ns, ts) == (node_dtype.itemsize, tri_dtype.itemsize):
+            return np.frombuffer(nodes, node_dtype).copy(), np.frombuffer(tris, tri_dtype).copy()
+    raise ValueError(f"{path}: no BVH with {node_dtype.itemsize}-byte nodes and {tri_dtype.itemsize}-byte triangles")
+
+
+def write_bvh_bin(path, nodes, tris, append=False):
+    with open(path, "ab" if append else "wb") as f:
+        f.write(struct.pack("<II", nodes.dtype.itemsize, tris.dtype.itemsize) + _pack_buffer(nodes.tobytes()) + _pack_buffer(tris.tobytes()))

@@ -6,6 +6,7 @@
 #include <unordered_map>
 #include <unordered_set>
 
+#include "buffer_io.h"
 #include "bvh_build.h"
 #include "image.h"
 
@@ -184,6 +185,46 @@ bool load_scene(const std::string& path, SceneData& s) {
     }
     fclose(f);
     return ok;
+}
+
+bool save_reference_data(const std::string& dir, const SceneData& s) {
+    std::remove((dir + "/bvh.bin").c_str());                              // bvh.bin is appended to (converter.cpp:430,716)
+    std::vector<float> light_verts, light_norms, light_areas, light_colors;
+    for (const RodentLight& L : s.lights) {
+        for (const float* v : {L.v0, L.v1, L.v2}) light_verts.insert(light_verts.end(), {v[0], v[1], v[2], 0.0f});
+        light_norms.insert(light_norms.end(), {L.n[0], L.n[1], L.n[2], 0.0f});
+        light_areas.push_back(L.inv_area);
+        light_colors.insert(light_colors.end(), {L.color[0], L.color[1], L.color[2], 0.0f});
+    }
+    return write_buffer_file(dir + "/vertices.bin", s.vertices) && write_buffer_file(dir + "/normals.bin", s.normals) &&
+           write_buffer_file(dir + "/face_normals.bin", s.face_normals) && write_buffer_file(dir + "/indices.bin", s.indices) &&
+           write_buffer_file(dir + "/texcoords.bin", s.texcoords) && append_bvh_bin(dir + "/bvh.bin", s.nodes, s.tris) &&
+           write_buffer_file(dir + "/light_ids.bin", s.light_ids) && write_buffer_file(dir + "/light_verts.bin", light_verts) &&
+           write_buffer_file(dir + "/light_norms.bin", light_norms) && write_buffer_file(dir + "/light_areas.bin", light_areas) &&
+           write_buffer_file(dir + "/light_colors.bin", light_colors);
+}
+
+bool load_reference_data(const std::string& dir, SceneData& s) {
+    std::vector<float> light_verts, light_norms, light_areas, light_colors;
+    if (!(read_buffer_file(dir + "/vertices.bin", s.vertices) && read_buffer_file(dir + "/normals.bin", s.normals) &&
+          read_buffer_file(dir + "/face_normals.bin", s.face_normals) && read_buffer_file(dir + "/indices.bin", s.indices) &&
+          read_buffer_file(dir + "/texcoords.bin", s.texcoords) && load_bvh_bin(dir + "/bvh.bin", s.nodes, s.tris) &&
+          read_buffer_file(dir + "/light_ids.bin", s.light_ids) && read_buffer_file(dir + "/light_verts.bin", light_verts) &&
+          read_buffer_file(dir + "/light_norms.bin", light_norms) && read_buffer_file(dir + "/light_areas.bin", light_areas) &&
+          read_buffer_file(dir + "/light_colors.bin", light_colors)))
+        return false;
+    const size_t nl = light_areas.size();
+    if (light_verts.size() != 12 * nl || light_norms.size() != 4 * nl || light_colors.size() != 4 * nl) return false;
+    s.lights.assign(nl, RodentLight{});
+    for (size_t i = 0; i < nl; i++) {
+        RodentLight& L = s.lights[i];
+        for (int k = 0; k < 3; k++) {
+            L.v0[k] = light_verts[12 * i + k]; L.v1[k] = light_verts[12 * i + 4 + k]; L.v2[k] = light_verts[12 * i + 8 + k];
+            L.n[k] = light_norms[4 * i + k]; L.color[k] = light_colors[4 * i + k];
+        }
+        L.inv_area = light_areas[i];
+    }
+    return true;
 }
 
 } // namespace rodent

@@ -41,4 +41,12 @@ bool build_scene_from_obj(const std::string& obj_path, SceneData& scene);
 bool save_scene(const std::string& path, const SceneData& scene);   // ".rscene" binary
 bool load_scene(const std::string& path, SceneData& scene);
 
+// The reference converter's data directory (LZ4 buffer files, src/driver/buffer.h; converter.cpp:403-437,805-815,848):
+// vertices / normals / face_normals / texcoords (float4 per element), indices (int4), bvh.bin (BVH2/Tri1 layout),
+// light_ids, light_verts / light_norms / light_areas / light_colors.  Materials live in the reference's generated
+// Impala source, not in these files.
+bool save_reference_data(const std::string& dir, const SceneData& scene);
+// Reads the same files back into the mesh / BVH / light fields of `scene` (materials are left alone).
+bool load_reference_data(const std::string& dir, SceneData& scene);
+
 } // namespace rodent
