@@ -13,7 +13,9 @@
  * The oracle is therefore pinned by (1) an exhaustive all-triangles checker
  * (oracle_brute_force below; closest t must equal the minimum over every
  * triangle), (2) an independent float64 Moeller-Trumbore in tests/, and
- * (3) fixtures generated on this side (tests/golden/).
+ * (3) fixtures generated on this side (tests/golden/).  Indirectly, the reference does hold it: the renderer
+ * oracle (render_oracle.c) traces every ray with oracle_bvh2_tri1 below and reproduces the reference's own
+ * golden image testing/ref-cornell.png.
  *
  * Arithmetic: fp32, IEEE, compiled with -ffp-contract=off.  Where a fused
  * multiply-add is used it is written explicitly as fmaf() so that the HIP
