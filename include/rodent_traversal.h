@@ -87,8 +87,15 @@ void amdgpu_occluded_single_ray1_bvh2_tri1(int32_t dev,
 
 /* ---- New entry points, same naming pattern ------------------------------ */
 
-/* BVH8/Tri4 on the GPU (the reference only has this layout on the CPU,
- * cpu_intersect_single_ray1_bvh8_tri4, bench_traversal.impala:429-441). */
+/* BVH4/Tri4 and BVH8/Tri4 on the GPU (the reference only has these layouts on the CPU,
+ * cpu_{intersect,occluded}_single_ray1_bvh{4,8}_tri4, bench_traversal.impala:399-455).  Per-ray visit order: the
+ * reference GPU kernel's branch for arity != 2 (src/traversal/mapping_gpu.impala:136-153,160-169). */
+void hip_intersect_single_ray1_bvh4_tri4(int32_t dev,
+        const struct Node4* nodes, const struct Tri4* tris,
+        const struct Ray1* rays, struct Hit1* hits, int32_t num_rays);
+void hip_occluded_single_ray1_bvh4_tri4(int32_t dev,
+        const struct Node4* nodes, const struct Tri4* tris,
+        const struct Ray1* rays, struct Hit1* hits, int32_t num_rays);
 void hip_intersect_single_ray1_bvh8_tri4(int32_t dev,
         const struct Node8* nodes, const struct Tri4* tris,
         const struct Ray1* rays, struct Hit1* hits, int32_t num_rays);
@@ -107,14 +114,24 @@ void hip_traverse_bvh2_tri1_async(int32_t dev,
         const struct Node2* nodes, const struct Tri1* tris,
         const struct Ray1* rays, struct Hit1* hits, int32_t num_rays,
         int32_t any_hit, int32_t variant, void* stream);
+void hip_traverse_bvh4_tri4_async(int32_t dev,
+        const struct Node4* nodes, const struct Tri4* tris,
+        const struct Ray1* rays, struct Hit1* hits, int32_t num_rays,
+        int32_t any_hit, int32_t variant, void* stream);
 void hip_traverse_bvh8_tri4_async(int32_t dev,
         const struct Node8* nodes, const struct Tri4* tris,
         const struct Ray1* rays, struct Hit1* hits, int32_t num_rays,
         int32_t any_hit, int32_t variant, void* stream);
+/* The reference's stack holds 64 entries, unchecked (src/traversal/stack.impala:53-54).  Here a ray that needs more
+ * raises a device-side flag: the synchronous entry points above abort() on it like the reference's runtime failures
+ * (bench_traversal.impala:17-21); after the asynchronous forms call this -- it waits for `stream`, returns 1 if any
+ * launch enqueued on it since the last call overflowed (those rays' hits are undefined), and clears the flag. */
+int32_t rodent_hip_check_errors(int32_t dev, void* stream);
 
 /* Introspection / plumbing. */
 int32_t     rodent_hip_device_count(void);              /* 0 when no GPU is visible */
-int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2 or 8 */
+int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2, 4 or 8 */
+int32_t     rodent_hip_is_lab_build(void);              /* 1 = librodent_hip_lab.so (-DRODENT_HIP_LAB: also the measured-and-lost kernels) */
 const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant);
 const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t any_hit);
 const char* rodent_hip_version(void);

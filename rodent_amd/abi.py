@@ -9,21 +9,29 @@ visible, calls raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 from . import formats as F
 
-LIB_PATH = Path(__file__).resolve().parent / "lib" / "librodent_hip.so"
+# RODENT_HIP_LAB=1 selects the lab build (librodent_hip_lab.so: the product kernels plus every measured-and-lost variant
+# and the instrumented builds; made by `RODENT_HIP_LAB=1 python -m rodent_amd.build`).  Default: the product library.
+LAB = os.environ.get("RODENT_HIP_LAB", "0") not in ("", "0")
+LIB_PATH = Path(__file__).resolve().parent / "lib" / ("librodent_hip_lab.so" if LAB else "librodent_hip.so")
 
-EXPORTS = [
+SYNC_ENTRY_POINTS = [
     "amdgpu_intersect_single_ray1_bvh2_tri1", "amdgpu_occluded_single_ray1_bvh2_tri1",
+    "hip_intersect_single_ray1_bvh4_tri4", "hip_occluded_single_ray1_bvh4_tri4",
     "hip_intersect_single_ray1_bvh8_tri4", "hip_occluded_single_ray1_bvh8_tri4",
-    "hip_traverse_bvh2_tri1_async", "hip_traverse_bvh8_tri4_async",
-    "rodent_hip_device_count", "rodent_hip_num_variants", "rodent_hip_variant_name",
-    "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_read_stats", "rodent_hip_read_trace",
 ]
+ASYNC_ENTRY_POINTS = ["hip_traverse_bvh2_tri1_async", "hip_traverse_bvh4_tri4_async", "hip_traverse_bvh8_tri4_async"]
+EXPORTS = SYNC_ENTRY_POINTS + ASYNC_ENTRY_POINTS + [
+    "rodent_hip_check_errors", "rodent_hip_device_count", "rodent_hip_num_variants", "rodent_hip_variant_name",
+    "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_is_lab_build", "rodent_hip_read_stats", "rodent_hip_read_trace",
+]
+BLOCK_OF_WIDTH = {2: F.BVH2_TRI1, 4: F.BVH4_TRI4, 8: F.BVH8_TRI4}
 
 _lib = None
 
@@ -40,10 +48,12 @@ def lib():
             raise MissingExtension(f"{LIB_PATH} not built: run `python -m rodent_amd.build` (needs hipcc)")
         l = C.CDLL(str(LIB_PATH))
         vp, i32 = C.c_void_p, C.c_int32
-        for name in EXPORTS[:4]:
+        for name in SYNC_ENTRY_POINTS:
             fn = getattr(l, name); fn.restype = None; fn.argtypes = [i32, vp, vp, vp, vp, i32]
-        for name in EXPORTS[4:6]:
+        for name in ASYNC_ENTRY_POINTS:
             fn = getattr(l, name); fn.restype = None; fn.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
+        l.rodent_hip_check_errors.restype = i32; l.rodent_hip_check_errors.argtypes = [i32, vp]
+        l.rodent_hip_is_lab_build.restype = i32; l.rodent_hip_is_lab_build.argtypes = []
         l.rodent_hip_device_count.restype = i32; l.rodent_hip_device_count.argtypes = []
         l.rodent_hip_num_variants.restype = i32; l.rodent_hip_num_variants.argtypes = [i32]
         l.rodent_hip_variant_name.restype = C.c_char_p; l.rodent_hip_variant_name.argtypes = [i32, i32]
@@ -81,10 +91,10 @@ def from_device(t, dtype: np.dtype) -> np.ndarray:
 
 
 class DeviceBvh:
-    """A BVH resident in HBM: nodes + tris of one layout (2 = Node2/Tri1, 8 = Node8/Tri4)."""
+    """A BVH resident in HBM: nodes + tris of one layout (2 = Node2/Tri1, 4 = Node4/Tri4, 8 = Node8/Tri4)."""
 
     def __init__(self, width, nodes, tris, dev=0):
-        assert width in (2, 8)
+        assert width in (2, 4, 8)
         self.width, self.dev = width, dev
         self.num_nodes, self.num_tris = len(nodes), len(tris)
         self.nodes = to_device(nodes, dev)
@@ -92,7 +102,7 @@ class DeviceBvh:
 
     @classmethod
     def load(cls, path, width, dev=0):
-        nodes, tris = F.read_bvh(path, F.BVH2_TRI1 if width == 2 else F.BVH8_TRI4)
+        nodes, tris = F.read_bvh(path, BLOCK_OF_WIDTH[width])
         return cls(width, nodes, tris, dev)
 
 
@@ -101,7 +111,7 @@ def traverse_async(bvh: DeviceBvh, rays_dev, hits_dev, num_rays, any_hit=False, 
     import torch
     if stream is None:
         stream = torch.cuda.current_stream(bvh.dev)
-    fn = lib().hip_traverse_bvh2_tri1_async if bvh.width == 2 else lib().hip_traverse_bvh8_tri4_async
+    fn = getattr(lib(), {2: "hip_traverse_bvh2_tri1_async", 4: "hip_traverse_bvh4_tri4_async", 8: "hip_traverse_bvh8_tri4_async"}[bvh.width])
     fn(bvh.dev, bvh.nodes.data_ptr(), bvh.tris.data_ptr(), rays_dev.data_ptr(), hits_dev.data_ptr(),
        int(num_rays), int(any_hit), int(variant), C.c_void_p(stream.cuda_stream))
 
@@ -118,12 +128,24 @@ def traverse(bvh: DeviceBvh, rays: np.ndarray, any_hit=False, variant=None) -> n
     if variant is None:
         torch.cuda.synchronize(bvh.dev)
         name = {(2, False): "amdgpu_intersect_single_ray1_bvh2_tri1", (2, True): "amdgpu_occluded_single_ray1_bvh2_tri1",
+                (4, False): "hip_intersect_single_ray1_bvh4_tri4", (4, True): "hip_occluded_single_ray1_bvh4_tri4",
                 (8, False): "hip_intersect_single_ray1_bvh8_tri4", (8, True): "hip_occluded_single_ray1_bvh8_tri4"}[(bvh.width, bool(any_hit))]
         getattr(lib(), name)(bvh.dev, bvh.nodes.data_ptr(), bvh.tris.data_ptr(), rays_dev.data_ptr(), hits_dev.data_ptr(), n)
     else:
         traverse_async(bvh, rays_dev, hits_dev, n, any_hit, variant)
         torch.cuda.synchronize(bvh.dev)
+        check_errors(bvh.dev)
     return from_device(hits_dev, F.HIT1)[:n]
+
+
+def check_errors(dev=0, stream=None):
+    """The asynchronous entry points report a traversal-stack overflow (more than the reference's 64 entries,
+    stack.impala:53) through a device-side flag: this waits for `stream`, reads and clears it, and raises."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream(dev)
+    if lib().rodent_hip_check_errors(dev, C.c_void_p(stream.cuda_stream)):
+        raise RuntimeError("rodent_hip: traversal stack overflow (more than 64 entries)")
 
 
 def read_stats(dev=0):

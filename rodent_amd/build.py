@@ -1,7 +1,9 @@
 """In-tree native build for rodent_amd (no cmake: hipcc / g++ driven directly).
 
 Artefacts (all git-ignored, they travel to the GPU box with the snapshot):
-  rodent_amd/lib/librodent_hip.so   HIP kernels + C ABI (include/*.h)
+  rodent_amd/lib/librodent_hip.so   HIP kernels + C ABI (include/*.h): the product, default mappings only
+  rodent_amd/lib/librodent_hip_lab.so  the same + every measured-and-lost kernel variant and the instrumented
+                                    builds (-DRODENT_HIP_LAB); only built when RODENT_HIP_LAB=1 is set
   rodent_amd/bin/<tool>             host tools: bvh_extractor, ray_gen, scene_gen,
                                     fbuf2png, bench_traversal, rodent
   oracle/liboracle.so               CPU parity oracle (test infrastructure only)
@@ -66,6 +68,10 @@ def build_hip_lib(force: bool = False) -> Path:
     srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
     if force or _newer(out, *srcs, *_headers()):
         _run([HIPCC, *HIP_FLAGS, "-shared", *srcs, "-o", out])
+    if os.environ.get("RODENT_HIP_LAB", "0") not in ("", "0"):
+        lab = LIB_DIR / "librodent_hip_lab.so"
+        if force or _newer(lab, *srcs, *_headers()):
+            _run([HIPCC, *HIP_FLAGS, "-DRODENT_HIP_LAB", "-shared", *srcs, "-o", lab])
     return out
 
 

@@ -21,8 +21,10 @@
 //  * arithmetic is written out with explicit fmaf() and compiled with
 //    -ffp-contract=off so results are bit-identical to the CPU parity oracle.
 //
-// This file: shared device helpers, the default kernel (k_bvh2_single), k_bvh2_finish, the BVH8 kernel, the host
-// side and the C ABI.  The other BVH2 kernels measured along the way are in traversal_variants.h.
+// This file: shared device helpers, the default BVH2 kernel (k_bvh2_single) and its follow-up kernel k_bvh2_finish, the
+// host side and the C ABI.  traversal_wide.h holds the BVH4 / BVH8 + Tri4 kernels (same schedule).  The kernels that
+// were measured along the way and lost (traversal_variants.h) are compiled only into the lab build
+// (-DRODENT_HIP_LAB, librodent_hip_lab.so): the product library ships the default mappings only.
 // Kernel variants ("mappings") are selected at run time; see kVariants below.
 #include <hip/hip_runtime.h>
 
@@ -31,6 +33,8 @@
 #include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 #include "rodent_traversal.h"
 #include "traversal_device.h"
@@ -48,25 +52,6 @@
 namespace {
 
 using namespace rodent_dev;
-
-// ---------------------------------------------------------------------------------------------
-// Per-lane stack: first LDS_N entries in LDS ([entry][lane]), the rest in scratch.
-// ---------------------------------------------------------------------------------------------
-template <int LDS_N>
-struct LaneStack {
-    int* lds;                        // this lane's column
-    int  spill[kStackCap - LDS_N];
-    int* err;
-    __device__ __forceinline__ void put(int e, int v) {
-        if (e < LDS_N) lds[e * kWave] = v;
-        else if (e < kStackCap) spill[e - LDS_N] = v;
-        else *err = 1;
-    }
-    __device__ __forceinline__ int get(int e) const {
-        return e < LDS_N ? lds[e * kWave] : spill[(e < kStackCap ? e : kStackCap - 1) - LDS_N];
-    }
-};
-
 
 // One leaf of Tri1 records (mapping_gpu.impala:156-174).  Returns true when an
 // any-hit query is finished.
@@ -282,79 +267,6 @@ __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// BVH8 / Tri4, variant 0: the reference's GPU "general case" for arity != 2
-// (mapping_gpu.impala:136-153) applied to the CPU layouts Node8 / Tri4
-// (mapping_cpu.impala:3-22): pop; test all children; the nearest hit child goes on
-// top, the others underneath in slot order; no distance stored, no culling on pop.
-// Triangles of a Tri4 packet are tested one after the other (mapping_gpu.impala:160-169).
-// ---------------------------------------------------------------------------------------------
-template <bool ANY>
-__device__ __forceinline__ bool leaf_tri4(const Tri4* __restrict__ tris, int first, RayX& ray, HitAcc& hit) {
-    int j = first;
-    for (;;) {
-        const float4* p = reinterpret_cast<const float4*>(tris + j++);
-        const int4 pid = *reinterpret_cast<const int4*>(p + 12);
-        const int ids[4] = {pid.x, pid.y, pid.z, pid.w};
-        float q[12][4];
-#pragma unroll
-        for (int r = 0; r < 12; r++) { const float4 x = p[r]; q[r][0] = x.x; q[r][1] = x.y; q[r][2] = x.z; q[r][3] = x.w; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (ids[k] == -1) break;                                  // is_valid (mapping_cpu.impala:38)
-            float t, u, v;
-            if (intersect_tri(ray, q[0][k], q[1][k], q[2][k], q[3][k], q[4][k], q[5][k],
-                              q[6][k], q[7][k], q[8][k], q[9][k], q[10][k], q[11][k], t, u, v)) {
-                hit.id = ids[k] & 0x7FFFFFFF; hit.t = t; hit.u = u; hit.v = v;
-                ray.tmax = t;
-                if (ANY) return true;
-            }
-        }
-        if (pid.w < 0) return false;                                  // is_last (mapping_cpu.impala:39)
-    }
-}
-
-template <bool ANY, int LDS_N>
-__global__ __launch_bounds__(kWave) void k_bvh8_lane(const Node8* __restrict__ nodes, const Tri4* __restrict__ tris,
-                                                      const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n, int* err) {
-    __shared__ int lds[LDS_N * kWave];
-    const int i = blockIdx.x * kWave + threadIdx.x;
-    if (i >= n) return;
-    RayX ray = load_ray(rays, i);
-    HitAcc hit{-1, ray.tmax, 0.0f, 0.0f};
-    LaneStack<LDS_N> st; st.lds = lds + threadIdx.x; st.err = err;
-    int ptr = 0, top = 1; st.put(0, 0);
-    while (top != 0) {
-        const float4* p = reinterpret_cast<const float4*>(nodes + (top - 1));
-        top = st.get(ptr); ptr--;                                     // pop (:138)
-        float tnear = ray.tmax;
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const float4 lx = p[0 + half], hx = p[2 + half], ly = p[4 + half], hy = p[6 + half], lz = p[8 + half], hz = p[10 + half];
-            const int4 ch = *reinterpret_cast<const int4*>(p + 12 + half);
-            const float blx[4] = {lx.x, lx.y, lx.z, lx.w}, bhx[4] = {hx.x, hx.y, hx.z, hx.w};
-            const float bly[4] = {ly.x, ly.y, ly.z, ly.w}, bhy[4] = {hy.x, hy.y, hy.z, hy.w};
-            const float blz[4] = {lz.x, lz.y, lz.z, lz.w}, bhz[4] = {hz.x, hz.y, hz.z, hz.w};
-            const int   chi[4] = {ch.x, ch.y, ch.z, ch.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float te;
-                if (slab(ray, blx[k], bhx[k], bly[k], bhy[k], blz[k], bhz[k], te) && chi[k] != 0) {
-                    if (ANY || te < tnear) { st.put(++ptr, top); top = chi[k]; tnear = te; }   // push      (:145-147)
-                    else st.put(++ptr, chi[k]);                                                   // push_after (:149)
-                }
-            }
-        }
-        bool done = false;
-        while (top < 0) {
-            const int first = ~top; top = st.get(ptr); ptr--;
-            if (leaf_tri4<ANY>(tris, first, ray, hit)) { done = true; break; }
-        }
-        if (ANY && done) break;
-    }
-    store_hit(hits, i, hit.id, hit.t, hit.u, hit.v);
-}
-
-// ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
 struct DeviceState {
@@ -416,12 +328,23 @@ void ensure_deep_list(DeviceState& s, int n) {
     s.deep_cap = n;
 }
 
-void check_error_flag(DeviceState& s, hipStream_t stream) {
+// Copies back and clears both stack-overflow flags (scratch[1]: the lab kernels' LaneStack; ctl->err: the follow-up
+// kernels' 64-entry global stack) after everything enqueued on `stream` has finished.
+bool read_and_clear_error_flags(DeviceState& s, hipStream_t stream) {
     int flag[2] = {0, 0};
     HIP_CHECK(hipMemcpyAsync(&flag[0], s.scratch + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(&flag[1], &s.ctl()->err, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    if (flag[0] || flag[1]) { fprintf(stderr, "rodent_hip: traversal stack overflow (more than %d entries)\n", kStackCap); abort(); }
+    if (flag[0] || flag[1]) {
+        HIP_CHECK(hipMemsetAsync(s.scratch + 1, 0, sizeof(int), stream));
+        HIP_CHECK(hipMemsetAsync(&s.ctl()->err, 0, sizeof(int), stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    return flag[0] || flag[1];
+}
+// the reference's entry points have no return code (bench_traversal.impala:17-21: message + abort)
+void check_error_flag(DeviceState& s, hipStream_t stream) {
+    if (read_and_clear_error_flags(s, stream)) { fprintf(stderr, "rodent_hip: traversal stack overflow (more than %d entries)\n", kStackCap); abort(); }
 }
 
 #define LAUNCH_ARGS DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
@@ -433,26 +356,29 @@ template <bool ANY, int LDS_N, int XCD, bool TR = false> void L_single(LAUNCH_AR
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
 }
 
-#include "traversal_variants.h"      // the other BVH2 kernels and their launchers (L_lane, L_ww, L_fast, L_sched)
+#include "traversal_wide.h"          // BVH4 / BVH8 + Tri4: k_wide_single, k_wide_finish, L_wide_single
+#ifdef RODENT_HIP_LAB
+#include "traversal_variants.h"      // lab build only: the kernels that were measured and lost, instrumented builds
+#endif
 
 using Launch2 = void (*)(LAUNCH_ARGS);
 struct Variant2 { const char* name; const char* kernel[2]; Launch2 launch[2]; };
-#define V2(name, fn, ...) {name, {#fn "<false," #__VA_ARGS__ ">", #fn "<true," #__VA_ARGS__ ">"}, {&fn<false, __VA_ARGS__>, &fn<true, __VA_ARGS__>}}
 #define K2(name, kname, fn, ...) {name, {kname "<false," #__VA_ARGS__ ">", kname "<true," #__VA_ARGS__ ">"}, {&fn<false, __VA_ARGS__>, &fn<true, __VA_ARGS__>}}
 const Variant2 kVariants2[] = {
     // 0 = default (used by the reference-named entry points).  All variants keep the reference's per-ray
     // visit order and are bit-identical; they differ in how a wavefront schedules its 64 rays.
-    //                                                      LDS_N NODE_EXIT PERSIST REFILL_IDLE CHUNK STATS XCD_GROUP
     //                                                        LDS_N XCD_GROUP
     K2("fast",               "k_bvh2_single",        L_single, 16, 32),                // default: single-step schedule, XCD-aware 32-chunk groups
+    K2("fast-noxcd",         "k_bvh2_single",        L_single, 16, 0),                 // same kernel, workgroup b traces chunk b
+#ifdef RODENT_HIP_LAB
     K2("lane",               "k_bvh2_lane",          L_lane, 24),                      // literal reference mapping
     K2("ww",                 "k_bvh2_ww",            L_ww, 24, 8),                     // while-while, LDS+scratch stack
+    //                                                      LDS_N NODE_EXIT PERSIST REFILL_IDLE CHUNK STATS XCD_GROUP
     K2("fast-ww",            "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32),   // while-while schedule (the default before the single-step loop)
     K2("fast-exit0",         "k_bvh2_fast",          L_fast, 16, 0,  false, 64, 64, false, 32),
     K2("fast-exit16",        "k_bvh2_fast",          L_fast, 16, 16, false, 64, 64, false, 32),
     K2("fast-lds24",         "k_bvh2_fast",          L_fast, 24, 8,  false, 64, 64, false, 32),
     K2("fast-persistent",    "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 128),
-    K2("fast-noxcd",         "k_bvh2_single",        L_single, 16, 0),
     K2("fast-ww-noxcd",      "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64),
     //                                                       LDS_N PERSIST REFILL_IDLE CHUNK TRI_BIAS(x/4) PERMUTE
     K2("sched",              "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false),
@@ -472,14 +398,37 @@ const Variant2 kVariants2[] = {
     K2("fast-static-r16",    "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 64, false, 32, false, true),
     K2("fast-static-r8",     "k_bvh2_fast",          L_fast, 16, 8,  true,  8,  64, false, 32, false, true),
     K2("trace-fast-static",  "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 64, false, 32, true,  true),
+#endif
 };
 constexpr int kNumVariants2 = sizeof(kVariants2) / sizeof(kVariants2[0]);
 
-struct VariantInfo { const char* name; const char* kernel_closest; const char* kernel_any; };
-const VariantInfo kVariants8[] = {
-    {"lane", "k_bvh8_lane<false,24>", "k_bvh8_lane<true,24>"},
+// BVH4 / BVH8 + Tri4 (traversal_wide.h).  LDS window: 16 entries for BVH4, 24 for BVH8 (deepest stack on the atrium's
+// benchmark dumps: 15 and 21); deeper rays go to k_wide_finish.
+using LaunchW = void (*)(WIDE_LAUNCH_ARGS);
+struct VariantW { const char* name; const char* kernel[2]; LaunchW launch[2]; };
+#define KW(name, kname, fn, ...) {name, {kname "<false," #__VA_ARGS__ ">", kname "<true," #__VA_ARGS__ ">"}, {&fn<false, __VA_ARGS__>, &fn<true, __VA_ARGS__>}}
+const VariantW kVariants4[] = {
+    //                                                   N LDS_N XCD_GROUP
+    KW("single",             "k_wide_single",        L_wide_single, 4, 16, 32),
+    KW("single-noxcd",       "k_wide_single",        L_wide_single, 4, 16, 0),
+#ifdef RODENT_HIP_LAB
+    KW("lane",               "k_wide_lane",          L_wide_lane, 4, 16),              // literal reference mapping
+#endif
 };
+const VariantW kVariants8[] = {
+    KW("single",             "k_wide_single",        L_wide_single, 8, 24, 32),
+    KW("single-noxcd",       "k_wide_single",        L_wide_single, 8, 24, 0),
+#ifdef RODENT_HIP_LAB
+    KW("lane",               "k_wide_lane",          L_wide_lane, 8, 24),
+#endif
+};
+constexpr int kNumVariants4 = sizeof(kVariants4) / sizeof(kVariants4[0]);
 constexpr int kNumVariants8 = sizeof(kVariants8) / sizeof(kVariants8[0]);
+inline const VariantW* wide_variants(int width, int* count) {
+    if (width == 4) { *count = kNumVariants4; return kVariants4; }
+    if (width == 8) { *count = kNumVariants8; return kVariants8; }
+    *count = 0; return nullptr;
+}
 
 template <bool ANY>
 void launch_bvh2(DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, int variant, hipStream_t stream) {
@@ -489,20 +438,17 @@ void launch_bvh2(DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray
     HIP_CHECK(hipGetLastError());
 }
 
-template <bool ANY>
-void launch_bvh8(DeviceState& s, const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int n, int variant, hipStream_t stream) {
+void launch_wide(int width, bool any_hit, DeviceState& s, const void* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int n, int variant, hipStream_t stream) {
     if (n <= 0) return;
-    int* err = s.scratch + 1;
-    const int blocks = (n + kWave - 1) / kWave;
-    switch (variant) {
-        case 0: hipLaunchKernelGGL((k_bvh8_lane<ANY, 24>), dim3(blocks), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, err); break;
-        default: fprintf(stderr, "rodent_hip: unknown BVH8 variant %d\n", variant); abort();
-    }
+    int count = 0;
+    const VariantW* table = wide_variants(width, &count);
+    if (variant < 0 || variant >= count) { fprintf(stderr, "rodent_hip: unknown BVH%d variant %d\n", width, variant); abort(); }
+    table[variant].launch[any_hit ? 1 : 0](s, nodes, tris, rays, hits, n, stream);
     HIP_CHECK(hipGetLastError());
 }
 
 int default_variant(int width) {
-    const char* e = getenv(width == 2 ? "RODENT_HIP_BVH2_VARIANT" : "RODENT_HIP_BVH8_VARIANT");
+    const char* e = getenv(width == 2 ? "RODENT_HIP_BVH2_VARIANT" : (width == 4 ? "RODENT_HIP_BVH4_VARIANT" : "RODENT_HIP_BVH8_VARIANT"));
     return e ? atoi(e) : 0;
 }
 
@@ -518,12 +464,24 @@ void hip_traverse_bvh2_tri1_async(int32_t dev, const Node2* nodes, const Tri1* t
     else         launch_bvh2<false>(s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
 }
 
+void hip_traverse_bvh4_tri4_async(int32_t dev, const Node4* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits,
+                                  int32_t num_rays, int32_t any_hit, int32_t variant, void* stream) {
+    DeviceState& s = device_state(dev, (hipStream_t)stream);
+    HIP_CHECK(hipSetDevice(dev));
+    launch_wide(4, any_hit != 0, s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
+}
+
 void hip_traverse_bvh8_tri4_async(int32_t dev, const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits,
                                   int32_t num_rays, int32_t any_hit, int32_t variant, void* stream) {
     DeviceState& s = device_state(dev, (hipStream_t)stream);
     HIP_CHECK(hipSetDevice(dev));
-    if (any_hit) launch_bvh8<true>(s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
-    else         launch_bvh8<false>(s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
+    launch_wide(8, any_hit != 0, s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
+}
+
+int32_t rodent_hip_check_errors(int32_t dev, void* stream) {
+    DeviceState& s = device_state(dev, (hipStream_t)stream);
+    HIP_CHECK(hipSetDevice(dev));
+    return read_and_clear_error_flags(s, (hipStream_t)stream) ? 1 : 0;
 }
 
 void amdgpu_intersect_single_ray1_bvh2_tri1(int32_t dev, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
@@ -532,6 +490,14 @@ void amdgpu_intersect_single_ray1_bvh2_tri1(int32_t dev, const Node2* nodes, con
 }
 void amdgpu_occluded_single_ray1_bvh2_tri1(int32_t dev, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
     hip_traverse_bvh2_tri1_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(2), nullptr);
+    check_error_flag(device_state(dev, nullptr), nullptr);
+}
+void hip_intersect_single_ray1_bvh4_tri4(int32_t dev, const Node4* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
+    hip_traverse_bvh4_tri4_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(4), nullptr);
+    check_error_flag(device_state(dev, nullptr), nullptr);
+}
+void hip_occluded_single_ray1_bvh4_tri4(int32_t dev, const Node4* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
+    hip_traverse_bvh4_tri4_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(4), nullptr);
     check_error_flag(device_state(dev, nullptr), nullptr);
 }
 void hip_intersect_single_ray1_bvh8_tri4(int32_t dev, const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
@@ -548,16 +514,26 @@ int32_t rodent_hip_device_count(void) {
     if (hipGetDeviceCount(&count) != hipSuccess) return 0;
     return count;
 }
-int32_t rodent_hip_num_variants(int32_t bvh_width) { return bvh_width == 2 ? kNumVariants2 : (bvh_width == 8 ? kNumVariants8 : 0); }
+int32_t rodent_hip_num_variants(int32_t bvh_width) {
+    if (bvh_width == 2) return kNumVariants2;
+    int count = 0; wide_variants(bvh_width, &count); return count;
+}
 const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant) {
-    if (bvh_width == 2 && variant >= 0 && variant < kNumVariants2) return kVariants2[variant].name;
-    if (bvh_width == 8 && variant >= 0 && variant < kNumVariants8) return kVariants8[variant].name;
-    return "";
+    if (bvh_width == 2) return variant >= 0 && variant < kNumVariants2 ? kVariants2[variant].name : "";
+    int count = 0; const VariantW* t = wide_variants(bvh_width, &count);
+    return variant >= 0 && variant < count ? t[variant].name : "";
 }
 const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t any_hit) {
-    if (bvh_width == 2 && variant >= 0 && variant < kNumVariants2) return kVariants2[variant].kernel[any_hit ? 1 : 0];
-    if (bvh_width == 8 && variant >= 0 && variant < kNumVariants8) return any_hit ? kVariants8[variant].kernel_any : kVariants8[variant].kernel_closest;
-    return "";
+    if (bvh_width == 2) return variant >= 0 && variant < kNumVariants2 ? kVariants2[variant].kernel[any_hit ? 1 : 0] : "";
+    int count = 0; const VariantW* t = wide_variants(bvh_width, &count);
+    return variant >= 0 && variant < count ? t[variant].kernel[any_hit ? 1 : 0] : "";
+}
+int32_t rodent_hip_is_lab_build(void) {
+#ifdef RODENT_HIP_LAB
+    return 1;
+#else
+    return 0;
+#endif
 }
 /* Debug aid for the instrumented ("stats-*") variants: copies the 8 phase counters to out[] and clears them. */
 /* Debug aid: enables the per-wave timeline of the instrumented variants and copies it out
@@ -582,6 +558,6 @@ void rodent_hip_read_stats(int32_t dev, uint64_t* out) {
     HIP_CHECK(hipMemcpy(out, s.ctl()->stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemset(s.ctl()->stats, 0, 8 * sizeof(uint64_t)));
 }
-const char* rodent_hip_version(void) { return "rodent_hip 0.1 (gfx950)"; }
+const char* rodent_hip_version(void) { return "rodent_hip 0.2 (gfx950)"; }
 
 } // extern "C"

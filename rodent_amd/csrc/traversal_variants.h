@@ -3,8 +3,28 @@
 // one-ray-per-lane mapping of the reference, the while-while family with its persistent / static-stride / instrumented
 // forms, and the per-step ballot scheduler.  All keep the reference's per-ray visit order and are bit-identical to the
 // default.  Included by traversal.hip inside its anonymous namespace, after Ctl, k_bvh2_finish, DeviceState,
-// LAUNCH_ARGS and ensure_deep_list.
+// LAUNCH_ARGS, ensure_deep_list and traversal_wide.h -- in the LAB build only (-DRODENT_HIP_LAB, librodent_hip_lab.so).
 #pragma once
+
+// ---------------------------------------------------------------------------------------------
+// Per-lane stack: first LDS_N entries in LDS ([entry][lane]), the rest in scratch.
+// ---------------------------------------------------------------------------------------------
+template <int LDS_N>
+struct LaneStack {
+    int* lds;                        // this lane's column
+    int  spill[kStackCap - LDS_N];
+    int* err;
+    __device__ __forceinline__ void put(int e, int v) {
+        if (e < LDS_N) lds[e * kWave] = v;
+        else if (e < kStackCap) spill[e - LDS_N] = v;
+        else *err = 1;
+    }
+    __device__ __forceinline__ int get(int e) const {
+        return e < LDS_N ? lds[e * kWave] : spill[(e < kStackCap ? e : kStackCap - 1) - LDS_N];
+    }
+};
+
+
 
 // ---------------------------------------------------------------------------------------------
 // BVH2 / Tri1, "lane": literal one-ray-per-lane mapping of the reference kernel.
@@ -402,3 +422,21 @@ template <bool ANY, int LDS_N, bool P, int RI, int CH, int TB, bool PERMUTE = fa
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// BVH4 / BVH8 + Tri4, "lane": the reference's general-arity loop, literally, one ray per lane (wide_ray_literal):
+// pop-first loop, hit record in registers, LDS window + scratch spill, no XCD mapping.  BVH8: 118 VGPRs.
+// ---------------------------------------------------------------------------------------------
+template <bool ANY, int N, int LDS_N>
+__global__ __launch_bounds__(kWave) void k_wide_lane(const char* __restrict__ nodes, const Tri4* __restrict__ tris,
+                                                      const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n, int* err) {
+    __shared__ int lds[LDS_N * kWave];
+    const int i = blockIdx.x * kWave + threadIdx.x;
+    if (i >= n) return;
+    LaneStack<LDS_N> st; st.lds = lds + threadIdx.x; st.err = err;
+    const HitAcc hit = wide_ray_literal<ANY, N>(nodes, tris, load_ray(rays, i), st);
+    store_hit(hits, i, hit.id, hit.t, hit.u, hit.v);
+}
+template <bool ANY, int N, int LDS_N> void L_wide_lane(WIDE_LAUNCH_ARGS) {
+    hipLaunchKernelGGL((k_wide_lane<ANY, N, LDS_N>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, n, s.scratch + 1);
+}

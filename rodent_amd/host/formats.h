@@ -33,9 +33,14 @@ inline bool load_bvh(const std::string& file, BvhType type, std::vector<Node>& n
             uint32_t hdr[2];
             ok = fread(hdr, 4, 2, f) == 2;
             if (ok) {
+                // the counts must agree with the block size and the block must fit in the file BEFORE anything is allocated
+                const uint64_t payload = sizeof(Node) * (uint64_t)hdr[0] + sizeof(Tri) * (uint64_t)hdr[1];
+                const long here = ftell(f);
+                ok = offset == 12 + payload && here >= 0 && fseek(f, 0, SEEK_END) == 0 && (uint64_t)(ftell(f) - here) >= payload && fseek(f, here, SEEK_SET) == 0;
+            }
+            if (ok) {
                 nodes.resize(hdr[0]); tris.resize(hdr[1]);
-                ok = offset == 12 + sizeof(Node) * (uint64_t)hdr[0] + sizeof(Tri) * (uint64_t)hdr[1]
-                  && fread(nodes.data(), sizeof(Node), hdr[0], f) == hdr[0]
+                ok = fread(nodes.data(), sizeof(Node), hdr[0], f) == hdr[0]
                   && fread(tris.data(), sizeof(Tri), hdr[1], f) == hdr[1];
             }
             break;

@@ -39,6 +39,7 @@ ALGOS = {  # name -> (bvh block, width, oracle algo)
     "bvh2_gpu": (F.BVH2_TRI1, 2, "ref"),    # mapping_gpu.impala:94-178 on BVH2/Tri1
     "bvh4_cpu": (F.BVH4_TRI4, 4, "ref"),    # mapping_cpu.impala:138-256 on BVH4/Tri4
     "bvh8_cpu": (F.BVH8_TRI4, 8, "ref"),    # mapping_cpu.impala:138-256 on BVH8/Tri4
+    "bvh4_gpu": (F.BVH4_TRI4, 4, "gpu"),    # mapping_gpu.impala general-arity branch (:136-153) on BVH4/Tri4
     "bvh8_gpu": (F.BVH8_TRI4, 8, "gpu"),    # mapping_gpu.impala general-arity branch on BVH8/Tri4
 }
 

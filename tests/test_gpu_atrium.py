@@ -1,0 +1,125 @@
+"""GPU parity on the benchmark scene at full size (BASELINE configs 2, 3 and 5 on the atrium substitute).
+
+* every one of the 1 048 576 primary and random rays of the benchmark dumps against oracle B1 / B1g, whole Hit1 record
+  bit for bit, for the BVH2, BVH4 and BVH8 kernels;
+* the wavefront path tracer on the atrium's real BVH (264 884 triangles, textures-free MTL with a Phong floor and
+  bronze): streaming sorted, streaming unsorted and megakernel mappings against the CPU oracle -- ray counts EXACT,
+  film within 1e-5 relative + 1e-6 absolute (order of the fp32 atomic adds only);
+* the same frame as 2, 3 and 8 row bands (rodent_hip_render_rows: the multi-GPU sharding of SURVEY 8e) equals the
+  full frame.
+Reference: src/traversal/mapping_gpu.impala:94-178 and src/render/mapping_gpu.impala:308-369,384-420.
+"""
+import numpy as np
+import pytest
+
+from rodent_amd import formats as F
+from rodent_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+FILM_RTOL, FILM_ATOL = 1e-5, 1e-6
+BLOCKS = {2: (F.BVH2_TRI1, "ref"), 4: (F.BVH4_TRI4, "gpu"), 8: (F.BVH8_TRI4, "gpu")}
+
+
+@pytest.fixture(scope="module")
+def gpu(native_build):
+    import torch
+    from rodent_amd import abi
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    abi.lib()
+    return abi
+
+
+@pytest.fixture(scope="module")
+def dumps(gpu):
+    from rodent_amd import raygen, scenes
+    path = scenes.scene_bvh("atrium")
+    eye, d, up, fov = scenes.CAMERAS["atrium"]
+    n4, _ = F.read_bvh(path, F.BVH4_TRI4)
+    lo, hi = raygen.scene_bounds(n4)
+    return path, {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, scenes.PRIMARY_TMAX),
+                  "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, scenes.RANDOM_TMAX)}
+
+
+@pytest.mark.parametrize("width", [2, 4, 8])
+@pytest.mark.parametrize("kind", ["primary", "random"])
+def test_all_benchmark_rays_bit_exact(gpu, oracle, dumps, width, kind):
+    """BASELINE configs 2 / 3 at full size: all 1 Mi rays, closest hit, every shipped variant of the layout."""
+    path, rays = dumps
+    block, algo = BLOCKS[width]
+    nodes, tris = F.read_bvh(path, block)
+    r = rays[kind]
+    assert len(r) == 1 << 20
+    ref, st = oracle.traverse(width, nodes, tris, r, algo=algo)
+    assert st["max_stack"] < 64
+    bvh = gpu.DeviceBvh(width, nodes, tris, 0)
+    for v in range(len(gpu.variants(width))):
+        got = gpu.traverse(bvh, r, variant=v)
+        bad = np.nonzero((got.view("<u4").reshape(-1, 4) != ref.view("<u4").reshape(-1, 4)).any(axis=1))[0]
+        assert len(bad) == 0, f"BVH{width} {gpu.variants(width)[v]}: {len(bad)} rays differ, first {bad[0]}: {got[bad[0]]} vs {ref[bad[0]]}"
+    occ = gpu.traverse(bvh, r, any_hit=True, variant=0)
+    ref_any, _ = oracle.traverse(width, nodes, tris, r, any_hit=True, algo=algo)
+    assert occ.tobytes() == ref_any.tobytes()
+
+
+@pytest.fixture(scope="module")
+def atrium_scene(native_build, tmp_path_factory):
+    from rodent_amd import scenes
+    scenes.scene_bvh("atrium")                                   # makes data/atrium.obj (procedural, seed 1)
+    return S.convert(scenes.DATA / "atrium.obj", tmp_path_factory.mktemp("atrium") / "atrium.rscene")
+
+
+@pytest.fixture()
+def R(native_build):
+    import torch
+    from rodent_amd import render
+    assert torch.cuda.is_available()
+    return render
+
+
+ATRIUM_FRAME = dict(W=256, H=144, SPP=4, MAXLEN=8, IT=3)
+
+
+def atrium_camera(W, H):
+    from rodent_amd import scenes
+    eye, d, up, fov = scenes.CAMERAS["atrium"]
+    return S.camera_settings(eye, d, up, fov, W, H)
+
+
+@pytest.fixture(scope="module")
+def atrium_reference(oracle, atrium_scene):
+    f = ATRIUM_FRAME
+    film, counts = oracle.render(atrium_scene, atrium_camera(f["W"], f["H"]), f["IT"], f["SPP"], f["MAXLEN"], f["W"], f["H"], threads=32)
+    assert film.mean() > 1e-3 and counts[0] > 2 * f["W"] * f["H"] * f["SPP"]        # lit, and paths really bounce
+    return film, counts
+
+
+@pytest.mark.parametrize("mapping,sort,capacity", [("streaming", True, 0), ("streaming", False, 0), ("streaming", True, 50_000), ("megakernel", True, 0)])
+def test_atrium_path_trace_matches_oracle(R, atrium_scene, atrium_reference, mapping, sort, capacity):
+    """BASELINE config 5's scene through every mapping: deep stacks, nine materials (diffuse, diffuse + Phong mixes), 12 emitter triangles."""
+    f = ATRIUM_FRAME
+    film_o, counts = atrium_reference
+    r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], mapping=mapping, sort=sort, capacity=capacity)
+    r.render(atrium_camera(f["W"], f["H"]), f["IT"])
+    c = r.counters(); film_g = r.film(); r.close()
+    assert (c["primary_rays"], c["shadow_rays"], c["generated"]) == (counts[0], counts[1], f["W"] * f["H"] * f["SPP"])     # exact
+    assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
+
+
+@pytest.mark.parametrize("bands", [2, 3, 8])
+@pytest.mark.parametrize("mapping", ["streaming", "megakernel"])
+def test_atrium_row_bands_equal_the_frame(R, atrium_scene, atrium_reference, bands, mapping):
+    """Tile sharding of config 5 (8 GPUs x row bands, render/mapping_gpu.impala:384-420): bands rendered one after the
+    other into one film equal the full frame, whatever the band count (144 rows: 72 / 48 / 18 per band)."""
+    from rodent_amd import parallel
+    f = ATRIUM_FRAME
+    film_o, counts = atrium_reference
+    cam = atrium_camera(f["W"], f["H"])
+    r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], mapping=mapping)
+    primary = shadow = 0
+    for k in range(bands):
+        y0, y1 = parallel.row_band(f["H"], k, bands)
+        r.render_rows(cam, f["IT"], y0, y1)
+        c = r.counters(); primary += c["primary_rays"]; shadow += c["shadow_rays"]
+    film_g = r.film(); r.close()
+    assert (primary, shadow) == (counts[0], counts[1])
+    assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)

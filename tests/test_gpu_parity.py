@@ -20,7 +20,8 @@ from rodent_amd import formats as F
 pytestmark = pytest.mark.gpu
 
 # (bvh width, golden/oracle algorithm name, oracle algo flag)
-LAYOUTS = {2: ("bvh2_gpu", "ref"), 8: ("bvh8_gpu", "gpu")}
+LAYOUTS = {2: ("bvh2_gpu", "ref"), 4: ("bvh4_gpu", "gpu"), 8: ("bvh8_gpu", "gpu")}
+BLOCKS = {2: F.BVH2_TRI1, 4: F.BVH4_TRI4, 8: F.BVH8_TRI4}
 
 
 @pytest.fixture(scope="module")
@@ -34,20 +35,20 @@ def gpu(native_build):
 
 @pytest.fixture(scope="module")
 def cornell_dev(gpu, cornell):
-    return {w: gpu.DeviceBvh(w, *cornell.blocks[w], 0) for w in (2, 8)}
+    return {w: gpu.DeviceBvh(w, *cornell.blocks[w], 0) for w in (2, 4, 8)}
 
 
 @pytest.fixture(scope="module")
 def atrium(gpu, oracle):
     from rodent_amd import scenes, raygen
     path = scenes.scene_bvh("atrium")
-    blocks = {2: F.read_bvh(path, F.BVH2_TRI1), 8: F.read_bvh(path, F.BVH8_TRI4)}
+    blocks = {w: F.read_bvh(path, BLOCKS[w]) for w in (2, 4, 8)}
     eye, d, up, fov = scenes.CAMERAS["atrium"]
     n4, _ = F.read_bvh(path, F.BVH4_TRI4)
     lo, hi = raygen.scene_bounds(n4)
 
     class A:
-        dev = {w: gpu.DeviceBvh(w, *blocks[w], 0) for w in (2, 8)}
+        dev = {w: gpu.DeviceBvh(w, *blocks[w], 0) for w in (2, 4, 8)}
         host = blocks
         primary = raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0)
         random = raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)
@@ -58,7 +59,7 @@ def variants(gpu, width):
     return list(range(len(gpu.variants(width))))
 
 
-@pytest.mark.parametrize("width", [2, 8])
+@pytest.mark.parametrize("width", [2, 4, 8])
 @pytest.mark.parametrize("rayset", ["primary", "primary_tmin", "random", "edge"])
 def test_cornell_golden_bit_exact(gpu, cornell, cornell_dev, width, rayset):
     name, _ = LAYOUTS[width]
@@ -71,7 +72,7 @@ def test_cornell_golden_bit_exact(gpu, cornell, cornell_dev, width, rayset):
             assert len(bad) == 0, f"width {width} variant {v} any={any_hit}: first diff ray {bad[0]}: {got[bad[0]]} vs {exp[bad[0]]}"
 
 
-@pytest.mark.parametrize("width", [2, 8])
+@pytest.mark.parametrize("width", [2, 4, 8])
 def test_reference_named_entry_points(gpu, cornell, cornell_dev, width):
     """amdgpu_{intersect,occluded}_single_ray1_bvh2_tri1 / hip_*_bvh8_tri4 (synchronous)."""
     name, _ = LAYOUTS[width]
@@ -80,7 +81,7 @@ def test_reference_named_entry_points(gpu, cornell, cornell_dev, width):
         assert got.tobytes() == cornell.expected[f"{name}.random.{'any' if any_hit else 'closest'}"].tobytes()
 
 
-@pytest.mark.parametrize("width", [2, 8])
+@pytest.mark.parametrize("width", [2, 4, 8])
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000])
 def test_ragged_sizes(gpu, cornell, cornell_dev, width, n):
     name, _ = LAYOUTS[width]
@@ -102,13 +103,23 @@ def test_chunk_mapping_is_a_bijection(gpu, cornell, cornell_dev, n):
     rays["org"][:, 0] += (np.arange(n, dtype=np.float32) % 977) * 1e-4          # not all copies identical
     rd = gpu.to_device(rays, 0)
     out = {}
-    for name in ("fast", "fast-noxcd", "fast-ww"):
+    for name in ("fast", "fast-noxcd"):
         hd = torch.full((n * 16,), 0xFF, dtype=torch.uint8, device="cuda:0")
         gpu.traverse_async(cornell_dev[2], rd, hd, n, False, names.index(name))
         torch.cuda.synchronize()
         out[name] = gpu.from_device(hd, F.HIT1)
-    assert out["fast"].tobytes() == out["fast-noxcd"].tobytes() == out["fast-ww"].tobytes()
+    assert out["fast"].tobytes() == out["fast-noxcd"].tobytes()
     assert (out["fast"]["tri_id"] >= -1).all() and (out["fast"]["tri_id"] < 64).all()
+    for width in (4, 8):                                       # the wide kernels use the same mapping
+        wn = gpu.variants(width)
+        wide = {}
+        for name in ("single", "single-noxcd"):
+            hd = torch.full((n * 16,), 0xFF, dtype=torch.uint8, device="cuda:0")
+            gpu.traverse_async(cornell_dev[width], rd, hd, n, False, wn.index(name))
+            torch.cuda.synchronize()
+            wide[name] = gpu.from_device(hd, F.HIT1)
+        assert wide["single"].tobytes() == wide["single-noxcd"].tobytes()
+        assert np.array_equal(wide["single"]["tri_id"] >= 0, out["fast"]["tri_id"] >= 0)
 
 
 def test_launches_on_several_streams_may_overlap(gpu, oracle):
@@ -220,9 +231,9 @@ def test_random_triangle_soups_bit_exact(gpu, oracle, native_build, tmp_path, se
     d[2300:3000] = mid - org[2300:3000]
     rays = F.make_rays(org, d, 0.0, 3.0)                        # dir is not normalised: t in units of |dir|
     rays["tmin"][3000:3500] = 0.5; rays["tmax"][3500:4000] = 0.7
-    for width in (2, 8):
+    for width in (2, 4, 8):
         name, algo = LAYOUTS[width]
-        nodes, prims = F.read_bvh(tmp_path / "soup.bvh", F.BVH2_TRI1 if width == 2 else F.BVH8_TRI4)
+        nodes, prims = F.read_bvh(tmp_path / "soup.bvh", BLOCKS[width])
         bvh = gpu.DeviceBvh(width, nodes, prims, 0)
         for any_hit in (False, True):
             ref, _ = oracle.traverse(width, nodes, prims, rays, any_hit=any_hit, algo=algo)
@@ -232,7 +243,7 @@ def test_random_triangle_soups_bit_exact(gpu, oracle, native_build, tmp_path, se
                 assert got.tobytes() == ref.tobytes(), f"BVH{width} variant {gpu.variants(width)[v]} any={any_hit}"
 
 
-@pytest.mark.parametrize("width", [2, 8])
+@pytest.mark.parametrize("width", [2, 4, 8])
 @pytest.mark.parametrize("kind", ["primary", "random"])
 def test_atrium_sample_bit_exact_vs_oracle(gpu, oracle, atrium, width, kind):
     """64 Ki rays of the benchmark dumps (every 16th ray) against the oracle run live."""
@@ -253,7 +264,7 @@ def test_atrium_cross_layout_parity(gpu, oracle, atrium, kind):
     ids exact except on order-dependent ties, t within 1e-4 relative -- for both GPU layouts."""
     rays = getattr(atrium, kind)[::64]
     cpu, _ = oracle.traverse(8, *atrium.host[8], rays, algo="ref")
-    for width in (2, 8):
+    for width in (2, 4, 8):
         got = gpu.traverse(atrium.dev[width], rays, variant=0)
         assert np.array_equal(got["tri_id"] >= 0, cpu["tri_id"] >= 0)
         hit = cpu["tri_id"] >= 0
@@ -284,11 +295,14 @@ def test_full_size_properties(gpu, atrium, kind):
     # any-hit agrees with closest-hit on occlusion
     occ = gpu.traverse(atrium.dev[2], rays, any_hit=True, variant=0)
     assert np.array_equal(occ["tri_id"] >= 0, hit)
-    # BVH8 layout agrees on hit/miss and on t to 1e-4
-    w8 = gpu.traverse(atrium.dev[8], rays, variant=0)
-    assert np.array_equal(w8["tri_id"] >= 0, hit)
-    assert np.allclose(w8["t"][hit], base["t"][hit], rtol=1e-4, atol=0)
-    assert (w8["tri_id"] != base["tri_id"]).mean() < 0.02
+    # the BVH4 / BVH8 layouts agree on hit/miss and on t to 1e-4
+    for width in (4, 8):
+        wide = gpu.traverse(atrium.dev[width], rays, variant=0)
+        assert np.array_equal(wide["tri_id"] >= 0, hit)
+        assert np.allclose(wide["t"][hit], base["t"][hit], rtol=1e-4, atol=0)
+        assert (wide["tri_id"] != base["tri_id"]).mean() < 0.02
+        for v in variants(gpu, width)[1:]:
+            assert gpu.traverse(atrium.dev[width], rays, variant=v).tobytes() == wide.tobytes()
     # idempotence: shrinking tmax to just beyond the hit returns the same primitive
     sub = rays[::8].copy()
     sub["tmax"] = np.where(hit[::8], base["t"][::8] * np.float32(1.0001), sub["tmax"])
@@ -308,7 +322,8 @@ def test_bench_traversal_cli(gpu, native_build, oracle, cornell, tmp_path):
     out = tmp_path / "o.fbuf"
     cmd = [native_build.BIN_DIR / "bench_traversal", "-bvh", cornell.bvh_path, "-ray", cornell.bvh_path.parent / "cornell-primary-64x64.rays",
            "--tmin", "0.01", "--tmax", "5000", "--bench", "3", "--warmup", "1", "-o", out]
-    for extra, name in ((["-gpu", "amdgpu"], "bvh2_gpu"), (["-gpu", "hip", "--variant", "1"], "bvh2_gpu"), (["-gpu", "hip", "--bvh-width", "8"], "bvh8_gpu")):
+    for extra, name in ((["-gpu", "amdgpu"], "bvh2_gpu"), (["-gpu", "hip", "--variant", "1"], "bvh2_gpu"), (["-gpu", "hip", "--bvh-width", "4"], "bvh4_gpu"),
+                        (["-gpu", "hip", "--bvh-width", "8"], "bvh8_gpu")):
         r = subprocess.run(cmd + extra, capture_output=True, text=True, check=True)
         lines = r.stdout.strip().splitlines()
         assert lines[0] == "4096 ray(s) in the distribution file."
