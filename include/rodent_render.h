@@ -101,8 +101,26 @@ void    rodent_gpu_get_second_primary_stream(int32_t dev, struct PrimaryStream* 
 void    rodent_gpu_get_secondary_stream(int32_t dev, struct SecondaryStream* secondary, int32_t size);
 void    rodent_gpu_get_tmp_buffer(int32_t dev, int32_t** buf, int32_t size);
 void    rodent_present(int32_t dev);                                 /* film device -> host */
+/* Scene-data services (src/driver/interface.cpp:432-492,584-619; prototypes src/render/driver.impala:11-16): load one of the
+ * reference converter's files onto device `dev` and return DEVICE pointers.  Results are cached by (dev, file name), owned
+ * by the library and valid until cleanup_interface(); a missing or malformed file prints a message and abort()s like the
+ * reference's error().  `dev` is the HIP device index (there is no host device 0 here: nothing is computed on the CPU). */
+uint8_t* rodent_load_buffer(int32_t dev, const char* file);           /* one LZ4 buffer file (data/vertices.bin, ...; src/driver/buffer.h) */
+void    rodent_load_bvh2_tri1(int32_t dev, const char* file, struct Node2** nodes, struct Tri1** tris);   /* the matching layout of data/bvh.bin */
+void    rodent_load_bvh4_tri4(int32_t dev, const char* file, struct Node4** nodes, struct Tri4** tris);
+void    rodent_load_bvh8_tri4(int32_t dev, const char* file, struct Node8** nodes, struct Tri4** tris);
+void    rodent_load_png(int32_t dev, const char* file, uint8_t** pixels, int32_t* width, int32_t* height); /* RGBA8, rows flipped, gamma 2.2 (image.cpp:10-18,85) */
+void    rodent_load_jpg(int32_t dev, const char* file, uint8_t** pixels, int32_t* width, int32_t* height);
+/* Host-side stream slabs with the device slabs' carving, one per calling thread (interface.cpp:341-342,367-373,621-629). */
+void    rodent_cpu_get_primary_stream(struct PrimaryStream* primary, int32_t size);
+void    rodent_cpu_get_secondary_stream(struct SecondaryStream* secondary, int32_t size);
+int64_t clock_us(void);                                              /* interface.cpp:665-673 */
 
 /* ---- additions ---- */
+/* Sizes of what the services above loaded (the reference's generated code knows them at compile time):
+ * bytes of a loaded buffer (-1 if `file` was not loaded on `dev`); node / primitive counts of a loaded BVH layout. */
+int64_t rodent_hip_buffer_size(int32_t dev, const char* file);
+void    rodent_hip_bvh_counts(int32_t dev, const char* file, int32_t bvh_width, int32_t* num_nodes, int32_t* num_tris);
 void    rodent_hip_set_device(int32_t dev);                          /* device used by render() (the reference bakes it in) */
 /* Renders only image rows [y0, y1) (tile sharding across GPUs: seeds depend on absolute (sample, iter, x, y),
  * renderer.impala:28-33, so any tiling reproduces the same samples).  Asynchronous on `stream`. */

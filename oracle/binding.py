@@ -81,6 +81,21 @@ def traverse(width, nodes, tris, rays, any_hit=False, algo="ref"):
     return hits, st.as_dict()
 
 
+def ray_steps(nodes, tris, rays, any_hit=False):
+    """Per-ray visit counts of B1 (BVH2/Tri1): array (n, 2) = inner nodes, triangles.  Analysis aid."""
+    rays = np.ascontiguousarray(rays)
+    buf = np.zeros((len(rays), 2), np.uint32)
+    l = lib()
+    l.oracle_set_ray_step_trace.restype = None
+    l.oracle_set_ray_step_trace.argtypes = [C.c_void_p]
+    l.oracle_set_ray_step_trace(_ptr(buf))
+    try:
+        traverse(2, nodes, tris, rays, any_hit=any_hit)
+    finally:
+        l.oracle_set_ray_step_trace(None)
+    return buf
+
+
 def brute_force(tris, rays):
     """Every ray against every triangle.  Returns (hits, second_t)."""
     tris = np.ascontiguousarray(tris)

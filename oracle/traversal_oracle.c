@@ -148,6 +148,11 @@ static inline void stats_merge(struct OracleStats* dst, const struct OracleStats
 /* ------------------------------------------------------------------------- */
 #define STACK_CAP 64   /* stack.impala:53-54 (unchecked there; checked here) */
 
+/* Analysis aid (scripts/model_phases.py): when set, oracle_bvh2_tri1 also writes per ray the number of inner nodes and
+ * triangles it visited (2 x uint32 per ray).  Not thread-safe; NULL switches it off. */
+static uint32_t* g_ray_steps = 0;
+void oracle_set_ray_step_trace(uint32_t* buf) { g_ray_steps = buf; }
+
 int oracle_bvh2_tri1(const struct Node2* nodes, const struct Tri1* tris,
                      const struct Ray1* rays, struct Hit1* hits, int32_t n,
                      int32_t any_hit, struct OracleStats* stats_out) {
@@ -159,6 +164,7 @@ int oracle_bvh2_tri1(const struct Node2* nodes, const struct Tri1* tris,
         int32_t mem[STACK_CAP + 2];
         int32_t ptr = 0, top = 1; mem[0] = 0;          /* push(1): old top (0) spilled */
         int done = 0;
+        const uint64_t inner_before = st.inner_nodes, prims_before = st.prim_packets;
         while (top != 0 && !done) {
             const struct Node2* nd = &nodes[top - 1];   /* top is NOT popped (:107-108) */
             st.inner_nodes++;
@@ -206,6 +212,7 @@ int oracle_bvh2_tri1(const struct Node2* nodes, const struct Tri1* tris,
         }
         hits[i].tri_id = hit_id; hits[i].t = hit_t; hits[i].u = hit_u; hits[i].v = hit_v;
         st.hits += hit_id >= 0;
+        if (g_ray_steps) { g_ray_steps[2 * i] = (uint32_t)(st.inner_nodes - inner_before); g_ray_steps[2 * i + 1] = (uint32_t)(st.prim_packets - prims_before); }
     }
     st.rays = (uint64_t)n;
     stats_merge(stats_out, &st);

@@ -40,7 +40,8 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contra
 HOST_FLAGS = ["-O2", "-std=c++17", "-Wall", "-fPIC", f"-I{ROOT / 'include'}"]
 ORACLE_FLAGS = ["-O2", "-std=c11", "-Wall", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma"]
 
-HIP_SOURCES = ["traversal.hip", "render.hip"]
+HIP_SOURCES = ["traversal.hip", "render.hip", "services.hip"]
+HIP_LIB_HOST_SOURCES = ["image.cpp"]             # host code the library links: texture decoders of rodent_load_png / _jpg
 HOST_LIB_SOURCES = ["mesh.cpp", "bvh_build.cpp", "atrium.cpp", "scene.cpp", "image.cpp"]
 HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png", "converter", "tex_dump", "buffer_tool"]
 HIP_TOOLS = {"bench_traversal": [], "rodent": ["mesh.o", "bvh_build.o", "scene.o", "image.o"]}   # tool -> host objects it links
@@ -65,13 +66,13 @@ def _headers():
 def build_hip_lib(force: bool = False) -> Path:
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     out = LIB_DIR / "librodent_hip.so"
-    srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
+    srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()] + [HOST / s for s in HIP_LIB_HOST_SOURCES]
     if force or _newer(out, *srcs, *_headers()):
-        _run([HIPCC, *HIP_FLAGS, "-shared", *srcs, "-o", out])
+        _run([HIPCC, *HIP_FLAGS, "-shared", *srcs, "-lz", "-o", out])
     if os.environ.get("RODENT_HIP_LAB", "0") not in ("", "0"):
         lab = LIB_DIR / "librodent_hip_lab.so"
         if force or _newer(lab, *srcs, *_headers()):
-            _run([HIPCC, *HIP_FLAGS, "-DRODENT_HIP_LAB", "-shared", *srcs, "-o", lab])
+            _run([HIPCC, *HIP_FLAGS, "-DRODENT_HIP_LAB", "-shared", *srcs, "-lz", "-o", lab])
     return out
 
 

@@ -774,6 +774,8 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     const CameraDev cam = to_cam(settings);
     const float inv_spp = 1.0f / (float)r.spp;
     const long long num_rays = (long long)r.spp * r.film_w * (y1 - y0);
+    // ray ids are 32-bit in the stream kernels (as in the reference, mapping_gpu.impala:236-241)
+    if (num_rays > 0x7FFFFFFFll) { fprintf(stderr, "rodent_hip: spp x width x rows = %lld samples in one call exceeds 2^31 - 1; render fewer rows per call or more frames of fewer spp\n", num_rays); abort(); }
     const int first_pixel = y0 * r.film_w;
     long long id = 0; int size = 0;
     HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 8, stream));
@@ -876,7 +878,12 @@ template <typename T> T* upload(DevScene& s, const T* host, size_t count) {
     return d;
 }
 
+// host-side stream slabs of rodent_cpu_get_*_stream: per thread, like the reference's (interface.cpp:341-342,507-508)
+thread_local std::vector<float> t_cpu_primary, t_cpu_secondary;
+
 } // namespace
+
+void rodent_services_cleanup();                                              // services.hip
 
 extern "C" {
 
@@ -940,6 +947,7 @@ int32_t get_spp(void) { return rdev(g_current_dev).spp; }
 void setup_interface(size_t width, size_t height) { g_host_w = width; g_host_h = height; g_host_film.assign(width * height * 3, 0.0f); }
 float* get_pixels(void) { return g_host_film.data(); }
 void cleanup_interface(void) {
+    rodent_services_cleanup();                                               // buffers / BVHs / images loaded through rodent_load_* (services.hip)
     for (auto& r : g_rdev) if (r.init && r.film) { hipSetDevice(r.dev); hipFree(r.film); r.film = nullptr; r.film_w = r.film_h = 0; }
     g_host_film.clear(); g_host_w = g_host_h = 0;
 }
@@ -959,6 +967,18 @@ void rodent_gpu_get_tmp_buffer(int32_t dev, int32_t** buf, int32_t size) {
     RenderDevice& r = rdev(dev);
     if (r.tmp_cap < round_cap(size)) { HIP_CHECK(hipSetDevice(dev)); if (r.tmp) HIP_CHECK(hipFree(r.tmp)); HIP_CHECK(hipMalloc(&r.tmp, sizeof(int) * round_cap(size))); r.tmp_cap = round_cap(size); }
     *buf = r.tmp;
+}
+// Host stream slabs with the same carving (interface.cpp:367-373,621-629).  The library computes nothing on the CPU;
+// a host that stages rays itself (or the reference's CPU mapping) gets the layout it expects.
+void rodent_cpu_get_primary_stream(PrimaryStream* p, int32_t size) {
+    const size_t cap = (size_t)round_cap(size);
+    if (t_cpu_primary.size() < cap * 20) t_cpu_primary.assign(cap * 20, 0.0f);
+    carve_primary(*p, t_cpu_primary.data(), t_cpu_primary.size() / 20);
+}
+void rodent_cpu_get_secondary_stream(SecondaryStream* s, int32_t size) {
+    const size_t cap = (size_t)round_cap(size);
+    if (t_cpu_secondary.size() < cap * 13) t_cpu_secondary.assign(cap * 13, 0.0f);
+    carve_secondary(*s, t_cpu_secondary.data(), t_cpu_secondary.size() / 13);
 }
 void rodent_present(int32_t dev) {                                           // interface.cpp:494-496,660-663
     RenderDevice& r = rdev(dev);
@@ -1013,6 +1033,7 @@ void hip_traverse_primary(int32_t dev, PrimaryStream* primary, void* stream) {
 void hip_sort_primary(int32_t dev, PrimaryStream* primary, PrimaryStream* other, int32_t* ray_ends, void* stream) {
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); ensure_film(r); require_scene(r);
     const int G = r.scene.dev.num_materials;
+    if (G + 1 > kMaxBins) { fprintf(stderr, "rodent_hip: too many geometries (%d)\n", G); abort(); }
     bin_stream(r, 0, *primary, *other, nullptr, primary->size, KEY_GEOM, G + 1, 1, G + 1, (hipStream_t)stream);
     HIP_CHECK(hipMemcpyAsync(r.host_pinned + 8, bin_end(r, 0), sizeof(int) * (G + 1), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));

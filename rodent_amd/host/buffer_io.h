@@ -18,6 +18,12 @@ template <typename T> bool write_buffer(FILE* f, const std::vector<T>& v) {
 template <typename T> bool read_buffer(FILE* f, std::vector<T>& v) {
     uint32_t hdr[2];
     if (fread(hdr, 4, 2, f) != 2 || hdr[0] % sizeof(T)) return false;
+    // nothing is allocated on the word of a header alone: the compressed bytes must be in the file, and an LZ4 block
+    // cannot expand by more than 255x (one length byte per 255 output bytes)
+    const long here = ftell(f);
+    if (here < 0 || fseek(f, 0, SEEK_END) != 0) return false;
+    const long end = ftell(f);
+    if (end < here || fseek(f, here, SEEK_SET) != 0 || (uint64_t)(end - here) < hdr[1] || (uint64_t)hdr[0] > 255ull * hdr[1] + 16) return false;
     std::vector<uint8_t> c(hdr[1]);
     if (hdr[1] && fread(c.data(), 1, c.size(), f) != c.size()) return false;
     v.resize(hdr[0] / sizeof(T));

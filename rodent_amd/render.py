@@ -32,7 +32,9 @@ RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent
                   "rodent_gpu_get_first_primary_stream", "rodent_gpu_get_second_primary_stream", "rodent_gpu_get_secondary_stream",
                   "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows",
                   "rodent_hip_render_counters", "hip_generate_rays", "hip_traverse_primary", "hip_sort_primary", "hip_shade",
-                  "hip_traverse_secondary", "hip_compact_primary"]
+                  "hip_traverse_secondary", "hip_compact_primary",
+                  "rodent_load_buffer", "rodent_load_bvh2_tri1", "rodent_load_bvh4_tri4", "rodent_load_bvh8_tri4", "rodent_load_png", "rodent_load_jpg",
+                  "rodent_cpu_get_primary_stream", "rodent_cpu_get_secondary_stream", "clock_us", "rodent_hip_buffer_size", "rodent_hip_bvh_counts"]
 
 _ready = False
 
@@ -58,6 +60,14 @@ def lib():
         l.rodent_hip_set_device.argtypes = [i32]; l.rodent_hip_set_device.restype = None
         l.rodent_hip_render_rows.argtypes = [i32, C.POINTER(Settings), i32, i32, i32, vp]; l.rodent_hip_render_rows.restype = None
         l.rodent_hip_render_counters.argtypes = [i32, C.POINTER(C.c_uint64)]; l.rodent_hip_render_counters.restype = None
+        l.rodent_load_buffer.argtypes = [i32, C.c_char_p]; l.rodent_load_buffer.restype = vp
+        for name in ("rodent_load_bvh2_tri1", "rodent_load_bvh4_tri4", "rodent_load_bvh8_tri4"):
+            fn = getattr(l, name); fn.argtypes = [i32, C.c_char_p, C.POINTER(vp), C.POINTER(vp)]; fn.restype = None
+        for name in ("rodent_load_png", "rodent_load_jpg"):
+            fn = getattr(l, name); fn.argtypes = [i32, C.c_char_p, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]; fn.restype = None
+        l.rodent_hip_buffer_size.argtypes = [i32, C.c_char_p]; l.rodent_hip_buffer_size.restype = C.c_int64
+        l.rodent_hip_bvh_counts.argtypes = [i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32)]; l.rodent_hip_bvh_counts.restype = None
+        l.clock_us.argtypes = []; l.clock_us.restype = C.c_int64
         _ready = True
     return l
 
