@@ -131,6 +131,10 @@ int32_t rodent_hip_check_errors(int32_t dev, void* stream);
 /* Introspection / plumbing. */
 int32_t     rodent_hip_device_count(void);              /* 0 when no GPU is visible */
 int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2, 4 or 8 */
+/* The phased BVH2 mappings ("phased-*": capped phases with ray compaction in between) take the single kernel for launches
+ * of fewer than this many rays (default 262 144: less than one round of resident waves); < 0 restores the default, 0 makes
+ * every launch phased (tests). */
+void        rodent_hip_phased_min_rays(int32_t rays);
 int32_t     rodent_hip_is_lab_build(void);              /* 1 = librodent_hip_lab.so (-DRODENT_HIP_LAB: also the measured-and-lost kernels) */
 const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant);
 const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t any_hit);

@@ -101,7 +101,7 @@ __device__ __forceinline__ int node2_step(const Node2* __restrict__ nodes, int t
 }
 
 // Launch control block in device memory (zero between launches).
-struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; };
+struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; int qcount[8]; };   // qcount[p]: rays suspended by phase p (k_bvh2_phase)
 
 
 // Per-lane stack of the fast / sched kernels: an LDS-only window of LDS_N entries behind an
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(kWave) void k_bvh2_finish(const Node2* __restrict__
         }
     }
     if (threadIdx.x == 0) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; }   // stats[7]: rays handed over (read by the tests); ready for the next launch
+    if (threadIdx.x < 8) ctl->qcount[threadIdx.x] = 0;
 }
 
 // Single-step schedule (the default "fast" variant).  Every lane advances by ONE step per wave iteration,
@@ -155,74 +156,176 @@ __global__ __launch_bounds__(kWave) void k_bvh2_finish(const Node2* __restrict__
 // the launch made 200+ descent iterations and 40+ leaf visits where no ray needs more than ~140 node steps;
 // letting triangle lanes queue up until N of them are ready was measured too: every N > 1 is slower).
 // The per-ray sequence of node and triangle tests is unchanged, so results stay bit-identical.
+//
+// Per-lane traversal state.  The hit record lives in memory, not in registers: the miss record is written up front and
+// every accepted triangle overwrites it (2-3 sixteen-byte stores per ray, off the critical path; same-address stores
+// of one lane stay in order).  That leaves top, sp and tmax as the only per-lane state carried around the loop -- with
+// the record in registers the compiler shuffled it between two register sets every iteration (a fifth of the loop's
+// VALU instructions were v_mov) -- and it is also all that has to move when a ray changes lanes (k_bvh2_phase).
+struct Lane {
+    RayX ray;                  // tmin / tmax canonical (see slab_canonical)
+    int top;                   // 0 = done, > 0 inner node id, < 0 ~(triangle index)
+    lds_int* sp;               // the stack entry under the top (entry `ptr` of the other kernels)
+    int ray_id;
+};
+typedef const __attribute__((address_space(1))) char* gptr;
+// Both array bases as 64-bit integers in VGPRs (the per-lane select in the step would otherwise copy them from SGPRs in
+// every iteration), turned back into GLOBAL pointers: laundering the pointers themselves leaves generic ones and flat loads.
+struct Bases { gptr node, tri; };
+__device__ __forceinline__ Bases make_bases(const Node2* nodes, const Tri1* tris) {
+    unsigned long long node_bits = reinterpret_cast<unsigned long long>(nodes - 1), tri_bits = reinterpret_cast<unsigned long long>(tris);   // node ids are 1-based
+    asm volatile("" : "+v"(node_bits), "+v"(tri_bits));
+    return Bases{(gptr)node_bits, (gptr)tri_bits};
+}
+
+// One step of one lane (top != 0): mapping_gpu.impala:107-134 for a node, one iteration of :156-174 for a triangle.
+template <bool ANY>
+__device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __restrict__ hits, lds_int* sp_limit, Ctl* ctl, int* __restrict__ deep_list) {
+    const bool is_node = L.top > 0;
+    // one address for both kinds: base + index * stride with per-lane selected operands (straight-line code)
+    const unsigned idx = (unsigned)(is_node ? L.top : ~L.top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
+    const gptr addr = (is_node ? base.node : base.tri) + (size_t)idx * stride;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
+    f32x4 q0 = p[0], q1 = p[1], q2 = p[2];
+    // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
+    // inside the array
+    i32x2 ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
+    const int popped = *L.sp;
+    // All four loads must be in flight together: without this barrier the compiler narrows the shared loads to
+    // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
+    // (Whole-vector operands: the loaded register quads stay where the loads put them.)
+    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
+    if (is_node) {
+        float te0, te1;
+        const bool h0 = slab_canonical(L.ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
+        const bool h1 = slab_canonical(L.ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
+        const bool c0first = te0 < te1, both = h0 && h1;
+        L.sp[kWave] = c0first ? ch.y : ch.x;
+        L.top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
+        L.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
+        if (both && L.sp >= sp_limit) {                                 // (`both`: popping the sentinel moves sp below col, which wraps)                                           // deeper than the LDS window: k_bvh2_finish redoes this ray
+            deep_list[atomicAdd(&ctl->deep_count, 1)] = L.ray_id;
+            L.top = 0;
+        }
+    } else {
+        const int prim_id = __float_as_int(q2.w);
+        const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
+        const float ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
+        const float nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
+        float t, u, v;
+        bool found = false;
+        if (intersect_tri(L.ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v)) {
+            store_hit(hits, L.ray_id, prim_id & 0x7FFFFFFF, t, u, v);
+            L.ray.tmax = t; found = true;
+        }
+        const bool leave = prim_id < 0;                               // sentinel: the leaf is done
+        L.top = (ANY && found) ? 0 : (leave ? popped : L.top - 1);    // top - 1 == ~(j + 1)
+        L.sp -= (leave && !(ANY && found)) ? kWave : 0;
+    }
+}
+
+// A fresh ray: loads it, stores the miss record, empty stack (col[0] = the 0 that ends the traversal when popped).
+__device__ __forceinline__ Lane start_lane(const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int ray_id, int any_valid_ray, lds_int* col) {
+    Lane L;
+    L.ray_id = ray_id;
+    L.ray = load_ray(rays, ray_id >= 0 ? ray_id : any_valid_ray);
+    if (ray_id >= 0) store_hit(hits, ray_id, -1, L.ray.tmax, 0.0f, 0.0f);
+    L.ray.tmin = canonical(L.ray.tmin); L.ray.tmax = canonical(L.ray.tmax);      // see slab_canonical (after the miss record: it keeps the file's bits)
+    L.top = ray_id >= 0 ? 1 : 0;
+    L.sp = col;
+    col[0] = 0;
+    return L;
+}
+
 template <bool ANY, int LDS_N>
 __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, const Ray1* __restrict__ rays,
                                               Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray) {
     const int lane_ray = first_ray + (int)threadIdx.x;
-    const int ray_id = lane_ray < n ? lane_ray : -1;
-    RayX ray = load_ray(rays, ray_id >= 0 ? ray_id : first_ray);
-    // The hit record lives in memory, not in registers: the miss record is written up front and every accepted
-    // triangle overwrites it (2-3 sixteen-byte stores per ray, off the critical path; same-address stores of one lane
-    // stay in order).  That leaves top, ptr and tmax as the only per-lane state carried around the loop -- with the
-    // record in registers the compiler shuffled it between two register sets every iteration (a fifth of the loop's
-    // VALU instructions were v_mov).
-    if (ray_id >= 0) store_hit(hits, ray_id, -1, ray.tmax, 0.0f, 0.0f);
-    ray.tmin = canonical(ray.tmin); ray.tmax = canonical(ray.tmax);      // see slab_canonical (after the miss record: it keeps the file's bits)
-    int top = ray_id >= 0 ? 1 : 0;
-    lds_int* sp = col;                             // the stack entry under the top (entry `ptr` of the other kernels)
+    Lane L = start_lane(rays, hits, lane_ray < n ? lane_ray : -1, first_ray, col);
     lds_int* const sp_limit = col + LDS_N * kWave;
-    col[0] = 0;
-    // Both bases as 64-bit integers in VGPRs (the per-lane select below would otherwise copy them from SGPRs in every
-    // iteration), turned back into GLOBAL pointers: laundering the pointers themselves leaves generic ones and flat loads.
-    typedef const __attribute__((address_space(1))) char* gptr;
-    unsigned long long node_bits = reinterpret_cast<unsigned long long>(nodes - 1), tri_bits = reinterpret_cast<unsigned long long>(tris);   // node ids are 1-based
-    asm volatile("" : "+v"(node_bits), "+v"(tri_bits));
-    const gptr node_base = (gptr)node_bits, tri_base = (gptr)tri_bits;
-    while (__ballot(top != 0)) {
-        if (top != 0) {
-            const bool is_node = top > 0;
-            // one address for both kinds: base + index * stride with per-lane selected operands (straight-line code)
-            const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
-            const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            typedef int i32x2 __attribute__((ext_vector_type(2)));
-            const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
-            f32x4 q0 = p[0], q1 = p[1], q2 = p[2];
-            // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
-            // inside the array
-            i32x2 ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
-            const int popped = *sp;
-            // All four loads must be in flight together: without this barrier the compiler narrows the shared loads to
-            // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
-            // (Whole-vector operands: the loaded register quads stay where the loads put them.)
-            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
-            if (is_node) {
-                float te0, te1;
-                const bool h0 = slab_canonical(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
-                const bool h1 = slab_canonical(ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
-                const bool c0first = te0 < te1, both = h0 && h1;
-                sp[kWave] = c0first ? ch.y : ch.x;
-                top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
-                sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
-                if (both && sp >= sp_limit) {                                 // (`both`: popping the sentinel moves sp below col, which wraps)                                           // deeper than the LDS window: k_bvh2_finish redoes this ray
-                    deep_list[atomicAdd(&ctl->deep_count, 1)] = ray_id;
-                    top = 0;
-                }
-            } else {
-                const int prim_id = __float_as_int(q2.w);
-                const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
-                const float ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
-                const float nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
-                float t, u, v;
-                bool found = false;
-                if (intersect_tri(ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v)) {
-                    store_hit(hits, ray_id, prim_id & 0x7FFFFFFF, t, u, v);
-                    ray.tmax = t; found = true;
-                }
-                const bool leave = prim_id < 0;                               // sentinel: the leaf is done
-                top = (ANY && found) ? 0 : (leave ? popped : top - 1);        // top - 1 == ~(j + 1)
-                sp -= (leave && !(ANY && found)) ? kWave : 0;
+    const Bases base = make_bases(nodes, tris);
+    while (__ballot(L.top != 0)) {
+        if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phased traversal with compaction (k_bvh2_phase).  A launch is a short chain of kernels; every wave of phase p runs
+// at most `max_iters` single-step iterations and then SUSPENDS the rays that are still alive -- ray id, current tmax,
+// top and the live stack entries, 16 + 4 x depth bytes; the hit record is in memory already -- into a queue in slots
+// handed out by one atomic per wave plus a ballot prefix.  Phase p + 1 resumes them 64 to a wave.  The last phase is
+// uncapped.  Per ray the sequence of node and triangle tests is untouched (a suspended ray continues exactly where it
+// stopped), so results stay bit-identical; what changes is who shares a wavefront with whom:
+//  * the rays that outlive their neighbours -- the ones a wave's other 60 lanes used to idle for -- are packed into full
+//    waves (random segments: lane utilisation bound 0.38 -> 0.68 with caps 32 / 24, scripts/model_phases.py);
+//  * no wave of the capped phases lives longer than `max_iters` round trips, so the two dispatch rounds of a 1 Mi-ray
+//    launch end together and the long rays start their remaining steps early and all at once, instead of
+//    (start of the last expensive waves) + (their whole life).
+// ---------------------------------------------------------------------------------------------
+struct RayQueue {              // SoA over slots, capacity = rays of the launch
+    int* ray; float* tmax; int* top; int* depth; int* stack;      // stack[e * capacity + slot], e < LDS_N
+    int capacity;
+};
+
+template <bool ANY, int LDS_N, bool RESUME, bool CAPPED>
+__global__ __launch_bounds__(kWave) void k_bvh2_phase(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                       const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                       Ctl* ctl, int* __restrict__ deep_list, RayQueue in, int phase, int max_iters, RayQueue out) {
+    __shared__ int lds_raw[(LDS_N + 1) * kWave];
+    lds_int* col = (lds_int*)lds_raw + threadIdx.x;
+    lds_int* const sp_limit = col + LDS_N * kWave;
+    Lane L;
+    if (!RESUME) {
+        const int total_chunks = (n + kWave - 1) / kWave;
+        int chunk = blockIdx.x;
+        constexpr int XCD = 32;                                               // as k_bvh2_single
+        const int span = 8 * XCD, full = (total_chunks / span) * span;
+        if ((int)blockIdx.x < full) {
+            const int x = blockIdx.x % 8, l = blockIdx.x / 8;
+            chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
+        }
+        const int lane_ray = chunk * kWave + (int)threadIdx.x;
+        L = start_lane(rays, hits, lane_ray < n ? lane_ray : -1, chunk * kWave, col);
+    } else {
+        const int count = ctl->qcount[phase - 1];                             // written by the previous kernel of the chain
+        const int slot = blockIdx.x * kWave + (int)threadIdx.x;
+        if ((int)(blockIdx.x * kWave) >= count) return;
+        const bool valid = slot < count;
+        const unsigned s = valid ? (unsigned)slot : (unsigned)(blockIdx.x * kWave);
+        L.ray_id = valid ? in.ray[s] : -1;
+        L.ray = load_ray(rays, in.ray[s]);
+        L.ray.tmin = canonical(L.ray.tmin); L.ray.tmax = in.tmax[s];          // already canonical
+        L.top = valid ? in.top[s] : 0;
+        const int depth = in.depth[s];
+        for (int e = 0; e < LDS_N; e++) {
+            if (!__ballot(valid && e < depth)) break;
+            if (valid && e < depth) col[e * kWave] = in.stack[(size_t)e * in.capacity + s];
+        }
+        L.sp = col + (depth - 1) * kWave;
+    }
+    const Bases base = make_bases(nodes, tris);
+    if (CAPPED) {
+        for (int it = 0; it < max_iters && __ballot(L.top != 0); it++) {
+            if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
+        }
+        const unsigned long long alive = __ballot(L.top != 0);
+        if (alive) {
+            const int lane = threadIdx.x, first = __ffsll((long long)alive) - 1;
+            int slot0 = 0;
+            if (lane == first) slot0 = atomicAdd(&ctl->qcount[phase], __popcll(alive));
+            slot0 = __shfl(slot0, first);
+            if (L.top != 0) {
+                const unsigned s = (unsigned)(slot0 + __popcll(alive & ((1ull << lane) - 1ull)));
+                const int depth = (int)(L.sp - col) / kWave + 1;
+                out.ray[s] = L.ray_id; out.tmax[s] = L.ray.tmax; out.top[s] = L.top; out.depth[s] = depth;
+                for (int e = 0; e < depth; e++) out.stack[(size_t)e * out.capacity + s] = col[e * kWave];
             }
+        }
+    } else {
+        while (__ballot(L.top != 0)) {
+            if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
         }
     }
 }
@@ -277,6 +380,8 @@ struct DeviceState {
     int   deep_cap = 0;
     int*  deep_stack = nullptr; // 64 x 64 ints: global-memory stack of k_bvh2_finish
     unsigned long long* trace = nullptr;   // debug: 16384 x 4 words (instrumented variants)
+    int*  queue_mem[2] = {nullptr, nullptr};   // suspended-ray queues of the phased traversal (ping-pong), queue_cap slots each
+    int   queue_cap = 0;
     Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
 };
 // One DeviceState per (device, stream): launches enqueued on different streams of a device may overlap, so each
@@ -318,6 +423,22 @@ DeviceState& device_state(int dev) {
     return device_state(dev, nullptr);
 }
 
+constexpr int kQueueWords = 4 + 16;             // per slot: ray, tmax, top, depth + a 16-entry stack window
+RayQueue ensure_queue(DeviceState& s, int which, int n) {
+    if (n > s.queue_cap) {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        HIP_CHECK(hipDeviceSynchronize());
+        const int cap = (n + 63) & ~63;
+        for (int k = 0; k < 2; k++) {
+            if (s.queue_mem[k]) HIP_CHECK(hipFree(s.queue_mem[k]));
+            HIP_CHECK(hipMalloc(&s.queue_mem[k], sizeof(int) * (size_t)kQueueWords * cap));
+        }
+        s.queue_cap = cap;
+    }
+    int* m = s.queue_mem[which]; const size_t cap = (size_t)s.queue_cap;
+    return RayQueue{m, reinterpret_cast<float*>(m + cap), m + 2 * cap, m + 3 * cap, m + 4 * cap, s.queue_cap};
+}
+
 void ensure_deep_list(DeviceState& s, int n) {
     if (n <= s.deep_cap) return;
     std::lock_guard<std::mutex> lock(g_mutex);
@@ -356,6 +477,24 @@ template <bool ANY, int LDS_N, int XCD, bool TR = false> void L_single(LAUNCH_AR
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
 }
 
+// Phased traversal: caps of the capped phases (the last, uncapped phase follows).  Launches too small to fill the chip
+// once take the single kernel.
+int g_phased_min_rays = 4096 * kWave;           // rodent_hip_phased_min_rays()
+struct PhaseCaps { int count; int cap[4]; };
+constexpr PhaseCaps kPhaseCaps[] = {{2, {40, 24}}, {2, {32, 24}}, {1, {40}}, {1, {32}}, {1, {48}}, {2, {48, 32}}, {3, {32, 32, 32}}, {3, {24, 24, 24}}, {2, {24, 24}}, {2, {64, 32}}};
+template <bool ANY, int LDS_N, int CAPS> void L_phased(LAUNCH_ARGS) {
+    constexpr PhaseCaps caps = kPhaseCaps[CAPS];
+    if (n < g_phased_min_rays) { L_single<ANY, LDS_N, 32>(s, nodes, tris, rays, hits, n, stream); return; }
+    ensure_deep_list(s, n);
+    RayQueue q[2] = {ensure_queue(s, 0, n), ensure_queue(s, 1, n)};
+    const int blocks = blocks_for(n);
+    hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, false, true>), dim3(blocks), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, q[1], 0, caps.cap[0], q[0]);
+    for (int p = 1; p < caps.count; p++)
+        hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, true, true>), dim3(blocks), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, q[(p - 1) & 1], p, caps.cap[p], q[p & 1]);
+    hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, true, false>), dim3(blocks), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, q[(caps.count - 1) & 1], caps.count, 0, q[caps.count & 1]);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
+}
+
 #include "traversal_wide.h"          // BVH4 / BVH8 + Tri4: k_wide_single, k_wide_finish, L_wide_single
 #ifdef RODENT_HIP_LAB
 #include "traversal_variants.h"      // lab build only: the kernels that were measured and lost, instrumented builds
@@ -370,6 +509,17 @@ const Variant2 kVariants2[] = {
     //                                                        LDS_N XCD_GROUP
     K2("fast",               "k_bvh2_single",        L_single, 16, 32),                // default: single-step schedule, XCD-aware 32-chunk groups
     K2("fast-noxcd",         "k_bvh2_single",        L_single, 16, 0),                 // same kernel, workgroup b traces chunk b
+    //                                                       LDS_N CAPS (index into kPhaseCaps)
+    K2("phased-40-24",       "k_bvh2_phase",         L_phased, 16, 0),                 // phased traversal with compaction
+    K2("phased-32-24",       "k_bvh2_phase",         L_phased, 16, 1),
+    K2("phased-40",          "k_bvh2_phase",         L_phased, 16, 2),
+    K2("phased-32",          "k_bvh2_phase",         L_phased, 16, 3),
+    K2("phased-48",          "k_bvh2_phase",         L_phased, 16, 4),
+    K2("phased-48-32",       "k_bvh2_phase",         L_phased, 16, 5),
+    K2("phased-32-32-32",    "k_bvh2_phase",         L_phased, 16, 6),
+    K2("phased-24-24-24",    "k_bvh2_phase",         L_phased, 16, 7),
+    K2("phased-24-24",       "k_bvh2_phase",         L_phased, 16, 8),
+    K2("phased-64-32",       "k_bvh2_phase",         L_phased, 16, 9),
 #ifdef RODENT_HIP_LAB
     K2("lane",               "k_bvh2_lane",          L_lane, 24),                      // literal reference mapping
     K2("ww",                 "k_bvh2_ww",            L_ww, 24, 8),                     // while-while, LDS+scratch stack
@@ -528,6 +678,7 @@ const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t a
     int count = 0; const VariantW* t = wide_variants(bvh_width, &count);
     return variant >= 0 && variant < count ? t[variant].kernel[any_hit ? 1 : 0] : "";
 }
+void rodent_hip_phased_min_rays(int32_t rays) { g_phased_min_rays = rays < 0 ? 4096 * kWave : rays; }
 int32_t rodent_hip_is_lab_build(void) {
 #ifdef RODENT_HIP_LAB
     return 1;

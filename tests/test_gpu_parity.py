@@ -29,8 +29,9 @@ def gpu(native_build):
     import torch
     from rodent_amd import abi
     assert torch.cuda.is_available(), "these tests need a GPU"
-    abi.lib()
-    return abi
+    abi.lib().rodent_hip_phased_min_rays(0)       # the phased mappings suspend and resume rays at every launch size in this module
+    yield abi
+    abi.lib().rodent_hip_phased_min_rays(-1)
 
 
 @pytest.fixture(scope="module")
