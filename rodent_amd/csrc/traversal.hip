@@ -101,7 +101,7 @@ __device__ __forceinline__ int node2_step(const Node2* __restrict__ nodes, int t
 }
 
 // Launch control block in device memory (zero between launches).
-struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; int qcount[8]; };   // qcount[p]: rays suspended by phase p (k_bvh2_phase)
+struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; };
 
 
 // Per-lane stack of the fast / sched kernels: an LDS-only window of LDS_N entries behind an
@@ -121,7 +121,9 @@ struct GlobalStack {
 template <bool ANY>
 __global__ __launch_bounds__(kWave) void k_bvh2_finish(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
-                                                        Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack) {
+                                                        Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* phase_counters) {
+    // behind the last phase of a phased launch: the stripe counters are zero again for the next launch on this stream
+    if (phase_counters) for (int k = threadIdx.x; k < 4 * 64; k += kWave) phase_counters[k * 16] = 0;
     const int count = ctl->deep_count;
     if (count > 0) {
         GlobalStack st{deep_stack + threadIdx.x, &ctl->err};
@@ -143,7 +145,6 @@ __global__ __launch_bounds__(kWave) void k_bvh2_finish(const Node2* __restrict__
         }
     }
     if (threadIdx.x == 0) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; }   // stats[7]: rays handed over (read by the tests); ready for the next launch
-    if (threadIdx.x < 8) ctl->qcount[threadIdx.x] = 0;
 }
 
 // Single-step schedule (the default "fast" variant).  Every lane advances by ONE step per wave iteration,
@@ -264,71 +265,85 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
 //    launch end together and the long rays start their remaining steps early and all at once, instead of
 //    (start of the last expensive waves) + (their whole life).
 // ---------------------------------------------------------------------------------------------
-struct RayQueue {              // SoA over slots, capacity = rays of the launch
+// One global counter word takes ~88 atomics/us on this chip: a slot counter shared by all 16 384 waves of a 1 Mi-ray
+// phase would serialise them (measured: the phased launch was 50 % SLOWER than the single kernel).  The queue is
+// therefore striped: wave b appends to stripe b % kStripes, which has its own counter in its own 64-byte line and its own
+// slot range; phase p + 1 maps workgroup b to chunk b / kStripes of stripe b % kStripes.
+constexpr int kStripes = 64;
+constexpr int kCounterStride = 16;             // ints between two counters (64 bytes)
+constexpr int kMaxPhases = 4;
+struct RayQueue {              // SoA over slots; stripe s owns slots [s * stripe_cap, (s + 1) * stripe_cap)
     int* ray; float* tmax; int* top; int* depth; int* stack;      // stack[e * capacity + slot], e < LDS_N
-    int capacity;
+    int capacity, stripe_cap;
 };
 
 template <bool ANY, int LDS_N, bool RESUME, bool CAPPED>
 __global__ __launch_bounds__(kWave) void k_bvh2_phase(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                        const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                       Ctl* ctl, int* __restrict__ deep_list, RayQueue in, int phase, int max_iters, RayQueue out) {
+                                                       Ctl* ctl, int* __restrict__ deep_list, int* __restrict__ qcount, RayQueue in, int phase, int max_iters, RayQueue out) {
     __shared__ int lds_raw[(LDS_N + 1) * kWave];
     lds_int* col = (lds_int*)lds_raw + threadIdx.x;
     lds_int* const sp_limit = col + LDS_N * kWave;
-    Lane L;
-    if (!RESUME) {
-        const int total_chunks = (n + kWave - 1) / kWave;
-        int chunk = blockIdx.x;
-        constexpr int XCD = 32;                                               // as k_bvh2_single
-        const int span = 8 * XCD, full = (total_chunks / span) * span;
-        if ((int)blockIdx.x < full) {
-            const int x = blockIdx.x % 8, l = blockIdx.x / 8;
-            chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
-        }
-        const int lane_ray = chunk * kWave + (int)threadIdx.x;
-        L = start_lane(rays, hits, lane_ray < n ? lane_ray : -1, chunk * kWave, col);
-    } else {
-        const int count = ctl->qcount[phase - 1];                             // written by the previous kernel of the chain
-        const int slot = blockIdx.x * kWave + (int)threadIdx.x;
-        if ((int)(blockIdx.x * kWave) >= count) return;
-        const bool valid = slot < count;
-        const unsigned s = valid ? (unsigned)slot : (unsigned)(blockIdx.x * kWave);
-        L.ray_id = valid ? in.ray[s] : -1;
-        L.ray = load_ray(rays, in.ray[s]);
-        L.ray.tmin = canonical(L.ray.tmin); L.ray.tmax = in.tmax[s];          // already canonical
-        L.top = valid ? in.top[s] : 0;
-        const int depth = in.depth[s];
-        for (int e = 0; e < LDS_N; e++) {
-            if (!__ballot(valid && e < depth)) break;
-            if (valid && e < depth) col[e * kWave] = in.stack[(size_t)e * in.capacity + s];
-        }
-        L.sp = col + (depth - 1) * kWave;
-    }
+    const int stripe = blockIdx.x % kStripes;
     const Bases base = make_bases(nodes, tris);
-    if (CAPPED) {
-        for (int it = 0; it < max_iters && __ballot(L.top != 0); it++) {
-            if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
-        }
-        const unsigned long long alive = __ballot(L.top != 0);
-        if (alive) {
-            const int lane = threadIdx.x, first = __ffsll((long long)alive) - 1;
-            int slot0 = 0;
-            if (lane == first) slot0 = atomicAdd(&ctl->qcount[phase], __popcll(alive));
-            slot0 = __shfl(slot0, first);
-            if (L.top != 0) {
-                const unsigned s = (unsigned)(slot0 + __popcll(alive & ((1ull << lane) - 1ull)));
-                const int depth = (int)(L.sp - col) / kWave + 1;
-                out.ray[s] = L.ray_id; out.tmax[s] = L.ray.tmax; out.top[s] = L.top; out.depth[s] = depth;
-                for (int e = 0; e < depth; e++) out.stack[(size_t)e * out.capacity + s] = col[e * kWave];
+    // RESUME: workgroup b works through chunks b / kStripes, + gridDim.x / kStripes, ... of its stripe (the grid is sized for
+    // the expected number of survivors; more than expected = more than one chunk per wave)
+    const int in_count = RESUME ? qcount[((phase - 1) * kStripes + stripe) * kCounterStride] : 0;   // written by the previous kernel of the chain
+    const int k0 = blockIdx.x / kStripes, kstep = RESUME ? gridDim.x / kStripes : 1;
+    for (int k = k0; RESUME ? k * kWave < in_count : k == k0; k += kstep) {
+        Lane L;
+        if (!RESUME) {
+            const int total_chunks = (n + kWave - 1) / kWave;
+            int chunk = blockIdx.x;
+            constexpr int XCD = 32;                                               // as k_bvh2_single
+            const int span = 8 * XCD, full = (total_chunks / span) * span;
+            if ((int)blockIdx.x < full) {
+                const int x = blockIdx.x % 8, l = blockIdx.x / 8;
+                chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
             }
+            const int lane_ray = chunk * kWave + (int)threadIdx.x;
+            L = start_lane(rays, hits, lane_ray < n ? lane_ray : -1, chunk * kWave, col);
+        } else {
+            const int first = stripe * in.stripe_cap + k * kWave;
+            const bool valid = k * kWave + (int)threadIdx.x < in_count;
+            const unsigned s = (unsigned)(valid ? first + (int)threadIdx.x : first);
+            L.ray_id = valid ? in.ray[s] : -1;
+            L.ray = load_ray(rays, in.ray[s]);
+            L.ray.tmin = canonical(L.ray.tmin); L.ray.tmax = in.tmax[s];          // already canonical
+            L.top = valid ? in.top[s] : 0;
+            const int depth = in.depth[s];
+            for (int e = 0; e < LDS_N; e++) {
+                if (!__ballot(valid && e < depth)) break;
+                if (valid && e < depth) col[e * kWave] = in.stack[(size_t)e * in.capacity + s];
+            }
+            L.sp = col + (depth - 1) * kWave;
         }
-    } else {
-        while (__ballot(L.top != 0)) {
-            if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
+        if (CAPPED) {
+            for (int it = 0; it < max_iters && __ballot(L.top != 0); it++) {
+                if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
+            }
+            const unsigned long long alive = __ballot(L.top != 0);
+            if (alive) {
+                const int lane = threadIdx.x, first = __ffsll((long long)alive) - 1;
+                int slot0 = 0;
+                if (lane == first) slot0 = atomicAdd(&qcount[(phase * kStripes + stripe) * kCounterStride], __popcll(alive));
+                slot0 = __shfl(slot0, first);
+                if (L.top != 0) {
+                    const unsigned s = (unsigned)(stripe * out.stripe_cap + slot0 + __popcll(alive & ((1ull << lane) - 1ull)));
+                    const int depth = (int)(L.sp - col) / kWave + 1;
+                    out.ray[s] = L.ray_id; out.tmax[s] = L.ray.tmax; out.top[s] = L.top; out.depth[s] = depth;
+                    for (int e = 0; e < depth; e++) out.stack[(size_t)e * out.capacity + s] = col[e * kWave];
+                }
+            }
+        } else {
+            while (__ballot(L.top != 0)) {
+                if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
+            }
         }
     }
 }
+
+static_assert(kMaxPhases == 4 && kStripes == 64 && kCounterStride == 16, "k_bvh2_finish clears 4 x 64 counters, 16 ints apart");
 
 // BVH2 / Tri1, the default kernel: one 64-ray chunk per wave, single-step schedule (unified_chunk), XCD-aware chunk
 // mapping as in k_bvh2_fast.
@@ -382,6 +397,7 @@ struct DeviceState {
     unsigned long long* trace = nullptr;   // debug: 16384 x 4 words (instrumented variants)
     int*  queue_mem[2] = {nullptr, nullptr};   // suspended-ray queues of the phased traversal (ping-pong), queue_cap slots each
     int   queue_cap = 0;
+    int*  qcount = nullptr;                    // [phase][stripe] suspended-ray counters, 64 bytes apart
     Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
 };
 // One DeviceState per (device, stream): launches enqueued on different streams of a device may overlap, so each
@@ -423,20 +439,28 @@ DeviceState& device_state(int dev) {
     return device_state(dev, nullptr);
 }
 
+inline int blocks_for(int n) { return (n + kWave - 1) / kWave; }
 constexpr int kQueueWords = 4 + 16;             // per slot: ray, tmax, top, depth + a 16-entry stack window
 RayQueue ensure_queue(DeviceState& s, int which, int n) {
-    if (n > s.queue_cap) {
+    // a stripe receives the survivors of at most ceil(blocks / kStripes) waves
+    const int stripe_cap = ((blocks_for(n) + kStripes - 1) / kStripes) * kWave, cap = stripe_cap * kStripes;
+    if (cap > s.queue_cap || !s.qcount) {
         std::lock_guard<std::mutex> lock(g_mutex);
         HIP_CHECK(hipDeviceSynchronize());
-        const int cap = (n + 63) & ~63;
-        for (int k = 0; k < 2; k++) {
-            if (s.queue_mem[k]) HIP_CHECK(hipFree(s.queue_mem[k]));
-            HIP_CHECK(hipMalloc(&s.queue_mem[k], sizeof(int) * (size_t)kQueueWords * cap));
+        if (cap > s.queue_cap) {
+            for (int k = 0; k < 2; k++) {
+                if (s.queue_mem[k]) HIP_CHECK(hipFree(s.queue_mem[k]));
+                HIP_CHECK(hipMalloc(&s.queue_mem[k], sizeof(int) * (size_t)kQueueWords * cap));
+            }
+            s.queue_cap = cap;
         }
-        s.queue_cap = cap;
+        if (!s.qcount) {
+            HIP_CHECK(hipMalloc(&s.qcount, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
+            HIP_CHECK(hipMemset(s.qcount, 0, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
+        }
     }
-    int* m = s.queue_mem[which]; const size_t cap = (size_t)s.queue_cap;
-    return RayQueue{m, reinterpret_cast<float*>(m + cap), m + 2 * cap, m + 3 * cap, m + 4 * cap, s.queue_cap};
+    int* m = s.queue_mem[which]; const size_t c = (size_t)s.queue_cap;
+    return RayQueue{m, reinterpret_cast<float*>(m + c), m + 2 * c, m + 3 * c, m + 4 * c, s.queue_cap, stripe_cap};
 }
 
 void ensure_deep_list(DeviceState& s, int n) {
@@ -469,30 +493,33 @@ void check_error_flag(DeviceState& s, hipStream_t stream) {
 }
 
 #define LAUNCH_ARGS DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
-inline int blocks_for(int n) { return (n + kWave - 1) / kWave; }
 
 template <bool ANY, int LDS_N, int XCD, bool TR = false> void L_single(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
-    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 
 // Phased traversal: caps of the capped phases (the last, uncapped phase follows).  Launches too small to fill the chip
 // once take the single kernel.
 int g_phased_min_rays = 4096 * kWave;           // rodent_hip_phased_min_rays()
-struct PhaseCaps { int count; int cap[4]; };
+struct PhaseCaps { int count; int cap[3]; };
 constexpr PhaseCaps kPhaseCaps[] = {{2, {40, 24}}, {2, {32, 24}}, {1, {40}}, {1, {32}}, {1, {48}}, {2, {48, 32}}, {3, {32, 32, 32}}, {3, {24, 24, 24}}, {2, {24, 24}}, {2, {64, 32}}};
 template <bool ANY, int LDS_N, int CAPS> void L_phased(LAUNCH_ARGS) {
     constexpr PhaseCaps caps = kPhaseCaps[CAPS];
+    static_assert(caps.count + 1 <= kMaxPhases, "too many phases");
     if (n < g_phased_min_rays) { L_single<ANY, LDS_N, 32>(s, nodes, tris, rays, hits, n, stream); return; }
     ensure_deep_list(s, n);
     RayQueue q[2] = {ensure_queue(s, 0, n), ensure_queue(s, 1, n)};
     const int blocks = blocks_for(n);
-    hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, false, true>), dim3(blocks), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, q[1], 0, caps.cap[0], q[0]);
+    // grids of the resuming phases: sized for the share of rays expected to survive (a multiple of kStripes; if more
+    // survive, waves take several chunks one after the other)
+    auto resume_grid = [&](int p) { const int g = blocks >> p; return ((g < kStripes ? kStripes : g) + kStripes - 1) / kStripes * kStripes; };
+    hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, false, true>), dim3(blocks), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.qcount, q[1], 0, caps.cap[0], q[0]);
     for (int p = 1; p < caps.count; p++)
-        hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, true, true>), dim3(blocks), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, q[(p - 1) & 1], p, caps.cap[p], q[p & 1]);
-    hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, true, false>), dim3(blocks), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, q[(caps.count - 1) & 1], caps.count, 0, q[caps.count & 1]);
-    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
+        hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, true, true>), dim3(resume_grid(p)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.qcount, q[(p - 1) & 1], p, caps.cap[p], q[p & 1]);
+    hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, true, false>), dim3(resume_grid(caps.count)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.qcount, q[(caps.count - 1) & 1], caps.count, 0, q[caps.count & 1]);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.qcount);
 }
 
 #include "traversal_wide.h"          // BVH4 / BVH8 + Tri4: k_wide_single, k_wide_finish, L_wide_single

@@ -400,7 +400,7 @@ template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false, 
         hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, TR, SC, true>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
     else
         hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, TR, SC, false>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
-    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 
 int coprime_stride(int count) {
@@ -419,7 +419,7 @@ template <bool ANY, int LDS_N, bool P, int RI, int CH, int TB, bool PERMUTE = fa
     if (P) grid = std::min(grid, s.num_cus * persistent_waves_per_cu());
     const ChunkPerm perm{chunks, PERMUTE ? coprime_stride(chunks) : 1};
     hipLaunchKernelGGL((k_bvh2_sched<ANY, LDS_N, P, RI, CH, TB, ST, TR>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, perm);
-    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 
 
