@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark: Mrays/s of the HIP BVH traversal (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Step  = one closest-hit traversal pass over one 1 048 576-ray batch resident in HBM
@@ -11,9 +11,16 @@ Scene = "sponza" if data/sponza.{bvh,-primary.rays,-random.rays} were supplied, 
         regenerable procedural "atrium" (the reference checkout lacks the Sponza blobs).
 value = rays traced by all ranks per second / 1e6, kernel passes only (rays, BVH and hit
         buffers resident in HBM; H2D/D2H excluded like bench_traversal.cpp:124-135).
-N > 1 = weak scaling, no data-path collective: the BVH is replicated, rank r traces sub-pixel
-        sample r of N through the same 1024x1024 pixel grid (primary) / seed 42 + r (random);
-        hit counts are all-gathered over RCCL after the timed region as a cross-check.
+N > 1 = no data-path collective: the BVH is replicated.
+        default (weak scaling): rank r traces sub-pixel sample r of N through the same 1024x1024 pixel grid (primary) /
+        seed 42 + r (random): 1 Mi rays per GPU per step;
+        --strong: ONE 1 Mi-ray set, rank r traces the contiguous range ray_range(n, r, N); after the timed
+        region one RCCL all-gather collects the Hit1 ranges and rank 0 compares the assembled array with its own trace
+        of the whole set.
+roofline: "bound: hbm" is SURVEY 8(d)'s algorithmic-bytes figure (it exceeds 1: the 22 MB BVH is served by L1 / L2 / MALL,
+        not by HBM).  The bounds that DO bind this kernel are reported next to it: the node-fetch rate of
+        the vector-memory pipeline (TA -> L1 -> L2) and the VALU issue rate, both against peaks measured on this chip by
+        the microbenchmarks under scripts/ubench (profiles/rNN_calibration.json), plus measured HBM traffic.
 """
 from __future__ import annotations
 
@@ -38,17 +45,46 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)        # README.md:34-37 uses --warmup 10 --bench 50
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", default=None)
-    ap.add_argument("--bvh-width", type=int, default=int(os.environ.get("RODENT_BENCH_WIDTH", "2")), choices=(2, 8))
+    ap.add_argument("--bvh-width", type=int, default=int(os.environ.get("RODENT_BENCH_WIDTH", "2")), choices=(2, 4, 8))
     ap.add_argument("--variant", type=int, default=int(os.environ.get("RODENT_BENCH_VARIANT", "-1")))
+    ap.add_argument("--strong", action="store_true", help="N > 1: shard ONE ray set in contiguous ranges (strong scaling) and gather the Hit1 array")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only", choices=("primary", "random"), default=None, help="profiling aid: time only one ray set")
     return ap.parse_args()
 
 
+def latest_json(pattern):
+    best = None
+    for f in sorted((ROOT / "profiles").glob(pattern)):
+        try:
+            best = (f.name, json.loads(f.read_text()))
+        except ValueError:
+            continue
+    return best
+
+
+def kernel_counters(kernel, ray_set):
+    """Per-launch counter means of `kernel` on the `ray_set` pass from the committed PMC passes (profiles/rNN_pmc_counters.json,
+    scripts/profile_pmc.sh: one small counter group per rocprofv3 --pmc run).  {} if this kernel was not profiled."""
+    found = latest_json("r*_pmc_counters.json")
+    out = {}
+    if found:
+        name, data = found
+        key = kernel.replace(" ", "").rstrip(">")
+        for group, kernels in data.items():
+            if f"_{ray_set}_" not in group:
+                continue
+            for k, counters in kernels.items():
+                if k.replace(" ", "").startswith(key):
+                    out.update(counters)
+        if out:
+            out["source"] = name
+    return out
+
+
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rNN_traffic.json, written by
-    scripts/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs; FETCH doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None if no profile of this kernel has been recorded."""
+    """HBM bytes per launch of `kernel` (primary pass): FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes
+    (profiles/rNN_traffic.json, scripts/profile_round.sh); FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950."""
     best = None
     for f in sorted((ROOT / "profiles").glob("r*_traffic.json")):
         try:
@@ -61,28 +97,42 @@ def measured_traffic(kernel):
     return best
 
 
-def measured_issue(kernel, kernel_ms):
-    """VALU occupancy of `kernel` on the primary pass from the committed SQ counter pass (profiles/rNN_traffic.json):
-    fraction of the launch during which the 1024 SIMDs issue VALU instructions (4 cycles per wave64 instruction at
-    2.4 GHz) and the fraction of lanes active in them.  None if no profile of this kernel has been recorded."""
-    best = None
-    for f in sorted((ROOT / "profiles").glob("r*_traffic.json")):
-        try:
-            data = json.loads(f.read_text())
-        except ValueError:
-            continue
-        for name, t in data.items():
-            if name.replace(" ", "").startswith(kernel.replace(" ", "").rstrip(">")) and "SQ_ACTIVE_INST_VALU" in t and "SQ_THREAD_CYCLES_VALU" in t:
-                best = {"valu_instructions_per_launch": int(t.get("SQ_INSTS_VALU", 0)),
-                        "valu_busy_frac": round(4.0 * t["SQ_ACTIVE_INST_VALU"] / (kernel_ms * 1e-3 * 2.4e9 * 1024), 4),
-                        "lane_utilisation": round(t["SQ_THREAD_CYCLES_VALU"] / (64.0 * t["SQ_ACTIVE_INST_VALU"]), 4),
-                        "source": f.name}
-    return best
+def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms):
+    """The bounds that bind the traversal kernel, against peaks MEASURED on this chip (profiles/rNN_calibration.json):
+    node fetches per ns through the vector-memory pipeline (live: oracle visit counts x rays / HIP-event kernel time) and
+    VALU wave-instructions per us per SIMD (instruction count from the committed SQ counter pass / live kernel time)."""
+    cal = latest_json("r*_calibration.json")
+    if not cal:
+        return None
+    cal_name, cal = cal
+    c = kernel_counters(kernel, ray_set)
+    fetches_per_ns = steps_per_ray * rays / (kernel_ms * 1e6)
+    if ray_set == "primary":
+        peak, peak_kind = cal["node_fetch_peak_coherent"], "64-byte node per lane, neighbouring lanes share nodes, L1/L2-resident (vmem_peak 'coherent')"
+    else:
+        # incoherent rays: every lane its own node; blend of the scattered-L2 and scattered-MALL rates by the measured L2 hit rate
+        hit = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if "TCC_HIT_sum" in c else 0.85
+        peak = 1.0 / (hit / cal["node_fetch_peak_scattered_l2"] + (1.0 - hit) / cal["node_fetch_peak_scattered_mall"])
+        peak_kind = f"64-byte node per lane, scattered: L2 rate x {hit:.3f} + MALL rate x {1 - hit:.3f} (measured TCC hit rate; vmem_peak 'scattered')"
+    out = {"node_fetch": {"bound": "vector-memory pipeline (TA/L1/L2), node fetches", "unit": "fetches/ns", "achieved": round(fetches_per_ns, 2), "peak": round(peak, 2),
+                          "frac": round(fetches_per_ns / peak, 4), "peak_kind": peak_kind, "steps_per_ray": round(steps_per_ray, 3), "peak_source": cal_name}}
+    if "SQ_INSTS_VALU" in c:
+        per_simd_us = c["SQ_INSTS_VALU"] / (kernel_ms * 1e3) / cal["simds"]
+        lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        out["valu_issue"] = {"bound": "VALU issue", "unit": "wave-instructions/us/SIMD", "achieved": round(per_simd_us, 1), "peak": cal["valu_issue_peak"],
+                             "frac": round(per_simd_us / cal["valu_issue_peak"], 4), "valu_instructions_per_launch": int(c["SQ_INSTS_VALU"]),
+                             "lane_utilisation": round(lane_util, 4), "useful_lane_frac": round(per_simd_us / cal["valu_issue_peak"] * lane_util, 4),
+                             "peak_source": cal_name, "counter_source": c.get("source")}
+    if "TA_TA_BUSY_sum" in c and "GRBM_GUI_ACTIVE" in c:
+        out["ta_busy_frac_profiled"] = round(c["TA_TA_BUSY_sum"] / cal["cus"] / (c["GRBM_GUI_ACTIVE"] / 8.0), 4)     # mean over the 256 TAs / cycles of one XCD
+    if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+        out["wave_cycles_waiting_frac_profiled"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
+    return out
 
 
 def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, dist, any_hit=False):
     """W untimed + K timed launches.  Returns (wall seconds for K steps [max over ranks is taken by
-    the caller], mean kernel ms from HIP events recorded on the launch stream)."""
+    the caller], mean / median / min kernel ms from HIP events recorded on the launch stream)."""
     stream = torch.cuda.current_stream()
     for _ in range(warmup):
         abi.traverse_async(bvh, rays_dev, hits_dev, n, any_hit, variant, stream)
@@ -114,7 +164,7 @@ def main():
                "--master-port", os.environ.get("MASTER_PORT", "29517"), os.path.abspath(__file__)] + sys.argv[1:]
         os.execv(sys.executable, cmd)
     import torch
-    from rodent_amd import abi, formats as F, raygen, scenes
+    from rodent_amd import abi, formats as F, parallel, raygen, scenes
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -131,6 +181,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP traversal has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = local_rank
+    strong = args.strong and world > 1
 
     # ---- inputs (rank 0 builds the files, the others wait) ----------------------------------
     scene = args.scene or scenes.default_scene()
@@ -143,15 +194,21 @@ def main():
     variant = args.variant if args.variant >= 0 else int(os.environ.get(f"RODENT_HIP_BVH{width}_VARIANT", "0"))
     bvh = abi.DeviceBvh.load(bvh_path, width, dev)
 
+    sample, samples = (0, 1) if strong else (rank, world)
     if scene == "sponza":
-        prim = F.read_rays(scenes.DATA / "sponza-primary.rays", 0.0, scenes.PRIMARY_TMAX)
-        rnd = F.read_rays(scenes.DATA / "sponza-random.rays", 0.0, scenes.RANDOM_TMAX)
+        prim_all = F.read_rays(scenes.DATA / "sponza-primary.rays", 0.0, scenes.PRIMARY_TMAX)
+        rnd_all = F.read_rays(scenes.DATA / "sponza-random.rays", 0.0, scenes.RANDOM_TMAX)
     else:
         eye, d, up, fov = scenes.CAMERAS[scene]
-        prim = raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, scenes.PRIMARY_TMAX, sample=rank, num_samples=world)
+        prim_all = raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, scenes.PRIMARY_TMAX, sample=sample, num_samples=samples)
         n4, _ = F.read_bvh(bvh_path, F.BVH4_TRI4)
         lo, hi = raygen.scene_bounds(n4)
-        rnd = raygen.random_rays(lo, hi, 1 << 20, 42 + rank, 0.0, scenes.RANDOM_TMAX)
+        rnd_all = raygen.random_rays(lo, hi, 1 << 20, 42 + sample, 0.0, scenes.RANDOM_TMAX)
+    if strong:                                                   # contiguous ranges keep coherent rays coherent
+        a, b = parallel.ray_range(len(prim_all), rank, world)
+        prim, rnd = prim_all[a:b], rnd_all[a:b]
+    else:
+        prim, rnd = prim_all, rnd_all
     n = len(prim)
 
     prim_dev, rnd_dev = abi.to_device(prim, dev), abi.to_device(rnd, dev)
@@ -163,10 +220,11 @@ def main():
     steps_r, warm_r = (args.steps, args.warmup) if args.only != "primary" else (1, 0)
     wall, k_mean, k_med, k_min = time_passes(abi, torch, bvh, prim_dev, hits_dev, n, variant, steps_p, warm_p, dist)
     wall_r, kr_mean, kr_med, kr_min = time_passes(abi, torch, bvh, rnd_dev, hits_rnd_dev, len(rnd), variant, steps_r, warm_r, dist)
+    abi.check_errors(dev)                                         # the asynchronous entry points report stack overflows through a flag
     # for information only (never `value`): independent batches in flight on two streams -- the fill of one launch
     # overlaps the drain of the other (every (device, stream) has its own launch state)
     overlapped = None
-    if args.only is None and not args.no_cpu_baseline:           # not in the profiling runs: their per-kernel averages are the serial launches
+    if args.only is None and not args.no_cpu_baseline and world == 1:      # not in the profiling runs: their per-kernel averages are the serial launches
         try:
             s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
             h2 = [hits_dev, torch.zeros_like(hits_dev)]
@@ -182,83 +240,104 @@ def main():
         except Exception as e:                                    # informational only: never lose the bench line over it
             print(f"bench.py: two-stream measurement skipped ({e})", file=sys.stderr)
     abi.lib()  # keep the handle alive
+    kernel_ms_ranks = [[k_mean, kr_mean]]
+    total_rays, total_rnd = n, len(rnd)
     if dist is not None:
         t = torch.tensor([wall, wall_r], dtype=torch.float64, device=f"cuda:{dev}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, wall_r = float(t[0]), float(t[1])
-    value = n * world * steps_p / wall / 1e6
-    value_rnd = len(rnd) * world * steps_r / wall_r / 1e6
+        km = torch.tensor([k_mean, kr_mean, float(n), float(len(rnd))], dtype=torch.float64, device=f"cuda:{dev}")
+        gathered_km = [torch.zeros_like(km) for _ in range(world)]
+        dist.all_gather(gathered_km, km)
+        kernel_ms_ranks = [[round(float(g[0]), 5), round(float(g[1]), 5)] for g in gathered_km]
+        total_rays, total_rnd = int(sum(float(g[2]) for g in gathered_km)), int(sum(float(g[3]) for g in gathered_km))
+    value = total_rays * steps_p / wall / 1e6
+    value_rnd = total_rnd * steps_r / wall_r / 1e6
 
-    # ---- cross-check after the timed region: one gather of the per-rank hit counts -------------
+    # ---- after the timed region: ONE gather --------------------------------------------------
     hits = abi.from_device(hits_dev, F.HIT1)
     hits_rnd = abi.from_device(hits_rnd_dev, F.HIT1)
-    counts = torch.tensor([int((hits["tri_id"] >= 0).sum()), int((hits_rnd["tri_id"] >= 0).sum())], device=f"cuda:{dev}")
-    if dist is not None:
-        gathered = [torch.zeros_like(counts) for _ in range(world)]
-        dist.all_gather(gathered, counts)
-        counts_all = [g.tolist() for g in gathered]
+    strong_check = None
+    if strong:
+        # the Hit1 ranges of all ranks, one RCCL all-gather (16 B/ray: 16 MiB in total), assembled in ray order on every rank
+        full = parallel.gather_hits_device(hits_dev, len(prim_all), dist, dev)
+        full_rnd = parallel.gather_hits_device(hits_rnd_dev, len(rnd_all), dist, dev)
+        if rank == 0:
+            whole = abi.traverse(bvh, prim_all, variant=variant)
+            whole_rnd = abi.traverse(bvh, rnd_all, variant=variant)
+            strong_check = {"primary_equal_to_single_gpu": bool(full.tobytes() == whole.tobytes()), "random_equal_to_single_gpu": bool(full_rnd.tobytes() == whole_rnd.tobytes())}
+        counts_all = None
     else:
-        counts_all = [counts.tolist()]
+        counts = torch.tensor([int((hits["tri_id"] >= 0).sum()), int((hits_rnd["tri_id"] >= 0).sum())], device=f"cuda:{dev}")
+        if dist is not None:
+            gathered = [torch.zeros_like(counts) for _ in range(world)]
+            dist.all_gather(gathered, counts)
+            counts_all = [g.tolist() for g in gathered]
+        else:
+            counts_all = [counts.tolist()]
 
     if rank != 0:
         if dist is not None:
             dist.barrier(); dist.destroy_process_group()
         return
 
-    # ---- rank 0: algorithmic bytes (oracle visit counts), roofline, CPU baseline ---------------
+    # ---- rank 0: algorithmic bytes (oracle visit counts), rooflines, CPU baseline ---------------
+    kname = abi.kernel_name(width, variant)
+    sharding = "ONE ray set in contiguous ranges (strong scaling), Hit1 all-gather after the timed region" if strong else "rays sharded by sub-pixel sample (weak scaling)"
     out = {
         "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * wall / steps_p, 5), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{scene}.bvh + {scene}-primary.rays (1024x1024 primary rays, tmax 5000, closest hit) per GPU",
-                   "rays_per_gpu_per_step": n, "bvh_layout": f"BVH{width}", "kernel": abi.kernel_name(width, variant),
-                   "variant": abi.variants(width)[variant], "parallelism": f"replicated BVH x {world}, rays sharded by sub-pixel sample"},
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{scene}.bvh + {scene}-primary.rays (1024x1024 primary rays, tmax 5000, closest hit)" + ("" if strong else " per GPU"),
+                   "rays_per_gpu_per_step": n, "bvh_layout": f"BVH{width}", "kernel": kname,
+                   "variant": abi.variants(width)[variant], "parallelism": f"replicated BVH x {world}, {sharding}",
+                   "world_size": world, "collective_backend": "nccl (RCCL)" if world > 1 else None},
         "extra": {"random_Mrays_s": round(value_rnd, 3), "random_ms_per_step": round(1e3 * wall_r / steps_r, 5),
                   "primary_kernel_ms": {"mean": round(k_mean, 5), "median": round(k_med, 5), "min": round(k_min, 5)},
                   "random_kernel_ms": {"mean": round(kr_mean, 5), "median": round(kr_med, 5), "min": round(kr_min, 5)},
-                  "hit_counts_per_rank[primary,random]": counts_all,
+                  "kernel_ms_per_rank[primary,random]": kernel_ms_ranks,
+                  "hit_counts_per_rank[primary,random]": counts_all, "strong_scaling_check": strong_check,
                   "two_streams_Mrays_s_per_gpu": None if overlapped is None else round(overlapped, 3)},
     }
     if not args.no_cpu_baseline:
         from oracle import binding as O      # checker / CPU baseline only: never on the measured path
-        # (1) visit counts of the reference algorithm for THIS layout -> algorithmic bytes per ray
-        if width == 2:
-            nodes, tris = F.read_bvh(bvh_path, F.BVH2_TRI1)
-            node_b, prim_b, algo = 64, 48, "ref"
-        else:
-            nodes, tris = F.read_bvh(bvh_path, F.BVH8_TRI4)
-            node_b, prim_b, algo = 256, 224, "gpu"
-        sample = slice(0, n, 4)                                  # every 4th ray: 262 144 rays, deterministic
-        ref_hits, st = O.traverse(width, nodes, tris, prim[sample], algo=algo)
+        # (1) visit counts of the reference algorithm for THIS layout over ALL rays -> algorithmic bytes per ray; full parity check
+        block = {2: F.BVH2_TRI1, 4: F.BVH4_TRI4, 8: F.BVH8_TRI4}[width]
+        nodes, tris = F.read_bvh(bvh_path, block)
+        node_b, prim_b, algo = {2: (64, 48, "ref"), 4: (128, 224, "gpu"), 8: (256, 224, "gpu")}[width]
+        ref_hits, st = O.traverse(width, nodes, tris, prim, algo=algo)
+        ref_rnd, st_r = O.traverse(width, nodes, tris, rnd, algo=algo)
         bytes_per_ray = 32 + 16 + node_b * st["inner_per_ray"] + prim_b * st["prims_per_ray"]
         achieved = bytes_per_ray * n / (k_mean * 1e-3) / 1e9
+        traffic = measured_traffic(kname)
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": measured_traffic(abi.kernel_name(width, variant)),
+                           "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                           "note": "frac > 1: SURVEY 8(d)'s algorithmic bytes count every node / triangle visit, and the BVH is served by L1 / L2 / MALL -- HBM does not bind this kernel; see hbm_measured and binding",
                            "bytes_per_ray": round(bytes_per_ray, 2),
                            "visits_per_ray": {"inner": round(st["inner_per_ray"], 3), "prim": round(st["prims_per_ray"], 3)},
                            "compulsory_bytes_per_ray": 48, "kernel_ms": round(k_mean, 5),
-                           "issue": measured_issue(abi.kernel_name(width, variant), k_mean)}
-        # parity spot check on the sample (bit-exact for the order-preserving kernels)
-        same = hits[sample].tobytes() == ref_hits.tobytes()
-        out["extra"]["sample_bit_exact_vs_oracle"] = bool(same)
-        if not same:
-            ids_equal = float((hits[sample]["tri_id"] == ref_hits["tri_id"]).mean())
-            out["extra"]["sample_id_match_fraction"] = ids_equal
+                           "hbm_measured": None if traffic is None else {"bytes_per_launch": traffic, "GBps": round(traffic / (k_mean * 1e-3) / 1e9, 1), "frac": round(traffic / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                           "binding": binding_bounds(kname, "primary", n, st["inner_per_ray"] + st["prims_per_ray"], k_mean),
+                           "random": {"kernel_ms": round(kr_mean, 5), "visits_per_ray": {"inner": round(st_r["inner_per_ray"], 3), "prim": round(st_r["prims_per_ray"], 3)},
+                                      "binding": binding_bounds(kname, "random", len(rnd), st_r["inner_per_ray"] + st_r["prims_per_ray"], kr_mean)}}
+        # parity on every ray of both sets (bit-exact for the order-preserving kernels)
+        out["extra"]["all_rays_bit_exact_vs_oracle"] = {"primary": bool(hits.tobytes() == ref_hits.tobytes()), "random": bool(hits_rnd.tobytes() == ref_rnd.tobytes())}
     if world == 1 and not args.no_cpu_baseline:
         # (2) CPU baseline: Rodent's CPU hybrid path (ray8 x bvh8 packets with single-ray fallback,
-        #     mapping_cpu.impala:259-402) restated with AVX2 (oracle/hybrid_baseline.cpp), timed on this host:
-        #     once on 1 core (the reference's bench loop is sequential) and once on all hardware threads.
+        #     mapping_cpu.impala:259-402) restated with AVX2 (oracle/hybrid_baseline.cpp), timed on this host on a
+        #     PERSISTENT thread pool (threads created outside the timed region), median of the passes.
         n8, t8 = F.read_bvh(bvh_path, F.BVH8_TRI4)
-        O.cpu_baseline(n8, t8, prim[:4096])                        # build / warm up
         threads = max(1, O.hardware_threads())
-        t0 = time.perf_counter(); cpu_hits = O.cpu_baseline(n8, t8, prim, mode="hybrid", threads=1); cpu1_s = time.perf_counter() - t0
-        t0 = time.perf_counter(); O.cpu_baseline(n8, t8, prim, mode="hybrid", threads=threads); cpuN_s = time.perf_counter() - t0
-        t0 = time.perf_counter(); O.cpu_baseline(n8, t8, rnd, mode="hybrid", threads=threads); cpuN_rnd_s = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(n / cpuN_s / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                               "sample": f"all {n} primary rays, 1 pass, hybrid ray8 x BVH8/Tri4 restatement of "
-                                         "mapping_cpu.impala:259-402 (AVX2+FMA, -O3), dynamic 2048-ray chunks over all hardware threads"}
-        out["extra"]["cpu_baseline_1core_Mrays_s"] = round(n / cpu1_s / 1e6, 3)
-        out["extra"]["cpu_baseline_random_Mrays_s"] = round(len(rnd) / cpuN_rnd_s / 1e6, 3)
+        passes = 12
+        secs, cpu_hits = O.cpu_baseline_bench(n8, t8, prim, threads, passes)
+        secs_rnd, _ = O.cpu_baseline_bench(n8, t8, rnd, threads, passes)
+        secs1, _ = O.cpu_baseline_bench(n8, t8, prim, 1, 2)
+        out["cpu_baseline"] = {"value": round(n / float(np.median(secs)) / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                               "sample": f"all {n} primary rays x {passes} passes (median; one warm-up pass before), hybrid ray8 x BVH8/Tri4 restatement of "
+                                         "mapping_cpu.impala:259-402 (AVX2+FMA, -O3), persistent pool of all hardware threads pulling 1024-ray chunks",
+                               "passes": passes, "pass_ms": [round(1e3 * float(s), 3) for s in secs]}
+        out["extra"]["cpu_baseline_1core_Mrays_s"] = round(n / float(np.median(secs1)) / 1e6, 3)
+        out["extra"]["cpu_baseline_random_Mrays_s"] = round(len(rnd) / float(np.median(secs_rnd)) / 1e6, 3)
         out["extra"]["cpu_vs_gpu_hit_mismatch"] = int(((cpu_hits["tri_id"] >= 0) != (hits[:len(cpu_hits)]["tri_id"] >= 0)).sum())
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -206,5 +206,18 @@ def cpu_baseline(nodes8, tris4, rays, any_hit=False, mode="hybrid", threads=1):
     return hits
 
 
+def cpu_baseline_bench(nodes8, tris4, rays, threads, passes, any_hit=False, mode="hybrid"):
+    """`passes` timed passes (after one warm-up pass) on a persistent pool of `threads` threads; returns (seconds per pass, hits)."""
+    nodes8 = np.ascontiguousarray(nodes8); tris4 = np.ascontiguousarray(tris4); rays = np.ascontiguousarray(rays)
+    n = len(rays) // 8 * 8
+    hits = np.zeros(n, HIT1)
+    secs = np.zeros(passes, np.float64)
+    l = baseline_lib()
+    l.cpu_baseline_bench.restype = None
+    l.cpu_baseline_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    l.cpu_baseline_bench(_ptr(nodes8), _ptr(tris4), _ptr(rays), _ptr(hits), n, int(any_hit), 0 if mode == "hybrid" else 1, int(threads), int(passes), _ptr(secs))
+    return secs, hits
+
+
 def hardware_threads():
     return int(baseline_lib().cpu_baseline_hardware_threads())

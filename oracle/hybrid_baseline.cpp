@@ -15,6 +15,7 @@
 // rounding (checked in tests to 1e-4 relative, ids exact off ties), they are not bit-pinned.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -232,6 +233,48 @@ void cpu_baseline_traverse(const Node8* nodes, const Tri4* tris, const Ray1* ray
     const int chunk = 256;
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; t++) pool.emplace_back([&] { for (;;) { const int p0 = next.fetch_add(chunk); if (p0 >= packets) break; work(p0, std::min(packets, p0 + chunk)); } });
+    for (auto& th : pool) th.join();
+}
+
+// Timed form for bench.py's cpu_baseline: a PERSISTENT pool of `threads` threads runs `passes` passes over the same rays
+// (one warm-up pass first); thread creation is outside the timed region, every pass starts and ends at a barrier and is
+// timed on its own.  seconds[p] = wall time of pass p.  (The one-shot entry point above spawns its threads inside the call:
+// at 256 threads that is a third of a 12 ms pass.)
+void cpu_baseline_bench(const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t n, int32_t any_hit, int32_t mode, int32_t threads,
+                        int32_t passes, double* seconds) {
+    const int packets = n / 8, chunk = 128;
+    if (threads < 1) threads = 1;
+    std::atomic<int> next{0}, arrived{0}, generation{0};
+    auto barrier = [&]() {                                   // sense-reversing; the last arriver resets the work counter
+        const int gen = generation.load();
+        if (arrived.fetch_add(1) + 1 == threads) { arrived.store(0); next.store(0); generation.fetch_add(1); }
+        else while (generation.load() == gen) std::this_thread::yield();
+    };
+    auto one_pass = [&]() {
+        for (;;) {
+            const int p0 = next.fetch_add(chunk);
+            if (p0 >= packets) break;
+            for (int p = p0; p < std::min(packets, p0 + chunk); p++) {
+                if (mode == 0) hybrid_packet(nodes, tris, rays + 8 * p, hits + 8 * p, any_hit != 0);
+                else for (int l = 0; l < 8; l++) {
+                    const Ray1& r = rays[8 * p + l];
+                    Hit1 h{-1, r.tmax, 0, 0};
+                    single_ray(nodes, tris, make_ray1(r.org, r.dir, r.tmin, r.tmax), any_hit != 0, 1, h);
+                    hits[8 * p + l] = h;
+                }
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back([&] { for (int pass = 0; pass < passes + 1; pass++) { barrier(); one_pass(); barrier(); } });
+    for (int pass = 0; pass < passes + 1; pass++) {          // the calling thread is worker 0 and the timekeeper
+        barrier();
+        const auto t0 = std::chrono::steady_clock::now();
+        one_pass();
+        barrier();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (pass > 0) seconds[pass - 1] = dt;
+    }
     for (auto& th : pool) th.join();
 }
 

@@ -920,6 +920,24 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
         if (d->materials[k].tex_kd < 0 || d->materials[k].tex_kd > d->num_textures || d->materials[k].tex_ks < 0 || d->materials[k].tex_ks > d->num_textures) {
             fprintf(stderr, "rodent_hip: material %d refers to a texture that does not exist\n", k); abort();
         }
+    // every index the kernels follow, checked once on the host tables (a corrupt scene must not become an out-of-bounds read in k_shade / trace_one)
+    auto invalid = [](const char* what) { fprintf(stderr, "rodent_hip: invalid scene: %s\n", what); abort(); };
+    if (d->num_vertices <= 0 || d->num_tris <= 0 || d->num_nodes <= 0 || d->num_bvh_tris <= 0 || d->num_materials <= 0 || d->num_lights < 0) invalid("empty table");
+    for (int32_t t = 0; t < d->num_tris; t++) {
+        for (int k = 0; k < 3; k++) if ((uint32_t)d->indices[4 * t + k] >= (uint32_t)d->num_vertices) invalid("vertex index out of range");
+        if ((uint32_t)d->indices[4 * t + 3] >= (uint32_t)d->num_materials) invalid("material index out of range");
+        if (d->light_ids[t] < 0 || (d->light_ids[t] > 0 && d->light_ids[t] >= d->num_lights)) invalid("light id out of range");
+    }
+    for (int32_t k = 0; k < d->num_nodes; k++)
+        for (int j = 0; j < 2; j++) {
+            const int32_t c = d->nodes[k].child[j];
+            if ((c > 0 && c > d->num_nodes) || (c < 0 && ~c >= d->num_bvh_tris)) invalid("BVH child id out of range");
+        }
+    if (d->tris[d->num_bvh_tris - 1].prim_id >= 0) invalid("the last BVH triangle lacks the end-of-leaf bit");
+    for (int32_t k = 0; k < d->num_bvh_tris; k++)
+        if ((d->tris[k].prim_id & 0x7FFFFFFF) >= d->num_tris || (uint32_t)d->tris[k].geom_id >= (uint32_t)d->num_materials) invalid("BVH triangle refers to a primitive or material that does not exist");
+    for (int32_t k = 0; k < d->num_textures; k++)
+        if (d->textures[k].width <= 0 || d->textures[k].height <= 0 || (uint64_t)d->textures[k].offset + (uint64_t)d->textures[k].width * (uint64_t)d->textures[k].height > d->num_texels) invalid("texture outside the texel pool");
     s.dev.num_tris = d->num_tris; s.dev.num_materials = d->num_materials; s.dev.num_lights = d->num_lights;
     s.loaded = true;
 }

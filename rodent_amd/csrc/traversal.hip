@@ -240,15 +240,29 @@ __device__ __forceinline__ Lane start_lane(const Ray1* __restrict__ rays, Hit1* 
     return L;
 }
 
-template <bool ANY, int LDS_N>
+// PRIO (lab): 0 = none; 1 = a wave raises its issue priority as it ages (48 / 96 / 144 iterations -> s_setprio 1 / 2 / 3);
+// 2 = the waves of the second dispatch round (workgroup index >= 8192) run at priority 2 from the start; 3 = both.
+template <bool ANY, int LDS_N, int PRIO = 0>
 __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, const Ray1* __restrict__ rays,
                                               Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray) {
     const int lane_ray = first_ray + (int)threadIdx.x;
     Lane L = start_lane(rays, hits, lane_ray < n ? lane_ray : -1, first_ray, col);
     lds_int* const sp_limit = col + LDS_N * kWave;
     const Bases base = make_bases(nodes, tris);
-    while (__ballot(L.top != 0)) {
-        if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
+    if (PRIO == 0) {
+        while (__ballot(L.top != 0)) {
+            if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
+        }
+    } else {
+        if ((PRIO & 2) && blockIdx.x >= 8192) __builtin_amdgcn_s_setprio(2);
+        for (int it = 0; __ballot(L.top != 0); it++) {
+            if (PRIO & 1) {
+                if (it == 48) __builtin_amdgcn_s_setprio(1);
+                if (it == 96) __builtin_amdgcn_s_setprio(2);
+                if (it == 144) __builtin_amdgcn_s_setprio(3);
+            }
+            if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
+        }
     }
 }
 
@@ -277,7 +291,11 @@ struct RayQueue {              // SoA over slots; stripe s owns slots [s * strip
     int capacity, stripe_cap;
 };
 
-template <bool ANY, int LDS_N, bool RESUME, bool CAPPED>
+// RAYS: rays a resuming wave takes (64, 32 or 16).  In the last phase the kernel time is the longest ray's remaining
+// steps x the time of one wave iteration, and an iteration executes the node path AND the triangle path whenever the
+// wave's rays are in both states: with fewer rays per wave a long ray seldom waits for the other path, and the same
+// rays spread over more waves keep more SIMDs issuing (one wave alone issues a VALU instruction every ~5.7 cycles).
+template <bool ANY, int LDS_N, bool RESUME, bool CAPPED, int RAYS = kWave>
 __global__ __launch_bounds__(kWave) void k_bvh2_phase(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                        const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                        Ctl* ctl, int* __restrict__ deep_list, int* __restrict__ qcount, RayQueue in, int phase, int max_iters, RayQueue out) {
@@ -290,7 +308,7 @@ __global__ __launch_bounds__(kWave) void k_bvh2_phase(const Node2* __restrict__ 
     // the expected number of survivors; more than expected = more than one chunk per wave)
     const int in_count = RESUME ? qcount[((phase - 1) * kStripes + stripe) * kCounterStride] : 0;   // written by the previous kernel of the chain
     const int k0 = blockIdx.x / kStripes, kstep = RESUME ? gridDim.x / kStripes : 1;
-    for (int k = k0; RESUME ? k * kWave < in_count : k == k0; k += kstep) {
+    for (int k = k0; RESUME ? k * RAYS < in_count : k == k0; k += kstep) {
         Lane L;
         if (!RESUME) {
             const int total_chunks = (n + kWave - 1) / kWave;
@@ -304,8 +322,8 @@ __global__ __launch_bounds__(kWave) void k_bvh2_phase(const Node2* __restrict__ 
             const int lane_ray = chunk * kWave + (int)threadIdx.x;
             L = start_lane(rays, hits, lane_ray < n ? lane_ray : -1, chunk * kWave, col);
         } else {
-            const int first = stripe * in.stripe_cap + k * kWave;
-            const bool valid = k * kWave + (int)threadIdx.x < in_count;
+            const int first = stripe * in.stripe_cap + k * RAYS;
+            const bool valid = (int)threadIdx.x < RAYS && k * RAYS + (int)threadIdx.x < in_count;
             const unsigned s = (unsigned)(valid ? first + (int)threadIdx.x : first);
             L.ray_id = valid ? in.ray[s] : -1;
             L.ray = load_ray(rays, in.ray[s]);
@@ -359,7 +377,7 @@ static_assert(kMaxPhases == 4 && kStripes == 64 && kCounterStride == 16, "k_bvh2
 // waiting workgroups hold slots.  An age-based s_setprio for long-running waves was slower as well, and so was giving
 // every wave two chunks (b and b + grid/2) with idle lanes refilled from the second one (one dispatch round, all waves
 // start at t = 0: 0.247 vs 0.214 ms -- the second chunk's expensive rays still start late, inside the wave).
-template <bool ANY, int LDS_N, int XCD, bool TRACE = false>
+template <bool ANY, int LDS_N, int XCD, bool TRACE = false, int PRIO = 0>
 __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                         Ctl* ctl, int* __restrict__ deep_list) {
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__
             chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
         }
     }
-    unified_chunk<ANY, LDS_N>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave);
+    unified_chunk<ANY, LDS_N, PRIO>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave);
     if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
         unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
         tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
@@ -494,9 +512,9 @@ void check_error_flag(DeviceState& s, hipStream_t stream) {
 
 #define LAUNCH_ARGS DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
 
-template <bool ANY, int LDS_N, int XCD, bool TR = false> void L_single(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int XCD, bool TR = false, int PRIO = 0> void L_single(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
-    hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
+    hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR, PRIO>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 
@@ -505,7 +523,7 @@ template <bool ANY, int LDS_N, int XCD, bool TR = false> void L_single(LAUNCH_AR
 int g_phased_min_rays = 4096 * kWave;           // rodent_hip_phased_min_rays()
 struct PhaseCaps { int count; int cap[3]; };
 constexpr PhaseCaps kPhaseCaps[] = {{2, {40, 24}}, {2, {32, 24}}, {1, {40}}, {1, {32}}, {1, {48}}, {2, {48, 32}}, {3, {32, 32, 32}}, {3, {24, 24, 24}}, {2, {24, 24}}, {2, {64, 32}}};
-template <bool ANY, int LDS_N, int CAPS> void L_phased(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int CAPS, int LAST_RAYS = kWave> void L_phased(LAUNCH_ARGS) {
     constexpr PhaseCaps caps = kPhaseCaps[CAPS];
     static_assert(caps.count + 1 <= kMaxPhases, "too many phases");
     if (n < g_phased_min_rays) { L_single<ANY, LDS_N, 32>(s, nodes, tris, rays, hits, n, stream); return; }
@@ -518,7 +536,7 @@ template <bool ANY, int LDS_N, int CAPS> void L_phased(LAUNCH_ARGS) {
     hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, false, true>), dim3(blocks), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.qcount, q[1], 0, caps.cap[0], q[0]);
     for (int p = 1; p < caps.count; p++)
         hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, true, true>), dim3(resume_grid(p)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.qcount, q[(p - 1) & 1], p, caps.cap[p], q[p & 1]);
-    hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, true, false>), dim3(resume_grid(caps.count)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.qcount, q[(caps.count - 1) & 1], caps.count, 0, q[caps.count & 1]);
+    hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, true, false, LAST_RAYS>), dim3(resume_grid(caps.count) * (kWave / LAST_RAYS)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.qcount, q[(caps.count - 1) & 1], caps.count, 0, q[caps.count & 1]);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.qcount);
 }
 
@@ -536,10 +554,13 @@ const Variant2 kVariants2[] = {
     //                                                        LDS_N XCD_GROUP
     K2("fast",               "k_bvh2_single",        L_single, 16, 32),                // default: single-step schedule, XCD-aware 32-chunk groups
     K2("fast-noxcd",         "k_bvh2_single",        L_single, 16, 0),                 // same kernel, workgroup b traces chunk b
-    //                                                       LDS_N CAPS (index into kPhaseCaps)
-    K2("phased-40-24",       "k_bvh2_phase",         L_phased, 16, 0),                 // phased traversal with compaction
+    //                                                       LDS_N CAPS (index into kPhaseCaps) [LAST_RAYS]
+    K2("phased",             "k_bvh2_phase",         L_phased, 16, 2),                 // phased traversal with ray compaction: one capped phase of 40 iterations, then the rest
+#ifdef RODENT_HIP_LAB
+    // what was swept on the way (profiles/r02_sweep_phased*.log, r02_sweep_prio.log): other phase caps, fewer rays per wave in
+    // the last phase, issue priorities by wave age / dispatch round
+    K2("phased-40-24",       "k_bvh2_phase",         L_phased, 16, 0),
     K2("phased-32-24",       "k_bvh2_phase",         L_phased, 16, 1),
-    K2("phased-40",          "k_bvh2_phase",         L_phased, 16, 2),
     K2("phased-32",          "k_bvh2_phase",         L_phased, 16, 3),
     K2("phased-48",          "k_bvh2_phase",         L_phased, 16, 4),
     K2("phased-48-32",       "k_bvh2_phase",         L_phased, 16, 5),
@@ -547,7 +568,14 @@ const Variant2 kVariants2[] = {
     K2("phased-24-24-24",    "k_bvh2_phase",         L_phased, 16, 7),
     K2("phased-24-24",       "k_bvh2_phase",         L_phased, 16, 8),
     K2("phased-64-32",       "k_bvh2_phase",         L_phased, 16, 9),
-#ifdef RODENT_HIP_LAB
+    K2("phased-40-24-r32",   "k_bvh2_phase",         L_phased, 16, 0, 32),
+    K2("phased-40-24-r16",   "k_bvh2_phase",         L_phased, 16, 0, 16),
+    K2("phased-40-r32",      "k_bvh2_phase",         L_phased, 16, 2, 32),
+    K2("phased-40-r16",      "k_bvh2_phase",         L_phased, 16, 2, 16),
+    K2("phased-48-r16",      "k_bvh2_phase",         L_phased, 16, 4, 16),
+    K2("fast-prio-age",      "k_bvh2_single",        L_single, 16, 32, false, 1),
+    K2("fast-prio-young",    "k_bvh2_single",        L_single, 16, 32, false, 2),
+    K2("fast-prio-both",     "k_bvh2_single",        L_single, 16, 32, false, 3),
     K2("lane",               "k_bvh2_lane",          L_lane, 24),                      // literal reference mapping
     K2("ww",                 "k_bvh2_ww",            L_ww, 24, 8),                     // while-while, LDS+scratch stack
     //                                                      LDS_N NODE_EXIT PERSIST REFILL_IDLE CHUNK STATS XCD_GROUP

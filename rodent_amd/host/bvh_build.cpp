@@ -340,7 +340,7 @@ void pack_tri4(const WideBvh& bvh, const std::vector<Triangle>& tris, const uint
             for (size_t j = c; j < 4; j++) t.prim_id[j] = -1;
             out.push_back(t);
         }
-        out.back().prim_id[3] |= (int32_t)0x80000000u;
+        if (!bvh.leaves[l].empty()) out.back().prim_id[3] |= (int32_t)0x80000000u;
     }
 }
 
@@ -362,7 +362,7 @@ void layout_bvh2_tri1(const WideBvh& bvh, const std::vector<Triangle>& tris, con
             t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z; t.prim_id = (int32_t)id;
             out.push_back(t);
         }
-        out.back().prim_id |= (int32_t)0x80000000u;
+        if (!bvh.leaves[l].empty()) out.back().prim_id |= (int32_t)0x80000000u;
     }
     nodes.resize(bvh.nodes.size());
     for (size_t i = 0; i < bvh.nodes.size(); i++) {

@@ -308,6 +308,9 @@ bool load_jpg(const std::string& path, ImageRgba8& img, std::string* error) {
         pos += 2 + len;
     }
     if (!scan || width <= 0 || height <= 0) return fail(error, "JPEG without image data");
+    // a scan with ONE component is not interleaved: its MCU is a single 8x8 block whatever the sampling factors say
+    // (ITU T.81 A.2.2; several encoders write greyscale files with 2x2 factors)
+    if (comps.size() == 1) comps[0].h = comps[0].v = 1;
     int hmax = 1, vmax = 1;
     for (auto& c : comps) { if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || !dc[c.td & 3].defined || !ac[c.ta & 3].defined) return fail(error, "bad JPEG component"); hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
     const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);

@@ -70,6 +70,7 @@ bool build_scene_from_obj(const std::string& obj_path, SceneData& scene) {
     for (auto& n : names)
         if (!n.empty() && !lib.count(n)) { std::clog << "Missing material definition for '" << n << "'. Replaced by dummy material." << std::endl; n = ""; }
 
+    if (mesh.num_tris() == 0) { std::cerr << "The OBJ file '" << obj_path << "' has no faces" << std::endl; return false; }
     // merge identical materials, drop unused ones (first occurrence keeps its place)
     const size_t nt = mesh.num_tris();
     std::vector<int> canon(names.size());
@@ -171,11 +172,49 @@ bool save_scene(const std::string& path, const SceneData& s) {
     return ok;
 }
 
+// Every index a kernel will follow is range-checked here, once: BVH child ids, leaf extents, geometry / vertex / light /
+// texture ids.  (A corrupt file must fail at load, not as an out-of-bounds read in k_shade.)
+bool validate_scene(const SceneData& s, std::string* why) {
+    auto bad = [&](const char* m) { if (why) *why = m; return false; };
+    const size_t nv = s.vertices.size() / 4, nt = s.indices.size() / 4;
+    if (s.vertices.size() % 4 || s.indices.size() % 4 || s.normals.size() != s.vertices.size() || s.face_normals.size() != 4 * nt ||
+        s.light_ids.size() != nt || (!s.texcoords.empty() && s.texcoords.size() != s.vertices.size())) return bad("table sizes disagree");
+    if (s.nodes.empty() || s.tris.empty() || s.materials.empty()) return bad("empty BVH or material table");
+    for (size_t t = 0; t < nt; t++) {
+        for (int k = 0; k < 3; k++) if ((uint32_t)s.indices[4 * t + k] >= nv) return bad("vertex index out of range");
+        if ((uint32_t)s.indices[4 * t + 3] >= s.materials.size()) return bad("material index out of range");
+        if (s.light_ids[t] < 0 || (s.light_ids[t] > 0 && (size_t)s.light_ids[t] >= s.lights.size())) return bad("light id out of range");
+    }
+    for (const Node2& n : s.nodes)
+        for (int k = 0; k < 2; k++) {
+            const int32_t c = n.child[k];
+            if (c > 0 && (size_t)c > s.nodes.size()) return bad("BVH child id out of range");
+            if (c < 0 && (size_t)~c >= s.tris.size()) return bad("BVH leaf id out of range");
+        }
+    if (s.tris.back().prim_id >= 0) return bad("last BVH triangle lacks the end-of-leaf bit");
+    for (const Tri1& t : s.tris) {
+        if ((size_t)(t.prim_id & 0x7FFFFFFF) >= nt) return bad("BVH triangle refers to a primitive that does not exist");
+        if ((uint32_t)t.geom_id >= s.materials.size()) return bad("BVH triangle refers to a material that does not exist");
+    }
+    for (const RodentMaterial& m : s.materials)
+        if (m.tex_kd < 0 || (size_t)m.tex_kd > s.textures.size() || m.tex_ks < 0 || (size_t)m.tex_ks > s.textures.size()) return bad("material refers to a texture that does not exist");
+    for (const RodentTexture& t : s.textures)
+        if (t.width <= 0 || t.height <= 0 || (uint64_t)t.offset + (uint64_t)t.width * (uint64_t)t.height > s.texels.size()) return bad("texture outside the texel pool");
+    return true;
+}
+
 bool load_scene(const std::string& path, SceneData& s) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
     uint32_t hdr[12];
     bool ok = fread(hdr, 4, 12, f) == 12 && hdr[0] == kMagic && hdr[1] == kVersion;
+    if (ok) {
+        // the header's counts must add up to the file's size before anything is allocated
+        const uint64_t nv = hdr[4], nt = hdr[5];
+        const uint64_t expect = 48 + 16 * nv * 2 + 16 * nt * 2 + sizeof(Node2) * (uint64_t)hdr[6] + sizeof(Tri1) * (uint64_t)hdr[7] + sizeof(RodentMaterial) * (uint64_t)hdr[8] +
+                                sizeof(RodentLight) * (uint64_t)hdr[9] + 4 * nt + 16 * nv + sizeof(RodentTexture) * (uint64_t)hdr[10] + 4ull * hdr[11];
+        ok = fseek(f, 0, SEEK_END) == 0 && (uint64_t)ftell(f) == expect && fseek(f, 48, SEEK_SET) == 0;
+    }
     if (ok) {
         s.default_spp = (int32_t)hdr[2]; s.default_max_path_len = (int32_t)hdr[3];
         auto get = [&](auto& vec, size_t count) { vec.resize(count); ok = ok && (count == 0 || fread(vec.data(), sizeof(vec[0]), count, f) == count); };
@@ -184,6 +223,8 @@ bool load_scene(const std::string& path, SceneData& s) {
         get(s.texcoords, 4ull * hdr[4]); get(s.textures, hdr[10]); get(s.texels, hdr[11]);
     }
     fclose(f);
+    std::string why;
+    if (ok && !validate_scene(s, &why)) { std::cerr << "Invalid scene file '" << path << "': " << why << std::endl; ok = false; }
     return ok;
 }
 

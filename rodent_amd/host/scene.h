@@ -39,7 +39,8 @@ struct SceneData {
 
 bool build_scene_from_obj(const std::string& obj_path, SceneData& scene);
 bool save_scene(const std::string& path, const SceneData& scene);   // ".rscene" binary
-bool load_scene(const std::string& path, SceneData& scene);
+bool load_scene(const std::string& path, SceneData& scene);           // validates counts against the file size and every index (validate_scene)
+bool validate_scene(const SceneData& scene, std::string* why = nullptr);
 
 // The reference converter's data directory (LZ4 buffer files, src/driver/buffer.h; converter.cpp:403-437,805-815,848):
 // vertices / normals / face_normals / texcoords (float4 per element), indices (int4), bvh.bin (BVH2/Tri1 layout),

@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
     TriMesh mesh;
     if (!load_obj(obj_file, mesh)) { std::cerr << "Cannot load OBJ file" << std::endl; return 1; }
     std::cout << "Loaded OBJ file with " << mesh.num_tris() << " triangle(s)" << std::endl;
+    if (mesh.num_tris() == 0) { std::cerr << "The OBJ file has no faces: nothing to build a BVH from" << std::endl; return 1; }
     const std::vector<Triangle> tris = mesh.triangles();
     std::vector<uint32_t> geom(mesh.num_tris());
     for (size_t i = 0; i < geom.size(); i++) geom[i] = mesh.indices[4 * i + 3];

@@ -63,8 +63,11 @@ def main():
         if dist is not None:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         rates.append(a.spp * a.width * a.height / float(dt[0]) / 1e6)
-    band = r.film()[y0:y1]
-    film = parallel.gather_film(band, a.height, dist, device=f"cuda:{local}")      # the one collective of the path
+    # the one collective of the path, on the DEVICE film (no host bounce): a view of the library's film memory, this rank's
+    # rows, one RCCL all-gather; the assembled frame comes to the host once, on rank 0
+    band = parallel.device_film(local)[y0:y1]
+    film = parallel.gather_film_tensor(band, a.height, dist)
+    film = film.cpu().numpy() if rank == 0 else None
     r.close()
     if rank == 0:
         if a.output:

@@ -148,3 +148,11 @@ def test_no_spatial_flag_gives_one_ref_per_triangle(tmp_path, native_build, corn
                    check=True, stdout=subprocess.DEVNULL)
     _, t1 = F.read_bvh(tmp_path / "c.bvh", F.BVH2_TRI1)
     assert len(t1) == 36
+
+
+def test_obj_without_faces_is_an_error_not_a_crash(tmp_path, native_build):
+    """A mesh with vertices but no faces used to make one empty leaf and out.back() on an empty vector (exit 139)."""
+    (tmp_path / "empty.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\n")
+    for tool, args in (("bvh_extractor", ["-obj", tmp_path / "empty.obj", "-o", tmp_path / "e.bvh"]), ("converter", [tmp_path / "empty.obj", "-o", tmp_path / "e.rscene"])):
+        r = subprocess.run([native_build.BIN_DIR / tool, *args], capture_output=True, text=True)
+        assert r.returncode == 1 and "no faces" in r.stderr, (tool, r.returncode, r.stderr)

@@ -35,6 +35,13 @@ rays = F.read_rays(sys.argv[3], 0.0, 1.0)
 a, b = parallel.ray_range(len(rays), rank, world)
 hits, _ = O.traverse(2, sc.nodes, sc.tris, rays[a:b])
 allhits = parallel.gather_hits(hits, len(rays), dist)
+# the tensor forms the GPU path uses (device film / device Hit1 ranges), with uneven shares: 7 rows, 1001 rays
+t = torch.arange(7 * 5 * 3, dtype=torch.float32).reshape(7, 5, 3)
+y0t, y1t = parallel.row_band(7, rank, world)
+assert torch.equal(parallel.gather_film_tensor(t[y0t:y1t].clone(), 7, dist), t)
+hb = torch.arange(1001 * 16, dtype=torch.int64).to(torch.uint8)
+at, bt = parallel.ray_range(1001, rank, world)
+assert torch.equal(parallel.gather_hits_tensor(hb[at * 16: bt * 16].clone(), 1001, dist), hb)
 if rank == 0:
     ref, _ = O.render(sc, cam, 2, 2, 8, W, H, threads=1)
     refh, _ = O.traverse(2, sc.nodes, sc.tris, rays)

@@ -325,3 +325,21 @@ def test_every_bsdf_matches_oracle(R, oracle, materials_scene, mapping, sort, ov
     film_g = r.film()
     r.close()
     assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
+
+
+def test_device_film_view_aliases_the_library_film(R, cornell_scene):
+    """parallel.device_film: a zero-copy torch view of the DEVICE film (rodent_get_film_data) -- what the multi-GPU path hands
+    to RCCL (gather_film_tensor) instead of bouncing the band through the host."""
+    import torch
+    from rodent_amd import parallel
+    W, H = 64, 40
+    cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
+    r = R.Renderer(cornell_scene, W, H, 2, 4)
+    r.render(cam, 0)
+    view = parallel.device_film(0)
+    assert view.is_cuda and tuple(view.shape) == (H, W, 3)
+    assert np.array_equal(view.cpu().numpy(), r.film())
+    r.render(cam, 1)                                             # the view follows the film: it is the same memory
+    assert np.array_equal(view.cpu().numpy(), r.film())
+    assert torch.equal(parallel.gather_film_tensor(view[10:20], H, None), view[10:20])     # single process: no collective
+    r.close()

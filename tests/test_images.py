@@ -124,3 +124,21 @@ def test_bad_files_fail_loudly(native_build, tmp_path):
     for name, msg in (("x.png", "not a PNG"), ("x.bmp", "cannot determine"), ("missing.jpg", "cannot read")):
         r = subprocess.run([native_build.BIN_DIR / "tex_dump", tmp_path / name, tmp_path / "o"], capture_output=True, text=True)
         assert r.returncode != 0 and msg in r.stderr
+
+
+def test_greyscale_jpeg_with_2x2_sampling_factors(native_build, tmp_path):
+    """A single-component scan is not interleaved: its MCU is one 8x8 block whatever the frame header's sampling factors say
+    (ITU T.81 A.2.2); some encoders write greyscale files with 2x2 factors.  Patching the factors of a greyscale file must
+    not change a texel (the entropy-coded data are the same)."""
+    rgb = picture(83, 61, seed=5)
+    path = tmp_path / "g.jpg"
+    Image.fromarray(rgb, "RGB").convert("L").save(path, quality=90)
+    plain = decode(native_build, path, tmp_path)
+    data = bytearray(path.read_bytes())
+    pos = data.find(b"\xff\xc0")                                   # SOF0: len(2) precision(1) height(2) width(2) ncomp(1) [id, HV, Tq]
+    assert pos > 0 and data[pos + 9] == 1 and data[pos + 11] == 0x11
+    data[pos + 11] = 0x22
+    (tmp_path / "g22.jpg").write_bytes(bytes(data))
+    patched = decode(native_build, tmp_path / "g22.jpg", tmp_path)
+    assert patched.shape == plain.shape and np.array_equal(patched, plain)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "g22.jpg")), np.asarray(Image.open(path)))      # PIL agrees that nothing changed
