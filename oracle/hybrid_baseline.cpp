@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -244,11 +246,14 @@ void cpu_baseline_bench(const Node8* nodes, const Tri4* tris, const Ray1* rays, 
                         int32_t passes, double* seconds) {
     const int packets = n / 8, chunk = 128;
     if (threads < 1) threads = 1;
-    std::atomic<int> next{0}, arrived{0}, generation{0};
-    auto barrier = [&]() {                                   // sense-reversing; the last arriver resets the work counter
-        const int gen = generation.load();
-        if (arrived.fetch_add(1) + 1 == threads) { arrived.store(0); next.store(0); generation.fetch_add(1); }
-        else while (generation.load() == gen) std::this_thread::yield();
+    std::atomic<int> next{0};
+    std::mutex m; std::condition_variable cv; int arrived = 0, generation = 0;
+    std::vector<std::chrono::steady_clock::time_point> tripped(2 * (passes + 1));
+    auto barrier = [&]() {                                   // sleeping barrier (256 yield-spinning threads starve the workers); the last arriver resets the work
+        std::unique_lock<std::mutex> lock(m);                // counter and stamps the time: a pass lasts from the trip of its start barrier to the trip of its end barrier
+        const int gen = generation;
+        if (++arrived == threads) { arrived = 0; next.store(0); tripped[generation] = std::chrono::steady_clock::now(); generation++; cv.notify_all(); }
+        else cv.wait(lock, [&] { return generation != gen; });
     };
     auto one_pass = [&]() {
         for (;;) {
@@ -267,15 +272,9 @@ void cpu_baseline_bench(const Node8* nodes, const Tri4* tris, const Ray1* rays, 
     };
     std::vector<std::thread> pool;
     for (int t = 1; t < threads; t++) pool.emplace_back([&] { for (int pass = 0; pass < passes + 1; pass++) { barrier(); one_pass(); barrier(); } });
-    for (int pass = 0; pass < passes + 1; pass++) {          // the calling thread is worker 0 and the timekeeper
-        barrier();
-        const auto t0 = std::chrono::steady_clock::now();
-        one_pass();
-        barrier();
-        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (pass > 0) seconds[pass - 1] = dt;
-    }
+    for (int pass = 0; pass < passes + 1; pass++) { barrier(); one_pass(); barrier(); }      // the calling thread is worker 0
     for (auto& th : pool) th.join();
+    for (int pass = 1; pass < passes + 1; pass++) seconds[pass - 1] = std::chrono::duration<double>(tripped[2 * pass + 1] - tripped[2 * pass]).count();
 }
 
 int32_t cpu_baseline_hardware_threads(void) { return (int32_t)std::thread::hardware_concurrency(); }

@@ -398,7 +398,12 @@ __device__ __forceinline__ ShadeOut shade_vertex(const SceneDev& sc, const PathV
     return o;
 }
 
-__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, SecondaryStream s, const int* size_ptr, int n_value, float* film,
+// `perm` != nullptr: the sort did not move the rays, it only computed where each would go (perm[sorted position] = stream
+// index); thread i then shades ray perm[i] of `p` and writes the ray that goes on to slot i of `q` (all 15 words a ray
+// carries) -- the sorted stream exists only as the shader's output.  One full read + write of the 18-word stream per bounce
+// less than sorting physically first (copy_primary_ray, mapping_gpu.impala:136-164) and shading in place.  `perm` ==
+// nullptr: in place, q == p.
+__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, PrimaryStream q, const int* __restrict__ perm, SecondaryStream s, const int* size_ptr, int n_value, float* film,
                                                    float inv_spp, int max_path_len, int unsorted) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int n_valid = stream_size(size_ptr, n_value);
@@ -406,17 +411,18 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, 
     // Every lane of the wave reaches the ONE film_add_wave call below (it reduces across lanes with shuffles, which must
     // not read lanes that took another path): lanes beyond the stream and rays that missed take part with nothing to add.
     const bool in_range = i < n_valid;
-    const bool live = in_range && !(unsorted && p.geom_id[i] >= sc.num_materials);
-    if (in_range && !live) { p.rays.id[i] = -1; s.rays.id[i] = -1; }                       // unsorted stream: a ray that missed ends here
+    const int src = (perm && in_range) ? perm[i] : i;
+    const bool live = in_range && !(unsorted && p.geom_id[src] >= sc.num_materials);
+    if (in_range && !live) { q.rays.id[i] = -1; s.rays.id[i] = -1; }                       // unsorted stream: a ray that missed ends here
     PathVertex pv; pv.pixel = -1; pv.depth = 0;
     ShadeOut o; o.emits = false; o.shadow = false; o.bounce = false; o.emitted = V(0, 0, 0);
     if (live) {
-        pv.pixel = p.rays.id[i];
-        pv.org = V(p.rays.org_x[i], p.rays.org_y[i], p.rays.org_z[i]); pv.dir = V(p.rays.dir_x[i], p.rays.dir_y[i], p.rays.dir_z[i]);
-        pv.prim = p.prim_id[i]; pv.geom = p.geom_id[i]; pv.t = p.t[i]; pv.u = p.u[i]; pv.v = p.v[i];
-        pv.rnd = p.rnd[i]; pv.mis = p.mis[i];
-        pv.contrib = V(p.contrib_r[i], p.contrib_g[i], p.contrib_b[i]);
-        pv.depth = p.depth[i];
+        pv.pixel = p.rays.id[src];
+        pv.org = V(p.rays.org_x[src], p.rays.org_y[src], p.rays.org_z[src]); pv.dir = V(p.rays.dir_x[src], p.rays.dir_y[src], p.rays.dir_z[src]);
+        pv.prim = p.prim_id[src]; pv.geom = p.geom_id[src]; pv.t = p.t[src]; pv.u = p.u[src]; pv.v = p.v[src];
+        pv.rnd = p.rnd[src]; pv.mis = p.mis[src];
+        pv.contrib = V(p.contrib_r[src], p.contrib_g[src], p.contrib_b[src]);
+        pv.depth = p.depth[src];
         o = shade_vertex(sc, pv, max_path_len);
     }
     film_add_wave(film, pv.pixel, live && o.emits, o.emitted.x * inv_spp, o.emitted.y * inv_spp, o.emitted.z * inv_spp);
@@ -431,12 +437,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, 
     }
     s.rays.id[i] = o.shadow ? pv.pixel : -1;
 
-    if (!o.bounce) { p.rays.id[i] = -1; return; }
-    p.rays.org_x[i] = o.b_org.x; p.rays.org_y[i] = o.b_org.y; p.rays.org_z[i] = o.b_org.z;
-    p.rays.dir_x[i] = o.b_dir.x; p.rays.dir_y[i] = o.b_dir.y; p.rays.dir_z[i] = o.b_dir.z;
-    p.rays.tmin[i] = kRayOffset; p.rays.tmax[i] = FLT_MAX_REF;
-    p.rnd[i] = o.rnd; p.mis[i] = o.mis;
-    p.contrib_r[i] = o.contrib.x; p.contrib_g[i] = o.contrib.y; p.contrib_b[i] = o.contrib.z; p.depth[i] = pv.depth + 1;
+    if (!o.bounce) { q.rays.id[i] = -1; return; }
+    if (perm) q.rays.id[i] = pv.pixel;                                                     // (in place the id is there already)
+    q.rays.org_x[i] = o.b_org.x; q.rays.org_y[i] = o.b_org.y; q.rays.org_z[i] = o.b_org.z;
+    q.rays.dir_x[i] = o.b_dir.x; q.rays.dir_y[i] = o.b_dir.y; q.rays.dir_z[i] = o.b_dir.z;
+    q.rays.tmin[i] = kRayOffset; q.rays.tmax[i] = FLT_MAX_REF;
+    q.rnd[i] = o.rnd; q.mis[i] = o.mis;
+    q.contrib_r[i] = o.contrib.x; q.contrib_g[i] = o.contrib.y; q.contrib_b[i] = o.contrib.z; q.depth[i] = pv.depth + 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -553,20 +560,50 @@ __global__ __launch_bounds__(kBlock) void k_bin_count(PrimaryStream p, const int
         hist[(size_t)k * num_blocks + blockIdx.x] = cnt[k] + cnt[num_bins + k] + cnt[2 * num_bins + k] + cnt[3 * num_bins + k];
 }
 
-// one workgroup per bin: exclusive scan of that bin's per-block counts (in place), total -> bin_total[bin]
+// one workgroup per bin: exclusive scan of that bin's per-block counts (in place), total -> bin_total[bin].
+// Tiles of kBlock x kScanItems consecutive counts (16 per thread as four 16-byte loads), in-wave scan of the thread sums
+// by lane shifts, waves joined through LDS, a running carry across tiles: 8 Mi rays = 32 768 counts per bin = 8 tiles.
+// (The first version gave each thread one contiguous run of counts and scanned the 256 run sums serially on thread 0,
+// the second scanned 256 counts per tile: with one workgroup per bin -- ten on the Cornell box -- both were a chain of
+// 128+ dependent steps, 11 % of the frame.)
+constexpr int kScanItems = 16;
 __global__ __launch_bounds__(kBlock) void k_bin_scan_blocks(int* hist, int num_blocks, int* bin_total) {
-    __shared__ int part[kBlock];
+    __shared__ int wave_sum[kBlock / kWave];
     int* row = hist + (size_t)blockIdx.x * num_blocks;
-    const int per = (num_blocks + kBlock - 1) / kBlock;
-    const int b0 = threadIdx.x * per, b1 = min(num_blocks, b0 + per);
-    int sum = 0;
-    for (int b = b0; b < b1; b++) sum += row[b];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) { int acc = 0; for (int k = 0; k < kBlock; k++) { const int v = part[k]; part[k] = acc; acc += v; } bin_total[blockIdx.x] = acc; }
-    __syncthreads();
-    int acc = part[threadIdx.x];
-    for (int b = b0; b < b1; b++) { const int v = row[b]; row[b] = acc; acc += v; }
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    const bool aligned = (((size_t)row) & 15) == 0;
+    int carry = 0;
+    for (int tile = 0; tile < num_blocks; tile += kBlock * kScanItems) {
+        const int b0 = tile + (int)threadIdx.x * kScanItems;
+        int v[kScanItems];
+        if (aligned && b0 + kScanItems <= num_blocks) {
+#pragma unroll
+            for (int k = 0; k < kScanItems / 4; k++) { const int4 x = *reinterpret_cast<const int4*>(row + b0 + 4 * k); v[4 * k] = x.x; v[4 * k + 1] = x.y; v[4 * k + 2] = x.z; v[4 * k + 3] = x.w; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kScanItems; k++) v[k] = b0 + k < num_blocks ? row[b0 + k] : 0;
+        }
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < kScanItems; k++) { const int x = v[k]; v[k] = sum; sum += x; }         // exclusive within the thread
+        int incl = sum;
+        for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        if (lane == kWave - 1) wave_sum[wave] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < kBlock / kWave; w++) { const int ws = wave_sum[w]; if (w < wave) before += ws; total += ws; }
+        const int base = carry + before + incl - sum;
+        if (aligned && b0 + kScanItems <= num_blocks) {
+#pragma unroll
+            for (int k = 0; k < kScanItems / 4; k++) *reinterpret_cast<int4*>(row + b0 + 4 * k) = make_int4(base + v[4 * k], base + v[4 * k + 1], base + v[4 * k + 2], base + v[4 * k + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kScanItems; k++) if (b0 + k < num_blocks) row[b0 + k] = base + v[k];
+        }
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
 }
 
 // single workgroup: exclusive scan over bins; bin_begin[k], bin_end[k] (= ray_ends of mapping_gpu.impala:203-207)
@@ -576,7 +613,7 @@ __global__ void k_bin_scan_bins(const int* bin_total, int num_bins, int* bin_beg
 
 // copy_primary_ray (mapping_gpu.impala:136-164) to the computed slot
 __global__ __launch_bounds__(kBlock) void k_scatter(PrimaryStream p, PrimaryStream q, const int* size_ptr, int n_value, int mode, int num_bins, int num_blocks,
-                                                     const int* hist, const int* bin_begin, int keep_hit, int drop_from_bin) {
+                                                     const int* hist, const int* bin_begin, int keep_hit, int drop_from_bin, int copy_interval, int* __restrict__ perm) {
     extern __shared__ int cnt[];
     const int n = stream_size(size_ptr, n_value);
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -585,10 +622,13 @@ __global__ __launch_bounds__(kBlock) void k_scatter(PrimaryStream p, PrimaryStre
     const int rank = block_rank(key, valid, num_bins, cnt);
     if (!valid || key >= drop_from_bin) return;
     const int d = bin_begin[key] + hist[(size_t)key * num_blocks + blockIdx.x] + rank;
+    if (perm) { perm[d] = i; return; }                          // index-only sort: the consumer gathers (k_shade)
     q.rays.id[d] = p.rays.id[i];
     q.rays.org_x[d] = p.rays.org_x[i]; q.rays.org_y[d] = p.rays.org_y[i]; q.rays.org_z[d] = p.rays.org_z[i];
     q.rays.dir_x[d] = p.rays.dir_x[i]; q.rays.dir_y[d] = p.rays.dir_y[i]; q.rays.dir_z[d] = p.rays.dir_z[i];
-    q.rays.tmin[d] = p.rays.tmin[i]; q.rays.tmax[d] = p.rays.tmax[i];
+    // the ray interval is dead between the traversal and the shader (which writes a new one for every ray that goes on):
+    // the sort before shading (copy_interval == 0) leaves the two words behind -- 10 % of its traffic
+    if (copy_interval) { q.rays.tmin[d] = p.rays.tmin[i]; q.rays.tmax[d] = p.rays.tmax[i]; }
     if (keep_hit) { q.geom_id[d] = p.geom_id[i]; q.prim_id[d] = p.prim_id[i]; q.t[d] = p.t[i]; q.u[d] = p.u[i]; q.v[d] = p.v[i]; }
     q.rnd[d] = p.rnd[i]; q.mis[d] = p.mis[i];
     q.contrib_r[d] = p.contrib_r[i]; q.contrib_g[d] = p.contrib_g[i]; q.contrib_b[d] = p.contrib_b[i]; q.depth[d] = p.depth[i];
@@ -611,6 +651,8 @@ struct RenderDevice {
     int spp = 4, max_path_len = 64;
     int capacity = 0;                          // rays per stream; 0 = default (env_capacity())
     int sort = 1;                              // 1 = sort hit rays by material before shading (mapping_gpu.impala:166-221), 0 = shade in stream order
+    int fused_sort = 1;                        // 1 = the sort only computes the permutation and the shader gathers through it; 0 = rays are moved, then shaded in place
+    int* perm = nullptr; int perm_cap = 0;     // sorted position -> stream index
     int mapping = 0;                           // 0 = streaming wavefront (mapping_gpu.impala:308-369), 1 = megakernel (:371-474)
     float* film = nullptr; int film_w = 0, film_h = 0;
     float* slab[3] = {nullptr, nullptr, nullptr}; int slab_cap[3] = {0, 0, 0};       // first primary, second primary, secondary
@@ -646,6 +688,7 @@ RenderDevice& rdev(int dev) {
         HIP_CHECK(hipHostMalloc(&r.host_pinned, sizeof(int) * (8 + kMaxBins)));
         if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
         if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
+        if (const char* e = getenv("RODENT_HIP_FUSED_SORT")) r.fused_sort = atoi(e) ? 1 : 0;
         if (const char* m = getenv("RODENT_HIP_MAPPING")) {
             if (!strcmp(m, "mega") || !strcmp(m, "megakernel") || !strcmp(m, "1")) r.mapping = 1;
             else if (strcmp(m, "streaming") && strcmp(m, "0")) { fprintf(stderr, "rodent_hip: RODENT_HIP_MAPPING must be 'streaming' or 'mega'\n"); abort(); }
@@ -723,14 +766,14 @@ int* bin_end(RenderDevice& r, int set)   { return r.ctl + 8 + set * 3 * kMaxBins
 
 // Bins `p` (size = *size_ptr if given, else max_n; never more than max_n) into `q`; bins >= drop_from_bin are not copied.
 void bin_stream(RenderDevice& r, int set, const PrimaryStream& p, const PrimaryStream& q, const int* size_ptr, int max_n, int mode, int num_bins,
-                int keep_hit, int drop_from_bin, hipStream_t stream) {
+                int keep_hit, int drop_from_bin, hipStream_t stream, int copy_interval = 1, int* perm = nullptr) {
     const int blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
     ensure_hist(r, (size_t)num_bins * blocks);
     const size_t lds = sizeof(int) * 4 * num_bins;
     hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kBlock), lds, stream, p, size_ptr, max_n, mode, num_bins, blocks, r.hist);
     hipLaunchKernelGGL(k_bin_scan_blocks, dim3(num_bins), dim3(kBlock), 0, stream, r.hist, blocks, bin_total(r, set));
     hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1), 0, stream, bin_total(r, set), num_bins, bin_begin(r, set), bin_end(r, set));
-    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBlock), lds, stream, p, q, size_ptr, max_n, mode, num_bins, blocks, r.hist, bin_begin(r, set), keep_hit, drop_from_bin);
+    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBlock), lds, stream, p, q, size_ptr, max_n, mode, num_bins, blocks, r.hist, bin_begin(r, set), keep_hit, drop_from_bin, copy_interval, perm);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -792,6 +835,12 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
         HIP_CHECK(hipEventCreateWithFlags(&r.ev_copy, hipEventDisableTiming));
     }
     ensure_deep(r, 0, kCapacity); ensure_deep(r, 1, kCapacity);       // before the loop: growing them synchronises the device
+    if (r.perm_cap < round_cap(kCapacity)) {
+        HIP_CHECK(hipDeviceSynchronize());
+        if (r.perm) HIP_CHECK(hipFree(r.perm));
+        HIP_CHECK(hipMalloc(&r.perm, sizeof(int) * (size_t)round_cap(kCapacity)));
+        r.perm_cap = round_cap(kCapacity);
+    }
     hipStream_t sstream = overlap ? r.aux : stream;
     while (id < num_rays || size > 0) {
         if (size < kCapacity && id < num_rays) {                                         // regenerate (mapping_gpu.impala:332-336)
@@ -804,10 +853,19 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
         launch_trace_primary(r, stream, *primary, size);
         if (r.sort) {
             if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_copy, 0));      // the aux stream has its copy of the previous valid count
-            bin_stream(r, 0, *primary, *other, nullptr, size, KEY_GEOM, G + 1, 1, G, stream);    // misses (bin G) are dropped (:347-357)
-            std::swap(primary, other);
-            if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));       // the previous shadow rays have been traced
-            hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, d_valid, 0, r.film, inv_spp, r.max_path_len, 0);
+            if (r.fused_sort) {
+                // sort by geometry WITHOUT moving the rays: the binning kernels only compute the permutation, the shader gathers
+                // through it and writes the sorted, shaded stream (misses, bin G, are not in the permutation: dropped, :347-357)
+                bin_stream(r, 0, *primary, *other, nullptr, size, KEY_GEOM, G + 1, 1, G, stream, 0, r.perm);
+                if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));   // the previous shadow rays have been traced
+                hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, *other, (const int*)r.perm, sec, d_valid, 0, r.film, inv_spp, r.max_path_len, 0);
+                std::swap(primary, other);
+            } else {
+                bin_stream(r, 0, *primary, *other, nullptr, size, KEY_GEOM, G + 1, 1, G, stream, 0);    // misses (bin G) are dropped (:347-357); tmin / tmax stay behind
+                std::swap(primary, other);
+                if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));       // the previous shadow rays have been traced
+                hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, *primary, (const int*)nullptr, sec, d_valid, 0, r.film, inv_spp, r.max_path_len, 0);
+            }
             if (overlap) {
                 HIP_CHECK(hipEventRecord(r.ev_shade, stream));
                 HIP_CHECK(hipStreamWaitEvent(r.aux, r.ev_shade, 0));
@@ -819,7 +877,7 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
             bin_stream(r, 1, *primary, *other, d_valid, size, KEY_ALIVE, 2, 0, 1, stream);       // compaction (:267-300)
         } else {                                     // option: no sort by material -- shade in stream order, misses end in the shader
             if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));
-            hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, sec, (const int*)nullptr, size, r.film, inv_spp, r.max_path_len, 1);
+            hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, *primary, (const int*)nullptr, sec, (const int*)nullptr, size, r.film, inv_spp, r.max_path_len, 1);
             if (overlap) {
                 HIP_CHECK(hipEventRecord(r.ev_shade, stream));
                 HIP_CHECK(hipStreamWaitEvent(r.aux, r.ev_shade, 0));
@@ -949,6 +1007,7 @@ void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
 
 void rodent_hip_render_sort(int32_t dev, int32_t enable) { rdev(dev).sort = enable ? 1 : 0; }
 void rodent_hip_render_overlap(int32_t dev, int32_t enable) { rdev(dev).overlap = enable ? 1 : 0; }
+void rodent_hip_render_fused_sort(int32_t dev, int32_t enable) { rdev(dev).fused_sort = enable ? 1 : 0; }
 
 void rodent_hip_render_capacity(int32_t dev, int32_t rays) {
     if (rays != 0 && (rays < 64 || rays > kMaxCapacity)) { fprintf(stderr, "rodent_hip: stream capacity must be 0 (default) or 64 .. %ld rays\n", kMaxCapacity); abort(); }
@@ -1063,7 +1122,7 @@ void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, 
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); ensure_film(r); require_scene(r);
     primary->size = num_rays; secondary->size = num_rays;
     if (num_rays <= 0) return;
-    hipLaunchKernelGGL(k_shade, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, r.scene.dev, *primary, *secondary, (const int*)nullptr, num_rays, r.film,
+    hipLaunchKernelGGL(k_shade, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, r.scene.dev, *primary, *primary, (const int*)nullptr, *secondary, (const int*)nullptr, num_rays, r.film,
                        1.0f / (float)r.spp, r.max_path_len, 0);
     HIP_CHECK(hipGetLastError());
 }
