@@ -47,7 +47,7 @@ org, end = rays["org"], rays["org"] + rays["dir"]
 octant = ((rays["dir"][:, 0] < 0).astype(np.uint64) | ((rays["dir"][:, 1] < 0).astype(np.uint64) << 1) | ((rays["dir"][:, 2] < 0).astype(np.uint64) << 2))
 print(f"{'order':44s} {'ms':>8s} {'Mrays/s':>9s}")
 print(f"{'file order':44s} {timed(rays):8.4f}")
-for bits in (3, 4, 5, 6, 8, 10):
+for bits in (4,):
     keys = {f"morton(origin) {bits} bits/axis": morton(org, bits),
             f"morton(origin) {bits} b + morton(end) {min(bits, 4)} b": (morton(org, bits) << np.uint64(3 * min(bits, 4))) | morton(end, min(bits, 4)),
             f"morton(origin) {bits} b + octant": (morton(org, bits) << np.uint64(3)) | octant,
@@ -56,3 +56,11 @@ for bits in (3, 4, 5, 6, 8, 10):
         order = np.argsort(k, kind="stable")
         ms = timed(np.ascontiguousarray(rays[order]))
         print(f"{name:44s} {ms:8.4f} {len(rays) / ms / 1e3:9.1f}", flush=True)
+
+# windowed sort: what a block-local sort in LDS (no global passes) would give
+print("windowed sort by morton(origin) 10 bits + octant")
+key = (morton(org, 10) << np.uint64(3)) | octant
+for W in (1024, 4096, 16384, 65536, 262144):
+    order = np.concatenate([s + np.argsort(key[s:s + W], kind="stable") for s in range(0, len(rays), W)])
+    ms = timed(np.ascontiguousarray(rays[order]))
+    print(f"window {W:7d} rays: {ms:8.4f} ms {len(rays) / ms / 1e3:9.1f} Mrays/s", flush=True)
