@@ -118,6 +118,17 @@ def build_hip_tools(force: bool = False) -> list[Path]:
     return outs
 
 
+def build_ubench(force: bool = False):
+    """Lab microbenchmarks (scripts/ubench/*.hip -> rodent_amd/bin/): only with RODENT_HIP_LAB=1."""
+    if os.environ.get("RODENT_HIP_LAB", "0") in ("", "0"):
+        return
+    BIN_DIR.mkdir(parents=True, exist_ok=True)
+    for src in sorted((ROOT / "scripts" / "ubench").glob("*.hip")):
+        out = BIN_DIR / src.stem
+        if force or _newer(out, src):
+            _run([HIPCC, "--offload-arch=gfx950", "-O3", src, "-o", out])
+
+
 def build_oracle(force: bool = False) -> Path:
     out = ORACLE / "liboracle.so"
     srcs = sorted(ORACLE.glob("*.c"))
@@ -142,6 +153,7 @@ def build_all(force: bool = False):
     build_host(force)
     build_hip_lib(force)
     build_hip_tools(force)
+    build_ubench(force)
     build_oracle(force)
     build_reference_tools(force)
 
