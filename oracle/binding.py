@@ -188,8 +188,11 @@ def baseline_lib():
     if _base is None:
         out = HERE / "libcpu_baseline.so"
         src = HERE / "hybrid_baseline.cpp"
-        if not out.exists() or src.stat().st_mtime > out.stat().st_mtime:
-            subprocess.run(["g++", "-O3", "-std=c++17", "-march=x86-64-v3", "-fPIC", "-shared", "-pthread", str(src), "-o", str(out)], check=True)
+        lib()                                                    # liboracle.so first: the baseline library links it (shading of the CPU wavefront renderer)
+        deps = [src, HERE / "cpu_wavefront.inc", LIB_PATH]
+        if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
+            subprocess.run(["g++", "-O3", "-std=c++17", "-march=x86-64-v3", "-fPIC", "-shared", "-pthread", str(src), f"-L{HERE}", "-l:liboracle.so", "-Wl,-rpath,$ORIGIN",
+                            "-o", str(out)], check=True)
         _base = C.CDLL(str(out))
         _base.cpu_baseline_traverse.restype = None
         _base.cpu_baseline_traverse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
@@ -217,6 +220,25 @@ def cpu_baseline_bench(nodes8, tris4, rays, threads, passes, any_hit=False, mode
     l.cpu_baseline_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     l.cpu_baseline_bench(_ptr(nodes8), _ptr(tris4), _ptr(rays), _ptr(hits), n, int(any_hit), 0 if mode == "hybrid" else 1, int(threads), int(passes), _ptr(secs))
     return secs, hits
+
+
+def render_wavefront(scene, nodes8, tris4, cam, iter_, spp, max_path_len, width, height, film=None, threads=8):
+    """CPU BASELINE for frames: the reference's tile-parallel wavefront mapping (mapping_cpu.impala:352-473) over the hybrid
+    ray8 x BVH8 traversal (oracle/cpu_wavefront.inc).  Returns (film, [primary rays, shadow rays])."""
+    l = baseline_lib()
+    l.cpu_wavefront_render.restype = None
+    l.cpu_wavefront_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(_Settings), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_int32, C.c_void_p]
+    if film is None:
+        film = np.zeros((height, width, 3), "<f4")
+    s, keep = _scene_struct(scene)
+    nodes8 = np.ascontiguousarray(nodes8); tris4 = np.ascontiguousarray(tris4)
+    indices = np.ascontiguousarray(scene.indices)
+    st = _Settings((C.c_float * 3)(*cam["eye"]), (C.c_float * 3)(*cam["dir"]), (C.c_float * 3)(*cam["up"]), (C.c_float * 3)(*cam["right"]), float(cam["w"]), float(cam["h"]))
+    counts = np.zeros(2, np.uint64)
+    l.cpu_wavefront_render(C.byref(s), _ptr(indices), len(scene.materials), _ptr(nodes8), _ptr(tris4), C.byref(st), iter_, spp, max_path_len, width, height,
+                           _ptr(film), int(threads), _ptr(counts))
+    return film, counts
 
 
 def hardware_threads():

@@ -1,12 +1,13 @@
 #!/usr/bin/env python
-"""CPU frame rate of the oracle path tracer, printed like `rodent --bench` (driver.cpp:344-347).
+"""CPU frame rate of the reference's CPU mapping, printed like `rodent --bench` (driver.cpp:344-347).
 
-TEST INFRASTRUCTURE: a CPU Msamples/s figure to quote beside the GPU renderer's.  The oracle
-traces one path at a time (oracle/render_oracle.c, the reference's renderer.impala semantics over the BVH2
-single-ray kernel), image rows split over host threads like the reference's CPU tiles
-(render/mapping_cpu.impala:352-473); it is not the reference's vectorised CPU renderer.
+TEST INFRASTRUCTURE: a CPU Msamples/s figure to quote beside the GPU renderer's.
+  --mapping wavefront (default): the reference's tile-parallel wavefront renderer restated (oracle/cpu_wavefront.inc:
+      render/mapping_cpu.impala:352-473 -- 16x16 tiles from an atomic counter, per-thread primary / secondary streams,
+      generate -> hybrid ray8 x BVH8 traversal -> sort by geometry -> shade -> compact -> shadow rays), scalar shading;
+  --mapping scalar: the parity oracle, one path at a time over the BVH2 single-ray kernel, rows split over threads.
 usage: python oracle/cpu_render_bench.py [--scene file.obj|file.rscene] [--width 1920 --height 1080 --spp 64
-       --max-path-len 4 --bench 2 --threads N]"""
+       --max-path-len 4 --bench 2 --threads N --mapping wavefront|scalar]"""
 import argparse
 import os
 import sys
@@ -35,19 +36,32 @@ def main(argv=None):
     ap.add_argument("--dir", type=float, nargs=3, default=[0, 0, -1])
     ap.add_argument("--up", type=float, nargs=3, default=[0, 1, 0])
     ap.add_argument("--fov", type=float, default=60.0)
+    ap.add_argument("--mapping", choices=("wavefront", "scalar"), default="wavefront")
     a = ap.parse_args(argv)
     path = Path(a.scene)
     scene = S.Scene(path) if path.suffix == ".rscene" else S.convert(path, Path("/tmp") / (path.stem + ".cpu_bench.rscene"))
     cam = S.camera_settings(a.eye, a.dir, a.up, a.fov, a.width, a.height)
+    if a.mapping == "wavefront":
+        # the reference's CPU targets trace a BVH8 / Tri4 (converter.cpp:152-259): built from the scene's own triangles
+        import subprocess
+        from rodent_amd import build, formats as F
+        if path.suffix == ".rscene":
+            raise SystemExit("--mapping wavefront needs the .obj (it builds the BVH8 the reference's CPU mapping traces)")
+        bvh = Path("/tmp") / (path.stem + ".cpu_bench.bvh")
+        subprocess.run([str(build.BIN_DIR / "bvh_extractor"), "-obj", str(path), "-o", str(bvh)], check=True, stdout=subprocess.DEVNULL)
+        n8, t8 = F.read_bvh(bvh, F.BVH8_TRI4)
     film, rates, rays = None, [], 0
     for it in range(a.bench):
         t0 = time.perf_counter()
-        film, counts = O.render(scene, cam, it, a.spp, a.max_path_len, a.width, a.height, film, threads=a.threads)
+        if a.mapping == "wavefront":
+            film, counts = O.render_wavefront(scene, n8, t8, cam, it, a.spp, a.max_path_len, a.width, a.height, film, threads=a.threads)
+        else:
+            film, counts = O.render(scene, cam, it, a.spp, a.max_path_len, a.width, a.height, film, threads=a.threads)
         dt = time.perf_counter() - t0
         rates.append(a.spp * a.width * a.height / dt / 1e6)
         rays += int(counts.sum())
     rates.sort()
-    print(f"# {rates[0]:g}/{rates[len(rates) // 2]:g}/{rates[-1]:g} (min/med/max Msamples/s)  [{a.threads} threads, {rays} rays]")
+    print(f"# {rates[0]:g}/{rates[len(rates) // 2]:g}/{rates[-1]:g} (min/med/max Msamples/s)  [{a.mapping} mapping, {a.threads} threads, {rays} rays]")
     assert np.isfinite(film).all()
     return 0
 

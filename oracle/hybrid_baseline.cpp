@@ -280,3 +280,5 @@ void cpu_baseline_bench(const Node8* nodes, const Tri4* tris, const Ray1* rays, 
 int32_t cpu_baseline_hardware_threads(void) { return (int32_t)std::thread::hardware_concurrency(); }
 
 } // extern "C"
+
+#include "cpu_wavefront.inc"        // the reference's CPU wavefront renderer on top of hybrid_packet (frame baseline)

@@ -289,77 +289,109 @@ static int trace(const struct Scene* sc, v3 org, v3 dir, float tmin, float tmax,
     return h->tri_id >= 0;
 }
 
-/* Renders rows [y0, y1) of one iteration into film (w*h*3 floats, accumulated), spp samples per pixel.
- * renderer.impala:62-162 + mapping_gpu.impala:82-134 (order: on_hit, on_shadow, on_bounce). */
+/* One path vertex (what a primary-stream entry holds, driver.impala:63-104) and what shading it produces: an emission
+ * sample, at most one shadow ray, at most one continuation.  Order: on_hit, on_shadow, on_bounce (renderer.impala:62-162,
+ * mapping_gpu.impala:82-134).  Used by oracle_render below and by the CPU wavefront restatement (cpu_wavefront.cpp). */
+struct OracleVertex { float org[3], dir[3]; int32_t prim; float t, u, v; uint32_t rnd; float mis; float contrib[3]; int32_t depth; };
+struct OracleShade  { int32_t emits; float emitted[3]; int32_t shadow; float s_org[3], s_dir[3], s_color[3];
+                      int32_t bounce; float b_org[3], b_dir[3], contrib[3]; uint32_t rnd; float mis; };
+#define ST3(dst, val) do { const v3 tmp_ = (val); (dst)[0] = tmp_.x; (dst)[1] = tmp_.y; (dst)[2] = tmp_.z; } while (0)
+
+void oracle_shade_vertex(const struct Scene* sc, const struct OracleVertex* pv, int32_t max_path_len, struct OracleShade* o) {
+    const float pdf_lightpick = 1.0f / (float)sc->num_lights;
+    uint32_t rnd = pv->rnd;
+    const v3 org = LD3(pv->org), dir = LD3(pv->dir), contrib = LD3(pv->contrib);
+    const int32_t prim = pv->prim;
+    struct Material textured;
+    const struct Material* m = resolve_material(sc, sc->materials + sc->indices[4 * prim + 3], &textured, prim, pv->u, pv->v);
+    const Surf s = surface_element(sc, org, dir, prim, pv->t, pv->u, pv->v);
+    const v3 out_dir = neg(dir);
+    o->emits = 0; o->shadow = 0; o->bounce = 0;
+    /* on_hit (renderer.impala:113-128) */
+    if (m->emissive && s.entering) {
+        const struct Light* L = sc->lights + sc->light_ids[prim];
+        const float pdf_dir = cosine_hemisphere_pdf(dot(LD3(L->n), out_dir));
+        const v3 intensity = pdf_dir > 0.0f ? LD3(L->color) : V(0, 0, 0);      /* make_emission_value, light.impala:87-102 */
+        const float pdf_area = pdf_dir > 0.0f ? L->inv_area : 1.0f;
+        const float next_mis = pv->mis * pv->t * pv->t / dot(out_dir, s.local.c2);
+        const float w = 1.0f / (1.0f + next_mis * pdf_lightpick * pdf_area);
+        o->emits = 1; ST3(o->emitted, mulf(mul(contrib, intensity), w));
+    }
+    /* on_shadow (renderer.impala:69-111) */
+    if (!bsdf_is_specular(m)) {
+        const int32_t light_id = (int32_t)(xorshift(&rnd) & 0x7FFFFFFFu) % sc->num_lights;
+        const struct Light* L = sc->lights + light_id;
+        const float lu = randf(&rnd), lv = randf(&rnd);
+        const v3 pos = sample_triangle(lu, lv, LD3(L->v0), LD3(L->v1), LD3(L->v2));
+        const v3 from_dir = sub(s.point, pos);
+        float lcos = dot(from_dir, LD3(L->n)) / len(from_dir);                    /* light.impala:124-128 */
+        v3 intensity = LD3(L->color); float pdf_area = L->inv_area;
+        if (!(pdf_area > 0.0f && cosine_hemisphere_pdf(lcos) > 0.0f && lcos > 0.0f)) { intensity = V(0, 0, 0); pdf_area = 1.0f; lcos = 0.0f; }
+        const v3 light_dir = sub(pos, s.point);
+        const float vis = dot(light_dir, s.local.c2);
+        if (vis > 0.0f && lcos > 0.0f) {
+            const float inv_d = 1.0f / len(light_dir), inv_d2 = inv_d * inv_d;
+            const v3 in_dir = mulf(light_dir, inv_d);
+            const float pdf_e = bsdf_pdf(m, &s, in_dir, out_dir);
+            const float pdf_l = pdf_area * pdf_lightpick, inv_pdf_l = 1.0f / pdf_l;
+            const float cos_e = vis * inv_d, cos_l = lcos;
+            const float w = 1.0f / (1.0f + pdf_e * cos_l * inv_d2 * inv_pdf_l);
+            const float geom = cos_e * cos_l * inv_d2 * inv_pdf_l;
+            o->shadow = 1;
+            ST3(o->s_color, mulf(mul(intensity, mul(contrib, bsdf_eval(m, &s, in_dir, out_dir))), geom * w));
+            ST3(o->s_org, s.point); ST3(o->s_dir, light_dir);
+        }
+    }
+    /* on_bounce (renderer.impala:130-152) */
+    const float lum2 = 2.0f * luminance(contrib); const float rr = lum2 > 0.75f ? 0.75f : lum2;
+    if (pv->depth >= max_path_len || randf(&rnd) >= rr) return;
+    const BsdfSample bs = bsdf_sample(m, &s, &rnd, out_dir);
+    const v3 c2 = mul(contrib, bs.color);
+    o->bounce = 1;
+    o->mis = bsdf_is_specular(m) ? 0.0f : 1.0f / bs.pdf;
+    ST3(o->contrib, mulf(c2, bs.cos / (bs.pdf * rr)));
+    ST3(o->b_org, s.point); ST3(o->b_dir, bs.in_dir); o->rnd = rnd;
+}
+
+/* on_emit (renderer.impala:26-40, camera.impala:35-44): the sample's seed state and camera ray direction */
+void oracle_emit_sample(const struct Settings* st, int32_t iter, int32_t width, int32_t height, int32_t x, int32_t y, int32_t sample, uint32_t* rnd_out, float* dir3) {
+    const v3 cdir = LD3(st->dir), cup = LD3(st->up), cright = LD3(st->right);
+    uint32_t rnd = fnv_hash(fnv_hash(fnv_hash(fnv_hash(0x811C9DC5u, (uint32_t)sample), (uint32_t)iter), (uint32_t)x), (uint32_t)y);
+    const float kx = 2.0f * ((float)x + randf(&rnd)) / (float)width - 1.0f;
+    const float ky = 1.0f - 2.0f * ((float)y + randf(&rnd)) / (float)height;
+    ST3(dir3, normalize(add(add(mulf(cright, st->w * kx), mulf(cup, st->h * ky)), cdir)));
+    *rnd_out = rnd;
+}
+
+/* Renders rows [y0, y1) of one iteration into film (w*h*3 floats, accumulated), spp samples per pixel, one path at a time. */
 void oracle_render(const struct Scene* sc, const struct Settings* st, int32_t iter, int32_t spp, int32_t max_path_len,
                    int32_t width, int32_t height, int32_t y0, int32_t y1, float* film, uint64_t* ray_counts) {
     const float offset = 0.001f;
-    const float pdf_lightpick = 1.0f / (float)sc->num_lights;
-    const v3 eye = LD3(st->eye), cdir = LD3(st->dir), cup = LD3(st->up), cright = LD3(st->right);
     uint64_t n_primary = 0, n_shadow = 0;
     for (int32_t y = y0; y < y1; y++) for (int32_t x = 0; x < width; x++) for (int32_t sample = 0; sample < spp; sample++) {
-        /* renderer.impala:26-40, camera.impala:35-44 */
-        uint32_t rnd = fnv_hash(fnv_hash(fnv_hash(fnv_hash(0x811C9DC5u, (uint32_t)sample), (uint32_t)iter), (uint32_t)x), (uint32_t)y);
-        const float kx = 2.0f * ((float)x + randf(&rnd)) / (float)width - 1.0f;
-        const float ky = 1.0f - 2.0f * ((float)y + randf(&rnd)) / (float)height;
-        v3 org = eye, dir = normalize(add(add(mulf(cright, st->w * kx), mulf(cup, st->h * ky)), cdir));
-        float tmin = 0.0f, tmax = FLT_MAX_REF, mis = 0.0f; v3 contrib = V(1, 1, 1); int32_t depth = 0;
+        struct OracleVertex pv;
+        oracle_emit_sample(st, iter, width, height, x, y, sample, &pv.rnd, pv.dir);
+        pv.org[0] = st->eye[0]; pv.org[1] = st->eye[1]; pv.org[2] = st->eye[2];
+        float tmin = 0.0f, tmax = FLT_MAX_REF;
+        pv.mis = 0.0f; pv.contrib[0] = pv.contrib[1] = pv.contrib[2] = 1.0f; pv.depth = 0;
         float* px = film + 3 * ((size_t)y * width + x);
         const float inv_spp = 1.0f / (float)spp;
         for (;;) {
             struct Hit1 h; n_primary++;
-            if (!trace(sc, org, dir, tmin, tmax, 0, &h)) break;                          /* miss: dropped (mapping_gpu.impala:347-357) */
-            const int32_t prim = h.tri_id;
-            struct Material textured;
-            const struct Material* m = resolve_material(sc, sc->materials + sc->indices[4 * prim + 3], &textured, prim, h.u, h.v);
-            const Surf s = surface_element(sc, org, dir, prim, h.t, h.u, h.v);
-            const v3 out_dir = neg(dir);
-            /* on_hit (renderer.impala:113-128) */
-            if (m->emissive && s.entering) {
-                const struct Light* L = sc->lights + sc->light_ids[prim];
-                const float pdf_dir = cosine_hemisphere_pdf(dot(LD3(L->n), out_dir));
-                const v3 intensity = pdf_dir > 0.0f ? LD3(L->color) : V(0, 0, 0);      /* make_emission_value, light.impala:87-102 */
-                const float pdf_area = pdf_dir > 0.0f ? L->inv_area : 1.0f;
-                const float next_mis = mis * h.t * h.t / dot(out_dir, s.local.c2);
-                const float w = 1.0f / (1.0f + next_mis * pdf_lightpick * pdf_area);
-                const v3 c = mulf(mul(contrib, intensity), w);
-                px[0] += c.x * inv_spp; px[1] += c.y * inv_spp; px[2] += c.z * inv_spp;
-            }
-            /* on_shadow (renderer.impala:69-111) */
-            if (!bsdf_is_specular(m)) {
-                const int32_t light_id = (int32_t)(xorshift(&rnd) & 0x7FFFFFFFu) % sc->num_lights;
-                const struct Light* L = sc->lights + light_id;
-                const float lu = randf(&rnd), lv = randf(&rnd);
-                const v3 pos = sample_triangle(lu, lv, LD3(L->v0), LD3(L->v1), LD3(L->v2));
-                const v3 from_dir = sub(s.point, pos);
-                float lcos = dot(from_dir, LD3(L->n)) / len(from_dir);                    /* light.impala:124-128 */
-                v3 intensity = LD3(L->color); float pdf_area = L->inv_area;
-                if (!(pdf_area > 0.0f && cosine_hemisphere_pdf(lcos) > 0.0f && lcos > 0.0f)) { intensity = V(0, 0, 0); pdf_area = 1.0f; lcos = 0.0f; }
-                const v3 light_dir = sub(pos, s.point);
-                const float vis = dot(light_dir, s.local.c2);
-                if (vis > 0.0f && lcos > 0.0f) {
-                    const float inv_d = 1.0f / len(light_dir), inv_d2 = inv_d * inv_d;
-                    const v3 in_dir = mulf(light_dir, inv_d);
-                    const float pdf_e = bsdf_pdf(m, &s, in_dir, out_dir);
-                    const float pdf_l = pdf_area * pdf_lightpick, inv_pdf_l = 1.0f / pdf_l;
-                    const float cos_e = vis * inv_d, cos_l = lcos;
-                    const float w = 1.0f / (1.0f + pdf_e * cos_l * inv_d2 * inv_pdf_l);
-                    const float geom = cos_e * cos_l * inv_d2 * inv_pdf_l;
-                    const v3 c = mulf(mul(intensity, mul(contrib, bsdf_eval(m, &s, in_dir, out_dir))), geom * w);
-                    struct Hit1 sh; n_shadow++;
-                    if (!trace(sc, s.point, light_dir, offset, 1.0f - offset, 1, &sh)) {      /* mapping_gpu.impala:47-80 */
-                        px[0] += c.x * inv_spp; px[1] += c.y * inv_spp; px[2] += c.z * inv_spp;
-                    }
+            if (!trace(sc, LD3(pv.org), LD3(pv.dir), tmin, tmax, 0, &h)) break;           /* miss: dropped (mapping_gpu.impala:347-357) */
+            pv.prim = h.tri_id; pv.t = h.t; pv.u = h.u; pv.v = h.v;
+            struct OracleShade o;
+            oracle_shade_vertex(sc, &pv, max_path_len, &o);
+            if (o.emits) { px[0] += o.emitted[0] * inv_spp; px[1] += o.emitted[1] * inv_spp; px[2] += o.emitted[2] * inv_spp; }
+            if (o.shadow) {
+                struct Hit1 sh; n_shadow++;
+                if (!trace(sc, LD3(o.s_org), LD3(o.s_dir), offset, 1.0f - offset, 1, &sh)) {      /* mapping_gpu.impala:47-80 */
+                    px[0] += o.s_color[0] * inv_spp; px[1] += o.s_color[1] * inv_spp; px[2] += o.s_color[2] * inv_spp;
                 }
             }
-            /* on_bounce (renderer.impala:130-152) */
-            const float lum2 = 2.0f * luminance(contrib); const float rr = lum2 > 0.75f ? 0.75f : lum2;
-            if (depth >= max_path_len || randf(&rnd) >= rr) break;
-            const BsdfSample bs = bsdf_sample(m, &s, &rnd, out_dir);
-            const v3 c2 = mul(contrib, bs.color);
-            mis = bsdf_is_specular(m) ? 0.0f : 1.0f / bs.pdf;
-            contrib = mulf(c2, bs.cos / (bs.pdf * rr));
-            org = s.point; dir = bs.in_dir; tmin = offset; tmax = FLT_MAX_REF; depth++;
+            if (!o.bounce) break;
+            for (int k = 0; k < 3; k++) { pv.org[k] = o.b_org[k]; pv.dir[k] = o.b_dir[k]; pv.contrib[k] = o.contrib[k]; }
+            pv.rnd = o.rnd; pv.mis = o.mis; pv.depth++; tmin = offset; tmax = FLT_MAX_REF;
         }
     }
     if (ray_counts) { ray_counts[0] += n_primary; ray_counts[1] += n_shadow; }

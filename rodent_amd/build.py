@@ -137,8 +137,9 @@ def build_oracle(force: bool = False) -> Path:
     cpp = sorted(ORACLE.glob("*_baseline.cpp"))
     if cpp:
         out2 = ORACLE / "libcpu_baseline.so"
-        if force or _newer(out2, *cpp):
-            _run([CXX, "-O3", "-std=c++17", "-march=x86-64-v3", "-fPIC", "-shared", "-pthread", *cpp, "-o", out2])
+        if force or _newer(out2, *cpp, *sorted(ORACLE.glob("*.inc")), out):
+            # links the parity oracle for its shading functions (cpu_wavefront.inc); both are test infrastructure
+            _run([CXX, "-O3", "-std=c++17", "-march=x86-64-v3", "-fPIC", "-shared", "-pthread", *cpp, f"-L{ORACLE}", "-l:liboracle.so", "-Wl,-rpath,$ORIGIN", "-o", out2])
     return out
 
 

@@ -180,8 +180,12 @@ __device__ __forceinline__ Bases make_bases(const Node2* nodes, const Tri1* tris
 }
 
 // One step of one lane (top != 0): mapping_gpu.impala:107-134 for a node, one iteration of :156-174 for a triangle.
-template <bool ANY>
-__device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __restrict__ hits, lds_int* sp_limit, Ctl* ctl, int* __restrict__ deep_list) {
+// PF (lab): when `prefetch` is set (wave-uniform), a node lane touches both children's records (one dword each, loaded
+// straight into a dummy LDS row: no register, nothing waits for it) as soon as their ids have arrived, so that the next
+// iteration's fetch of the chosen child finds its line in L1 or already on its way -- the slab tests overlap the round trip.
+template <bool ANY, bool PF = false>
+__device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __restrict__ hits, lds_int* sp_limit, Ctl* ctl, int* __restrict__ deep_list,
+                                          bool prefetch = false, lds_int* pf_row = nullptr) {
     const bool is_node = L.top > 0;
     // one address for both kinds: base + index * stride with per-lane selected operands (straight-line code)
     const unsigned idx = (unsigned)(is_node ? L.top : ~L.top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
@@ -198,6 +202,15 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
     // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
     // (Whole-vector operands: the loaded register quads stay where the loads put them.)
     asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
+    if (PF && prefetch && is_node) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int c = k ? ch.y : ch.x;
+            const bool inner = c > 0;
+            const gptr a = (inner ? base.node : base.tri) + (size_t)(unsigned)(inner ? c : ~c) * (inner ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1));
+            if (c != 0) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a, (__attribute__((address_space(3))) void*)pf_row, 4, 0, 0);
+        }
+    }
     if (is_node) {
         float te0, te1;
         const bool h0 = slab_canonical(L.ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
@@ -252,6 +265,11 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
     if (PRIO == 0) {
         while (__ballot(L.top != 0)) {
             if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
+        }
+    } else if (PRIO >= 16) {                          // lab: child prefetch from iteration PRIO - 16 on (row LDS_N + 1 of the LDS block is the dummy target)
+        lds_int* pf_row = col - threadIdx.x + (LDS_N + 1) * kWave;
+        for (int it = 0; __ballot(L.top != 0); it++) {
+            if (L.top != 0) bvh2_step<ANY, true>(L, base, hits, sp_limit, ctl, deep_list, it >= PRIO - 16, pf_row);
         }
     } else {
         if ((PRIO & 2) && blockIdx.x >= 8192) __builtin_amdgcn_s_setprio(2);
@@ -381,7 +399,7 @@ template <bool ANY, int LDS_N, int XCD, bool TRACE = false, int PRIO = 0>
 __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                         Ctl* ctl, int* __restrict__ deep_list) {
-    __shared__ int lds_raw[(LDS_N + 1) * kWave];
+    __shared__ int lds_raw[(LDS_N + (PRIO >= 16 ? 2 : 1)) * kWave];
     lds_int* col = (lds_int*)lds_raw + threadIdx.x;
     const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int total_chunks = (n + kWave - 1) / kWave;
@@ -576,6 +594,10 @@ const Variant2 kVariants2[] = {
     K2("fast-prio-age",      "k_bvh2_single",        L_single, 16, 32, false, 1),
     K2("fast-prio-young",    "k_bvh2_single",        L_single, 16, 32, false, 2),
     K2("fast-prio-both",     "k_bvh2_single",        L_single, 16, 32, false, 3),
+    K2("fast-pf0",           "k_bvh2_single",        L_single, 16, 32, false, 16),     // child prefetch from iteration 0 / 48 / 80 / 112 on
+    K2("fast-pf48",          "k_bvh2_single",        L_single, 16, 32, false, 64),
+    K2("fast-pf80",          "k_bvh2_single",        L_single, 16, 32, false, 96),
+    K2("fast-pf112",         "k_bvh2_single",        L_single, 16, 32, false, 128),
     K2("lane",               "k_bvh2_lane",          L_lane, 24),                      // literal reference mapping
     K2("ww",                 "k_bvh2_ww",            L_ww, 24, 8),                     // while-while, LDS+scratch stack
     //                                                      LDS_N NODE_EXIT PERSIST REFILL_IDLE CHUNK STATS XCD_GROUP
