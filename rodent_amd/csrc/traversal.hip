@@ -172,6 +172,9 @@ struct Lane {
 typedef const __attribute__((address_space(1))) char* gptr;
 // Both array bases as 64-bit integers in VGPRs (the per-lane select in the step would otherwise copy them from SGPRs in
 // every iteration), turned back into GLOBAL pointers: laundering the pointers themselves leaves generic ones and flat loads.
+// (32-bit offsets from one SGPR base -- global_load ... v_off, s[base:base+1], a v_mad_u32_u24 instead of the 64-bit
+// multiply-add -- save one VALU instruction per iteration but need both arrays within 4 GiB of each other, which separate
+// hipMalloc allocations are not: measured on the test harness' arrays, the precondition never held.)
 struct Bases { gptr node, tri; };
 __device__ __forceinline__ Bases make_bases(const Node2* nodes, const Tri1* tris) {
     unsigned long long node_bits = reinterpret_cast<unsigned long long>(nodes - 1), tri_bits = reinterpret_cast<unsigned long long>(tris);   // node ids are 1-based
@@ -189,9 +192,9 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
     const bool is_node = L.top > 0;
     // one address for both kinds: base + index * stride with per-lane selected operands (straight-line code)
     const unsigned idx = (unsigned)(is_node ? L.top : ~L.top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
-    const gptr addr = (is_node ? base.node : base.tri) + (size_t)idx * stride;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const gptr addr = (is_node ? base.node : base.tri) + (size_t)idx * stride;
     const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
     f32x4 q0 = p[0], q1 = p[1], q2 = p[2];
     // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
