@@ -220,6 +220,14 @@ def main():
     steps_r, warm_r = (args.steps, args.warmup) if args.only != "primary" else (1, 0)
     wall, k_mean, k_med, k_min = time_passes(abi, torch, bvh, prim_dev, hits_dev, n, variant, steps_p, warm_p, dist)
     wall_r, kr_mean, kr_med, kr_min = time_passes(abi, torch, bvh, rnd_dev, hits_rnd_dev, len(rnd), variant, steps_r, warm_r, dist)
+    # BASELINE config 3 ("ray compaction/sorting on"): the same random set through the "sorted" mapping -- the permutation by
+    # origin cell is rebuilt inside every timed launch
+    sorted_variant = abi.variants(width).index("sorted") if "sorted" in abi.variants(width) else None
+    wall_s = ks_mean = None
+    hits_sorted_dev = None
+    if sorted_variant is not None and args.only != "primary":
+        hits_sorted_dev = torch.zeros_like(hits_rnd_dev)
+        wall_s, ks_mean, _, _ = time_passes(abi, torch, bvh, rnd_dev, hits_sorted_dev, len(rnd), sorted_variant, steps_r, warm_r, dist)
     abi.check_errors(dev)                                         # the asynchronous entry points report stack overflows through a flag
     # for information only (never `value`): independent batches in flight on two streams -- the fill of one launch
     # overlaps the drain of the other (every (device, stream) has its own launch state)
@@ -253,6 +261,10 @@ def main():
         total_rays, total_rnd = int(sum(float(g[2]) for g in gathered_km)), int(sum(float(g[3]) for g in gathered_km))
     value = total_rays * steps_p / wall / 1e6
     value_rnd = total_rnd * steps_r / wall_r / 1e6
+    if wall_s is not None and dist is not None:
+        t = torch.tensor([wall_s], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall_s = float(t[0])
 
     # ---- after the timed region: ONE gather --------------------------------------------------
     hits = abi.from_device(hits_dev, F.HIT1)
@@ -299,6 +311,10 @@ def main():
                   "hit_counts_per_rank[primary,random]": counts_all, "strong_scaling_check": strong_check,
                   "two_streams_Mrays_s_per_gpu": None if overlapped is None else round(overlapped, 3)},
     }
+    if wall_s is not None:
+        out["extra"]["random_sorted"] = {"Mrays_s": round(total_rnd * steps_r / wall_s / 1e6, 3), "ms_per_step": round(1e3 * wall_s / steps_r, 5), "kernels_ms": round(ks_mean, 5),
+                                         "variant": "sorted: counting sort of the rays on 512 Morton cells of their origin inside every launch, then the default kernel through the permutation",
+                                         "identical_to_unsorted": bool(abi.from_device(hits_sorted_dev, F.HIT1).tobytes() == hits_rnd.tobytes())}
     if not args.no_cpu_baseline:
         from oracle import binding as O      # checker / CPU baseline only: never on the measured path
         # (1) visit counts of the reference algorithm for THIS layout over ALL rays -> algorithmic bytes per ray; full parity check

@@ -260,9 +260,11 @@ __device__ __forceinline__ Lane start_lane(const Ray1* __restrict__ rays, Hit1* 
 // 2 = the waves of the second dispatch round (workgroup index >= 8192) run at priority 2 from the start; 3 = both.
 template <bool ANY, int LDS_N, int PRIO = 0>
 __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, const Ray1* __restrict__ rays,
-                                              Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray) {
+                                              Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray,
+                                              const int* __restrict__ perm = nullptr) {
     const int lane_ray = first_ray + (int)threadIdx.x;
-    Lane L = start_lane(rays, hits, lane_ray < n ? lane_ray : -1, first_ray, col);
+    // perm (k_bvh2_single's "sorted" mapping): lane j traces ray perm[j]; its hit still goes to hits[ray id]
+    Lane L = start_lane(rays, hits, lane_ray < n ? (perm ? perm[lane_ray] : lane_ray) : -1, perm ? perm[first_ray] : first_ray, col);
     lds_int* const sp_limit = col + LDS_N * kWave;
     const Bases base = make_bases(nodes, tris);
     if (PRIO == 0) {
@@ -401,7 +403,7 @@ static_assert(kMaxPhases == 4 && kStripes == 64 && kCounterStride == 16, "k_bvh2
 template <bool ANY, int LDS_N, int XCD, bool TRACE = false, int PRIO = 0>
 __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                        Ctl* ctl, int* __restrict__ deep_list) {
+                                                        Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm) {
     __shared__ int lds_raw[(LDS_N + (PRIO >= 16 ? 2 : 1)) * kWave];
     lds_int* col = (lds_int*)lds_raw + threadIdx.x;
     const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -414,12 +416,89 @@ __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__
             chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
         }
     }
-    unified_chunk<ANY, LDS_N, PRIO>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave);
+    unified_chunk<ANY, LDS_N, PRIO>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, perm);
     if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
         unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
         tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
         tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
         tr[3] = (unsigned long long)chunk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ray sorting for incoherent ray sets (BASELINE config 3: "ray compaction/sorting on"; variant "sorted").
+// 3.1's counters say what a set of random segments waits for: every lane fetches its own 64-byte node, 85 % from L2 and 15 %
+// from the Infinity Cache, at 97.5 % of what that path delivers.  Only coherence moves that roofline: the same rays
+// grouped by the cell of their origin trace 20-25 % faster (profiles/r02_sort_experiment.txt).  Three small kernels build
+// the permutation -- a counting sort on 512 Morton cells (3 bits per axis of the scene box, read from the root node):
+//   k_raysort_count   256 threads x 16 rays: cell keys, per-block histogram in LDS, block totals added to the 512 global
+//                     counters (non-returning atomics, 512 distinct addresses)
+//   k_raysort_scan    one workgroup: exclusive scan of the 512 totals -> bin cursors
+//   k_raysort_scatter per block: histogram again from the stored keys, one RETURNING atomic per (block, non-empty cell) claims
+//                     the block's range of the cell, LDS atomics rank the rays inside it; perm[position] = ray index
+// The order of blocks inside a cell is whatever the atomics make it: perm differs from run to run, the hits do not (every ray
+// is traced exactly as before and stores to hits[ray index]).  k_bvh2_single then takes ray perm[j] in lane j.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSortCells = 512, kSortThreads = 256, kSortRaysPerThread = 16, kSortBlockRays = kSortThreads * kSortRaysPerThread;
+
+__device__ __forceinline__ unsigned spread3(unsigned x) { return (x & 1u) | ((x & 2u) << 2) | ((x & 4u) << 4); }      // 3 bits -> every third bit
+__device__ __forceinline__ unsigned ray_cell(const Ray1* __restrict__ rays, int i, float lox, float loy, float loz, float sx, float sy, float sz) {
+    const float4 o = *reinterpret_cast<const float4*>(rays + i);
+    const int cx = min(7, max(0, (int)((o.x - lox) * sx))), cy = min(7, max(0, (int)((o.y - loy) * sy))), cz = min(7, max(0, (int)((o.z - loz) * sz)));
+    return spread3((unsigned)cx) | (spread3((unsigned)cy) << 1) | (spread3((unsigned)cz) << 2);
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_raysort_count(const Node2* __restrict__ nodes, const Ray1* __restrict__ rays, int n, unsigned short* __restrict__ keys, int* __restrict__ totals) {
+    __shared__ int hist[kSortCells];
+    for (int k = threadIdx.x; k < kSortCells; k += kSortThreads) hist[k] = 0;
+    // scene box = union of the root's child boxes (converter.cpp:318-341 layout; an empty slot is +inf / -inf: min / max ignore it)
+    const float* b = nodes[0].bounds;
+    const float lox = fminf(b[0], b[6]), hix = fmaxf(b[1], b[7]), loy = fminf(b[2], b[8]), hiy = fmaxf(b[3], b[9]), loz = fminf(b[4], b[10]), hiz = fmaxf(b[5], b[11]);
+    const float sx = 8.0f / fmaxf(hix - lox, 1e-30f), sy = 8.0f / fmaxf(hiy - loy, 1e-30f), sz = 8.0f / fmaxf(hiz - loz, 1e-30f);
+    __syncthreads();
+    const int first = blockIdx.x * kSortBlockRays;
+#pragma unroll 4
+    for (int k = 0; k < kSortRaysPerThread; k++) {
+        const int i = first + k * kSortThreads + (int)threadIdx.x;
+        if (i < n) { const unsigned c = ray_cell(rays, i, lox, loy, loz, sx, sy, sz); keys[i] = (unsigned short)c; atomicAdd(&hist[c], 1); }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kSortCells; k += kSortThreads) if (hist[k]) atomicAdd(&totals[k], hist[k]);
+}
+
+__global__ __launch_bounds__(kSortCells) void k_raysort_scan(int* __restrict__ totals /* in: counts, out: zero */, int* __restrict__ cursor) {
+    __shared__ int wave_sum[kSortCells / kWave];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    const int v = totals[threadIdx.x];
+    totals[threadIdx.x] = 0;                                      // ready for the next launch on this stream
+    int incl = v;
+    for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    if (lane == kWave - 1) wave_sum[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; w++) before += wave_sum[w];
+    cursor[threadIdx.x] = before + incl - v;
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_raysort_scatter(const unsigned short* __restrict__ keys, int n, int* __restrict__ cursor, int* __restrict__ perm) {
+    __shared__ int slot[kSortCells];
+    for (int k = threadIdx.x; k < kSortCells; k += kSortThreads) slot[k] = 0;
+    __syncthreads();
+    const int first = blockIdx.x * kSortBlockRays;
+    unsigned short key[kSortRaysPerThread];
+#pragma unroll
+    for (int k = 0; k < kSortRaysPerThread; k++) {
+        const int i = first + k * kSortThreads + (int)threadIdx.x;
+        key[k] = i < n ? keys[i] : (unsigned short)0xFFFF;
+        if (i < n) atomicAdd(&slot[key[k]], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kSortCells; k += kSortThreads) { const int c = slot[k]; if (c) slot[k] = atomicAdd(&cursor[k], c); }     // this block's range of cell k
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortRaysPerThread; k++) {
+        const int i = first + k * kSortThreads + (int)threadIdx.x;
+        if (i < n) perm[atomicAdd(&slot[key[k]], 1)] = i;
     }
 }
 
@@ -437,6 +516,8 @@ struct DeviceState {
     int*  queue_mem[2] = {nullptr, nullptr};   // suspended-ray queues of the phased traversal (ping-pong), queue_cap slots each
     int   queue_cap = 0;
     int*  qcount = nullptr;                    // [phase][stripe] suspended-ray counters, 64 bytes apart
+    int*  sort_perm = nullptr; unsigned short* sort_keys = nullptr; int sort_cap = 0;     // "sorted" mapping: permutation and cell keys
+    int*  sort_totals = nullptr;               // [0, 512) cell counts (zero between launches), [512, 1024) cell cursors
     Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
 };
 // One DeviceState per (device, stream): launches enqueued on different streams of a device may overlap, so each
@@ -502,6 +583,23 @@ RayQueue ensure_queue(DeviceState& s, int which, int n) {
     return RayQueue{m, reinterpret_cast<float*>(m + c), m + 2 * c, m + 3 * c, m + 4 * c, s.queue_cap, stripe_cap};
 }
 
+void ensure_sort_buffers(DeviceState& s, int n) {
+    if (n <= s.sort_cap && s.sort_totals) return;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (n > s.sort_cap) {
+        if (s.sort_perm) HIP_CHECK(hipFree(s.sort_perm));
+        if (s.sort_keys) HIP_CHECK(hipFree(s.sort_keys));
+        HIP_CHECK(hipMalloc(&s.sort_perm, sizeof(int) * (size_t)n));
+        HIP_CHECK(hipMalloc(&s.sort_keys, sizeof(unsigned short) * (size_t)n));
+        s.sort_cap = n;
+    }
+    if (!s.sort_totals) {
+        HIP_CHECK(hipMalloc(&s.sort_totals, sizeof(int) * 2 * kSortCells));
+        HIP_CHECK(hipMemset(s.sort_totals, 0, sizeof(int) * 2 * kSortCells));
+    }
+}
+
 void ensure_deep_list(DeviceState& s, int n) {
     if (n <= s.deep_cap) return;
     std::lock_guard<std::mutex> lock(g_mutex);
@@ -535,12 +633,24 @@ void check_error_flag(DeviceState& s, hipStream_t stream) {
 
 template <bool ANY, int LDS_N, int XCD, bool TR = false, int PRIO = 0> void L_single(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
-    hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR, PRIO>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
+    hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR, PRIO>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 
 // Phased traversal: caps of the capped phases (the last, uncapped phase follows).  Launches too small to fill the chip
 // once take the single kernel.
+// "sorted": permutation by origin cell, then the single kernel through it
+template <bool ANY, int LDS_N> void L_sorted(LAUNCH_ARGS) {
+    ensure_deep_list(s, n);
+    ensure_sort_buffers(s, n);
+    const int blocks = (n + kSortBlockRays - 1) / kSortBlockRays;
+    hipLaunchKernelGGL(k_raysort_count, dim3(blocks), dim3(kSortThreads), 0, stream, nodes, rays, n, s.sort_keys, s.sort_totals);
+    hipLaunchKernelGGL(k_raysort_scan, dim3(1), dim3(kSortCells), 0, stream, s.sort_totals, s.sort_totals + kSortCells);
+    hipLaunchKernelGGL(k_raysort_scatter, dim3(blocks), dim3(kSortThreads), 0, stream, s.sort_keys, n, s.sort_totals + kSortCells, s.sort_perm);
+    hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, 32, false, 0>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)s.sort_perm);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
+}
+
 int g_phased_min_rays = 4096 * kWave;           // rodent_hip_phased_min_rays()
 struct PhaseCaps { int count; int cap[3]; };
 constexpr PhaseCaps kPhaseCaps[] = {{2, {40, 24}}, {2, {32, 24}}, {1, {40}}, {1, {32}}, {1, {48}}, {2, {48, 32}}, {3, {32, 32, 32}}, {3, {24, 24, 24}}, {2, {24, 24}}, {2, {64, 32}}};
@@ -577,6 +687,7 @@ const Variant2 kVariants2[] = {
     K2("fast-noxcd",         "k_bvh2_single",        L_single, 16, 0),                 // same kernel, workgroup b traces chunk b
     //                                                       LDS_N CAPS (index into kPhaseCaps) [LAST_RAYS]
     K2("phased",             "k_bvh2_phase",         L_phased, 16, 2),                 // phased traversal with ray compaction: one capped phase of 40 iterations, then the rest
+    K2("sorted",             "k_bvh2_single",        L_sorted, 16),                    // rays grouped by the Morton cell of their origin first (for incoherent ray sets)
 #ifdef RODENT_HIP_LAB
     // what was swept on the way (profiles/r02_sweep_phased*.log, r02_sweep_prio.log): other phase caps, fewer rays per wave in
     // the last phase, issue priorities by wave age / dispatch round
