@@ -271,6 +271,14 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
         while (__ballot(L.top != 0)) {
             if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
         }
+    } else if (PRIO >= 256) {                         // lab: triangle turns.  Lanes at a triangle step only every K-th iteration while the wave is
+        // young (iteration < SWITCH), so that most iterations run the node path alone (62 instead of 127 VALU instructions); old
+        // waves -- the ones the launch waits for at its end -- go back to one step per lane per iteration.  PRIO = 256 + K * 1024 + SWITCH
+        constexpr int K = (PRIO - 256) / 1024, SWITCH = (PRIO - 256) % 1024;
+        for (int it = 0; __ballot(L.top != 0); it++) {
+            const bool tri_turn = it >= SWITCH || it % K == K - 1 || !__ballot(L.top > 0);
+            if (L.top != 0 && (L.top > 0 || tri_turn)) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
+        }
     } else if (PRIO >= 16) {                          // lab: child prefetch from iteration PRIO - 16 on (row LDS_N + 1 of the LDS block is the dummy target)
         lds_int* pf_row = col - threadIdx.x + (LDS_N + 1) * kWave;
         for (int it = 0; __ballot(L.top != 0); it++) {
@@ -404,7 +412,7 @@ template <bool ANY, int LDS_N, int XCD, bool TRACE = false, int PRIO = 0>
 __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                         Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm) {
-    __shared__ int lds_raw[(LDS_N + (PRIO >= 16 ? 2 : 1)) * kWave];
+    __shared__ int lds_raw[(LDS_N + (PRIO >= 16 && PRIO < 256 ? 2 : 1)) * kWave];
     lds_int* col = (lds_int*)lds_raw + threadIdx.x;
     const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int total_chunks = (n + kWave - 1) / kWave;
@@ -708,6 +716,14 @@ const Variant2 kVariants2[] = {
     K2("fast-prio-age",      "k_bvh2_single",        L_single, 16, 32, false, 1),
     K2("fast-prio-young",    "k_bvh2_single",        L_single, 16, 32, false, 2),
     K2("fast-prio-both",     "k_bvh2_single",        L_single, 16, 32, false, 3),
+    K2("fast-tri2-48",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 2 * 1024 + 48),    // triangle turns every K-th iteration until iteration SWITCH
+    K2("fast-tri4-48",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 4 * 1024 + 48),
+    K2("fast-tri4-32",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 4 * 1024 + 32),
+    K2("fast-tri4-64",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 4 * 1024 + 64),
+    K2("fast-tri4-999",      "k_bvh2_single",        L_single, 16, 32, false, 256 + 4 * 1024 + 999),
+    K2("fast-tri2-999",      "k_bvh2_single",        L_single, 16, 32, false, 256 + 2 * 1024 + 999),
+    K2("fast-tri8-48",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 8 * 1024 + 48),
+    K2("fast-tri3-40",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 3 * 1024 + 40),
     K2("fast-pf0",           "k_bvh2_single",        L_single, 16, 32, false, 16),     // child prefetch from iteration 0 / 48 / 80 / 112 on
     K2("fast-pf48",          "k_bvh2_single",        L_single, 16, 32, false, 64),
     K2("fast-pf80",          "k_bvh2_single",        L_single, 16, 32, false, 96),
