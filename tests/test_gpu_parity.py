@@ -335,3 +335,24 @@ def test_bench_traversal_cli(gpu, native_build, oracle, cornell, tmp_path):
         assert np.array_equal(F.read_fbuf(out), exp["t"])
     r = subprocess.run(cmd + ["-gpu", "amdgpu", "-any"], capture_output=True, text=True, check=True)
     assert "4096 intersection(s)" in r.stdout
+
+
+def test_bench_py_contract(native_build):
+    """bench.py prints ONE JSON line with the contract's keys, the roofline and cpu_baseline objects, the binding bounds, and
+    reports every ray of both sets bit-exact against the oracle (variant 0 = what the driver runs)."""
+    import json, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1"], capture_output=True, text=True, check=True, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["peak"] == 8000.0
+    assert 0 < rf["binding"]["node_fetch"]["frac"] < 1.2 and 0 < rf["random"]["binding"]["node_fetch"]["frac"] < 1.2
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["passes"] >= 10 and "sample" in cb
+    assert d["value"] > 1000 and d["extra"]["all_rays_bit_exact_vs_oracle"] == {"primary": True, "random": True}
+    assert d["extra"]["random_sorted"]["identical_to_unsorted"] is True
