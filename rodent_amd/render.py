@@ -83,7 +83,7 @@ class Renderer:
 
     MAPPINGS = {"streaming": 0, "megakernel": 1}       # mapping_gpu.impala:308-369 / :371-474
 
-    def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming", capacity=0, sort=True, overlap=True, fused_sort=True):
+    def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming", capacity=0, sort=True, overlap=True, fused_sort=False):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("rodent_amd: no GPU visible (the renderer has no CPU fallback)")

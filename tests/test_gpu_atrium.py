@@ -105,12 +105,12 @@ def test_atrium_path_trace_matches_oracle(R, atrium_scene, atrium_reference, map
     assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
 
 
-def test_atrium_physical_sort_matches_oracle(R, atrium_scene, atrium_reference):
-    """rodent_hip_render_fused_sort(0): rays are moved by the sort (copy_primary_ray, mapping_gpu.impala:136-164) and shaded in
-    place, instead of the default permutation + gathering shader; same paths, same film."""
+def test_atrium_fused_sort_matches_oracle(R, atrium_scene, atrium_reference):
+    """rodent_hip_render_fused_sort(1): the sort only computes the permutation and the shader gathers through it, instead of
+    the default (rays moved by the sort, copy_primary_ray, mapping_gpu.impala:136-164, and shaded in place); same paths, same film."""
     f = ATRIUM_FRAME
     film_o, counts = atrium_reference
-    r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], fused_sort=False, capacity=70_000)
+    r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], fused_sort=True, capacity=70_000)
     r.render(atrium_camera(f["W"], f["H"]), f["IT"])
     c = r.counters(); film_g = r.film(); r.close()
     assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1])
