@@ -45,6 +45,11 @@ namespace {
 using namespace rodent_dev;
 
 constexpr int kBlock = 256;                    // workgroup of the streaming (non-traversal) kernels
+// Rays per workgroup of the binning kernels (k_bin_count, k_scatter).  A workgroup's rays of one bin land in ONE contiguous
+// run of the output: with 1024 rays and ten bins a run is ~400 bytes per array instead of ~100 -- whole cache lines instead
+// of lines shared with the neighbouring workgroup (which usually runs on another XCD, behind another L2) -- and the per-block
+// histogram is a quarter of the size.
+constexpr int kBinBlock = 1024;
 constexpr int kMaxBins = 1025;                 // mapping_gpu.impala:200,342 (1024 geometries + the "miss" bin)
 // Rays per stream.  The reference uses 1 Mi (mapping_gpu.impala:319, sized for ~12 GB boards).  On this chip a 1 Mi-ray
 // launch is two rounds of resident waves, all fill and drain; 8 Mi-ray streams (1.8 GB of streams +
@@ -530,9 +535,9 @@ __device__ __forceinline__ int stream_key(const PrimaryStream& p, int i, int mod
 }
 
 // in-block rank of thread `tid` among threads with the same key; also leaves the block's per-key counts in cnt[]
-__device__ __forceinline__ int block_rank(int key, bool valid, int num_bins, int* cnt /* LDS [4][num_bins] */) {
+__device__ __forceinline__ int block_rank(int key, bool valid, int num_bins, int* cnt /* LDS [kBinBlock / kWave][num_bins] */) {
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    for (int k = threadIdx.x; k < 4 * num_bins; k += kBlock) cnt[k] = 0;
+    for (int k = threadIdx.x; k < (kBinBlock / kWave) * num_bins; k += kBinBlock) cnt[k] = 0;
     __syncthreads();
     int rank = 0;
     unsigned long long todo = __ballot(valid);
@@ -549,15 +554,30 @@ __device__ __forceinline__ int block_rank(int key, bool valid, int num_bins, int
     return rank;
 }
 
+// counts only (no ranks): 256 threads take the kBinBlock rays of one binning block four at a time; one LDS add per wave and
+// distinct key.  (As a 1024-thread workgroup with the ranking of k_scatter it waited for sixteen free wave slots on one CU
+// while the shadow-ray pass filled the chip on the other stream: 13 -> 98 ms per five cfg4 frames.)
 __global__ __launch_bounds__(kBlock) void k_bin_count(PrimaryStream p, const int* size_ptr, int n_value, int mode, int num_bins, int num_blocks, int* hist /* [num_bins][num_blocks] */) {
     extern __shared__ int cnt[];
     const int n = stream_size(size_ptr, n_value);
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = i < n;
-    const int key = valid ? stream_key(p, i, mode) : 0;
-    block_rank(key, valid, num_bins, cnt);
-    for (int k = threadIdx.x; k < num_bins; k += kBlock)
-        hist[(size_t)k * num_blocks + blockIdx.x] = cnt[k] + cnt[num_bins + k] + cnt[2 * num_bins + k] + cnt[3 * num_bins + k];
+    for (int k = threadIdx.x; k < num_bins; k += kBlock) cnt[k] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x % kWave;
+    for (int r = 0; r < kBinBlock / kBlock; r++) {
+        const int i = blockIdx.x * kBinBlock + r * kBlock + threadIdx.x;
+        const bool valid = i < n;
+        const int key = valid ? stream_key(p, i, mode) : 0;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {                                       // one round per distinct key present in the wave
+            const int leader = __ffsll((long long)todo) - 1;
+            const int k0 = __shfl(key, leader);
+            const unsigned long long same = __ballot(valid && key == k0);
+            if (lane == leader) atomicAdd(&cnt[k0], __popcll(same));
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < num_bins; k += kBlock) hist[(size_t)k * num_blocks + blockIdx.x] = cnt[k];
 }
 
 // one workgroup per bin: exclusive scan of that bin's per-block counts (in place), total -> bin_total[bin].
@@ -612,29 +632,35 @@ __global__ void k_bin_scan_bins(const int* bin_total, int num_bins, int* bin_beg
 }
 
 // copy_primary_ray (mapping_gpu.impala:136-164) to the computed slot
-__global__ __launch_bounds__(kBlock) void k_scatter(PrimaryStream p, PrimaryStream q, const int* size_ptr, int n_value, int mode, int num_bins, int num_blocks,
+__global__ __launch_bounds__(kBinBlock) void k_scatter(PrimaryStream p, PrimaryStream q, const int* size_ptr, int n_value, int mode, int num_bins, int num_blocks,
                                                      const int* hist, const int* bin_begin, int keep_hit, int drop_from_bin, int copy_interval, int* __restrict__ perm) {
     extern __shared__ int cnt[];
     const int n = stream_size(size_ptr, n_value);
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int i = blockIdx.x * kBinBlock + threadIdx.x;
     const bool valid = i < n;
     const int key = valid ? stream_key(p, i, mode) : 0;
+    // ALL loads first -- and before the in-block ranking, whose two barriers and LDS rounds then overlap their latency -- then
+    // all stores.  Written as q.x[d] = p.x[i] pairs the copy compiled to load - wait - store, one word at a time (p and q may
+    // alias as far as the compiler knows, so no load moves above the store before it; 14 VGPRs): every word paid a full memory
+    // latency and the kernel ran at 1.7 TB/s.
+    const bool copy = valid && key < drop_from_bin && !perm;
+    int id = 0; float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, tmin = 0, tmax = 0, t = 0, u = 0, v = 0, mis = 0, cr = 0, cg = 0, cb = 0;
+    int geom = 0, prim = 0, depth = 0; uint32_t rnd = 0;
+    int begin = 0, before = 0;
+    if (valid && key < drop_from_bin) { begin = bin_begin[key]; before = hist[(size_t)key * num_blocks + blockIdx.x]; }
+    if (copy) {
+        id = p.rays.id[i];
+        ox = p.rays.org_x[i]; oy = p.rays.org_y[i]; oz = p.rays.org_z[i]; dx = p.rays.dir_x[i]; dy = p.rays.dir_y[i]; dz = p.rays.dir_z[i];
+        // the ray interval is dead between the traversal and the shader (which writes a new one for every ray that goes on):
+        // the sort before shading (copy_interval == 0) leaves the two words behind -- 10 % of its traffic
+        if (copy_interval) { tmin = p.rays.tmin[i]; tmax = p.rays.tmax[i]; }
+        if (keep_hit) { geom = p.geom_id[i]; prim = p.prim_id[i]; t = p.t[i]; u = p.u[i]; v = p.v[i]; }
+        rnd = p.rnd[i]; mis = p.mis[i]; cr = p.contrib_r[i]; cg = p.contrib_g[i]; cb = p.contrib_b[i]; depth = p.depth[i];
+    }
     const int rank = block_rank(key, valid, num_bins, cnt);
     if (!valid || key >= drop_from_bin) return;
-    const int d = bin_begin[key] + hist[(size_t)key * num_blocks + blockIdx.x] + rank;
+    const int d = begin + before + rank;
     if (perm) { perm[d] = i; return; }                          // index-only sort: the consumer gathers (k_shade)
-    // ALL loads first, then all stores.  Written as q.x[d] = p.x[i] pairs the copy compiled to load - wait - store, one word
-    // at a time (p and q may alias as far as the compiler knows, so no load moves above the store before it; 14 VGPRs): every
-    // word paid a full memory latency and the kernel ran at 1.7 TB/s.
-    const int id = p.rays.id[i];
-    const float ox = p.rays.org_x[i], oy = p.rays.org_y[i], oz = p.rays.org_z[i], dx = p.rays.dir_x[i], dy = p.rays.dir_y[i], dz = p.rays.dir_z[i];
-    // the ray interval is dead between the traversal and the shader (which writes a new one for every ray that goes on):
-    // the sort before shading (copy_interval == 0) leaves the two words behind -- 10 % of its traffic
-    float tmin = 0.0f, tmax = 0.0f;
-    if (copy_interval) { tmin = p.rays.tmin[i]; tmax = p.rays.tmax[i]; }
-    int geom = 0, prim = 0; float t = 0.0f, u = 0.0f, v = 0.0f;
-    if (keep_hit) { geom = p.geom_id[i]; prim = p.prim_id[i]; t = p.t[i]; u = p.u[i]; v = p.v[i]; }
-    const uint32_t rnd = p.rnd[i]; const float mis = p.mis[i], cr = p.contrib_r[i], cg = p.contrib_g[i], cb = p.contrib_b[i]; const int depth = p.depth[i];
     asm volatile("" ::: "memory");                               // (keeps the stores below the loads whatever the optimiser thinks of the pairs)
     q.rays.id[d] = id;
     q.rays.org_x[d] = ox; q.rays.org_y[d] = oy; q.rays.org_z[d] = oz; q.rays.dir_x[d] = dx; q.rays.dir_y[d] = dy; q.rays.dir_z[d] = dz;
@@ -776,13 +802,13 @@ int* bin_end(RenderDevice& r, int set)   { return r.ctl + 8 + set * 3 * kMaxBins
 // Bins `p` (size = *size_ptr if given, else max_n; never more than max_n) into `q`; bins >= drop_from_bin are not copied.
 void bin_stream(RenderDevice& r, int set, const PrimaryStream& p, const PrimaryStream& q, const int* size_ptr, int max_n, int mode, int num_bins,
                 int keep_hit, int drop_from_bin, hipStream_t stream, int copy_interval = 1, int* perm = nullptr) {
-    const int blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
+    const int blocks = std::max(1, (max_n + kBinBlock - 1) / kBinBlock);
     ensure_hist(r, (size_t)num_bins * blocks);
-    const size_t lds = sizeof(int) * 4 * num_bins;
-    hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kBlock), lds, stream, p, size_ptr, max_n, mode, num_bins, blocks, r.hist);
+    const size_t lds = sizeof(int) * (kBinBlock / kWave) * num_bins;
+    hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kBlock), sizeof(int) * num_bins, stream, p, size_ptr, max_n, mode, num_bins, blocks, r.hist);
     hipLaunchKernelGGL(k_bin_scan_blocks, dim3(num_bins), dim3(kBlock), 0, stream, r.hist, blocks, bin_total(r, set));
     hipLaunchKernelGGL(k_bin_scan_bins, dim3(1), dim3(1), 0, stream, bin_total(r, set), num_bins, bin_begin(r, set), bin_end(r, set));
-    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBlock), lds, stream, p, q, size_ptr, max_n, mode, num_bins, blocks, r.hist, bin_begin(r, set), keep_hit, drop_from_bin, copy_interval, perm);
+    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBinBlock), lds, stream, p, q, size_ptr, max_n, mode, num_bins, blocks, r.hist, bin_begin(r, set), keep_hit, drop_from_bin, copy_interval, perm);
     HIP_CHECK(hipGetLastError());
 }
 
