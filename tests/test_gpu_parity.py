@@ -4,6 +4,7 @@ Bar (BASELINE.json): primitive ids bit-exact, t within 1e-4 relative.  Kernels t
 reference's per-ray visit order are held to the stronger bar: the whole Hit1 record
 (id, t, u, v) bit-identical to the oracle, ties and any-hit results included.
 """
+import ctypes
 import subprocess
 
 import numpy as np
@@ -124,8 +125,9 @@ def test_chunk_mapping_is_a_bijection(gpu, cornell, cornell_dev, n):
 
 
 def test_launches_on_several_streams_may_overlap(gpu, oracle):
-    """Every (device, stream) has its own control words and deep-ray list: four streams trace different ray sets of the
-    deep-chain scene (every launch hands rays to its follow-up kernel) at the same time, repeatedly; all results exact."""
+    """Every (device, stream) has its own control words, deep-ray list, suspended-ray queues and sort buffers: four streams
+    trace different ray sets of the deep-chain scene (every launch hands rays to its follow-up kernel) at the same time,
+    repeatedly, with every shipped mapping (the phased one suspends and resumes, the sorted one permutes); all results exact."""
     import torch
     from conftest import chain_bvh2
     nodes, tris = chain_bvh2(40)
@@ -140,14 +142,17 @@ def test_launches_on_several_streams_may_overlap(gpu, oracle):
         sets.append((rays, ref, gpu.to_device(rays, 0), torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0"), torch.cuda.Stream()))
     torch.cuda.synchronize()
     for rep in range(5):
-        for rays, ref, rd, hd, st in sets:
-            hd.fill_(0xFF)
-        torch.cuda.synchronize()
-        for rays, ref, rd, hd, st in sets:
-            gpu.traverse_async(bvh, rd, hd, len(rays), False, 0, st)
-        torch.cuda.synchronize()
-        for rays, ref, rd, hd, st in sets:
-            assert gpu.from_device(hd, F.HIT1).tobytes() == ref.tobytes()
+        for v in variants(gpu, 2):
+            for rays, ref, rd, hd, st in sets:
+                hd.fill_(0xFF)
+            torch.cuda.synchronize()
+            for k, (rays, ref, rd, hd, st) in enumerate(sets):
+                gpu.traverse_async(bvh, rd, hd, len(rays), False, (v + k) % len(variants(gpu, 2)) if rep % 2 else v, st)     # same / mixed mappings in flight
+            torch.cuda.synchronize()
+            for rays, ref, rd, hd, st in sets:
+                assert gpu.from_device(hd, F.HIT1).tobytes() == ref.tobytes(), (rep, gpu.variants(2)[v])
+        for st in (s[4] for s in sets):
+            assert gpu.lib().rodent_hip_check_errors(0, ctypes.c_void_p(st.cuda_stream)) == 0
 
 
 def test_special_tmin_tmax_values(gpu, oracle, cornell, cornell_dev):
