@@ -361,3 +361,23 @@ def test_bench_py_contract(native_build):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["passes"] >= 10 and "sample" in cb
     assert d["value"] > 1000 and d["extra"]["all_rays_bit_exact_vs_oracle"] == {"primary": True, "random": True}
     assert d["extra"]["random_sorted"]["identical_to_unsorted"] is True
+
+
+def test_stack_overflow_is_reported_not_silent(gpu, oracle):
+    """The reference's stack holds 64 entries, unchecked (stack.impala:53-54).  A ray that needs more raises a device flag:
+    rodent_hip_check_errors reports it once and clears it (the synchronous entry points abort on it); launches that stay
+    within 64 entries are unaffected afterwards."""
+    from conftest import chain_bvh2
+    nodes, tris = chain_bvh2(70)                                 # 70 entries deep
+    org = np.zeros((200, 3), "<f4"); org[:, :2] = np.random.default_rng(2).uniform(-4, 4, (200, 2))
+    rays = F.make_rays(org, np.tile(np.float32([0.001, 0.002, 1.0]), (200, 1)), 0.0, 1000.0)
+    deep = gpu.DeviceBvh(2, nodes, tris, 0)
+    for v in variants(gpu, 2):
+        with pytest.raises(RuntimeError, match="stack overflow"):
+            gpu.traverse(deep, rays, variant=v)
+        assert gpu.lib().rodent_hip_check_errors(0, None) == 0   # cleared by the report
+    ok_nodes, ok_tris = chain_bvh2(60)
+    ok = gpu.DeviceBvh(2, ok_nodes, ok_tris, 0)
+    ref, st = oracle.traverse(2, ok_nodes, ok_tris, rays)
+    assert st["max_stack"] == 60
+    assert gpu.traverse(ok, rays, variant=0).tobytes() == ref.tobytes()
