@@ -6,14 +6,16 @@
  * link or call it.  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg use it.
  *
- * PARITY PINNING: "parity unpinned by the reference".  The reference's traversal
+ * PARITY PINNING: "parity unpinned by the reference" -- by reference OUTPUTS.  The reference's traversal
  * is Impala source that needs the AnyDSL toolchain (absent here), and its only
  * golden vectors (testing/ref-primary.png, ref-random.png) depend on sponza.bvh /
  * sponza-*.rays which are missing from the checkout (.MISSING_LARGE_BLOBS).
  * The oracle is therefore pinned by (1) an exhaustive all-triangles checker
  * (oracle_brute_force below; closest t must equal the minimum over every
- * triangle), (2) an independent float64 Moeller-Trumbore in tests/, and
- * (3) fixtures generated on this side (tests/golden/).  Indirectly, the reference does hold it: the renderer
+ * triangle), (2) an independent float64 Moeller-Trumbore in tests/, (3) fixtures generated on this side
+ * (tests/golden/), and (4) hierarchies the REFERENCE'S OWN BUILDER made (oracle/_ref/ref_bvh_builder = the reference's
+ * obj.cpp + bvh.h compiled where they lie; tests/golden/*-refbuilt.bvh, tests/test_refbuilt.py): B1 / B1g / B2 on those against
+ * the exhaustive checker.  Indirectly, the reference does hold it: the renderer
  * oracle (render_oracle.c) traces every ray with oracle_bvh2_tri1 below and reproduces the reference's own
  * golden image testing/ref-cornell.png.
  *
