@@ -37,6 +37,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LDS_CLOCK_GHZ = 2.4             # same guide: 2.4 GHz engine clock
 
 
 def parse_args():
@@ -97,16 +98,18 @@ def measured_traffic(kernel):
     return best
 
 
-def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms):
+def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms, lds_steps_per_ray=0.0):
     """The bounds that bind the traversal kernel, against peaks MEASURED on this chip (profiles/rNN_calibration.json):
-    node fetches per ns through the vector-memory pipeline (live: oracle visit counts x rays / HIP-event kernel time) and
-    VALU wave-instructions per us per SIMD (instruction count from the committed SQ counter pass / live kernel time)."""
+    node / triangle fetches per ns through the vector-memory pipeline (live: oracle visit counts x rays / HIP-event kernel
+    time; `lds_steps_per_ray` of them are served from the LDS image of the default mapping instead and are reported against
+    the LDS rate) and VALU wave-instructions per us per SIMD (instruction count from the committed SQ counter pass / live
+    kernel time)."""
     cal = latest_json("r*_calibration.json")
     if not cal:
         return None
     cal_name, cal = cal
     c = kernel_counters(kernel, ray_set)
-    fetches_per_ns = steps_per_ray * rays / (kernel_ms * 1e6)
+    fetches_per_ns = (steps_per_ray - lds_steps_per_ray) * rays / (kernel_ms * 1e6)
     if ray_set == "primary":
         peak, peak_kind = cal["node_fetch_peak_coherent"], "64-byte node per lane, neighbouring lanes share nodes, L1/L2-resident (vmem_peak 'coherent')"
     else:
@@ -115,7 +118,14 @@ def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms):
         peak = 1.0 / (hit / cal["node_fetch_peak_scattered_l2"] + (1.0 - hit) / cal["node_fetch_peak_scattered_mall"])
         peak_kind = f"64-byte node per lane, scattered: L2 rate x {hit:.3f} + MALL rate x {1 - hit:.3f} (measured TCC hit rate; vmem_peak 'scattered')"
     out = {"node_fetch": {"bound": "vector-memory pipeline (TA/L1/L2), node fetches", "unit": "fetches/ns", "achieved": round(fetches_per_ns, 2), "peak": round(peak, 2),
-                          "frac": round(fetches_per_ns / peak, 4), "peak_kind": peak_kind, "steps_per_ray": round(steps_per_ray, 3), "peak_source": cal_name}}
+                          "frac": round(fetches_per_ns / peak, 4), "peak_kind": peak_kind, "steps_per_ray": round(steps_per_ray - lds_steps_per_ray, 3), "peak_source": cal_name}}
+    if lds_steps_per_ray:
+        # MI355X_MICROARCH.md, LDS table: ds_read_b128 4 and ds_read_b64 2 LDS cycles per wave-instruction when conflict-free -> 3 x 4 + 2 per 64 node records
+        lds_peak = LDS_CLOCK_GHZ * cal["cus"] * 64 / 14.0
+        lds_per_ns = lds_steps_per_ray * rays / (kernel_ms * 1e6)
+        out["lds_fetch"] = {"bound": "LDS (top-of-tree image: 3 x ds_read_b128 + ds_read_b64 per node)", "unit": "fetches/ns", "achieved": round(lds_per_ns, 2),
+                            "peak": round(lds_peak, 1), "frac": round(lds_per_ns / lds_peak, 4), "steps_per_ray": round(lds_steps_per_ray, 3),
+                            "peak_kind": "conflict-free rate of the guide's LDS table at 2.4 GHz; distinct records on one bank quarter serialise"}
     if "SQ_INSTS_VALU" in c:
         per_simd_us = c["SQ_INSTS_VALU"] / (kernel_ms * 1e3) / cal["simds"]
         lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
@@ -323,6 +333,13 @@ def main():
         node_b, prim_b, algo = {2: (64, 48, "ref"), 4: (128, 224, "gpu"), 8: (256, 224, "gpu")}[width]
         ref_hits, st = O.traverse(width, nodes, tris, prim, algo=algo)
         ref_rnd, st_r = O.traverse(width, nodes, tris, rnd, algo=algo)
+        lds_p = lds_r = 0.0
+        if width == 2 and abi.variants(2)[variant] == "top" and n >= 8192 * 64:
+            # the share of the node visits that the default mapping serves from its LDS image (host restatement of the image's node set)
+            from rodent_amd import topimage
+            ids = topimage.image_nodes(nodes)
+            lds_p = float(O.node_visits(nodes, tris, prim)[ids].sum()) / len(prim)
+            lds_r = float(O.node_visits(nodes, tris, rnd)[ids].sum()) / len(rnd)
         bytes_per_ray = 32 + 16 + node_b * st["inner_per_ray"] + prim_b * st["prims_per_ray"]
         achieved = bytes_per_ray * n / (k_mean * 1e-3) / 1e9
         traffic = measured_traffic(kname)
@@ -333,9 +350,9 @@ def main():
                            "visits_per_ray": {"inner": round(st["inner_per_ray"], 3), "prim": round(st["prims_per_ray"], 3)},
                            "compulsory_bytes_per_ray": 48, "kernel_ms": round(k_mean, 5),
                            "hbm_measured": None if traffic is None else {"bytes_per_launch": traffic, "GBps": round(traffic / (k_mean * 1e-3) / 1e9, 1), "frac": round(traffic / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-                           "binding": binding_bounds(kname, "primary", n, st["inner_per_ray"] + st["prims_per_ray"], k_mean),
+                           "binding": binding_bounds(kname, "primary", n, st["inner_per_ray"] + st["prims_per_ray"], k_mean, lds_p),
                            "random": {"kernel_ms": round(kr_mean, 5), "visits_per_ray": {"inner": round(st_r["inner_per_ray"], 3), "prim": round(st_r["prims_per_ray"], 3)},
-                                      "binding": binding_bounds(kname, "random", len(rnd), st_r["inner_per_ray"] + st_r["prims_per_ray"], kr_mean)}}
+                                      "binding": binding_bounds(kname, "random", len(rnd), st_r["inner_per_ray"] + st_r["prims_per_ray"], kr_mean, lds_r)}}
         # parity on every ray of both sets (bit-exact for the order-preserving kernels)
         out["extra"]["all_rays_bit_exact_vs_oracle"] = {"primary": bool(hits.tobytes() == ref_hits.tobytes()), "random": bool(hits_rnd.tobytes() == ref_rnd.tobytes())}
     if world == 1 and not args.no_cpu_baseline:

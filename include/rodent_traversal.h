@@ -135,6 +135,10 @@ int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2, 4 or 8 
  * of fewer than this many rays (default 262 144: less than one round of resident waves); < 0 restores the default, 0 makes
  * every launch phased (tests). */
 void        rodent_hip_phased_min_rays(int32_t rays);
+/* The default BVH2 mapping ("top": top of the tree staged in LDS, persistent workgroups) takes the one-chunk-per-workgroup
+ * kernel ("fast") for launches of fewer than this many rays (default 524 288 = one round of resident waves: the per-launch
+ * image build does not pay below that); < 0 restores the default, 0 sends every launch through the LDS-image kernel (tests). */
+void        rodent_hip_top_min_rays(int32_t rays);
 int32_t     rodent_hip_is_lab_build(void);              /* 1 = librodent_hip_lab.so (-DRODENT_HIP_LAB: also the measured-and-lost kernels) */
 const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant);
 const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t any_hit);

@@ -96,6 +96,21 @@ def ray_steps(nodes, tris, rays, any_hit=False):
     return buf
 
 
+def node_visits(nodes, tris, rays, any_hit=False):
+    """Visit count of every inner node under B1 (BVH2/Tri1).  Analysis aid (scripts/model_top_levels.py)."""
+    rays = np.ascontiguousarray(rays)
+    buf = np.zeros(len(nodes), np.uint64)
+    l = lib()
+    l.oracle_set_node_visit_trace.restype = None
+    l.oracle_set_node_visit_trace.argtypes = [C.c_void_p]
+    l.oracle_set_node_visit_trace(_ptr(buf))
+    try:
+        traverse(2, nodes, tris, rays, any_hit=any_hit)
+    finally:
+        l.oracle_set_node_visit_trace(None)
+    return buf
+
+
 def brute_force(tris, rays):
     """Every ray against every triangle.  Returns (hits, second_t)."""
     tris = np.ascontiguousarray(tris)

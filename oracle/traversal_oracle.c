@@ -154,6 +154,10 @@ static inline void stats_merge(struct OracleStats* dst, const struct OracleStats
  * triangles it visited (2 x uint32 per ray).  Not thread-safe; NULL switches it off. */
 static uint32_t* g_ray_steps = 0;
 void oracle_set_ray_step_trace(uint32_t* buf) { g_ray_steps = buf; }
+/* Analysis aid (scripts/model_top_levels.py): when set, oracle_bvh2_tri1 counts the visits of every inner node
+ * (one uint64 per node).  Not thread-safe; NULL switches it off. */
+static uint64_t* g_node_visits = 0;
+void oracle_set_node_visit_trace(uint64_t* buf) { g_node_visits = buf; }
 
 int oracle_bvh2_tri1(const struct Node2* nodes, const struct Tri1* tris,
                      const struct Ray1* rays, struct Hit1* hits, int32_t n,
@@ -170,6 +174,7 @@ int oracle_bvh2_tri1(const struct Node2* nodes, const struct Tri1* tris,
         while (top != 0 && !done) {
             const struct Node2* nd = &nodes[top - 1];   /* top is NOT popped (:107-108) */
             st.inner_nodes++;
+            if (g_node_visits) g_node_visits[top - 1]++;
             int hk[2]; float te[2];
             for (int k = 0; k < 2; k++) {
                 const float* b = nd->bounds + 6 * k;

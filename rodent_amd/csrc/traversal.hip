@@ -28,6 +28,7 @@
 // Kernel variants ("mappings") are selected at run time; see kVariants below.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -100,6 +101,9 @@ __device__ __forceinline__ int node2_step(const Node2* __restrict__ nodes, int t
     return h0 ? ch.x : ch.y;
 }
 
+constexpr int kMaxTopNodes = 1024;       // capacity of a launch context's top-of-tree image buffer
+constexpr int kLdsTag = 0x40000000;      // node ids from here on: byte offset into the LDS top-of-tree image (k_bvh2_top)
+
 // Launch control block in device memory (zero between launches).
 struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; };
 
@@ -119,9 +123,9 @@ struct GlobalStack {
 };
 
 template <bool ANY>
-__global__ __launch_bounds__(kWave) void k_bvh2_finish(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
-                                                        const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
-                                                        Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* phase_counters) {
+__device__ __forceinline__ void finish_launch(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                              const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
+                                              Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* phase_counters) {
     // behind the last phase of a phased launch: the stripe counters are zero again for the next launch on this stream
     if (phase_counters) for (int k = threadIdx.x; k < 4 * 64; k += kWave) phase_counters[k * 16] = 0;
     const int count = ctl->deep_count;
@@ -145,6 +149,13 @@ __global__ __launch_bounds__(kWave) void k_bvh2_finish(const Node2* __restrict__
         }
     }
     if (threadIdx.x == 0) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; }   // stats[7]: rays handed over (read by the tests); ready for the next launch
+}
+
+template <bool ANY>
+__global__ __launch_bounds__(kWave) void k_bvh2_finish(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                        const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
+                                                        Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* phase_counters) {
+    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, phase_counters);
 }
 
 // Single-step schedule (the default "fast" variant).  Every lane advances by ONE step per wave iteration,
@@ -186,20 +197,33 @@ __device__ __forceinline__ Bases make_bases(const Node2* nodes, const Tri1* tris
 // PF (lab): when `prefetch` is set (wave-uniform), a node lane touches both children's records (one dword each, loaded
 // straight into a dummy LDS row: no register, nothing waits for it) as soon as their ids have arrived, so that the next
 // iteration's fetch of the chosen child finds its line in L1 or already on its way -- the slab tests overlap the round trip.
-template <bool ANY, bool PF = false>
+// TOP: the launch's top-of-tree image is staged in LDS (k_bvh2_top): a node id >= kLdsTag is the byte offset of a 64-byte
+// record inside `image` (same layout as Node2, child ids of resident children rewritten the same way), fetched with
+// ds_read_b128 instead of through the texture path.
+template <bool ANY, bool PF = false, bool TOP = false>
 __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __restrict__ hits, lds_int* sp_limit, Ctl* ctl, int* __restrict__ deep_list,
-                                          bool prefetch = false, lds_int* pf_row = nullptr) {
+                                          bool prefetch = false, lds_int* pf_row = nullptr, lds_int* image = nullptr) {
     const bool is_node = L.top > 0;
-    // one address for both kinds: base + index * stride with per-lane selected operands (straight-line code)
-    const unsigned idx = (unsigned)(is_node ? L.top : ~L.top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x2 __attribute__((ext_vector_type(2)));
-    const gptr addr = (is_node ? base.node : base.tri) + (size_t)idx * stride;
-    const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
-    f32x4 q0 = p[0], q1 = p[1], q2 = p[2];
-    // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
-    // inside the array
-    i32x2 ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
+    f32x4 q0, q1, q2;
+    i32x2 ch;
+    if (TOP && L.top >= kLdsTag) {
+        typedef __attribute__((address_space(3))) const char* lds_bytes;
+        const lds_bytes rec = (lds_bytes)image + (unsigned)(L.top - kLdsTag);
+        const __attribute__((address_space(3))) f32x4* p = (const __attribute__((address_space(3))) f32x4*)rec;
+        q0 = p[0]; q1 = p[1]; q2 = p[2];
+        ch = *(const __attribute__((address_space(3))) i32x2*)(rec + 48);
+    } else {
+        // one address for both kinds: base + index * stride with per-lane selected operands (straight-line code)
+        const unsigned idx = (unsigned)(is_node ? L.top : ~L.top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
+        const gptr addr = (is_node ? base.node : base.tri) + (size_t)idx * stride;
+        const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
+        q0 = p[0]; q1 = p[1]; q2 = p[2];
+        // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
+        // inside the array
+        ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
+    }
     const int popped = *L.sp;
     // All four loads must be in flight together: without this barrier the compiler narrows the shared loads to
     // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
@@ -434,6 +458,249 @@ __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-staged top of the tree (variants "top*").  A third to a half of all node visits fall on the top 4 - 8 levels of the
+// hierarchy (scripts/model_top_levels.py: atrium, 15 nodes 22 %, 63 nodes 41 / 38 %, 255 nodes 52 / 57 % of the visits of the
+// primary / random set).  k_bvh2_top_image copies the first TOPN nodes in breadth-first order into a 64-byte-per-node image
+// whose child ids, where the child is in the image too, are kLdsTag + its byte offset; every workgroup of k_bvh2_top stages
+// the image in LDS behind its stacks and a lane whose top is such an id reads its node with ds_read_b128 -- LDS bandwidth
+// instead of the TA -> L1 path the kernel saturates.  The caller's Node2 array is in no particular order and
+// may change between launches, so the image is rebuilt by every launch (one wave, one dependent load per level).
+// Ids with the tag never leave the kernel: a ray deeper than the LDS window restarts from the root in k_bvh2_finish.
+// ---------------------------------------------------------------------------------------------
+// One wave.  Record layout: ints 0..11 bounds, 12..13 child ids / links, 14 = the node's own 1-based id (0: slot unused), 15 = 0.
+__device__ __forceinline__ void build_top_image(const Node2* __restrict__ nodes, int4* __restrict__ image, int capacity) {
+    __shared__ int slot_node[kMaxTopNodes];                           // 1-based node id held by each slot
+    const int lane = threadIdx.x;
+    if (lane == 0) slot_node[0] = 1;
+    __syncthreads();
+    int begin = 0, end = 1;                                           // slots of the current level
+    while (begin < end) {
+        int next = end;
+        for (int first = begin; first < end; first += kWave) {
+            const int slot = first + lane;
+            const bool on = slot < end;
+            int4 r0 = {}, r1 = {}, r2 = {}, r3 = {};
+            if (on) { const int4* p = reinterpret_cast<const int4*>(nodes + (slot_node[slot] - 1)); r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3]; }
+            const bool in0 = on && r3.x > 0, in1 = on && r3.y > 0;   // inner children (r3.x / r3.y = Node2::child)
+            const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1), below = (1ull << lane) - 1ull;
+            const int s0 = next + __popcll(m0 & below), s1 = next + __popcll(m0) + __popcll(m1 & below);
+            if (in0 && s0 < capacity) { slot_node[s0] = r3.x; r3.x = kLdsTag + s0 * (int)sizeof(Node2); }
+            if (in1 && s1 < capacity) { slot_node[s1] = r3.y; r3.y = kLdsTag + s1 * (int)sizeof(Node2); }
+            next = min(capacity, next + __popcll(m0) + __popcll(m1));
+            if (on) { r3.z = slot_node[slot]; r3.w = 0; int4* q = image + 4 * slot; q[0] = r0; q[1] = r1; q[2] = r2; q[3] = r3; }
+        }
+        __syncthreads();
+        begin = end; end = next;
+    }
+    for (int slot = end + lane; slot < capacity; slot += kWave) image[4 * slot + 3] = int4{0, 0, 0, 0};       // unused slots
+}
+template <int TOPN>
+__global__ __launch_bounds__(kWave) void k_bvh2_top_image(const Node2* __restrict__ nodes, int4* __restrict__ image) { build_top_image(nodes, image, TOPN); }
+
+// The follow-up kernel of the persistent form: k_bvh2_finish's work, plus the image for the NEXT launch when this launch found
+// none or a stale one (ctl->reserved, set by any workgroup whose validation failed).
+template <bool ANY>
+__global__ __launch_bounds__(kWave) void k_bvh2_top_finish(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                            const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
+                                                            Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* tickets,
+                                                            int4* __restrict__ image, int capacity) {
+    const bool stale = ctl->reserved != 0;
+    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, tickets);
+    if (stale) {
+        build_top_image(nodes, image, capacity);
+        if (threadIdx.x == 0) ctl->reserved = 0;
+    }
+}
+
+template <bool ANY, int LDS_N, int XCD, int TOPN, int WAVES>
+__global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                             const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                             Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm,
+                                                             const int4* __restrict__ top_image) {
+    constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave;
+    static_assert((kStackInts + TOPN * 16) * 4 * (32 / WAVES) <= 160 * 1024, "32 waves per CU must fit their stacks and images in LDS");
+    static_assert(XCD % WAVES == 0, "a workgroup's chunks stay inside one XCD group");
+    __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
+    lds_int* image = (lds_int*)lds_raw + kStackInts;
+    // the image first (in flight while the ray is loaded and set up)
+    constexpr int kStage = (TOPN * 4 + kWave * WAVES - 1) / (kWave * WAVES);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 stage[kStage];
+#pragma unroll
+    for (int k = 0; k < kStage; k++) { const int j = k * kWave * WAVES + (int)threadIdx.x; if (j < TOPN * 4) stage[k] = reinterpret_cast<const i32x4*>(top_image)[j]; }
+    const int total_chunks = (n + kWave - 1) / kWave;
+    int chunk = blockIdx.x * WAVES + wave;
+    if (XCD > 0) {
+        const int span = 8 * XCD, full = (total_chunks / span) * span;        // region where the mapping is a bijection
+        if ((int)blockIdx.x * WAVES < full) {
+            const int x = blockIdx.x % 8, l = (blockIdx.x / 8) * WAVES + wave;
+            chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
+        }
+    }
+    const int first_ray = chunk * kWave, lane_ray = first_ray + lane;
+    const bool live_chunk = first_ray < n;                                   // (whole waves beyond the last chunk only help with the image)
+    Lane L = start_lane(rays, hits, live_chunk && lane_ray < n ? (perm ? perm[lane_ray] : lane_ray) : -1, live_chunk ? (perm ? perm[first_ray] : first_ray) : 0, col);
+    if (L.top != 0) L.top = kLdsTag;                                         // the root is record 0 of the image
+#pragma unroll
+    for (int k = 0; k < kStage; k++) {
+        const int j = k * kWave * WAVES + (int)threadIdx.x;
+        if (j < TOPN * 4) reinterpret_cast<__attribute__((address_space(3))) i32x4*>(image)[j] = stage[k];
+    }
+    if (WAVES > 1) __syncthreads();
+    lds_int* const sp_limit = col + LDS_N * kWave;
+    const Bases base = make_bases(nodes, tris);
+    while (__ballot(L.top != 0)) {
+        if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+    }
+}
+
+// Stages the context's image into LDS and checks it against the caller's nodes: every record must equal the node whose id it
+// carries (bounds bit for bit; a child entry either the node's own child id or a link to a slot that carries that id) and
+// record 0 must be the root.  Then following links through the image is the same as following child ids through `nodes`,
+// whatever happened to the array since the image was built.  Returns false (workgroup-uniform) for an absent or stale image:
+// the workgroup then starts its rays at node id 1 and never meets a link; ctl->reserved asks the follow-up kernel for a new image.
+// `max_id`: node ids the caller's allocation is known to hold (the host asks the runtime for the mapped range behind `nodes`):
+// a record whose id lies beyond it is stale, and is not dereferenced.
+template <int TOPN, int THREADS>
+__device__ __forceinline__ bool stage_top_image(const Node2* __restrict__ nodes, const int4* __restrict__ top_image, lds_int* image, lds_int* flag, Ctl* ctl, int max_id) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    bool ok = true;
+    const int* image_ints = reinterpret_cast<const int*>(top_image);
+    for (int j = threadIdx.x; j < TOPN * 4; j += THREADS) {
+        const int slot = j >> 2, quarter = j & 3, id = image_ints[slot * 16 + 14];
+        const i32x4 rec = reinterpret_cast<const i32x4*>(top_image)[j];
+        reinterpret_cast<__attribute__((address_space(3))) i32x4*>(image)[j] = rec;
+        if (id > max_id) ok = false;
+        else if (id > 0) {
+            const i32x4 real = reinterpret_cast<const i32x4*>(nodes + (id - 1))[quarter];
+            if (quarter < 3) ok &= rec.x == real.x && rec.y == real.y && rec.z == real.z && rec.w == real.w;
+            else ok &= (rec.x >= kLdsTag || rec.x == real.x) && (rec.y >= kLdsTag || rec.y == real.y);     // links: after the barrier
+        } else if (slot == 0) ok = false;
+        if (j == 0) ok &= id == 1;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < TOPN * 4; j += THREADS) {
+        if ((j & 3) != 3) continue;
+        const int slot = j >> 2, id = image[slot * 16 + 14];
+        if (id <= 0 || id > max_id) continue;
+        const int2 real = *reinterpret_cast<const int2*>(&nodes[id - 1].child[0]);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int link = image[slot * 16 + 12 + k], child = k ? real.y : real.x;
+            if (link >= kLdsTag) {
+                const unsigned target = (unsigned)(link - kLdsTag) / (unsigned)sizeof(Node2);
+                ok &= (link - kLdsTag) % (int)sizeof(Node2) == 0 && target < (unsigned)TOPN && child > 0 && image[(target < (unsigned)TOPN ? target : 0u) * 16 + 14] == child;
+            }
+        }
+    }
+    // the verdict through one LDS word (`flag`: any word the caller does not need yet; __syncthreads_and would take 256 bytes of
+    // LDS of its own, and two 16-wave workgroups fill the CU's 160 KB to within 128 bytes)
+    if (threadIdx.x == 0) *flag = 1;
+    __syncthreads();
+    if (!ok) *flag = 0;
+    __syncthreads();
+    const bool all_ok = *flag != 0;
+    __syncthreads();
+    if (!all_ok && threadIdx.x == 0) ctl->reserved = 1;
+    return all_ok;
+}
+
+// Persistent form: the grid is one generation of workgroups (32 / WAVES per CU), every workgroup stages the image once and
+// its waves keep drawing 64-ray chunks -- a ticket from the counter of their stripe (64 counters, 64 bytes apart: one counter
+// saturates near 88 atomics/us, a 1 Mi-ray launch draws 83 per us), ticket t of stripe s = chunk ((t / 32) * 64 + s) * 32 + t % 32,
+// the same XCD-aware order as k_bvh2_single (stripe s runs on XCD s % 8) -- until their stripe's share is used up.  No workgroup waits for LDS that a
+// finished neighbour wave still pins (what makes WAVES > 2 lose at 16 Mi rays in the non-persistent form), the image is
+// staged 512 times per launch instead of 16 384 times, and the next ticket is drawn while the current chunk is traced.
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int OCC = 32>
+__global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_persist(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                                     const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                                     Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm,
+                                                                     const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id) {
+    constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroup = 32;
+    static_assert((kStackInts + TOPN * 16) * 4 * (OCC / WAVES) <= 160 * 1024, "OCC waves per CU must fit their stacks and images in LDS");
+    __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
+    lds_int* image = (lds_int*)lds_raw + kStackInts;
+    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;      // record 0 of the image, or node 1
+    if (root != 1 && threadIdx.x == 0) atomicAdd(&ctl->stats[6], 1ull);     // stats[6]: workgroups that ran on the image (read by the tests)
+    // stripe = workgroup index mod 64 (its XCD = stripe mod 8); the first ticket of a wave is its rank inside the stripe, the
+    // counter hands out the tickets behind those
+    const int total_chunks = (n + kWave - 1) / kWave, stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
+    int* counter = tickets + stripe * kCounterStride;
+    int t = (blockIdx.x / kStripes) * WAVES + wave;
+    lds_int* const sp_limit = col + LDS_N * kWave;
+    const Bases base = make_bases(nodes, tris);
+    for (;;) {
+        const int group_first = ((t / kGroup) * kStripes + stripe) * kGroup, chunk = group_first + t % kGroup;
+        if (group_first >= total_chunks) break;                              // this stripe's share is used up
+        int t_next = 0;
+        if (PREFETCH && lane == 0) t_next = atomicAdd(counter, 1);           // in flight while this chunk is traced
+        if (chunk < total_chunks) {
+            const int first_ray = chunk * kWave, lane_ray = first_ray + lane;
+            Lane L = start_lane(rays, hits, lane_ray < n ? (perm ? perm[lane_ray] : lane_ray) : -1, perm ? perm[first_ray] : first_ray, col);
+            if (L.top != 0) L.top = root;
+            while (__ballot(L.top != 0)) {
+                if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+            }
+        }
+        if (!PREFETCH && lane == 0) t_next = atomicAdd(counter, 1);
+        t = stripe_waves + __builtin_amdgcn_readfirstlane(t_next);
+    }
+}
+
+// Persistent form with lane refill: a wave does not wait for the last ray of a 64-ray chunk.  As soon as REFILL of its lanes
+// are idle it draws that many rays from its stripe's counter (one atomic per refill) and starts them in the idle lanes; the
+// rest keep stepping.  Ticket t of stripe s is ray ((t / 2048) * 64 + s) * 2048 + t % 2048 (the same 32-chunk groups), the first
+// 64 tickets of a wave are static.  Which rays share a wave changes, what a ray visits does not.
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL>
+__global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                                    const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                                    Ctl* ctl, int* __restrict__ deep_list, const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id) {
+    constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroupRays = 32 * kWave;
+    static_assert((kStackInts + TOPN * 16) * 4 * (32 / WAVES) <= 160 * 1024, "32 waves per CU must fit their stacks and images in LDS");
+    __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
+    lds_int* image = (lds_int*)lds_raw + kStackInts;
+    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;
+    const int stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
+    int* counter = tickets + stripe * kCounterStride;
+    const auto ray_of = [&](int t) { return ((t / kGroupRays) * kStripes + stripe) * kGroupRays + t % kGroupRays; };
+    lds_int* const sp_limit = col + LDS_N * kWave;
+    const Bases base = make_bases(nodes, tris);
+    Lane L;
+    {
+        const int r = ray_of(((blockIdx.x / kStripes) * WAVES + wave) * kWave + lane);
+        L = start_lane(rays, hits, r < n ? r : -1, 0, col);
+        if (L.top != 0) L.top = root;
+    }
+    bool more = true;                                                        // wave-uniform: the stripe may have rays left
+    for (;;) {
+        const unsigned long long live = __ballot(L.top != 0);
+        if (more && __popcll(live) <= kWave - REFILL) {
+            const int want = kWave - __popcll(live);
+            int first = 0;
+            if (lane == 0) first = atomicAdd(counter, want);
+            first = stripe_waves * kWave + __builtin_amdgcn_readfirstlane(first);
+            more = ray_of(first) < n;                                            // ray_of grows with the ticket: once past the end, always past the end
+            if (L.top == 0) {
+                const int r = ray_of(first + __popcll(~live & ((1ull << lane) - 1ull)));
+                if (r < n) {
+                    L = start_lane(rays, hits, r, r, col);
+                    L.top = root;
+                }
+            }
+            continue;
+        }
+        if (live == 0) break;
+        if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Ray sorting for incoherent ray sets (BASELINE config 3: "ray compaction/sorting on"; variant "sorted").
 // 3.1's counters say what a set of random segments waits for: every lane fetches its own 64-byte node, 85 % from L2 and 15 %
 // from the Infinity Cache, at 97.5 % of what that path delivers.  Only coherence moves that roofline: the same rays
@@ -526,6 +793,9 @@ struct DeviceState {
     int*  qcount = nullptr;                    // [phase][stripe] suspended-ray counters, 64 bytes apart
     int*  sort_perm = nullptr; unsigned short* sort_keys = nullptr; int sort_cap = 0;     // "sorted" mapping: permutation and cell keys
     int*  sort_totals = nullptr;               // [0, 512) cell counts (zero between launches), [512, 1024) cell cursors
+    int4* top_image = nullptr;                 // "top*" mappings: kMaxTopNodes x 64 bytes, rebuilt by every launch
+    const Node2* top_image_nodes = nullptr; int top_image_n = 0;
+    int*  tickets = nullptr;                   // persistent "top*p" mappings: chunk tickets per XCD (zero between launches)
     Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
 };
 // One DeviceState per (device, stream): launches enqueued on different streams of a device may overlap, so each
@@ -637,12 +907,106 @@ void check_error_flag(DeviceState& s, hipStream_t stream) {
     if (read_and_clear_error_flags(s, stream)) { fprintf(stderr, "rodent_hip: traversal stack overflow (more than %d entries)\n", kStackCap); abort(); }
 }
 
+// How many Node2 records the mapped range behind `nodes` can hold (0 when the runtime does not know the pointer): the bound
+// inside which the persistent kernel may dereference the ids of an image built by an earlier launch.
+int mapped_node_ids(const Node2* nodes) {
+    hipDeviceptr_t range_base = nullptr; size_t range_size = 0;
+    if (hipMemGetAddressRange(&range_base, &range_size, (hipDeviceptr_t)nodes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const size_t bytes = (size_t)((const char*)range_base + range_size - (const char*)nodes);
+    return (int)std::min<size_t>(bytes / sizeof(Node2), 0x3FFFFFFF);
+}
+
 #define LAUNCH_ARGS DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
 
 template <bool ANY, int LDS_N, int XCD, bool TR = false, int PRIO = 0> void L_single(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR, PRIO>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
+}
+
+// "top*": top-of-tree image per launch, then k_bvh2_top (SORTED: through the "sorted" mapping's permutation)
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool SORTED = false, bool KEEP = false> void L_top(LAUNCH_ARGS) {
+    ensure_deep_list(s, n);
+    if (!s.top_image) {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (!s.top_image) HIP_CHECK(hipMalloc(&s.top_image, kMaxTopNodes * sizeof(Node2)));
+    }
+    static_assert(TOPN <= kMaxTopNodes, "image buffer");
+    // KEEP (measurement only): the image is reused while the array pointer and the image size stay the same -- shows what the
+    // per-launch rebuild costs
+    if (!KEEP || s.top_image_nodes != nodes || s.top_image_n != TOPN) {
+        hipLaunchKernelGGL((k_bvh2_top_image<TOPN>), dim3(1), dim3(kWave), 0, stream, nodes, s.top_image);
+        s.top_image_nodes = nodes; s.top_image_n = TOPN;
+    }
+    const int* perm = nullptr;
+    if (SORTED) {
+        ensure_sort_buffers(s, n);
+        const int blocks = (n + kSortBlockRays - 1) / kSortBlockRays;
+        hipLaunchKernelGGL(k_raysort_count, dim3(blocks), dim3(kSortThreads), 0, stream, nodes, rays, n, s.sort_keys, s.sort_totals);
+        hipLaunchKernelGGL(k_raysort_scan, dim3(1), dim3(kSortCells), 0, stream, s.sort_totals, s.sort_totals + kSortCells);
+        hipLaunchKernelGGL(k_raysort_scatter, dim3(blocks), dim3(kSortThreads), 0, stream, s.sort_keys, n, s.sort_totals + kSortCells, s.sort_perm);
+        perm = s.sort_perm;
+    }
+    const int groups = (blocks_for(n) + WAVES - 1) / WAVES;
+    hipLaunchKernelGGL((k_bvh2_top<ANY, LDS_N, 32, TOPN, WAVES>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, perm,
+                       (const int4*)s.top_image);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
+}
+
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, int OCC> void launch_top_persist(LAUNCH_ARGS, int max_id) {
+    ensure_deep_list(s, n);
+    if (!s.top_image || !s.tickets) {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (!s.top_image) { HIP_CHECK(hipMalloc(&s.top_image, kMaxTopNodes * sizeof(Node2))); HIP_CHECK(hipMemset(s.top_image, 0, kMaxTopNodes * sizeof(Node2))); }
+        if (!s.tickets) {
+            HIP_CHECK(hipMalloc(&s.tickets, sizeof(int) * kMaxPhases * kStripes * kCounterStride));      // the size k_bvh2_finish clears
+            HIP_CHECK(hipMemset(s.tickets, 0, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
+        }
+    }
+    s.top_image_nodes = nullptr;
+    const int* perm = nullptr;
+    if (SORTED) {
+        ensure_sort_buffers(s, n);
+        const int blocks = (n + kSortBlockRays - 1) / kSortBlockRays;
+        hipLaunchKernelGGL(k_raysort_count, dim3(blocks), dim3(kSortThreads), 0, stream, nodes, rays, n, s.sort_keys, s.sort_totals);
+        hipLaunchKernelGGL(k_raysort_scan, dim3(1), dim3(kSortCells), 0, stream, s.sort_totals, s.sort_totals + kSortCells);
+        hipLaunchKernelGGL(k_raysort_scatter, dim3(blocks), dim3(kSortThreads), 0, stream, s.sort_keys, n, s.sort_totals + kSortCells, s.sort_perm);
+        perm = s.sort_perm;
+    }
+    const int groups = ((s.num_cus * (OCC / WAVES) + kStripes - 1) / kStripes) * kStripes;   // one resident generation, the same number in every stripe
+    hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, OCC>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+                       perm, (const int4*)s.top_image, s.tickets, max_id);
+    hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
+}
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool SORTED = false, int OCC = 32> void L_top_persist(LAUNCH_ARGS) {
+    launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, SORTED, OCC>(s, nodes, tris, rays, hits, n, stream, mapped_node_ids(nodes));
+}
+
+// The default mapping: launches that fill the chip at least once take the persistent kernel with the LDS image, smaller ones
+// the single kernel (256 Ki rays: 0.098 ms against 0.122 ms -- staging and validating the image does not pay yet), and so do
+// launches whose node array the runtime cannot give a mapped range for (nothing bounds the ids of an older image then).
+int g_top_min_rays = 8192 * kWave;              // rodent_hip_top_min_rays()
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH> void L_default(LAUNCH_ARGS) {
+    const int max_id = n < g_top_min_rays ? 0 : mapped_node_ids(nodes);
+    if (max_id == 0) L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream);
+    else launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, false, 32>(s, nodes, tris, rays, hits, n, stream, max_id);
+}
+
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL> void L_top_refill(LAUNCH_ARGS) {
+    ensure_deep_list(s, n);
+    if (!s.top_image || !s.tickets) {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (!s.top_image) { HIP_CHECK(hipMalloc(&s.top_image, kMaxTopNodes * sizeof(Node2))); HIP_CHECK(hipMemset(s.top_image, 0, kMaxTopNodes * sizeof(Node2))); }
+        if (!s.tickets) {
+            HIP_CHECK(hipMalloc(&s.tickets, sizeof(int) * kMaxPhases * kStripes * kCounterStride));      // the size k_bvh2_finish clears
+            HIP_CHECK(hipMemset(s.tickets, 0, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
+        }
+    }
+    s.top_image_nodes = nullptr;
+    const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;
+    hipLaunchKernelGGL((k_bvh2_top_refill<ANY, LDS_N, TOPN, WAVES, REFILL>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+                       (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes));
+    hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 
 // Phased traversal: caps of the capped phases (the last, uncapped phase follows).  Launches too small to fill the chip
@@ -690,13 +1054,41 @@ struct Variant2 { const char* name; const char* kernel[2]; Launch2 launch[2]; };
 const Variant2 kVariants2[] = {
     // 0 = default (used by the reference-named entry points).  All variants keep the reference's per-ray
     // visit order and are bit-identical; they differ in how a wavefront schedules its 64 rays.
+    //                                                              LDS_N TOPN WAVES PREFETCH
+    K2("top",                "k_bvh2_top_persist",   L_default, 15, 255, 16, false),   // default: LDS-staged top of the tree (255 nodes), persistent 16-wave workgroups
+                                                                                       // (launches under rodent_hip_top_min_rays: k_bvh2_single)
     //                                                        LDS_N XCD_GROUP
-    K2("fast",               "k_bvh2_single",        L_single, 16, 32),                // default: single-step schedule, XCD-aware 32-chunk groups
+    K2("fast",               "k_bvh2_single",        L_single, 16, 32),                // single-step schedule, one 64-ray chunk per workgroup, XCD-aware 32-chunk groups (default of rounds 1-2)
     K2("fast-noxcd",         "k_bvh2_single",        L_single, 16, 0),                 // same kernel, workgroup b traces chunk b
     //                                                       LDS_N CAPS (index into kPhaseCaps) [LAST_RAYS]
     K2("phased",             "k_bvh2_phase",         L_phased, 16, 2),                 // phased traversal with ray compaction: one capped phase of 40 iterations, then the rest
     K2("sorted",             "k_bvh2_single",        L_sorted, 16),                    // rays grouped by the Morton cell of their origin first (for incoherent ray sets)
 #ifdef RODENT_HIP_LAB
+    // LDS-staged top of the tree, what was swept (profiles/r02_sweep_top_*.log): image size x workgroup shape, one chunk per
+    // workgroup wave (L_top) or persistent (L_top_persist), ticket prefetch, waves per CU, lane refill
+    //                                                      LDS_N TOPN WAVES [SORTED KEEP]
+    K2("top15",              "k_bvh2_top",           L_top, 15, 15, 1),
+    K2("top31w2",            "k_bvh2_top",           L_top, 15, 31, 2),
+    K2("top63w4",            "k_bvh2_top",           L_top, 15, 63, 4),
+    K2("top127w8",           "k_bvh2_top",           L_top, 15, 127, 8),
+    K2("top255w16",          "k_bvh2_top",           L_top, 15, 255, 16),
+    K2("top23",              "k_bvh2_top",           L_top, 13, 23, 1),
+    K2("top15-keep",         "k_bvh2_top",           L_top, 15, 15, 1, false, true),
+    K2("top127w8-keep",      "k_bvh2_top",           L_top, 15, 127, 8, false, true),
+    K2("sorted-top63w4",     "k_bvh2_top",           L_top, 15, 63, 4, true),
+    //                                                                     LDS_N TOPN WAVES PREFETCH [SORTED waves per CU]
+    K2("top255p16-pf",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, true),
+    K2("top127p8",           "k_bvh2_top_persist",   L_top_persist, 15, 127, 8, false),
+    K2("top63p4",            "k_bvh2_top_persist",   L_top_persist, 15, 63, 4, false),
+    K2("top15p1",            "k_bvh2_top_persist",   L_top_persist, 15, 15, 1, false),
+    K2("sorted-top255p16",   "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, true),
+    K2("top255p16-o16",      "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 16),
+    K2("top1023p16-o16",     "k_bvh2_top_persist",   L_top_persist, 15, 1023, 16, false, false, 16),
+    K2("top255p8-o24",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 8, false, false, 24),
+    K2("top63p4-o28",        "k_bvh2_top_persist",   L_top_persist, 15, 63, 4, false, false, 28),
+    //                                                                    LDS_N TOPN WAVES REFILL (idle lanes that trigger a refill)
+    K2("top255r16-32",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 32),
+    K2("top255r16-48",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 48),
     // what was swept on the way (profiles/r02_sweep_phased*.log, r02_sweep_prio.log): other phase caps, fewer rays per wave in
     // the last phase, issue priorities by wave age / dispatch round
     K2("phased-40-24",       "k_bvh2_phase",         L_phased, 16, 0),
@@ -886,6 +1278,7 @@ const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t a
     return variant >= 0 && variant < count ? t[variant].kernel[any_hit ? 1 : 0] : "";
 }
 void rodent_hip_phased_min_rays(int32_t rays) { g_phased_min_rays = rays < 0 ? 4096 * kWave : rays; }
+void rodent_hip_top_min_rays(int32_t rays) { g_top_min_rays = rays < 0 ? 8192 * kWave : rays; }
 int32_t rodent_hip_is_lab_build(void) {
 #ifdef RODENT_HIP_LAB
     return 1;

@@ -15,6 +15,8 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--widths", default="2,4,8")
 ap.add_argument("--all-variants", action="store_true")
 ap.add_argument("--big", action="store_true", help="also 16 Mi primary rays per launch")
+ap.add_argument("--mid", action="store_true", help="also 256 Ki, 2 Mi and 4 Mi primary rays per launch")
+ap.add_argument("--only", default=None, help="comma-separated variant names")
 ap.add_argument("--scene", default="atrium")
 a = ap.parse_args()
 
@@ -26,6 +28,10 @@ sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0)
         "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
 if a.big:
     sets["primary16Mi"] = raygen.primary_rays(eye, d, up, fov, 4096, 4096, 0.0, 5000.0)
+if a.mid:
+    sets["primary256Ki"] = raygen.primary_rays(eye, d, up, fov, 512, 512, 0.0, 5000.0)
+    sets["primary2Mi"] = raygen.primary_rays(eye, d, up, fov, 2048, 1024, 0.0, 5000.0)
+    sets["primary4Mi"] = raygen.primary_rays(eye, d, up, fov, 2048, 2048, 0.0, 5000.0)
 dev = {k: abi.to_device(v, 0) for k, v in sets.items()}
 
 
@@ -50,6 +56,8 @@ for width in [int(x) for x in a.widths.split(",")]:
     names = abi.variants(width)
     base = {}
     for v in (range(len(names)) if a.all_variants else [0]):
+        if a.only and v != 0 and names[v] not in a.only.split(","):
+            continue
         cols, anycols, ok = [], [], True
         for k in sets:
             ms, h = timed(bvh, k, False, v)

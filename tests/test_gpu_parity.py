@@ -31,8 +31,10 @@ def gpu(native_build):
     from rodent_amd import abi
     assert torch.cuda.is_available(), "these tests need a GPU"
     abi.lib().rodent_hip_phased_min_rays(0)       # the phased mappings suspend and resume rays at every launch size in this module
+    abi.lib().rodent_hip_top_min_rays(0)          # ... and the default mapping takes its LDS-image kernel, not the small-launch kernel
     yield abi
     abi.lib().rodent_hip_phased_min_rays(-1)
+    abi.lib().rodent_hip_top_min_rays(-1)
 
 
 @pytest.fixture(scope="module")
@@ -96,8 +98,8 @@ def test_ragged_sizes(gpu, cornell, cornell_dev, width, n):
 
 @pytest.mark.parametrize("n", [8192 * 64 + 16384, 600_000, (1 << 20) + 12345, 3 << 20])
 def test_chunk_mapping_is_a_bijection(gpu, cornell, cornell_dev, n):
-    """The default kernel maps workgroups to ray chunks XCD-aware (k_bvh2_single): every chunk must be traced exactly
-    once at sizes with ragged tails and several dispatch rounds; the hit buffer starts as 0xFF."""
+    """The kernels map workgroups (k_bvh2_single) / tickets (k_bvh2_top_persist, the default) to ray chunks XCD-aware: every
+    chunk must be traced exactly once at sizes with ragged tails and several dispatch rounds; the hit buffer starts as 0xFF."""
     import torch
     names = gpu.variants(2)
     base = cornell.ray_sets["primary"]
@@ -105,12 +107,12 @@ def test_chunk_mapping_is_a_bijection(gpu, cornell, cornell_dev, n):
     rays["org"][:, 0] += (np.arange(n, dtype=np.float32) % 977) * 1e-4          # not all copies identical
     rd = gpu.to_device(rays, 0)
     out = {}
-    for name in ("fast", "fast-noxcd"):
+    for name in ("top", "fast", "fast-noxcd"):
         hd = torch.full((n * 16,), 0xFF, dtype=torch.uint8, device="cuda:0")
         gpu.traverse_async(cornell_dev[2], rd, hd, n, False, names.index(name))
         torch.cuda.synchronize()
         out[name] = gpu.from_device(hd, F.HIT1)
-    assert out["fast"].tobytes() == out["fast-noxcd"].tobytes()
+    assert out["fast"].tobytes() == out["fast-noxcd"].tobytes() and out["top"].tobytes() == out["fast"].tobytes()
     assert (out["fast"]["tri_id"] >= -1).all() and (out["fast"]["tri_id"] < 64).all()
     for width in (4, 8):                                       # the wide kernels use the same mapping
         wn = gpu.variants(width)
@@ -381,3 +383,4 @@ def test_stack_overflow_is_reported_not_silent(gpu, oracle):
     ref, st = oracle.traverse(2, ok_nodes, ok_tris, rays)
     assert st["max_stack"] == 60
     assert gpu.traverse(ok, rays, variant=0).tobytes() == ref.tobytes()
+

@@ -160,6 +160,7 @@ def test_hip_kernels_on_reference_built_hierarchies(native_build, oracle, refbui
     rays = np.concatenate([scene_rays(n4, 50000, 3, 1.0, t1), scene_rays(n4, 50000, 4, 5000.0, t1)])     # unit segments and long rays
     bvh = abi.DeviceBvh(width, nodes, tris, 0)
     abi.lib().rodent_hip_phased_min_rays(0)
+    abi.lib().rodent_hip_top_min_rays(0)
     try:
         for any_hit in (False, True):
             ref, st = oracle.traverse(width, nodes, tris, rays, any_hit=any_hit, algo=algo)
@@ -169,3 +170,55 @@ def test_hip_kernels_on_reference_built_hierarchies(native_build, oracle, refbui
                 assert got.tobytes() == ref.tobytes(), (name, width, abi.variants(width)[v], any_hit)
     finally:
         abi.lib().rodent_hip_phased_min_rays(-1)
+        abi.lib().rodent_hip_top_min_rays(-1)
+
+
+@pytest.mark.gpu
+def test_lds_image_follows_the_callers_nodes(native_build, oracle, refbuilt, intree):
+    """The default mapping keeps an image of the top of the tree from launch to launch and every workgroup checks it against the
+    caller's node array before using it: a hierarchy replaced IN PLACE (same device pointers: here the reference-built and the
+    in-tree-built atrium take turns) must be noticed -- that launch runs without the image, the next one on a fresh image --
+    and every launch must return the oracle's hits."""
+    import torch
+    from rodent_amd import abi
+    assert torch.cuda.is_available()
+    a_nodes, a_tris = F.read_bvh(refbuilt["atrium"], F.BVH2_TRI1)
+    b_nodes, b_tris = F.read_bvh(intree["atrium"], F.BVH2_TRI1)
+    n4, _ = F.read_bvh(refbuilt["atrium"], F.BVH4_TRI4)
+    rays = scene_rays(n4, 40000, 5, 5000.0, a_tris)
+    bvh = abi.DeviceBvh(2, np.zeros(max(len(a_nodes), len(b_nodes)), F.NODE2), np.zeros(max(len(a_tris), len(b_tris)), F.TRI1), 0)
+    top = abi.variants(2).index("top")
+    st = torch.cuda.Stream()                                   # a fresh launch context: no image yet
+    rd = abi.to_device(rays, 0)
+    hd = torch.zeros(len(rays) * 16, dtype=torch.uint8, device="cuda:0")
+    abi.lib().rodent_hip_top_min_rays(0)
+    try:
+        used = []
+        for nodes, tris in ((a_nodes, a_tris), (a_nodes, a_tris), (b_nodes, b_tris), (b_nodes, b_tris), (a_nodes, a_tris), (a_nodes, a_tris)):
+            bvh.nodes[:nodes.nbytes].copy_(torch.from_numpy(nodes.view(np.uint8).reshape(-1).copy()))
+            bvh.tris[:tris.nbytes].copy_(torch.from_numpy(tris.view(np.uint8).reshape(-1).copy()))
+            torch.cuda.synchronize()
+            abi.traverse_async(bvh, rd, hd, len(rays), False, top, st)
+            abi.check_errors(0, st)
+            abi.read_stats(0)                                  # (the stream's context is the one used last: clear, then measure one launch)
+            abi.traverse_async(bvh, rd, hd, len(rays), False, top, st)
+            abi.check_errors(0, st)
+            ref, _ = oracle.traverse(2, nodes, tris, rays)
+            assert abi.from_device(hd, F.HIT1).tobytes() == ref.tobytes()
+            used.append(abi.read_stats(0)[6])
+        assert all(u > 0 and u == used[0] for u in used), used      # the second launch on each hierarchy ran on a validated image
+        # ... and the FIRST launch after each swap did not (it found no image / a stale one), with correct hits all the same
+        stale = []
+        for nodes, tris in ((b_nodes, b_tris), (a_nodes, a_tris)):
+            bvh.nodes[:nodes.nbytes].copy_(torch.from_numpy(nodes.view(np.uint8).reshape(-1).copy()))
+            bvh.tris[:tris.nbytes].copy_(torch.from_numpy(tris.view(np.uint8).reshape(-1).copy()))
+            torch.cuda.synchronize()
+            abi.read_stats(0)
+            abi.traverse_async(bvh, rd, hd, len(rays), False, top, st)
+            abi.check_errors(0, st)
+            ref, _ = oracle.traverse(2, nodes, tris, rays)
+            assert abi.from_device(hd, F.HIT1).tobytes() == ref.tobytes()
+            stale.append(abi.read_stats(0)[6])
+        assert stale == [0, 0], stale
+    finally:
+        abi.lib().rodent_hip_top_min_rays(-1)
