@@ -467,12 +467,13 @@ __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__
 // may change between launches, so the image is rebuilt by every launch (one wave, one dependent load per level).
 // Ids with the tag never leave the kernel: a ray deeper than the LDS window restarts from the root in k_bvh2_finish.
 // ---------------------------------------------------------------------------------------------
-// One wave.  Record layout: ints 0..11 bounds, 12..13 child ids / links, 14 = the node's own 1-based id (0: slot unused), 15 = 0.
-__device__ __forceinline__ void build_top_image(const Node2* __restrict__ nodes, int4* __restrict__ image, int capacity) {
-    __shared__ int slot_node[kMaxTopNodes];                           // 1-based node id held by each slot
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// One wave (the LDS operations of a wave complete in program order: between one lane's write and another lane's read the
+// compiler only has to keep that order).  Record layout: ints 0..11 bounds, 12..13 child ids / links, 14 = the node's own 1-based id (0: slot unused), 15 = 0.
+__device__ __forceinline__ void build_top_image(const Node2* __restrict__ nodes, int4* __restrict__ image, int capacity, lds_int* slot_node /* [capacity]: 1-based node id held by each slot */) {
     const int lane = threadIdx.x;
     if (lane == 0) slot_node[0] = 1;
-    __syncthreads();
+    wave_lds_sync();
     int begin = 0, end = 1;                                           // slots of the current level
     while (begin < end) {
         int next = end;
@@ -489,13 +490,16 @@ __device__ __forceinline__ void build_top_image(const Node2* __restrict__ nodes,
             next = min(capacity, next + __popcll(m0) + __popcll(m1));
             if (on) { r3.z = slot_node[slot]; r3.w = 0; int4* q = image + 4 * slot; q[0] = r0; q[1] = r1; q[2] = r2; q[3] = r3; }
         }
-        __syncthreads();
+        wave_lds_sync();
         begin = end; end = next;
     }
     for (int slot = end + lane; slot < capacity; slot += kWave) image[4 * slot + 3] = int4{0, 0, 0, 0};       // unused slots
 }
 template <int TOPN>
-__global__ __launch_bounds__(kWave) void k_bvh2_top_image(const Node2* __restrict__ nodes, int4* __restrict__ image) { build_top_image(nodes, image, TOPN); }
+__global__ __launch_bounds__(kWave) void k_bvh2_top_image(const Node2* __restrict__ nodes, int4* __restrict__ image) {
+    __shared__ int slot_node[TOPN];
+    build_top_image(nodes, image, TOPN, (lds_int*)slot_node);
+}
 
 // The follow-up kernel of the persistent form: k_bvh2_finish's work, plus the image for the NEXT launch when this launch found
 // none or a stale one (ctl->reserved, set by any workgroup whose validation failed).
@@ -507,7 +511,8 @@ __global__ __launch_bounds__(kWave) void k_bvh2_top_finish(const Node2* __restri
     const bool stale = ctl->reserved != 0;
     finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, tickets);
     if (stale) {
-        build_top_image(nodes, image, capacity);
+        __shared__ int slot_node[kMaxTopNodes];
+        build_top_image(nodes, image, capacity, (lds_int*)slot_node);
         if (threadIdx.x == 0) ctl->reserved = 0;
     }
 }
@@ -613,18 +618,18 @@ __device__ __forceinline__ bool stage_top_image(const Node2* __restrict__ nodes,
 // the same XCD-aware order as k_bvh2_single (stripe s runs on XCD s % 8) -- until their stripe's share is used up.  No workgroup waits for LDS that a
 // finished neighbour wave still pins (what makes WAVES > 2 lose at 16 Mi rays in the non-persistent form), the image is
 // staged 512 times per launch instead of 16 384 times, and the next ticket is drawn while the current chunk is traced.
-template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int OCC = 32>
-__global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_persist(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int OCC = 32, bool TRACE = false, int PRIO = 0, bool FUSED = false>
+__global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_persist(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                      const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                                      Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm,
-                                                                     const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id) {
+                                                                     int4* __restrict__ top_image, int* __restrict__ tickets, int max_id, int* deep_stack) {
     constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroup = 32;
     static_assert((kStackInts + TOPN * 16) * 4 * (OCC / WAVES) <= 160 * 1024, "OCC waves per CU must fit their stacks and images in LDS");
     __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
     lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
     lds_int* image = (lds_int*)lds_raw + kStackInts;
-    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;      // record 0 of the image, or node 1
+    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, (const int4*)top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;      // record 0 of the image, or node 1
     if (root != 1 && threadIdx.x == 0) atomicAdd(&ctl->stats[6], 1ull);     // stats[6]: workgroups that ran on the image (read by the tests)
     // stripe = workgroup index mod 64 (its XCD = stripe mod 8); the first ticket of a wave is its rank inside the stripe, the
     // counter hands out the tickets behind those
@@ -642,12 +647,42 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_persist(
             const int first_ray = chunk * kWave, lane_ray = first_ray + lane;
             Lane L = start_lane(rays, hits, lane_ray < n ? (perm ? perm[lane_ray] : lane_ray) : -1, perm ? perm[first_ray] : first_ray, col);
             if (L.top != 0) L.top = root;
+            const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            int iterations = 0;
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
             while (__ballot(L.top != 0)) {
                 if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+                if (TRACE || PRIO) iterations++;
+                if (PRIO && iterations == PRIO) __builtin_amdgcn_s_setprio(3);          // lab: a chunk that is still running after PRIO iterations is on the critical path
+            }
+            if (TRACE && lane == 0 && ctl->trace && chunk < 16384) {        // lab: per chunk start / end (100 MHz), iterations, wave << 32 | ticket
+                unsigned long long* tr = ctl->trace + 4 * (size_t)chunk;
+                tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime(); tr[2] = (unsigned long long)iterations;
+                tr[3] = ((unsigned long long)(blockIdx.x * WAVES + wave) << 32) | (unsigned)t;
             }
         }
         if (!PREFETCH && lane == 0) t_next = atomicAdd(counter, 1);
         t = stripe_waves + __builtin_amdgcn_readfirstlane(t_next);
+    }
+    if (FUSED) {
+        // The workgroup that finishes last does the follow-up kernel's work (deep rays, counters, a new image if this launch found
+        // none or a stale one): one launch instead of two.  Every workgroup publishes what it wrote (agent-scope release: its
+        // XCD's L2 is written back) before it counts itself done; the last one acquires before it reads the deep list.
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const int done = __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            lds_raw[0] = done == (int)gridDim.x - 1;
+        }
+        __syncthreads();
+        if (!lds_raw[0] || wave != 0) return;
+        __threadfence();
+        const bool stale = __hip_atomic_load(&ctl->reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, tickets);
+        if (stale) {
+            build_top_image(nodes, top_image, TOPN, (lds_int*)lds_raw);        // (the stacks are idle now)
+            if (lane == 0) ctl->reserved = 0;
+        }
     }
 }
 
@@ -953,7 +988,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool SORTED = false, bool KE
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 
-template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, int OCC> void launch_top_persist(LAUNCH_ARGS, int max_id) {
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, int OCC, bool TRACE = false, int PRIO = 0, bool FUSED = false> void launch_top_persist(LAUNCH_ARGS, int max_id) {
     ensure_deep_list(s, n);
     if (!s.top_image || !s.tickets) {
         std::lock_guard<std::mutex> lock(g_mutex);
@@ -974,12 +1009,12 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, 
         perm = s.sort_perm;
     }
     const int groups = ((s.num_cus * (OCC / WAVES) + kStripes - 1) / kStripes) * kStripes;   // one resident generation, the same number in every stripe
-    hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, OCC>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                       perm, (const int4*)s.top_image, s.tickets, max_id);
-    hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
+    hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, OCC, TRACE, PRIO, FUSED>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+                       perm, s.top_image, s.tickets, max_id, s.deep_stack);
+    if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
-template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool SORTED = false, int OCC = 32> void L_top_persist(LAUNCH_ARGS) {
-    launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, SORTED, OCC>(s, nodes, tris, rays, hits, n, stream, mapped_node_ids(nodes));
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool SORTED = false, int OCC = 32, bool TRACE = false, int PRIO = 0, bool FUSED = false> void L_top_persist(LAUNCH_ARGS) {
+    launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, SORTED, OCC, TRACE, PRIO, FUSED>(s, nodes, tris, rays, hits, n, stream, mapped_node_ids(nodes));
 }
 
 // The default mapping: launches that fill the chip at least once take the persistent kernel with the LDS image, smaller ones
@@ -1087,6 +1122,10 @@ const Variant2 kVariants2[] = {
     K2("top255p8-o24",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 8, false, false, 24),
     K2("top63p4-o28",        "k_bvh2_top_persist",   L_top_persist, 15, 63, 4, false, false, 28),
     //                                                                    LDS_N TOPN WAVES REFILL (idle lanes that trigger a refill)
+    K2("top-fused",          "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, true),   // the last workgroup does the follow-up kernel's work
+    K2("top-prio64",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 64),    // s_setprio 3 once a chunk has run 64 / 96 / 128 iterations
+    K2("top-prio96",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 96),
+    K2("top-prio128",        "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 128),
     K2("top255r16-32",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 32),
     K2("top255r16-48",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 48),
     // what was swept on the way (profiles/r02_sweep_phased*.log, r02_sweep_prio.log): other phase caps, fewer rays per wave in
@@ -1140,6 +1179,7 @@ const Variant2 kVariants2[] = {
     K2("trace-sched",        "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false, false, true),
     K2("trace-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, false, true),
     K2("trace-fast",         "k_bvh2_single",        L_single, 16, 32, true),
+    K2("trace-top",          "k_bvh2_top_persist",   L_top_persist, 15, 63, 4, false, false, 28, true),     // (the trace costs 2 VGPRs = one wave per SIMD: 7 four-wave workgroups per CU)
     K2("trace-fast-ww",      "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32, true),
     //   static-stride persistent waves: one wave per resident slot, tickets b, b + grid, ... (no atomics)
     K2("fast-static-r64",    "k_bvh2_fast",          L_fast, 16, 8,  true,  64, 64, false, 32, false, true),
