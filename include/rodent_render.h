@@ -92,6 +92,10 @@ void    rodent_hip_render_overlap(int32_t dev, int32_t enable);
  * 18-word stream per bounce less, but a gathering shader: measured 3 % slower on the Cornell box, equal on the atrium).
  * Same paths and film.  RODENT_HIP_FUSED_SORT=0|1. */
 void    rodent_hip_render_fused_sort(int32_t dev, int32_t enable);
+/* 1 (default): the stream traversal kernels run as 2-wave workgroups that stage the first 31 inner nodes of the scene's BVH
+ * (breadth first, built at scene creation) in LDS and fetch those with ds_read instead of through the vector-memory pipeline.
+ * 0: one wave per workgroup, every node from memory (rounds 1-2).  Same per-ray visit order, same film.  RODENT_HIP_LDS_IMAGE=0|1. */
+void    rodent_hip_render_lds_image(int32_t dev, int32_t enable);
 
 /* ---- the reference's renderer ABI ---- */
 int32_t get_spp(void);

@@ -128,7 +128,7 @@ using StreamStack = StreamStackT<false>;
 // handling inside the hot loop.
 struct CursorStack {
     lds_int* sp; lds_int* limit; bool overflow;
-    __device__ __forceinline__ void init(lds_int* col) { sp = col; limit = col + kLdsStack * kWave; overflow = false; col[0] = 0; }
+    __device__ __forceinline__ void init(lds_int* col, int window = kLdsStack) { sp = col; limit = col + window * kWave; overflow = false; col[0] = 0; }
 };
 // 64 entries in global memory ([entry][lane]), the reference's capacity (stack.impala:53); used by k_trace_deep only.
 struct DeepStack {
@@ -182,11 +182,13 @@ __device__ __forceinline__ void film_add_wave(float* film, int pixel, bool valid
 // one triangle test per wave iteration and the loads of both kinds are in flight together.
 // on_hit(prim, geom, t, u, v) is called for every accepted triangle (the last call is the closest hit); returns whether
 // anything was hit.  The stream kernels store from on_hit instead of carrying a hit record in registers.
-template <bool ANY, typename Stack, typename OnHit>
-__device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, Stack& st, OnHit on_hit) {
+// TOP: `image` is the scene's top-of-tree image staged in LDS by the workgroup (traversal_device.h); a node id >= kLdsTag is a
+// link into it and is fetched with ds_read_b128 instead of through the vector-memory pipeline.
+template <bool ANY, bool TOP = false, typename Stack, typename OnHit>
+__device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, Stack& st, OnHit on_hit, lds_int* image = nullptr) {
     constexpr bool kCursor = is_cursor<Stack>::value;
     bool any_found = false;
-    int ptr = 0, top = 1;
+    int ptr = 0, top = TOP ? kLdsTag : 1;
     if constexpr (!kCursor) st.put(0, 0);
     ray.tmin = canonical(ray.tmin); ray.tmax = canonical(ray.tmax);           // see slab_canonical (traversal_device.h)
     // both bases as integers in VGPRs for the per-lane select, then GLOBAL pointers again (see unified_chunk)
@@ -197,13 +199,23 @@ __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const
     while (__ballot(top != 0)) {
         if (top != 0) {
             const bool is_node = top > 0;
-            const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
-            const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             typedef int i32x2 __attribute__((ext_vector_type(2)));
-            const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
-            f32x4 q0 = p[0], q1 = p[1], q2 = p[2];
-            i32x2 ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));   // child ids / (triangle lanes) own last 8 bytes
+            f32x4 q0, q1, q2;
+            i32x2 ch;
+            if (TOP && top >= kLdsTag) {
+                typedef __attribute__((address_space(3))) const char* lds_bytes;
+                const lds_bytes rec = (lds_bytes)image + (unsigned)(top - kLdsTag);
+                const __attribute__((address_space(3))) f32x4* p = (const __attribute__((address_space(3))) f32x4*)rec;
+                q0 = p[0]; q1 = p[1]; q2 = p[2];
+                ch = *(const __attribute__((address_space(3))) i32x2*)(rec + 48);
+            } else {
+                const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
+                const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
+                const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
+                q0 = p[0]; q1 = p[1]; q2 = p[2];
+                ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));   // child ids / (triangle lanes) own last 8 bytes
+            }
             int popped;
             if constexpr (kCursor) popped = *st.sp; else popped = st.get(ptr);
             // keep all four loads in flight together (see unified_chunk)
@@ -253,7 +265,8 @@ __device__ __forceinline__ RayX load_stream_ray(const RayStream& r, int i) {   /
 }
 
 // primary: writes geom_id (num_geometries on a miss, driver.impala:106-115), prim_id, t, u, v
-__device__ __forceinline__ void trace_primary_ray(const SceneDev& sc, const PrimaryStream& p, int i, CursorStack* cursor, DeepStack* deep) {
+template <bool TOP = false>
+__device__ __forceinline__ void trace_primary_ray(const SceneDev& sc, const PrimaryStream& p, int i, CursorStack* cursor, DeepStack* deep, lds_int* image = nullptr) {
     const RayX ray = load_stream_ray(p.rays, i);
     p.geom_id[i] = sc.num_materials; p.prim_id[i] = -1; p.t[i] = ray.tmax; p.u[i] = 0.0f; p.v[i] = 0.0f;     // the miss record; hits overwrite it
     auto on_hit = [&](int prim, int geom, float t, float u, float v) {
@@ -261,40 +274,70 @@ __device__ __forceinline__ void trace_primary_ray(const SceneDev& sc, const Prim
         asm volatile("" : "+v"(k));                  // opaque index: SGPR bases + one VGPR offset here, instead of five 64-bit addresses held across the loop
         p.geom_id[k] = geom; p.prim_id[k] = prim; p.t[k] = t; p.u[k] = u; p.v[k] = v;
     };
-    if (cursor) trace_one<false>(sc.nodes, sc.tris, ray, *cursor, on_hit);
+    if (cursor) trace_one<false, TOP>(sc.nodes, sc.tris, ray, *cursor, on_hit, image);
     else trace_one<false>(sc.nodes, sc.tris, ray, *deep, on_hit);
 }
 
-__global__ __launch_bounds__(kWave) void k_trace_primary(SceneDev sc, PrimaryStream p, const int* size_ptr, int n_value, int* deep_count, unsigned long long* counters,
-                                                         int* deep_list) {
-    __shared__ int lds[(kLdsStack + 1) * kWave];
+// WAVES x 64 threads per workgroup; TOPN > 0: the scene's top-of-tree image (first TOPN records) is staged in LDS behind the
+// WAVES stack windows (kTopStack entries each then: 2 x 4 KB + 31 x 64 B = 16 workgroups per CU, all 32 wave slots).
+constexpr int kTopStack = 15, kSceneTopNodes = 31, kTraceWaves = 2;
+template <int WAVES, int TOPN>
+__device__ __forceinline__ lds_int* stage_scene_image(const SceneDev& sc, int* lds, int& chunk, int total_chunks) {
+    constexpr int kWindow = TOPN ? kTopStack : kLdsStack;
+    lds_int* image = (lds_int*)lds + WAVES * (kWindow + 1) * kWave;
+    if (TOPN) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        for (int j = threadIdx.x; j < TOPN * 4; j += WAVES * kWave)
+            reinterpret_cast<__attribute__((address_space(3))) i32x4*>(image)[j] = reinterpret_cast<const i32x4*>(sc.top_image)[j];
+    }
+    // XCD-aware wave -> chunk mapping (xcd_chunk): wave l of XCD x, l counted over the workgroups of that XCD
+    const int wave = threadIdx.x / kWave;
+    constexpr int G = 32;
+    const int span = 8 * G, full = (total_chunks / span) * span;
+    chunk = blockIdx.x * WAVES + wave;
+    if ((int)blockIdx.x * WAVES < full) {
+        const int x = blockIdx.x % 8, l = (blockIdx.x / 8) * WAVES + wave;
+        chunk = ((l / G) * 8 + x) * G + l % G;
+    }
+    if (TOPN && WAVES > 1) __syncthreads();
+    return image;
+}
+
+template <int WAVES, int TOPN>
+__global__ __launch_bounds__(kWave * WAVES) void k_trace_primary(SceneDev sc, PrimaryStream p, const int* size_ptr, int n_value, int* deep_count, unsigned long long* counters,
+                                                                 int* deep_list) {
+    constexpr int kWindow = TOPN ? kTopStack : kLdsStack;
+    __shared__ __attribute__((aligned(16))) int lds[WAVES * (kWindow + 1) * kWave + TOPN * 16];
     const int n = stream_size(size_ptr, n_value);
-    const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
-    const int i = chunk * kWave + threadIdx.x;
-    if (chunk * kWave >= n) return;
+    int chunk;
+    lds_int* image = stage_scene_image<WAVES, TOPN>(sc, lds, chunk, (n + kWave - 1) / kWave);
+    const int lane = threadIdx.x % kWave, i = chunk * kWave + lane;
     if (i >= n) return;
-    CursorStack st; st.init((lds_int*)lds + threadIdx.x);
-    trace_primary_ray(sc, p, i, &st, nullptr);
+    CursorStack st; st.init((lds_int*)lds + (threadIdx.x / kWave) * (kWindow + 1) * kWave + lane, kWindow);
+    trace_primary_ray<(TOPN > 0)>(sc, p, i, &st, nullptr, image);
     if (st.overflow) deep_list[atomicAdd(deep_count, 1)] = i;
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)n);
 }
 
 // secondary: any-hit; unoccluded rays add their colour to the film (mapping_gpu.impala:32-45,47-80)
-__global__ __launch_bounds__(kWave) void k_trace_secondary(SceneDev sc, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
-                                                           int* deep_count, unsigned long long* counters, int* deep_list) {
-    __shared__ int lds[(kLdsStack + 1) * kWave];
+template <int WAVES, int TOPN>
+__global__ __launch_bounds__(kWave * WAVES) void k_trace_secondary(SceneDev sc, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
+                                                                   int* deep_count, unsigned long long* counters, int* deep_list) {
+    constexpr int kWindow = TOPN ? kTopStack : kLdsStack;
+    __shared__ __attribute__((aligned(16))) int lds[WAVES * (kWindow + 1) * kWave + TOPN * 16];
     const int n = stream_size(size_ptr, n_value);
-    const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
-    const int i = chunk * kWave + threadIdx.x;
+    int chunk;
+    lds_int* image = stage_scene_image<WAVES, TOPN>(sc, lds, chunk, (n_value + kWave - 1) / kWave);      // (the grid covers n_value rays: the mapping must not depend on the device-side n)
+    const int lane = threadIdx.x % kWave, i = chunk * kWave + lane;
     if (chunk * kWave >= n) return;
     const int pixel = i < n ? s.rays.id[i] : -1;
     const unsigned long long live = __ballot(pixel >= 0);
     // striped over 64 words: one counter word saturates near 88 atomics/us and made this kernel 3x slower
-    if (threadIdx.x == 0 && live) atomicAdd(&counters[4 + (blockIdx.x & 63)], (unsigned long long)__popcll(live));
+    if (lane == 0 && live) atomicAdd(&counters[4 + (chunk & 63)], (unsigned long long)__popcll(live));
     bool lit = false;
     if (pixel >= 0) {
-        CursorStack st; st.init((lds_int*)lds + threadIdx.x);
-        lit = !trace_one<true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {});
+        CursorStack st; st.init((lds_int*)lds + (threadIdx.x / kWave) * (kWindow + 1) * kWave + lane, kWindow);
+        lit = !trace_one<true, (TOPN > 0)>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {}, image);
         if (st.overflow) { deep_list[atomicAdd(deep_count, 1)] = i; lit = false; }      // k_trace_deep decides
     }
     film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
@@ -686,6 +729,7 @@ struct RenderDevice {
     int spp = 4, max_path_len = 64;
     int capacity = 0;                          // rays per stream; 0 = default (env_capacity())
     int sort = 1;                              // 1 = sort hit rays by material before shading (mapping_gpu.impala:166-221), 0 = shade in stream order
+    int lds_image = 1;                         // 1 = the stream traversal kernels stage the scene's top-of-tree image in LDS (2-wave workgroups); 0 = every node from memory
     int fused_sort = 0;                        // 0 = rays are moved by the sort (copy_primary_ray), then shaded in place; 1 = the sort only computes the permutation and the shader gathers through it
     int* perm = nullptr; int perm_cap = 0;     // sorted position -> stream index
     int mapping = 0;                           // 0 = streaming wavefront (mapping_gpu.impala:308-369), 1 = megakernel (:371-474)
@@ -724,6 +768,7 @@ RenderDevice& rdev(int dev) {
         if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
         if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
         if (const char* e = getenv("RODENT_HIP_FUSED_SORT")) r.fused_sort = atoi(e) ? 1 : 0;
+        if (const char* e = getenv("RODENT_HIP_LDS_IMAGE")) r.lds_image = atoi(e) ? 1 : 0;
         if (const char* m = getenv("RODENT_HIP_MAPPING")) {
             if (!strcmp(m, "mega") || !strcmp(m, "megakernel") || !strcmp(m, "1")) r.mapping = 1;
             else if (strcmp(m, "streaming") && strcmp(m, "0")) { fprintf(stderr, "rodent_hip: RODENT_HIP_MAPPING must be 'streaming' or 'mega'\n"); abort(); }
@@ -777,12 +822,14 @@ void ensure_deep(RenderDevice& r, int which, int rays) {
 // ctl words: [2] error flag, [3] primary deep count, [4] secondary deep count, [5] secondary stream size (copy for the aux stream)
 void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n) {
     ensure_deep(r, 0, n);
-    hipLaunchKernelGGL(k_trace_primary, dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
+    if (r.lds_image) hipLaunchKernelGGL((k_trace_primary<kTraceWaves, kSceneTopNodes>), dim3((n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
+    else hipLaunchKernelGGL((k_trace_primary<1, 0>), dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
     hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_stack[0]);
 }
 void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const SecondaryStream& s, const int* size_ptr, int max_n, float inv_spp) {
     ensure_deep(r, 1, max_n);
-    hipLaunchKernelGGL(k_trace_secondary, dim3((max_n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
+    if (r.lds_image) hipLaunchKernelGGL((k_trace_secondary<kTraceWaves, kSceneTopNodes>), dim3((max_n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
+    else hipLaunchKernelGGL((k_trace_secondary<1, 0>), dim3((max_n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
     hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_stack[1]);
 }
 
@@ -1032,6 +1079,23 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
     for (int32_t k = 0; k < d->num_textures; k++)
         if (d->textures[k].width <= 0 || d->textures[k].height <= 0 || (uint64_t)d->textures[k].offset + (uint64_t)d->textures[k].width * (uint64_t)d->textures[k].height > d->num_texels) invalid("texture outside the texel pool");
     s.dev.num_tris = d->num_tris; s.dev.num_materials = d->num_materials; s.dev.num_lights = d->num_lights;
+    // top-of-tree image of the stream traversal kernels (record layout: traversal_device.h build_top_image): breadth first from
+    // the root; a child that got a slot is a link (kLdsTag + byte offset of its record), the others keep their ids
+    {
+        std::vector<int32_t> image((size_t)kSceneTopNodes * 16, 0), slots{1};
+        for (size_t k = 0; k < slots.size(); k++) {
+            const Node2& nd = d->nodes[slots[k] - 1];
+            int32_t* rec = image.data() + 16 * k;
+            memcpy(rec, nd.bounds, 12 * sizeof(float));
+            for (int j = 0; j < 2; j++) {
+                const int32_t c = nd.child[j];
+                rec[12 + j] = c;
+                if (c > 0 && (int)slots.size() < kSceneTopNodes) { rec[12 + j] = kLdsTag + (int32_t)slots.size() * (int32_t)sizeof(Node2); slots.push_back(c); }
+            }
+            rec[14] = slots[k];
+        }
+        s.dev.top_image = reinterpret_cast<const int4*>(upload(s, image.data(), image.size()));
+    }
     s.loaded = true;
 }
 
@@ -1043,6 +1107,7 @@ void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
 void rodent_hip_render_sort(int32_t dev, int32_t enable) { rdev(dev).sort = enable ? 1 : 0; }
 void rodent_hip_render_overlap(int32_t dev, int32_t enable) { rdev(dev).overlap = enable ? 1 : 0; }
 void rodent_hip_render_fused_sort(int32_t dev, int32_t enable) { rdev(dev).fused_sort = enable ? 1 : 0; }
+void rodent_hip_render_lds_image(int32_t dev, int32_t enable) { rdev(dev).lds_image = enable ? 1 : 0; }
 
 void rodent_hip_render_capacity(int32_t dev, int32_t rays) {
     if (rays != 0 && (rays < 64 || rays > kMaxCapacity)) { fprintf(stderr, "rodent_hip: stream capacity must be 0 (default) or 64 .. %ld rays\n", kMaxCapacity); abort(); }

@@ -19,6 +19,7 @@ struct SceneDev {                 // device pointers (uploaded by rodent_hip_sce
     const RodentMaterial* materials; const RodentLight* lights; const int32_t* light_ids;
     int32_t num_tris, num_materials, num_lights, pad;
     const float* texcoords; const RodentTexture* textures; const uint32_t* texels;
+    const int4* top_image;        // the first kSceneTopNodes inner nodes, breadth first, as LDS-image records (traversal_device.h); built at scene creation
 };
 
 #define FLT_MAX_REF 3.4028234664e+38f

@@ -108,4 +108,39 @@ struct HitAcc { int id; float t, u, v; };
 
 typedef __attribute__((address_space(3))) int lds_int;
 
+// ---------------------------------------------------------------------------------------------
+// Top-of-tree image (traversal.hip: k_bvh2_top_persist; render.hip: the stream traversal kernels): the first `capacity`
+// inner nodes in breadth-first order as 64-byte records that a workgroup stages in LDS.  A node id >= kLdsTag is a LINK:
+// the byte offset of a record inside the image.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLdsTag = 0x40000000;
+
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// One wave (the LDS operations of a wave complete in program order: between one lane's write and another lane's read the
+// compiler only has to keep that order).  Record layout: ints 0..11 bounds, 12..13 child ids / links, 14 = the node's own 1-based id (0: slot unused), 15 = 0.
+__device__ __forceinline__ void build_top_image(const Node2* __restrict__ nodes, int4* __restrict__ image, int capacity, lds_int* slot_node /* [capacity]: 1-based node id held by each slot */) {
+    const int lane = threadIdx.x;
+    if (lane == 0) slot_node[0] = 1;
+    wave_lds_sync();
+    int begin = 0, end = 1;                                           // slots of the current level
+    while (begin < end) {
+        int next = end;
+        for (int first = begin; first < end; first += kWave) {
+            const int slot = first + lane;
+            const bool on = slot < end;
+            int4 r0 = {}, r1 = {}, r2 = {}, r3 = {};
+            if (on) { const int4* p = reinterpret_cast<const int4*>(nodes + (slot_node[slot] - 1)); r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3]; }
+            const bool in0 = on && r3.x > 0, in1 = on && r3.y > 0;   // inner children (r3.x / r3.y = Node2::child)
+            const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1), below = (1ull << lane) - 1ull;
+            const int s0 = next + __popcll(m0 & below), s1 = next + __popcll(m0) + __popcll(m1 & below);
+            if (in0 && s0 < capacity) { slot_node[s0] = r3.x; r3.x = kLdsTag + s0 * (int)sizeof(Node2); }
+            if (in1 && s1 < capacity) { slot_node[s1] = r3.y; r3.y = kLdsTag + s1 * (int)sizeof(Node2); }
+            next = min(capacity, next + __popcll(m0) + __popcll(m1));
+            if (on) { r3.z = slot_node[slot]; r3.w = 0; int4* q = image + 4 * slot; q[0] = r0; q[1] = r1; q[2] = r2; q[3] = r3; }
+        }
+        wave_lds_sync();
+        begin = end; end = next;
+    }
+    for (int slot = end + lane; slot < capacity; slot += kWave) image[4 * slot + 3] = int4{0, 0, 0, 0};       // unused slots
+}
 } // namespace rodent_dev

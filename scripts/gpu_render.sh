@@ -5,7 +5,7 @@ timeout 900 python -m pytest tests/test_gpu_render.py tests/test_gpu_atrium.py -
 C="--scene tests/golden/cornell_box.obj --bench 5 --eye 0 1 2.7 --dir 0 0 -1 --up 0 1 0 --width 1920 --height 1080 --spp 64 --max-path-len 4"
 python -c "from rodent_amd import scenes; scenes.scene_bvh('atrium')"
 A="--scene data/atrium.obj --bench 3 --eye -1150 350 30 --dir 1 0.12 -0.05 --up 0 1 0 --width 1920 --height 1080 --spp 16 --max-path-len 8"
-echo "RODENT_HIP_FUSED_SORT=0 rodent $C"; RODENT_HIP_FUSED_SORT=0 timeout 300 rodent_amd/bin/rodent $C 2>&1 | tail -1
+for args in "$C" "$A"; do echo "RODENT_HIP_LDS_IMAGE=0 rodent $args"; RODENT_HIP_LDS_IMAGE=0 timeout 300 rodent_amd/bin/rodent $args 2>&1 | tail -1; done | tee gpurun_out/r02/render_rates_no_lds_image.txt
 for args in "$C" "$C --no-sort" "$C --target amdgpu-megakernel" "$A" "$A --no-sort" "$A --target amdgpu-megakernel"; do
   echo "rodent $args"; timeout 300 rodent_amd/bin/rodent $args 2>&1 | tail -1
 done | tee gpurun_out/r02/render_rates.txt

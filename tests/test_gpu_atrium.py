@@ -117,6 +117,18 @@ def test_atrium_fused_sort_matches_oracle(R, atrium_scene, atrium_reference):
     assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
 
 
+def test_atrium_without_the_lds_image_matches_oracle(R, atrium_scene, atrium_reference):
+    """rodent_hip_render_lds_image(0): one-wave traversal workgroups that fetch every node from memory (the default stages the
+    top 31 nodes of the BVH in LDS; every other test here runs on that); same paths, same film."""
+    f = ATRIUM_FRAME
+    film_o, counts = atrium_reference
+    r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], lds_image=False)
+    r.render(atrium_camera(f["W"], f["H"]), f["IT"])
+    c = r.counters(); film_g = r.film(); r.close()
+    assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1])
+    assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
+
+
 @pytest.mark.parametrize("bands", [2, 3, 8])
 @pytest.mark.parametrize("mapping", ["streaming", "megakernel"])
 def test_atrium_row_bands_equal_the_frame(R, atrium_scene, atrium_reference, bands, mapping):
