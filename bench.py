@@ -230,6 +230,21 @@ def main():
     steps_r, warm_r = (args.steps, args.warmup) if args.only != "primary" else (1, 0)
     wall, k_mean, k_med, k_min = time_passes(abi, torch, bvh, prim_dev, hits_dev, n, variant, steps_p, warm_p, dist)
     wall_r, kr_mean, kr_med, kr_min = time_passes(abi, torch, bvh, rnd_dev, hits_rnd_dev, len(rnd), variant, steps_r, warm_r, dist)
+    # the same two sets with the schedule history on (rodent_hip_schedule_history: chunks traced longest first by the previous
+    # launch's per-chunk cost -- state carried from step to step, therefore NOT the headline; same hit records)
+    history = None
+    if width == 2 and abi.variants(2)[variant] == "top" and world == 1 and args.only is None:
+        abi.lib().rodent_hip_schedule_history(1)
+        hits_h, hits_rnd_h = torch.zeros_like(hits_dev), torch.zeros_like(hits_rnd_dev)
+        wall_h, kh_mean, _, _ = time_passes(abi, torch, bvh, prim_dev, hits_h, n, variant, steps_p, warm_p, None)
+        wall_hr, khr_mean, _, _ = time_passes(abi, torch, bvh, rnd_dev, hits_rnd_h, len(rnd), variant, steps_r, warm_r, None)
+        abi.lib().rodent_hip_schedule_history(0)
+        torch.cuda.synchronize()
+        history = {"primary_Mrays_s": round(n * steps_p / wall_h / 1e6, 3), "primary_ms_per_step": round(1e3 * wall_h / steps_p, 5), "primary_kernels_ms": round(kh_mean, 5),
+                   "random_Mrays_s": round(len(rnd) * steps_r / wall_hr / 1e6, 3), "random_ms_per_step": round(1e3 * wall_hr / steps_r, 5), "random_kernels_ms": round(khr_mean, 5),
+                   "identical_hits": bool(torch.equal(hits_h, hits_dev) and torch.equal(hits_rnd_h, hits_rnd_dev)),
+                   "what": "rodent_hip_schedule_history(1): every launch records the wave iterations of each 64-ray chunk, the next launch of the same size traces its "
+                           "chunks longest first; off by default, not the headline value"}
     # BASELINE config 3 ("ray compaction/sorting on"): the same random set through the "sorted" mapping -- the permutation by
     # origin cell is rebuilt inside every timed launch
     sorted_variant = abi.variants(width).index("sorted") if "sorted" in abi.variants(width) else None
@@ -321,6 +336,8 @@ def main():
                   "hit_counts_per_rank[primary,random]": counts_all, "strong_scaling_check": strong_check,
                   "two_streams_Mrays_s_per_gpu": None if overlapped is None else round(overlapped, 3)},
     }
+    if history is not None:
+        out["extra"]["with_schedule_history"] = history
     if wall_s is not None:
         out["extra"]["random_sorted"] = {"Mrays_s": round(total_rnd * steps_r / wall_s / 1e6, 3), "ms_per_step": round(1e3 * wall_s / steps_r, 5), "kernels_ms": round(ks_mean, 5),
                                          "variant": "sorted: counting sort of the rays on 512 Morton cells of their origin inside every launch, then the default kernel through the permutation",

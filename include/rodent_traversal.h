@@ -139,6 +139,12 @@ void        rodent_hip_phased_min_rays(int32_t rays);
  * kernel ("fast") for launches of fewer than this many rays (default 524 288 = one round of resident waves: the per-launch
  * image build does not pay below that); < 0 restores the default, 0 sends every launch through the LDS-image kernel (tests). */
 void        rodent_hip_top_min_rays(int32_t rays);
+/* Schedule history of the default BVH2 mapping (off by default; RODENT_HIP_SCHEDULE_HISTORY=1): every launch records how many
+ * wave iterations each 64-ray chunk took, and the next launch of the SAME ray count on that (device, stream) traces its chunks
+ * longest first -- frame-to-frame cost feedback for callers that trace similar ray sets again and again (1 Mi primary rays of the
+ * atrium: 0.187 -> 0.150 ms).  It changes only the order in which chunks are traced, never a hit record; a launch without a
+ * usable history takes the default order.  State is per (device, stream); launches of more than 4 Mi rays do not use it (they are throughput-bound: measured -8 % at 16 Mi). */
+void        rodent_hip_schedule_history(int32_t enable);
 int32_t     rodent_hip_is_lab_build(void);              /* 1 = librodent_hip_lab.so (-DRODENT_HIP_LAB: also the measured-and-lost kernels) */
 const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant);
 const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t any_hit);
@@ -151,6 +157,9 @@ void        rodent_hip_read_stats(int32_t dev, uint64_t* out8);
  * later calls copy 16384 x 4 words {start tick, end tick (100 MHz), hw_id | xcc_id << 32,
  * outer iterations | rays << 32} and clear the buffer. */
 void        rodent_hip_read_trace(int32_t dev, uint64_t* out);
+/* Lab build: the ray permutation (device pointer, one int per ray, owned by the caller) that the "top-userperm" mapping of the
+ * context used last traces through; nullptr = none.  For scheduling experiments (scripts/lpt_experiment.py). */
+void        rodent_hip_debug_set_perm(int32_t dev, const int32_t* device_perm);
 
 #ifdef __cplusplus
 }

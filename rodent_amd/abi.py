@@ -29,7 +29,7 @@ SYNC_ENTRY_POINTS = [
 ASYNC_ENTRY_POINTS = ["hip_traverse_bvh2_tri1_async", "hip_traverse_bvh4_tri4_async", "hip_traverse_bvh8_tri4_async"]
 EXPORTS = SYNC_ENTRY_POINTS + ASYNC_ENTRY_POINTS + [
     "rodent_hip_check_errors", "rodent_hip_device_count", "rodent_hip_num_variants", "rodent_hip_variant_name",
-    "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_is_lab_build", "rodent_hip_phased_min_rays", "rodent_hip_top_min_rays", "rodent_hip_read_stats", "rodent_hip_read_trace",
+    "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_is_lab_build", "rodent_hip_phased_min_rays", "rodent_hip_top_min_rays", "rodent_hip_schedule_history", "rodent_hip_read_stats", "rodent_hip_read_trace", "rodent_hip_debug_set_perm",
 ]
 BLOCK_OF_WIDTH = {2: F.BVH2_TRI1, 4: F.BVH4_TRI4, 8: F.BVH8_TRI4}
 
@@ -56,12 +56,14 @@ def lib():
         l.rodent_hip_is_lab_build.restype = i32; l.rodent_hip_is_lab_build.argtypes = []
         l.rodent_hip_phased_min_rays.restype = None; l.rodent_hip_phased_min_rays.argtypes = [i32]
         l.rodent_hip_top_min_rays.restype = None; l.rodent_hip_top_min_rays.argtypes = [i32]
+        l.rodent_hip_schedule_history.restype = None; l.rodent_hip_schedule_history.argtypes = [i32]
         l.rodent_hip_device_count.restype = i32; l.rodent_hip_device_count.argtypes = []
         l.rodent_hip_num_variants.restype = i32; l.rodent_hip_num_variants.argtypes = [i32]
         l.rodent_hip_variant_name.restype = C.c_char_p; l.rodent_hip_variant_name.argtypes = [i32, i32]
         l.rodent_hip_kernel_name.restype = C.c_char_p; l.rodent_hip_kernel_name.argtypes = [i32, i32, i32]
         l.rodent_hip_version.restype = C.c_char_p; l.rodent_hip_version.argtypes = []
         l.rodent_hip_read_trace.restype = None; l.rodent_hip_read_trace.argtypes = [i32, C.c_void_p]
+        l.rodent_hip_debug_set_perm.restype = None; l.rodent_hip_debug_set_perm.argtypes = [i32, C.c_void_p]
         l.rodent_hip_read_stats.restype = None; l.rodent_hip_read_stats.argtypes = [i32, C.POINTER(C.c_uint64)]
         _lib = l
     return _lib

@@ -532,6 +532,54 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top(const No
     }
 }
 
+struct History { const int* order; int* cost; int stride; };               // order[stripe * stride + ticket] = chunk; either may be null
+// chunks of stripe s under the default order: its complete 32-chunk groups plus, for one stripe, the ragged last group
+__device__ __forceinline__ int stripe_chunks(int total_chunks, int stripe) {
+    const int full_groups = total_chunks / 32, rest = total_chunks % 32;
+    return (full_groups / kStripes + (stripe < full_groups % kStripes ? 1 : 0)) * 32 + (stripe == full_groups % kStripes ? rest : 0);
+}
+// The follow-up kernel when the schedule history is on: workgroup 0's first wave does k_bvh2_top_finish's work, then workgroup s
+// sorts the chunks of stripe s by the wave iterations this launch took for them, longest first (ties: default order), into
+// order[s * stride ...] -- bitonic in LDS, at most kMaxStripeChunks keys.
+constexpr int kMaxStripeChunks = 1024, kHistoryThreads = 256;      // 4 Mi rays: beyond that the launch is throughput-bound and the sorted order only costs locality (16 Mi: -8 %)
+template <bool ANY>
+__global__ __launch_bounds__(kHistoryThreads) void k_bvh2_top_finish_history(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                                              const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
+                                                                              Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* tickets,
+                                                                              int4* __restrict__ image, int capacity, int total_chunks,
+                                                                              const int* __restrict__ cost, int* __restrict__ order, int stride) {
+    __shared__ int keys[kMaxStripeChunks];
+    if (blockIdx.x == 0 && threadIdx.x < kWave) {
+        const bool stale = ctl->reserved != 0;
+        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, tickets);
+        if (stale) {
+            build_top_image(nodes, image, capacity, (lds_int*)keys);
+            if (threadIdx.x == 0) ctl->reserved = 0;
+        }
+    }
+    __syncthreads();
+    const int stripe = blockIdx.x, count = stripe_chunks(total_chunks, stripe);
+    int padded = 1;
+    while (padded < count) padded *= 2;
+    const auto chunk_of = [&](int t) { return ((t / 32) * kStripes + stripe) * 32 + t % 32; };
+    for (int i = threadIdx.x; i < padded; i += kHistoryThreads)
+        keys[i] = i < count ? (min(cost[chunk_of(i)], 0x3FFFF) << 13) | (8191 - i) : -1;
+    __syncthreads();
+    for (int k = 2; k <= padded; k *= 2)
+        for (int j = k / 2; j > 0; j /= 2) {
+            for (int i = threadIdx.x; i < padded; i += kHistoryThreads) {
+                const int partner = i ^ j;
+                if (partner > i) {
+                    const int a = keys[i], b = keys[partner];
+                    const bool descending = (i & k) == 0;
+                    if (descending ? a < b : a > b) { keys[i] = b; keys[partner] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < count; i += kHistoryThreads) order[stripe * stride + i] = chunk_of(8191 - (keys[i] & 8191));
+}
+
 // Stages the context's image into LDS and checks it against the caller's nodes: every record must equal the node whose id it
 // carries (bounds bit for bit; a child entry either the node's own child id or a link to a slot that carries that id) and
 // record 0 must be the root.  Then following links through the image is the same as following child ids through `nodes`,
@@ -589,11 +637,15 @@ __device__ __forceinline__ bool stage_top_image(const Node2* __restrict__ nodes,
 // the same XCD-aware order as k_bvh2_single (stripe s runs on XCD s % 8) -- until their stripe's share is used up.  No workgroup waits for LDS that a
 // finished neighbour wave still pins (what makes WAVES > 2 lose at 16 Mi rays in the non-persistent form), the image is
 // staged 512 times per launch instead of 16 384 times, and the next ticket is drawn while the current chunk is traced.
-template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int OCC = 32, bool TRACE = false, int PRIO = 0, bool FUSED = false>
+// Schedule history (HISTORY; rodent_hip_schedule_history): every chunk's wave iterations are recorded, the follow-up kernel
+// sorts each stripe's chunks by them, and the next launch of the same size draws its chunks in that order -- longest first
+// (frame-to-frame cost feedback, as renderers balance tiles by the previous frame's cost).  The order only decides WHEN a chunk
+// is traced; a launch without usable history (first launch, other size) takes the default order.
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int OCC = 32, bool TRACE = false, int PRIO = 0, bool FUSED = false, bool HISTORY = false>
 __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_persist(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                      const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                                      Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm,
-                                                                     int4* __restrict__ top_image, int* __restrict__ tickets, int max_id, int* deep_stack) {
+                                                                     int4* __restrict__ top_image, int* __restrict__ tickets, int max_id, int* deep_stack, History hist) {
     constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroup = 32;
     static_assert((kStackInts + TOPN * 16) * 4 * (OCC / WAVES) <= 160 * 1024, "OCC waves per CU must fit their stacks and images in LDS");
     __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
@@ -609,9 +661,17 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     int t = (blockIdx.x / kStripes) * WAVES + wave;
     lds_int* const sp_limit = col + LDS_N * kWave;
     const Bases base = make_bases(nodes, tris);
+    const int my_chunks = HISTORY ? stripe_chunks(total_chunks, stripe) : 0;
     for (;;) {
-        const int group_first = ((t / kGroup) * kStripes + stripe) * kGroup, chunk = group_first + t % kGroup;
-        if (group_first >= total_chunks) break;                              // this stripe's share is used up
+        int chunk;
+        if (HISTORY && hist.order) {
+            if (t >= my_chunks) break;
+            chunk = hist.order[stripe * hist.stride + t];
+        } else {
+            const int group_first = ((t / kGroup) * kStripes + stripe) * kGroup;
+            if (group_first >= total_chunks) break;                          // this stripe's share is used up
+            chunk = group_first + t % kGroup;
+        }
         int t_next = 0;
         if (PREFETCH && lane == 0) t_next = atomicAdd(counter, 1);           // in flight while this chunk is traced
         if (chunk < total_chunks) {
@@ -620,12 +680,13 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
             if (L.top != 0) L.top = root;
             const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
             int iterations = 0;
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            if (PRIO > 0) __builtin_amdgcn_s_setprio(0);
             while (__ballot(L.top != 0)) {
                 if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
-                if (TRACE || PRIO) iterations++;
-                if (PRIO && iterations == PRIO) __builtin_amdgcn_s_setprio(3);          // lab: a chunk that is still running after PRIO iterations is on the critical path
+                if (TRACE || PRIO > 0 || HISTORY) iterations++;
+                if (PRIO > 0 && iterations == PRIO) __builtin_amdgcn_s_setprio(3);          // lab: a chunk that is still running after PRIO iterations is on the critical path
             }
+            if (HISTORY && hist.cost && lane == 0) hist.cost[chunk] = iterations;
             if (TRACE && lane == 0 && ctl->trace && chunk < 16384) {        // lab: per chunk start / end (100 MHz), iterations, wave << 32 | ticket
                 unsigned long long* tr = ctl->trace + 4 * (size_t)chunk;
                 tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime(); tr[2] = (unsigned long long)iterations;
@@ -801,6 +862,9 @@ struct DeviceState {
     int*  sort_totals = nullptr;               // [0, 512) cell counts (zero between launches), [512, 1024) cell cursors
     int4* top_image = nullptr;                 // "top*" mappings: kMaxTopNodes x 64 bytes, rebuilt by every launch
     const Node2* top_image_nodes = nullptr; int top_image_n = 0;
+    int*  chunk_cost = nullptr; int* chunk_order = nullptr;    // schedule history: wave iterations per chunk of the last launch, the order sorted from them
+    int   order_rays = 0;                      // ray count of the launch chunk_order was sorted for (0: none)
+    const int* debug_perm = nullptr;           // lab: caller-supplied ray permutation of the "top-userperm" mapping (rodent_hip_debug_set_perm)
     int*  tickets = nullptr;                   // persistent "top*p" mappings: chunk tickets per XCD (zero between launches)
     Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
 };
@@ -922,6 +986,7 @@ int mapped_node_ids(const Node2* nodes) {
     return (int)std::min<size_t>(bytes / sizeof(Node2), 0x3FFFFFFF);
 }
 
+int g_schedule_history = [] { const char* e = getenv("RODENT_HIP_SCHEDULE_HISTORY"); return e && atoi(e) ? 1 : 0; }();      // rodent_hip_schedule_history()
 #define LAUNCH_ARGS DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
 
 template <bool ANY, int LDS_N, int XCD, bool TR = false, int PRIO = 0> void L_single(LAUNCH_ARGS) {
@@ -979,9 +1044,28 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, 
         hipLaunchKernelGGL(k_raysort_scatter, dim3(blocks), dim3(kSortThreads), 0, stream, s.sort_keys, n, s.sort_totals + kSortCells, s.sort_perm);
         perm = s.sort_perm;
     }
+    if (!SORTED && PRIO == -1) perm = s.debug_perm;                          // lab "top-userperm"
     const int groups = ((s.num_cus * (OCC / WAVES) + kStripes - 1) / kStripes) * kStripes;   // one resident generation, the same number in every stripe
+    const int total_chunks = blocks_for(n), stride = ((total_chunks + 31) / 32 + kStripes - 1) / kStripes * 32;       // chunks of the fullest stripe
+    if (g_schedule_history && !SORTED && !TRACE && PRIO == 0 && !FUSED && !PREFETCH && stride <= kMaxStripeChunks) {
+        // schedule history: this launch records its chunks' costs; it draws them in the order the previous launch of the same
+        // size left behind, if there is one (all on `stream`: the follow-up kernel writes the order before the next launch reads it)
+        if (!s.chunk_cost) {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            HIP_CHECK(hipMalloc(&s.chunk_cost, sizeof(int) * kStripes * kMaxStripeChunks));
+            HIP_CHECK(hipMalloc(&s.chunk_order, sizeof(int) * kStripes * kMaxStripeChunks));
+        }
+        const History hist{s.order_rays == n ? s.chunk_order : nullptr, s.chunk_cost, stride};
+        hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, false, OCC, false, 0, false, true>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(),
+                           s.deep_list, perm, s.top_image, s.tickets, max_id, s.deep_stack, hist);
+        hipLaunchKernelGGL((k_bvh2_top_finish_history<ANY>), dim3(kStripes), dim3(kHistoryThreads), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets,
+                           s.top_image, TOPN, total_chunks, (const int*)s.chunk_cost, s.chunk_order, stride);
+        s.order_rays = n;
+        return;
+    }
+    s.order_rays = 0;
     hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, OCC, TRACE, PRIO, FUSED>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                       perm, s.top_image, s.tickets, max_id, s.deep_stack);
+                       perm, s.top_image, s.tickets, max_id, s.deep_stack, History{nullptr, nullptr, 0});
     if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool SORTED = false, int OCC = 32, bool TRACE = false, int PRIO = 0, bool FUSED = false> void L_top_persist(LAUNCH_ARGS) {
@@ -1094,6 +1178,7 @@ const Variant2 kVariants2[] = {
     K2("top63p4-o28",        "k_bvh2_top_persist",   L_top_persist, 15, 63, 4, false, false, 28),
     //                                                                    LDS_N TOPN WAVES REFILL (idle lanes that trigger a refill)
     K2("top-fused",          "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, true),   // the last workgroup does the follow-up kernel's work
+    K2("top-userperm",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, -1),    // lane j traces ray perm[j] of a caller-supplied permutation (scheduling experiments)
     K2("top-prio64",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 64),    // s_setprio 3 once a chunk has run 64 / 96 / 128 iterations
     K2("top-prio96",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 96),
     K2("top-prio128",        "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 128),
@@ -1150,7 +1235,7 @@ const Variant2 kVariants2[] = {
     K2("trace-sched",        "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false, false, true),
     K2("trace-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, false, true),
     K2("trace-fast",         "k_bvh2_single",        L_single, 16, 32, true),
-    K2("trace-top",          "k_bvh2_top_persist",   L_top_persist, 15, 63, 4, false, false, 28, true),     // (the trace costs 2 VGPRs = one wave per SIMD: 7 four-wave workgroups per CU)
+    K2("trace-top",          "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, true),
     K2("trace-fast-ww",      "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32, true),
     //   static-stride persistent waves: one wave per resident slot, tickets b, b + grid, ... (no atomics)
     K2("fast-static-r64",    "k_bvh2_fast",          L_fast, 16, 8,  true,  64, 64, false, 32, false, true),
@@ -1289,6 +1374,8 @@ const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t a
     return variant >= 0 && variant < count ? t[variant].kernel[any_hit ? 1 : 0] : "";
 }
 void rodent_hip_phased_min_rays(int32_t rays) { g_phased_min_rays = rays < 0 ? 4096 * kWave : rays; }
+void rodent_hip_debug_set_perm(int32_t dev, const int32_t* device_perm) { device_state(dev).debug_perm = device_perm; }   // lab: see "top-userperm"
+void rodent_hip_schedule_history(int32_t enable) { g_schedule_history = enable ? 1 : 0; }
 void rodent_hip_top_min_rays(int32_t rays) { g_top_min_rays = rays < 0 ? 8192 * kWave : rays; }
 int32_t rodent_hip_is_lab_build(void) {
 #ifdef RODENT_HIP_LAB

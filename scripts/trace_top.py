@@ -21,7 +21,7 @@ v = abi.variants(2).index("trace-top")
 abi.read_trace(arm_only=True)
 
 
-def replay(durations, slots=7168):
+def replay(durations, slots=8192):
     """Greedy list scheduling: every chunk goes to the slot that frees first; returns the makespan."""
     free = [0.0] * slots
     heapq.heapify(free)
@@ -44,10 +44,11 @@ for k, rays in sets.items():
     t0 = tr[:, 0].min(); start = (tr[:, 0] - t0) / 100.0; end = (tr[:, 1] - t0) / 100.0; it = tr[:, 2].astype(float)
     wave = (tr[:, 3] >> 32).astype(int); ticket = (tr[:, 3] & 0xFFFFFFFF).astype(int)
     dur = end - start
-    second = ticket >= 112          # 1792 workgroups x 4 waves / 64 stripes
+    second = ticket >= 128          # 512 workgroups x 16 waves / 64 stripes
     print(f"{k}: {len(tr)} chunks, span {end.max():.1f} us; chunk duration mean {dur.mean():.1f} p50 {np.median(dur):.1f} p99 {np.percentile(dur, 99):.1f} max {dur.max():.1f} us; "
           f"iterations mean {it.mean():.1f} max {it.max():.0f}; us per iteration mean {(dur / np.maximum(it, 1)).mean():.3f}")
     print(f"   first generation: start max {start[~second].max():.1f}, end mean {end[~second].mean():.1f} max {end[~second].max():.1f}; drawn chunks: start mean {start[second].mean():.1f} max {start[second].max():.1f}, end max {end[second].max():.1f}")
+    print("   first-generation start times (us): p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(start[~second], [1, 10, 50, 90, 99, 100])))
     ts = np.linspace(0, end.max(), 21)[1:-1]
     print("   chunks in flight at 5%..95% of the span:", [int(((start <= t) & (end > t)).sum()) for t in ts])
     last = np.argsort(-end)[:6]
@@ -57,7 +58,7 @@ for k, rays in sets.items():
         if m.sum():
             print(f"   {lab}: {int(m.sum())} chunks, us/iteration {(dur[m] / np.maximum(it[m], 1)).mean():.3f}, duration mean {dur[m].mean():.1f}")
     order = np.argsort(start)
-    print(f"   replay of the measured durations on 7168 slots: in start order {replay(dur[order]):.1f} us, longest first {replay(np.sort(dur)[::-1]):.1f} us, "
-          f"lower bounds: work / slots {dur.sum() / 7168:.1f} us, longest chunk {dur.max():.1f} us")
+    print(f"   replay of the measured durations on 8192 slots: in start order {replay(dur[order]):.1f} us, longest first {replay(np.sort(dur)[::-1]):.1f} us, "
+          f"lower bounds: work / slots {dur.sum() / 8192:.1f} us, longest chunk {dur.max():.1f} us")
     # the same with durations rescaled to iterations x the unloaded rate (what the chain of the longest ray costs alone)
     print(f"   critical chain: {it.max():.0f} iterations x {np.percentile(dur / np.maximum(it, 1), 5):.3f} us (fastest 5 % of the chunks) = {it.max() * np.percentile(dur / np.maximum(it, 1), 5):.1f} us")

@@ -384,3 +384,29 @@ def test_stack_overflow_is_reported_not_silent(gpu, oracle):
     assert st["max_stack"] == 60
     assert gpu.traverse(ok, rays, variant=0).tobytes() == ref.tobytes()
 
+
+
+def test_schedule_history_only_reorders_the_chunks(gpu, oracle, cornell, cornell_dev):
+    """rodent_hip_schedule_history(1): a launch traces its chunks in the order the previous launch of the same size sorted them
+    into (longest first).  Whatever the order -- none yet, one from the same rays, one from OTHER rays of the same count, ragged
+    sizes -- every ray must be traced exactly once and get the oracle's hit."""
+    import torch
+    top = gpu.variants(2).index("top")
+    base = cornell.ray_sets["primary"]
+    nodes, tris = cornell.blocks[2]
+    st = torch.cuda.Stream()
+    gpu.lib().rodent_hip_schedule_history(1)
+    try:
+        for k, n in enumerate((100_000, 100_000, 100_000, 70_001, 70_001, 100_000, 4096 * 64 + 7, 4096 * 64 + 7)):
+            rays = np.tile(base, (n + len(base) - 1) // len(base))[:n].copy()
+            rays["org"][:, 0] += (np.arange(n, dtype=np.float32) % 977) * 1e-4
+            if k == 2:
+                rays = rays[::-1].copy()                       # same count, other rays: the history mispredicts, nothing else
+            rd = gpu.to_device(rays, 0)
+            hd = torch.full((n * 16,), 0xFF, dtype=torch.uint8, device="cuda:0")
+            gpu.traverse_async(cornell_dev[2], rd, hd, n, False, top, st)
+            gpu.check_errors(0, st)
+            ref, _ = oracle.traverse(2, nodes, tris, rays)
+            assert gpu.from_device(hd, F.HIT1).tobytes() == ref.tobytes(), (k, n)
+    finally:
+        gpu.lib().rodent_hip_schedule_history(0)
