@@ -410,3 +410,28 @@ def test_schedule_history_only_reorders_the_chunks(gpu, oracle, cornell, cornell
             assert gpu.from_device(hd, F.HIT1).tobytes() == ref.tobytes(), (k, n)
     finally:
         gpu.lib().rodent_hip_schedule_history(0)
+
+
+def test_default_mapping_switches_kernels_at_its_size_threshold(gpu, oracle, cornell, cornell_dev):
+    """With the shipped threshold (rodent_hip_top_min_rays(-1): 524 288 rays) launches just under it take the one-chunk kernel and
+    launches from it on the persistent LDS-image kernel (stats[6]: workgroups that ran on the image); the hits are the oracle's."""
+    import torch
+    top = gpu.variants(2).index("top")
+    base = cornell.ray_sets["primary"]
+    nodes, tris = cornell.blocks[2]
+    gpu.lib().rodent_hip_top_min_rays(-1)
+    try:
+        for n, persistent in ((8192 * 64 - 1, False), (8192 * 64, True), (8192 * 64 + 1, True)):
+            rays = np.tile(base, (n + len(base) - 1) // len(base))[:n].copy()
+            rays["org"][:, 1] += (np.arange(n, dtype=np.float32) % 613) * 1e-4
+            rd = gpu.to_device(rays, 0)
+            hd = torch.full((n * 16,), 0xFF, dtype=torch.uint8, device="cuda:0")
+            for _ in range(2):                                  # the second launch finds the image the first one left
+                gpu.read_stats(0)
+                gpu.traverse_async(cornell_dev[2], rd, hd, n, False, top)
+                gpu.check_errors(0)
+            assert (gpu.read_stats(0)[6] > 0) == persistent, n
+            ref, _ = oracle.traverse(2, nodes, tris, rays)
+            assert gpu.from_device(hd, F.HIT1).tobytes() == ref.tobytes(), n
+    finally:
+        gpu.lib().rodent_hip_top_min_rays(0)
