@@ -96,6 +96,10 @@ void    rodent_hip_render_fused_sort(int32_t dev, int32_t enable);
  * (breadth first, built at scene creation) in LDS and fetch those with ds_read instead of through the vector-memory pipeline.
  * 0: one wave per workgroup, every node from memory (rounds 1-2).  Same per-ray visit order, same film.  RODENT_HIP_LDS_IMAGE=0|1. */
 void    rodent_hip_render_lds_image(int32_t dev, int32_t enable);
+/* 1: the stream traversal kernels run in their persistent form (one resident generation of 16-wave workgroups, the first 255
+ * inner nodes in LDS, 64-ray chunks drawn from striped ticket counters -- traversal.hip's default mapping) for streams of at
+ * least 524 288 rays.  0 (default): the 2-wave form above.  Same film.  RODENT_HIP_TRACE_PERSISTENT=0|1. */
+void    rodent_hip_render_trace_persistent(int32_t dev, int32_t enable);
 
 /* ---- the reference's renderer ABI ---- */
 int32_t get_spp(void);

@@ -281,6 +281,7 @@ __device__ __forceinline__ void trace_primary_ray(const SceneDev& sc, const Prim
 // WAVES x 64 threads per workgroup; TOPN > 0: the scene's top-of-tree image (first TOPN records) is staged in LDS behind the
 // WAVES stack windows (kTopStack entries each then: 2 x 4 KB + 31 x 64 B = 16 workgroups per CU, all 32 wave slots).
 constexpr int kTopStack = 15, kSceneTopNodes = 31, kTraceWaves = 2;
+constexpr int kPersistMinRays = 8192 * kWave;          // below one resident generation of rays the persistent form does not pay (traversal.hip)
 template <int WAVES, int TOPN>
 __device__ __forceinline__ lds_int* stage_scene_image(const SceneDev& sc, int* lds, int& chunk, int total_chunks) {
     constexpr int kWindow = TOPN ? kTopStack : kLdsStack;
@@ -343,11 +344,65 @@ __global__ __launch_bounds__(kWave * WAVES) void k_trace_secondary(SceneDev sc, 
     film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
 }
 
+// Persistent form of the two kernels above (rodent_hip_render_trace_persistent; traversal.hip k_bvh2_top_persist): one resident
+// generation of 16-wave workgroups, each stages the scene's 255-record image once and its waves draw 64-ray chunks from 64
+// striped ticket counters (ticket t of stripe s = chunk ((t / 32) * 64 + s) * 32 + t % 32; a wave's first ticket is its rank in
+// the stripe).  The stream size may live on the device: the grid does not depend on it.  k_trace_deep zeroes the counters.
+constexpr int kPersistWaves = 16, kPersistTopNodes = 255, kTraceStripes = 64, kTraceCounterStride = 16;
+template <bool SECONDARY>
+__global__ __launch_bounds__(kWave * kPersistWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_trace_persist(SceneDev sc, PrimaryStream p, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
+                     int* deep_count, unsigned long long* counters, int* deep_list, int* tickets) {
+    constexpr int kStackInts = kPersistWaves * (kTopStack + 1) * kWave;
+    __shared__ __attribute__((aligned(16))) int lds[kStackInts + kPersistTopNodes * 16];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    lds_int* image = (lds_int*)lds + kStackInts;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    for (int j = threadIdx.x; j < kPersistTopNodes * 4; j += kWave * kPersistWaves)
+        reinterpret_cast<__attribute__((address_space(3))) i32x4*>(image)[j] = reinterpret_cast<const i32x4*>(sc.top_image_large)[j];
+    const int n = stream_size(size_ptr, n_value), total_chunks = (n + kWave - 1) / kWave;
+    const int stripe = blockIdx.x % kTraceStripes, stripe_waves = (gridDim.x / kTraceStripes) * kPersistWaves;
+    int* counter = tickets + stripe * kTraceCounterStride;
+    int t = (blockIdx.x / kTraceStripes) * kPersistWaves + wave;
+    lds_int* col = (lds_int*)lds + wave * (kTopStack + 1) * kWave + lane;
+    __syncthreads();
+    if (!SECONDARY && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)n);
+    for (;;) {
+        const int group_first = ((t / 32) * kTraceStripes + stripe) * 32, chunk = group_first + t % 32;
+        if (group_first >= total_chunks) break;
+        if (chunk < total_chunks) {
+            const int i = chunk * kWave + lane;
+            if (!SECONDARY) {
+                if (i < n) {
+                    CursorStack st; st.init(col, kTopStack);
+                    trace_primary_ray<true>(sc, p, i, &st, nullptr, image);
+                    if (st.overflow) deep_list[atomicAdd(deep_count, 1)] = i;
+                }
+            } else {
+                const int pixel = i < n ? s.rays.id[i] : -1;
+                const unsigned long long live = __ballot(pixel >= 0);
+                if (lane == 0 && live) atomicAdd(&counters[4 + (chunk & 63)], (unsigned long long)__popcll(live));
+                bool lit = false;
+                if (pixel >= 0) {
+                    CursorStack st; st.init(col, kTopStack);
+                    lit = !trace_one<true, true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {}, image);
+                    if (st.overflow) { deep_list[atomicAdd(deep_count, 1)] = i; lit = false; }      // k_trace_deep decides
+                }
+                film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
+            }
+        }
+        int t_next = 0;
+        if (lane == 0) t_next = atomicAdd(counter, 1);
+        t = stripe_waves + __builtin_amdgcn_readfirstlane(t_next);
+    }
+}
+
 // The rays the two kernels above abandoned (stack deeper than the LDS window), traced again from the root with the
 // 64-entry stack in global memory; one wave, enqueued behind every stream traversal launch; resets the list.
 template <bool SECONDARY>
 __global__ __launch_bounds__(kWave) void k_trace_deep(SceneDev sc, PrimaryStream p, SecondaryStream s, float* film, float inv_spp, int* err, int* deep_count,
-                                                      const int* deep_list, int* deep_stack) {
+                                                      const int* deep_list, int* deep_stack, int* tickets) {
+    if (tickets) tickets[threadIdx.x * kTraceCounterStride] = 0;            // the persistent kernel's 64 ticket counters, ready for its next launch
     const int count = *deep_count;
     DeepStack st{deep_stack + threadIdx.x, err};
     for (int k = threadIdx.x; k < count; k += kWave) {
@@ -729,6 +784,8 @@ struct RenderDevice {
     int spp = 4, max_path_len = 64;
     int capacity = 0;                          // rays per stream; 0 = default (env_capacity())
     int sort = 1;                              // 1 = sort hit rays by material before shading (mapping_gpu.impala:166-221), 0 = shade in stream order
+    int trace_persistent = 0;                  // 1 = persistent stream traversal kernels (k_trace_persist: 16-wave workgroups, 255-record image, ticket counters)
+    int* tickets[2] = {nullptr, nullptr}; int num_cus = 0;
     int lds_image = 1;                         // 1 = the stream traversal kernels stage the scene's top-of-tree image in LDS (2-wave workgroups); 0 = every node from memory
     int fused_sort = 0;                        // 0 = rays are moved by the sort (copy_primary_ray), then shaded in place; 1 = the sort only computes the permutation and the shader gathers through it
     int* perm = nullptr; int perm_cap = 0;     // sorted position -> stream index
@@ -769,6 +826,7 @@ RenderDevice& rdev(int dev) {
         if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
         if (const char* e = getenv("RODENT_HIP_FUSED_SORT")) r.fused_sort = atoi(e) ? 1 : 0;
         if (const char* e = getenv("RODENT_HIP_LDS_IMAGE")) r.lds_image = atoi(e) ? 1 : 0;
+        if (const char* e = getenv("RODENT_HIP_TRACE_PERSISTENT")) r.trace_persistent = atoi(e) ? 1 : 0;
         if (const char* m = getenv("RODENT_HIP_MAPPING")) {
             if (!strcmp(m, "mega") || !strcmp(m, "megakernel") || !strcmp(m, "1")) r.mapping = 1;
             else if (strcmp(m, "streaming") && strcmp(m, "0")) { fprintf(stderr, "rodent_hip: RODENT_HIP_MAPPING must be 'streaming' or 'mega'\n"); abort(); }
@@ -820,17 +878,38 @@ void ensure_deep(RenderDevice& r, int which, int rays) {
 
 // Stream traversal launches: the main kernel, then the one-wave kernel for the rays it abandoned.
 // ctl words: [2] error flag, [3] primary deep count, [4] secondary deep count, [5] secondary stream size (copy for the aux stream)
+void ensure_tickets(RenderDevice& r) {
+    for (int k = 0; k < 2; k++)
+        if (!r.tickets[k]) {
+            HIP_CHECK(hipMalloc(&r.tickets[k], sizeof(int) * kTraceStripes * kTraceCounterStride));
+            HIP_CHECK(hipMemset(r.tickets[k], 0, sizeof(int) * kTraceStripes * kTraceCounterStride));
+        }
+}
+int persistent_grid(RenderDevice& r) {
+    if (!r.num_cus) { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, r.dev)); r.num_cus = prop.multiProcessorCount; }
+    return ((r.num_cus * (32 / kPersistWaves) + kTraceStripes - 1) / kTraceStripes) * kTraceStripes;
+}
 void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n) {
     ensure_deep(r, 0, n);
-    if (r.lds_image) hipLaunchKernelGGL((k_trace_primary<kTraceWaves, kSceneTopNodes>), dim3((n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
+    int* tickets = nullptr;
+    if (r.trace_persistent && n >= kPersistMinRays) {
+        ensure_tickets(r); tickets = r.tickets[0];
+        hipLaunchKernelGGL(k_trace_persist<false>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, SecondaryStream{}, (const int*)nullptr, n, (float*)nullptr, 0.0f,
+                           r.ctl + 3, r.counters, r.deep_list[0], tickets);
+    } else if (r.lds_image) hipLaunchKernelGGL((k_trace_primary<kTraceWaves, kSceneTopNodes>), dim3((n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
     else hipLaunchKernelGGL((k_trace_primary<1, 0>), dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
-    hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_stack[0]);
+    hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_stack[0], tickets);
 }
 void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const SecondaryStream& s, const int* size_ptr, int max_n, float inv_spp) {
     ensure_deep(r, 1, max_n);
-    if (r.lds_image) hipLaunchKernelGGL((k_trace_secondary<kTraceWaves, kSceneTopNodes>), dim3((max_n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
+    int* tickets = nullptr;
+    if (r.trace_persistent && max_n >= kPersistMinRays) {
+        ensure_tickets(r); tickets = r.tickets[1];
+        hipLaunchKernelGGL(k_trace_persist<true>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, s, size_ptr, max_n, r.film, inv_spp,
+                           r.ctl + 4, r.counters, r.deep_list[1], tickets);
+    } else if (r.lds_image) hipLaunchKernelGGL((k_trace_secondary<kTraceWaves, kSceneTopNodes>), dim3((max_n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
     else hipLaunchKernelGGL((k_trace_secondary<1, 0>), dim3((max_n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
-    hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_stack[1]);
+    hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_stack[1], tickets);
 }
 
 void ensure_hist(RenderDevice& r, size_t ints) {
@@ -1079,10 +1158,10 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
     for (int32_t k = 0; k < d->num_textures; k++)
         if (d->textures[k].width <= 0 || d->textures[k].height <= 0 || (uint64_t)d->textures[k].offset + (uint64_t)d->textures[k].width * (uint64_t)d->textures[k].height > d->num_texels) invalid("texture outside the texel pool");
     s.dev.num_tris = d->num_tris; s.dev.num_materials = d->num_materials; s.dev.num_lights = d->num_lights;
-    // top-of-tree image of the stream traversal kernels (record layout: traversal_device.h build_top_image): breadth first from
+    // top-of-tree images of the stream traversal kernels (record layout: traversal_device.h build_top_image): breadth first from
     // the root; a child that got a slot is a link (kLdsTag + byte offset of its record), the others keep their ids
-    {
-        std::vector<int32_t> image((size_t)kSceneTopNodes * 16, 0), slots{1};
+    const auto build_image = [&](int capacity) {
+        std::vector<int32_t> image((size_t)capacity * 16, 0), slots{1};
         for (size_t k = 0; k < slots.size(); k++) {
             const Node2& nd = d->nodes[slots[k] - 1];
             int32_t* rec = image.data() + 16 * k;
@@ -1090,12 +1169,14 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
             for (int j = 0; j < 2; j++) {
                 const int32_t c = nd.child[j];
                 rec[12 + j] = c;
-                if (c > 0 && (int)slots.size() < kSceneTopNodes) { rec[12 + j] = kLdsTag + (int32_t)slots.size() * (int32_t)sizeof(Node2); slots.push_back(c); }
+                if (c > 0 && (int)slots.size() < capacity) { rec[12 + j] = kLdsTag + (int32_t)slots.size() * (int32_t)sizeof(Node2); slots.push_back(c); }
             }
             rec[14] = slots[k];
         }
-        s.dev.top_image = reinterpret_cast<const int4*>(upload(s, image.data(), image.size()));
-    }
+        return reinterpret_cast<const int4*>(upload(s, image.data(), image.size()));
+    };
+    s.dev.top_image = build_image(kSceneTopNodes);
+    s.dev.top_image_large = build_image(kPersistTopNodes);
     s.loaded = true;
 }
 
@@ -1108,6 +1189,7 @@ void rodent_hip_render_sort(int32_t dev, int32_t enable) { rdev(dev).sort = enab
 void rodent_hip_render_overlap(int32_t dev, int32_t enable) { rdev(dev).overlap = enable ? 1 : 0; }
 void rodent_hip_render_fused_sort(int32_t dev, int32_t enable) { rdev(dev).fused_sort = enable ? 1 : 0; }
 void rodent_hip_render_lds_image(int32_t dev, int32_t enable) { rdev(dev).lds_image = enable ? 1 : 0; }
+void rodent_hip_render_trace_persistent(int32_t dev, int32_t enable) { rdev(dev).trace_persistent = enable ? 1 : 0; }
 
 void rodent_hip_render_capacity(int32_t dev, int32_t rays) {
     if (rays != 0 && (rays < 64 || rays > kMaxCapacity)) { fprintf(stderr, "rodent_hip: stream capacity must be 0 (default) or 64 .. %ld rays\n", kMaxCapacity); abort(); }

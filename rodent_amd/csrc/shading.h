@@ -20,6 +20,7 @@ struct SceneDev {                 // device pointers (uploaded by rodent_hip_sce
     int32_t num_tris, num_materials, num_lights, pad;
     const float* texcoords; const RodentTexture* textures; const uint32_t* texels;
     const int4* top_image;        // the first kSceneTopNodes inner nodes, breadth first, as LDS-image records (traversal_device.h); built at scene creation
+    const int4* top_image_large;  // the same with kPersistTopNodes records (persistent stream traversal kernels)
 };
 
 #define FLT_MAX_REF 3.4028234664e+38f

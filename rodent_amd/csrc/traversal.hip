@@ -8,21 +8,24 @@
 //   tools/bench_traversal/bench_traversal.impala:67-83,495-529  Ray1/Hit1 accessors, entry points
 //
 // Design notes (CDNA4):
-//  * one ray per lane, 64-lane workgroups (= one wavefront, no barriers needed), one 64-ray chunk per wave, chunks
-//    mapped to workgroups XCD-aware;
-//  * single-step schedule (unified_chunk): every lane advances by one node step or one triangle test per wave
+//  * one ray per lane, one 64-ray chunk per wave at a time, chunks handed to waves XCD-aware;
+//  * single-step schedule (bvh2_step): every lane advances by one node step or one triangle test per wave
 //    iteration, the loads of both kinds in flight together; the hit record lives in memory, not in registers;
-//  * the traversal stack is an LDS-only window of 16 entries, laid out [entry][lane] (bank = lane % 32 for
+//  * the default mapping (k_bvh2_top_persist): the top 255 nodes of the caller's hierarchy are staged in LDS as an image
+//    that every workgroup validates against the node array before using it (the ABI passes a pointer, not a handle); the
+//    grid is one resident generation of 16-wave workgroups whose waves draw chunks from 64 striped ticket counters;
+//    launches under 512 Ki rays take k_bvh2_single (64-lane workgroups = one wavefront, one chunk each);
+//  * the traversal stack is an LDS-only window of 15 / 16 entries, laid out [entry][lane] (bank = lane % 32 for
 //    ds_read/write_b32: conflict free whatever each lane's depth is) and walked with a cursor pointer; a ray that
-//    needs more is finished by the one-wave follow-up kernel k_bvh2_finish with the reference's 64-entry stack
-//    (stack.impala:53) in global memory; beyond 64 a device-side error flag makes the host abort();
-//  * nodes and triangles are fetched with 16-byte loads (global_load_dwordx4);
+//    needs more is finished by the one-wave follow-up kernel (k_bvh2_finish / k_bvh2_top_finish) with the reference's
+//    64-entry stack (stack.impala:53) in global memory; beyond 64 a device-side error flag makes the host abort();
+//  * nodes and triangles are fetched with 16-byte loads (global_load_dwordx4 / ds_read_b128);
 //  * no MFMA: this is branchy scalar fp32 work;
 //  * arithmetic is written out with explicit fmaf() and compiled with
 //    -ffp-contract=off so results are bit-identical to the CPU parity oracle.
 //
-// This file: shared device helpers, the default BVH2 kernel (k_bvh2_single) and its follow-up kernel k_bvh2_finish, the
-// host side and the C ABI.  traversal_wide.h holds the BVH4 / BVH8 + Tri4 kernels (same schedule).  The kernels that
+// This file: shared device helpers, the BVH2 kernels (k_bvh2_top_persist, k_bvh2_single, k_bvh2_phase, the ray sort) and
+// their follow-up kernels, the host side and the C ABI.  traversal_wide.h holds the BVH4 / BVH8 + Tri4 kernels (same schedule).  The kernels that
 // were measured along the way and lost (traversal_variants.h) are compiled only into the lab build
 // (-DRODENT_HIP_LAB, librodent_hip_lab.so): the product library ships the default mappings only.
 // Kernel variants ("mappings") are selected at run time; see kVariants below.

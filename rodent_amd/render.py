@@ -27,7 +27,7 @@ class SceneDesc(C.Structure):
                [(n, vp) for n in ("texcoords", "textures", "texels")] + [("num_textures", i32), ("num_texels", C.c_uint32)]
 
 
-RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_lds_image", "get_spp", "render",
+RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_lds_image", "rodent_hip_render_trace_persistent", "get_spp", "render",
                   "setup_interface", "get_pixels", "clear_pixels", "cleanup_interface", "rodent_get_film_data",
                   "rodent_gpu_get_first_primary_stream", "rodent_gpu_get_second_primary_stream", "rodent_gpu_get_secondary_stream",
                   "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows",
@@ -52,6 +52,7 @@ def lib():
         l.rodent_hip_render_overlap.argtypes = [i32, i32]; l.rodent_hip_render_overlap.restype = None
         l.rodent_hip_render_fused_sort.argtypes = [i32, i32]; l.rodent_hip_render_fused_sort.restype = None
         l.rodent_hip_render_lds_image.argtypes = [i32, i32]; l.rodent_hip_render_lds_image.restype = None
+        l.rodent_hip_render_trace_persistent.argtypes = [i32, i32]; l.rodent_hip_render_trace_persistent.restype = None
         l.get_spp.argtypes = []; l.get_spp.restype = i32
         l.render.argtypes = [C.POINTER(Settings), i32]; l.render.restype = None
         l.setup_interface.argtypes = [C.c_size_t, C.c_size_t]; l.setup_interface.restype = None
@@ -84,7 +85,7 @@ class Renderer:
 
     MAPPINGS = {"streaming": 0, "megakernel": 1}       # mapping_gpu.impala:308-369 / :371-474
 
-    def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming", capacity=0, sort=True, overlap=True, fused_sort=False, lds_image=True):
+    def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming", capacity=0, sort=True, overlap=True, fused_sort=False, lds_image=True, trace_persistent=None):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("rodent_amd: no GPU visible (the renderer has no CPU fallback)")
@@ -103,6 +104,8 @@ class Renderer:
         l.rodent_hip_render_overlap(dev, int(bool(overlap)))  # shadow rays on a second HIP stream
         l.rodent_hip_render_fused_sort(dev, int(bool(fused_sort)))   # the sort computes a permutation, the shader gathers through it
         l.rodent_hip_render_lds_image(dev, int(bool(lds_image)))     # stream traversal kernels stage the top of the BVH in LDS (default)
+        if trace_persistent is not None:
+            l.rodent_hip_render_trace_persistent(dev, int(bool(trace_persistent)))    # persistent form of those kernels for streams of >= 512 Ki rays
         l.setup_interface(width, height)
         l.clear_pixels()
 
