@@ -166,3 +166,19 @@ def test_fbuf2png(tmp_path, native_build):
     assert im.shape == (8, 16, 4) and im[-1, -1, 0] == 255 and im[0, 0, 0] == 0 and (im[..., 3] == 255).all()
     exp = (255.0 * t / t.max()).astype(np.uint8).reshape(8, 16)              # fbuf2png.cpp:108-110
     assert np.array_equal(im[..., 0], exp)
+
+
+def test_top_image_node_set_is_a_breadth_first_prefix(cornell):
+    """rodent_amd.topimage restates which nodes the default traversal kernel keeps in LDS (bench.py's accounting): the root
+    first, every node after its parent, no node twice, never more than the capacity, the whole tree when it is small."""
+    from rodent_amd import topimage
+    nodes, _ = cornell.blocks[2]
+    child = np.asarray(nodes["child"]).reshape(-1, 2)
+    inner = 1 + int((child > 0).sum())                            # the root + every inner child
+    for cap in (1, 3, 15, 255):
+        ids = topimage.image_nodes(nodes, cap)
+        assert ids[0] == 0 and len(ids) == min(cap, inner) and len(set(ids.tolist())) == len(ids)
+        seen = {0}
+        for i in ids:
+            assert int(i) in seen                                  # reached from a node earlier in the list
+            seen.update(int(c) - 1 for c in child[i] if c > 0)
