@@ -1,0 +1,328 @@
+// traversal_top.h -- the default BVH2 mapping: top of the tree staged in LDS, persistent workgroups.
+// Included by traversal.hip inside its anonymous namespace, after Ctl, finish_launch, Lane, bvh2_step, start_lane, make_bases and
+// the stripe constants (kStripes, kCounterStride); the host side (DeviceState, launchers, variant table) stays in traversal.hip.
+//   k_bvh2_top_image / build_top_image (traversal_device.h)   the image: first TOPN inner nodes, breadth first, links for resident children
+//   stage_top_image                                            a workgroup stages the image and VALIDATES it against the caller's nodes
+//   k_bvh2_top_persist                                         the kernel: one resident generation of workgroups, chunks from striped tickets
+//   k_bvh2_top_finish, k_bvh2_top_finish_history               follow-up kernels (deep rays, stale image, schedule history)
+//   k_bvh2_top, k_bvh2_top_refill                              lab build: one chunk per workgroup wave; lane refill
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// LDS-staged top of the tree (variants "top*").  A third to a half of all node visits fall on the top 4 - 8 levels of the
+// hierarchy (scripts/model_top_levels.py: atrium, 15 nodes 22 %, 63 nodes 41 / 38 %, 255 nodes 52 / 57 % of the visits of the
+// primary / random set).  build_top_image copies the first TOPN nodes in breadth-first order into a 64-byte-per-node image
+// whose child ids, where the child is in the image too, are kLdsTag + its byte offset; a workgroup stages the image in LDS
+// behind its stacks and a lane whose top is such an id reads its node with ds_read_b128 -- LDS bandwidth instead of the
+// TA -> L1 path the kernel saturates.  The caller's Node2 array is in no particular order and may change between
+// launches: the image is kept per (device, stream) context and VALIDATED by every workgroup that stages it (stage_top_image);
+// the follow-up kernel rebuilds it when a launch found none or a stale one (the lab's one-chunk form, k_bvh2_top, rebuilds it
+// in front of every launch instead).  Ids with the tag never leave the kernel: a ray deeper than the LDS window restarts
+// from the root in the follow-up kernel.
+// ---------------------------------------------------------------------------------------------
+template <int TOPN>
+__global__ __launch_bounds__(kWave) void k_bvh2_top_image(const Node2* __restrict__ nodes, int4* __restrict__ image) {
+    __shared__ int slot_node[TOPN];
+    build_top_image(nodes, image, TOPN, (lds_int*)slot_node);
+}
+
+// The follow-up kernel of the persistent form: k_bvh2_finish's work, plus the image for the NEXT launch when this launch found
+// none or a stale one (ctl->reserved, set by any workgroup whose validation failed).
+template <bool ANY>
+__global__ __launch_bounds__(kWave) void k_bvh2_top_finish(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                            const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
+                                                            Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* tickets,
+                                                            int4* __restrict__ image, int capacity) {
+    const bool stale = ctl->reserved != 0;
+    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, tickets);
+    if (stale) {
+        __shared__ int slot_node[kMaxTopNodes];
+        build_top_image(nodes, image, capacity, (lds_int*)slot_node);
+        if (threadIdx.x == 0) ctl->reserved = 0;
+    }
+}
+
+#ifdef RODENT_HIP_LAB      // one chunk per workgroup wave with the image: measured, superseded by the persistent form below
+template <bool ANY, int LDS_N, int XCD, int TOPN, int WAVES>
+__global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                             const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                             Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm,
+                                                             const int4* __restrict__ top_image) {
+    constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave;
+    static_assert((kStackInts + TOPN * 16) * 4 * (32 / WAVES) <= 160 * 1024, "32 waves per CU must fit their stacks and images in LDS");
+    static_assert(XCD % WAVES == 0, "a workgroup's chunks stay inside one XCD group");
+    __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
+    lds_int* image = (lds_int*)lds_raw + kStackInts;
+    // the image first (in flight while the ray is loaded and set up)
+    constexpr int kStage = (TOPN * 4 + kWave * WAVES - 1) / (kWave * WAVES);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 stage[kStage];
+#pragma unroll
+    for (int k = 0; k < kStage; k++) { const int j = k * kWave * WAVES + (int)threadIdx.x; if (j < TOPN * 4) stage[k] = reinterpret_cast<const i32x4*>(top_image)[j]; }
+    const int total_chunks = (n + kWave - 1) / kWave;
+    int chunk = blockIdx.x * WAVES + wave;
+    if (XCD > 0) {
+        const int span = 8 * XCD, full = (total_chunks / span) * span;        // region where the mapping is a bijection
+        if ((int)blockIdx.x * WAVES < full) {
+            const int x = blockIdx.x % 8, l = (blockIdx.x / 8) * WAVES + wave;
+            chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
+        }
+    }
+    const int first_ray = chunk * kWave, lane_ray = first_ray + lane;
+    const bool live_chunk = first_ray < n;                                   // (whole waves beyond the last chunk only help with the image)
+    Lane L = start_lane(rays, hits, live_chunk && lane_ray < n ? (perm ? perm[lane_ray] : lane_ray) : -1, live_chunk ? (perm ? perm[first_ray] : first_ray) : 0, col);
+    if (L.top != 0) L.top = kLdsTag;                                         // the root is record 0 of the image
+#pragma unroll
+    for (int k = 0; k < kStage; k++) {
+        const int j = k * kWave * WAVES + (int)threadIdx.x;
+        if (j < TOPN * 4) reinterpret_cast<__attribute__((address_space(3))) i32x4*>(image)[j] = stage[k];
+    }
+    if (WAVES > 1) __syncthreads();
+    lds_int* const sp_limit = col + LDS_N * kWave;
+    const Bases base = make_bases(nodes, tris);
+    while (__ballot(L.top != 0)) {
+        if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+    }
+}
+
+#endif
+
+struct History { const int* order; int* cost; int stride; };               // order[stripe * stride + ticket] = chunk; either may be null
+// chunks of stripe s under the default order: its complete 32-chunk groups plus, for one stripe, the ragged last group
+__device__ __forceinline__ int stripe_chunks(int total_chunks, int stripe) {
+    const int full_groups = total_chunks / 32, rest = total_chunks % 32;
+    return (full_groups / kStripes + (stripe < full_groups % kStripes ? 1 : 0)) * 32 + (stripe == full_groups % kStripes ? rest : 0);
+}
+// The follow-up kernel when the schedule history is on: workgroup 0's first wave does k_bvh2_top_finish's work, then workgroup s
+// sorts the chunks of stripe s by the wave iterations this launch took for them, longest first (ties: default order), into
+// order[s * stride ...] -- bitonic in LDS, at most kMaxStripeChunks keys.
+constexpr int kMaxStripeChunks = 1024, kHistoryThreads = 256;      // 4 Mi rays: beyond that the launch is throughput-bound and the sorted order only costs locality (16 Mi: -8 %)
+template <bool ANY>
+__global__ __launch_bounds__(kHistoryThreads) void k_bvh2_top_finish_history(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                                              const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
+                                                                              Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* tickets,
+                                                                              int4* __restrict__ image, int capacity, int total_chunks,
+                                                                              const int* __restrict__ cost, int* __restrict__ order, int stride) {
+    __shared__ int keys[kMaxStripeChunks];
+    if (blockIdx.x == 0 && threadIdx.x < kWave) {
+        const bool stale = ctl->reserved != 0;
+        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, tickets);
+        if (stale) {
+            build_top_image(nodes, image, capacity, (lds_int*)keys);
+            if (threadIdx.x == 0) ctl->reserved = 0;
+        }
+    }
+    __syncthreads();
+    const int stripe = blockIdx.x, count = stripe_chunks(total_chunks, stripe);
+    int padded = 1;
+    while (padded < count) padded *= 2;
+    const auto chunk_of = [&](int t) { return ((t / 32) * kStripes + stripe) * 32 + t % 32; };
+    for (int i = threadIdx.x; i < padded; i += kHistoryThreads)
+        keys[i] = i < count ? (min(cost[chunk_of(i)], 0x3FFFF) << 13) | (8191 - i) : -1;
+    __syncthreads();
+    for (int k = 2; k <= padded; k *= 2)
+        for (int j = k / 2; j > 0; j /= 2) {
+            for (int i = threadIdx.x; i < padded; i += kHistoryThreads) {
+                const int partner = i ^ j;
+                if (partner > i) {
+                    const int a = keys[i], b = keys[partner];
+                    const bool descending = (i & k) == 0;
+                    if (descending ? a < b : a > b) { keys[i] = b; keys[partner] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < count; i += kHistoryThreads) order[stripe * stride + i] = chunk_of(8191 - (keys[i] & 8191));
+}
+
+// Stages the context's image into LDS and checks it against the caller's nodes: every record must equal the node whose id it
+// carries (bounds bit for bit; a child entry either the node's own child id or a link to a slot that carries that id) and
+// record 0 must be the root.  Then following links through the image is the same as following child ids through `nodes`,
+// whatever happened to the array since the image was built.  Returns false (workgroup-uniform) for an absent or stale image:
+// the workgroup then starts its rays at node id 1 and never meets a link; ctl->reserved asks the follow-up kernel for a new image.
+// `max_id`: node ids the caller's allocation is known to hold (the host asks the runtime for the mapped range behind `nodes`):
+// a record whose id lies beyond it is stale, and is not dereferenced.
+template <int TOPN, int THREADS>
+__device__ __forceinline__ bool stage_top_image(const Node2* __restrict__ nodes, const int4* __restrict__ top_image, lds_int* image, lds_int* flag, Ctl* ctl, int max_id) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    bool ok = true;
+    const int* image_ints = reinterpret_cast<const int*>(top_image);
+    for (int j = threadIdx.x; j < TOPN * 4; j += THREADS) {
+        const int slot = j >> 2, quarter = j & 3, id = image_ints[slot * 16 + 14];
+        const i32x4 rec = reinterpret_cast<const i32x4*>(top_image)[j];
+        reinterpret_cast<__attribute__((address_space(3))) i32x4*>(image)[j] = rec;
+        if (id > max_id) ok = false;
+        else if (id > 0) {
+            const i32x4 real = reinterpret_cast<const i32x4*>(nodes + (id - 1))[quarter];
+            if (quarter < 3) ok &= rec.x == real.x && rec.y == real.y && rec.z == real.z && rec.w == real.w;
+            else ok &= (rec.x >= kLdsTag || rec.x == real.x) && (rec.y >= kLdsTag || rec.y == real.y);     // links: after the barrier
+        } else if (slot == 0) ok = false;
+        if (j == 0) ok &= id == 1;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < TOPN * 4; j += THREADS) {
+        if ((j & 3) != 3) continue;
+        const int slot = j >> 2, id = image[slot * 16 + 14];
+        if (id <= 0 || id > max_id) continue;
+        const int2 real = *reinterpret_cast<const int2*>(&nodes[id - 1].child[0]);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int link = image[slot * 16 + 12 + k], child = k ? real.y : real.x;
+            if (link >= kLdsTag) {
+                const unsigned target = (unsigned)(link - kLdsTag) / (unsigned)sizeof(Node2);
+                ok &= (link - kLdsTag) % (int)sizeof(Node2) == 0 && target < (unsigned)TOPN && child > 0 && image[(target < (unsigned)TOPN ? target : 0u) * 16 + 14] == child;
+            }
+        }
+    }
+    // the verdict through one LDS word (`flag`: any word the caller does not need yet; __syncthreads_and would take 256 bytes of
+    // LDS of its own, and two 16-wave workgroups fill the CU's 160 KB to within 128 bytes)
+    if (threadIdx.x == 0) *flag = 1;
+    __syncthreads();
+    if (!ok) *flag = 0;
+    __syncthreads();
+    const bool all_ok = *flag != 0;
+    __syncthreads();
+    if (!all_ok && threadIdx.x == 0) ctl->reserved = 1;
+    return all_ok;
+}
+
+// Persistent form: the grid is one generation of workgroups (32 / WAVES per CU), every workgroup stages the image once and
+// its waves keep drawing 64-ray chunks -- a ticket from the counter of their stripe (64 counters, 64 bytes apart: one counter
+// saturates near 88 atomics/us, a 1 Mi-ray launch draws 83 per us), ticket t of stripe s = chunk ((t / 32) * 64 + s) * 32 + t % 32,
+// the same XCD-aware order as k_bvh2_single (stripe s runs on XCD s % 8) -- until their stripe's share is used up.  No workgroup waits for LDS that a
+// finished neighbour wave still pins (what makes WAVES > 2 lose at 16 Mi rays in the non-persistent form), the image is
+// staged 512 times per launch instead of 16 384 times, and the next ticket is drawn while the current chunk is traced.
+// Schedule history (HISTORY; rodent_hip_schedule_history): every chunk's wave iterations are recorded, the follow-up kernel
+// sorts each stripe's chunks by them, and the next launch of the same size draws its chunks in that order -- longest first
+// (frame-to-frame cost feedback, as renderers balance tiles by the previous frame's cost).  The order only decides WHEN a chunk
+// is traced; a launch without usable history (first launch, other size) takes the default order.
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int OCC = 32, bool TRACE = false, int PRIO = 0, bool FUSED = false, bool HISTORY = false>
+__global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_persist(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                                     const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                                     Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm,
+                                                                     int4* __restrict__ top_image, int* __restrict__ tickets, int max_id, int* deep_stack, History hist) {
+    constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroup = 32;
+    static_assert((kStackInts + TOPN * 16) * 4 * (OCC / WAVES) <= 160 * 1024, "OCC waves per CU must fit their stacks and images in LDS");
+    __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
+    lds_int* image = (lds_int*)lds_raw + kStackInts;
+    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, (const int4*)top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;      // record 0 of the image, or node 1
+    if (root != 1 && threadIdx.x == 0) atomicAdd(&ctl->stats[6], 1ull);     // stats[6]: workgroups that ran on the image (read by the tests)
+    // stripe = workgroup index mod 64 (its XCD = stripe mod 8); the first ticket of a wave is its rank inside the stripe, the
+    // counter hands out the tickets behind those
+    const int total_chunks = (n + kWave - 1) / kWave, stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
+    int* counter = tickets + stripe * kCounterStride;
+    int t = (blockIdx.x / kStripes) * WAVES + wave;
+    lds_int* const sp_limit = col + LDS_N * kWave;
+    const Bases base = make_bases(nodes, tris);
+    const int my_chunks = HISTORY ? stripe_chunks(total_chunks, stripe) : 0;
+    for (;;) {
+        int chunk;
+        if (HISTORY && hist.order) {
+            if (t >= my_chunks) break;
+            chunk = hist.order[stripe * hist.stride + t];
+        } else {
+            const int group_first = ((t / kGroup) * kStripes + stripe) * kGroup;
+            if (group_first >= total_chunks) break;                          // this stripe's share is used up
+            chunk = group_first + t % kGroup;
+        }
+        int t_next = 0;
+        if (PREFETCH && lane == 0) t_next = atomicAdd(counter, 1);           // in flight while this chunk is traced
+        if (chunk < total_chunks) {
+            const int first_ray = chunk * kWave, lane_ray = first_ray + lane;
+            Lane L = start_lane(rays, hits, lane_ray < n ? (perm ? perm[lane_ray] : lane_ray) : -1, perm ? perm[first_ray] : first_ray, col);
+            if (L.top != 0) L.top = root;
+            const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            int iterations = 0;
+            if (PRIO > 0) __builtin_amdgcn_s_setprio(0);
+            while (__ballot(L.top != 0)) {
+                if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+                if (TRACE || PRIO > 0 || HISTORY) iterations++;
+                if (PRIO > 0 && iterations == PRIO) __builtin_amdgcn_s_setprio(3);          // lab: a chunk that is still running after PRIO iterations is on the critical path
+            }
+            if (HISTORY && hist.cost && lane == 0) hist.cost[chunk] = iterations;
+            if (TRACE && lane == 0 && ctl->trace && chunk < 16384) {        // lab: per chunk start / end (100 MHz), iterations, wave << 32 | ticket
+                unsigned long long* tr = ctl->trace + 4 * (size_t)chunk;
+                tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime(); tr[2] = (unsigned long long)iterations;
+                tr[3] = ((unsigned long long)(blockIdx.x * WAVES + wave) << 32) | (unsigned)t;
+            }
+        }
+        if (!PREFETCH && lane == 0) t_next = atomicAdd(counter, 1);
+        t = stripe_waves + __builtin_amdgcn_readfirstlane(t_next);
+    }
+    if (FUSED) {
+        // The workgroup that finishes last does the follow-up kernel's work (deep rays, counters, a new image if this launch found
+        // none or a stale one): one launch instead of two.  Every workgroup publishes what it wrote (agent-scope release: its
+        // XCD's L2 is written back) before it counts itself done; the last one acquires before it reads the deep list.
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const int done = __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            lds_raw[0] = done == (int)gridDim.x - 1;
+        }
+        __syncthreads();
+        if (!lds_raw[0] || wave != 0) return;
+        __threadfence();
+        const bool stale = __hip_atomic_load(&ctl->reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, tickets);
+        if (stale) {
+            build_top_image(nodes, top_image, TOPN, (lds_int*)lds_raw);        // (the stacks are idle now)
+            if (lane == 0) ctl->reserved = 0;
+        }
+    }
+}
+
+#ifdef RODENT_HIP_LAB
+// Persistent form with lane refill: a wave does not wait for the last ray of a 64-ray chunk.  As soon as REFILL of its lanes
+// are idle it draws that many rays from its stripe's counter (one atomic per refill) and starts them in the idle lanes; the
+// rest keep stepping.  Ticket t of stripe s is ray ((t / 2048) * 64 + s) * 2048 + t % 2048 (the same 32-chunk groups), the first
+// 64 tickets of a wave are static.  Which rays share a wave changes, what a ray visits does not.
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL>
+__global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                                    const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                                    Ctl* ctl, int* __restrict__ deep_list, const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id) {
+    constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroupRays = 32 * kWave;
+    static_assert((kStackInts + TOPN * 16) * 4 * (32 / WAVES) <= 160 * 1024, "32 waves per CU must fit their stacks and images in LDS");
+    __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
+    lds_int* image = (lds_int*)lds_raw + kStackInts;
+    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;
+    const int stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
+    int* counter = tickets + stripe * kCounterStride;
+    const auto ray_of = [&](int t) { return ((t / kGroupRays) * kStripes + stripe) * kGroupRays + t % kGroupRays; };
+    lds_int* const sp_limit = col + LDS_N * kWave;
+    const Bases base = make_bases(nodes, tris);
+    Lane L;
+    {
+        const int r = ray_of(((blockIdx.x / kStripes) * WAVES + wave) * kWave + lane);
+        L = start_lane(rays, hits, r < n ? r : -1, 0, col);
+        if (L.top != 0) L.top = root;
+    }
+    bool more = true;                                                        // wave-uniform: the stripe may have rays left
+    for (;;) {
+        const unsigned long long live = __ballot(L.top != 0);
+        if (more && __popcll(live) <= kWave - REFILL) {
+            const int want = kWave - __popcll(live);
+            int first = 0;
+            if (lane == 0) first = atomicAdd(counter, want);
+            first = stripe_waves * kWave + __builtin_amdgcn_readfirstlane(first);
+            more = ray_of(first) < n;                                            // ray_of grows with the ticket: once past the end, always past the end
+            if (L.top == 0) {
+                const int r = ray_of(first + __popcll(~live & ((1ull << lane) - 1ull)));
+                if (r < n) {
+                    L = start_lane(rays, hits, r, r, col);
+                    L.top = root;
+                }
+            }
+            continue;
+        }
+        if (live == 0) break;
+        if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+    }
+}
+#endif
+
