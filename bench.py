@@ -272,6 +272,20 @@ def main():
             overlapped = 2 * max(1, args.steps // 2) * n / (time.perf_counter() - t0) / 1e6
         except Exception as e:                                    # informational only: never lose the bench line over it
             print(f"bench.py: two-stream measurement skipped ({e})", file=sys.stderr)
+    # informational: the same camera at 4096 x 4096 = 16 Mi primary rays per launch -- the kernel's throughput regime (at 1 Mi rays
+    # the launch is bound by its schedule)
+    big = None
+    if args.only is None and not args.no_cpu_baseline and world == 1 and scene != "sponza":
+        try:
+            eye, d, up, fov = scenes.CAMERAS[scene]
+            big_rays = raygen.primary_rays(eye, d, up, fov, 4096, 4096, 0.0, scenes.PRIMARY_TMAX)
+            big_dev = abi.to_device(big_rays, dev)
+            big_hits = torch.zeros(len(big_rays) * F.HIT1.itemsize, dtype=torch.uint8, device=f"cuda:{dev}")
+            wall_b, kb_mean, _, _ = time_passes(abi, torch, bvh, big_dev, big_hits, len(big_rays), variant, 10, 3, None)
+            big = {"rays_per_launch": len(big_rays), "Mrays_s": round(len(big_rays) * 10 / wall_b / 1e6, 3), "ms_per_step": round(1e3 * wall_b / 10, 5), "kernels_ms": round(kb_mean, 5)}
+            del big_dev, big_hits, big_rays
+        except Exception as e:
+            print(f"bench.py: 16 Mi-ray measurement skipped ({e})", file=sys.stderr)
     abi.lib()  # keep the handle alive
     kernel_ms_ranks = [[k_mean, kr_mean]]
     total_rays, total_rnd = n, len(rnd)
@@ -334,7 +348,8 @@ def main():
                   "random_kernel_ms": {"mean": round(kr_mean, 5), "median": round(kr_med, 5), "min": round(kr_min, 5)},
                   "kernel_ms_per_rank[primary,random]": kernel_ms_ranks,
                   "hit_counts_per_rank[primary,random]": counts_all, "strong_scaling_check": strong_check,
-                  "two_streams_Mrays_s_per_gpu": None if overlapped is None else round(overlapped, 3)},
+                  "two_streams_Mrays_s_per_gpu": None if overlapped is None else round(overlapped, 3),
+                  "primary_16Mi_rays_per_launch": big},
     }
     if history is not None:
         out["extra"]["with_schedule_history"] = history
