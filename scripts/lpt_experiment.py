@@ -55,6 +55,11 @@ for k, rays in sets.items():
         c = pos[s]
         full[s] = c[np.argsort(-cost[c], kind="stable")]
         second[s, half:] = c[half:][np.argsort(-cost[c[half:]], kind="stable")]
+    groups = per_stripe // GROUP
+    inter = np.concatenate([np.arange(0, groups, 2), np.arange(1, groups, 2)])                     # even 32-chunk groups of the stripe first, then the odd ones
+    orders["even groups first, then odd groups (stateless)"] = np.stack([pos[s].reshape(groups, GROUP)[inter].ravel() for s in range(STRIPES)])
+    rev = np.arange(groups)[::-1]
+    orders["groups in reverse order (stateless)"] = np.stack([pos[s].reshape(groups, GROUP)[rev].ravel() for s in range(STRIPES)])
     orders["longest first (whole stripe)"] = full
     orders["first generation unchanged, drawn chunks longest first"] = second
     for name, order in orders.items():
