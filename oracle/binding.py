@@ -111,6 +111,21 @@ def node_visits(nodes, tris, rays, any_hit=False):
     return buf
 
 
+def ray_depths(nodes, tris, rays, any_hit=False):
+    """Deepest stack pointer of every ray under B1 (BVH2/Tri1), uint8.  Analysis aid (scripts/model_stack_depth.py)."""
+    rays = np.ascontiguousarray(rays)
+    buf = np.zeros(len(rays), np.uint8)
+    l = lib()
+    l.oracle_set_ray_depth_trace.restype = None
+    l.oracle_set_ray_depth_trace.argtypes = [C.c_void_p]
+    l.oracle_set_ray_depth_trace(_ptr(buf))
+    try:
+        traverse(2, nodes, tris, rays, any_hit=any_hit)
+    finally:
+        l.oracle_set_ray_depth_trace(None)
+    return buf
+
+
 def brute_force(tris, rays):
     """Every ray against every triangle.  Returns (hits, second_t)."""
     tris = np.ascontiguousarray(tris)

@@ -158,6 +158,10 @@ void oracle_set_ray_step_trace(uint32_t* buf) { g_ray_steps = buf; }
  * (one uint64 per node).  Not thread-safe; NULL switches it off. */
 static uint64_t* g_node_visits = 0;
 void oracle_set_node_visit_trace(uint64_t* buf) { g_node_visits = buf; }
+/* Analysis aid (scripts/model_stack_depth.py): when set, oracle_bvh2_tri1 writes every ray's deepest stack pointer (one byte
+ * per ray; the HIP kernels' LDS window of N entries holds rays whose value is below N).  Not thread-safe; NULL switches it off. */
+static uint8_t* g_ray_depth = 0;
+void oracle_set_ray_depth_trace(uint8_t* buf) { g_ray_depth = buf; }
 
 int oracle_bvh2_tri1(const struct Node2* nodes, const struct Tri1* tris,
                      const struct Ray1* rays, struct Hit1* hits, int32_t n,
@@ -169,7 +173,7 @@ int oracle_bvh2_tri1(const struct Node2* nodes, const struct Tri1* tris,
         int32_t hit_id = -1; float hit_t = ray.tmax, hit_u = 0.0f, hit_v = 0.0f;
         int32_t mem[STACK_CAP + 2];
         int32_t ptr = 0, top = 1; mem[0] = 0;          /* push(1): old top (0) spilled */
-        int done = 0;
+        int done = 0, deepest = 0;
         const uint64_t inner_before = st.inner_nodes, prims_before = st.prim_packets;
         while (top != 0 && !done) {
             const struct Node2* nd = &nodes[top - 1];   /* top is NOT popped (:107-108) */
@@ -199,6 +203,7 @@ int oracle_bvh2_tri1(const struct Node2* nodes, const struct Tri1* tris,
                 if (ptr >= STACK_CAP) { overflow = 1; ptr = STACK_CAP - 1; }
                 mem[ptr] = second;
                 if ((uint32_t)ptr > st.max_stack) st.max_stack = (uint32_t)ptr;
+                if (ptr > deepest) deepest = ptr;
             } else top = hk[0] ? nd->child[0] : nd->child[1];
 
             while (top < 0) {                           /* leaf loop (:156-174) */
@@ -220,6 +225,7 @@ int oracle_bvh2_tri1(const struct Node2* nodes, const struct Tri1* tris,
         hits[i].tri_id = hit_id; hits[i].t = hit_t; hits[i].u = hit_u; hits[i].v = hit_v;
         st.hits += hit_id >= 0;
         if (g_ray_steps) { g_ray_steps[2 * i] = (uint32_t)(st.inner_nodes - inner_before); g_ray_steps[2 * i + 1] = (uint32_t)(st.prim_packets - prims_before); }
+        if (g_ray_depth) g_ray_depth[i] = (uint8_t)deepest;
     }
     st.rays = (uint64_t)n;
     stats_merge(stats_out, &st);

@@ -130,9 +130,10 @@ struct CursorStack {
     lds_int* sp; lds_int* limit; bool overflow;
     __device__ __forceinline__ void init(lds_int* col, int window = kLdsStack) { sp = col; limit = col + window * kWave; overflow = false; col[0] = 0; }
 };
-// 64 entries in global memory ([entry][lane]), the reference's capacity (stack.impala:53); used by k_trace_deep only.
+// 64 entries ([entry][lane]), the reference's capacity (stack.impala:53), in 16 KB of LDS; used by k_trace_deep only.  (In global
+// memory, rounds 1-2, every push and pop was a round trip: ~100 us for the first deep ray of a launch.)
 struct DeepStack {
-    int* base; int* err;
+    lds_int* base; int* err;
     __device__ __forceinline__ int get(int e) const { return base[(e < kStackCap ? e : kStackCap - 1) * kWave]; }
     __device__ __forceinline__ void put(int e, int v) { if (e < kStackCap) base[e * kWave] = v; else *err = 1; }
 };
@@ -402,9 +403,10 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, SecondaryStream s, const int*
 template <bool SECONDARY>
 __global__ __launch_bounds__(kWave) void k_trace_deep(SceneDev sc, PrimaryStream p, SecondaryStream s, float* film, float inv_spp, int* err, int* deep_count,
                                                       const int* deep_list, int* deep_stack, int* tickets) {
+    __shared__ int stack_lds[kStackCap * kWave];
     if (tickets) tickets[threadIdx.x * kTraceCounterStride] = 0;            // the persistent kernel's 64 ticket counters, ready for its next launch
     const int count = *deep_count;
-    DeepStack st{deep_stack + threadIdx.x, err};
+    DeepStack st{(lds_int*)stack_lds + threadIdx.x, err};
     for (int k = threadIdx.x; k < count; k += kWave) {
         const int i = deep_list[k];
         if (SECONDARY) {

@@ -107,7 +107,7 @@ __device__ __forceinline__ int node2_step(const Node2* __restrict__ nodes, int t
 constexpr int kMaxTopNodes = 1024;       // capacity of a launch context's top-of-tree image buffer
 
 // Launch control block in device memory (zero between launches).
-struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; };
+struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; int finish_done; };
 
 
 // Per-lane stack of the fast / sched kernels: an LDS-only window of LDS_N entries behind an
@@ -118,22 +118,27 @@ struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long l
 // alternatives: spilling to scratch inside the kernel costs ~6 % (scratch allocation per wave),
 // detecting the last wave with one atomic per wave ~15 % (a single counter saturates near
 // 88 atomics/us); the extra launch costs ~4 us per pass.
-struct GlobalStack {
-    int* base; int* err;
+// The follow-up kernels' stack: the reference's 64 entries (stack.impala:53), [entry][lane] in 16 KB of LDS.  (Rounds 1-2 kept
+// it in global memory: every push and pop a round trip, ~100 us for the first deep ray of a launch.)
+struct DeepStack {
+    lds_int* base; int* err;
     __device__ __forceinline__ void put(int e, int v) { if (e < kStackCap) base[e * kWave] = v; else *err = 1; }
     __device__ __forceinline__ int  get(int e) const { return base[(e < kStackCap ? e : kStackCap - 1) * kWave]; }
 };
 
+// The deep rays of a launch, restarted from the root with the 64-entry stack; `stack_lds`: kStackCap x kWave ints of LDS.  Run by
+// ONE wave per workgroup (threads 0..63); with a grid of several workgroups each takes every gridDim.x-th batch of 64 rays and
+// the last one to finish resets the launch's control words (with a grid of one this is the old one-wave kernel).
 template <bool ANY>
 __device__ __forceinline__ void finish_launch(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                               const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
-                                              Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* phase_counters) {
+                                              Ctl* ctl, const int* __restrict__ deep_list, lds_int* stack_lds, int* phase_counters) {
     // behind the last phase of a phased launch: the stripe counters are zero again for the next launch on this stream
-    if (phase_counters) for (int k = threadIdx.x; k < 4 * 64; k += kWave) phase_counters[k * 16] = 0;
+    if (phase_counters && blockIdx.x == 0) for (int k = threadIdx.x; k < 4 * 64; k += kWave) phase_counters[k * 16] = 0;
     const int count = ctl->deep_count;
     if (count > 0) {
-        GlobalStack st{deep_stack + threadIdx.x, &ctl->err};
-        for (int k = threadIdx.x; k < count; k += kWave) {
+        DeepStack st{stack_lds + threadIdx.x, &ctl->err};
+        for (int k = blockIdx.x * kWave + threadIdx.x; k < count; k += gridDim.x * kWave) {
             const int i = deep_list[k];
             RayX ray = load_ray(rays, i);
             HitAcc hit{-1, ray.tmax, 0.0f, 0.0f};
@@ -150,14 +155,19 @@ __device__ __forceinline__ void finish_launch(const Node2* __restrict__ nodes, c
             store_hit(hits, i, hit.id, hit.t, hit.u, hit.v);
         }
     }
-    if (threadIdx.x == 0) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; }   // stats[7]: rays handed over (read by the tests); ready for the next launch
+    if (threadIdx.x == 0) {
+        // (every workgroup has read deep_count before it counts itself done, so the last one may zero it)
+        const bool last = gridDim.x == 1 || atomicAdd(&ctl->finish_done, 1) == (int)gridDim.x - 1;
+        if (last) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; ctl->finish_done = 0; }   // stats[7]: rays handed over (read by the tests); ready for the next launch
+    }
 }
 
 template <bool ANY>
 __global__ __launch_bounds__(kWave) void k_bvh2_finish(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
-                                                        Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* phase_counters) {
-    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, phase_counters);
+                                                        Ctl* ctl, const int* __restrict__ deep_list, int* /* unused since the stack moved to LDS */, int* phase_counters) {
+    __shared__ int stack_lds[kStackCap * kWave];
+    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)stack_lds, phase_counters);
 }
 
 // Single-step schedule (the default "fast" variant).  Every lane advances by ONE step per wave iteration,
@@ -681,12 +691,14 @@ int mapped_node_ids(const Node2* nodes) {
 }
 
 int g_schedule_history = [] { const char* e = getenv("RODENT_HIP_SCHEDULE_HISTORY"); return e && atoi(e) ? 1 : 0; }();      // rodent_hip_schedule_history()
+// workgroups (of one wave) of the follow-up kernels in the shipped mappings: a launch's deep rays are restarted 64 x 64 at a time
+constexpr int kFinishGroups = 64;
 #define LAUNCH_ARGS DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
 
 template <bool ANY, int LDS_N, int XCD, bool TR = false, int PRIO = 0> void L_single(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR, PRIO>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr);
-    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 
 #ifdef RODENT_HIP_LAB
@@ -762,7 +774,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, 
     s.order_rays = 0;
     hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, OCC, TRACE, PRIO, FUSED>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
                        perm, s.top_image, s.tickets, max_id, s.deep_stack, History{nullptr, nullptr, 0});
-    if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
+    if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool SORTED = false, int OCC = 32, bool TRACE = false, int PRIO = 0, bool FUSED = false> void L_top_persist(LAUNCH_ARGS) {
     launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, SORTED, OCC, TRACE, PRIO, FUSED>(s, nodes, tris, rays, hits, n, stream, mapped_node_ids(nodes));
@@ -808,7 +820,7 @@ template <bool ANY, int LDS_N> void L_sorted(LAUNCH_ARGS) {
     hipLaunchKernelGGL(k_raysort_scan, dim3(1), dim3(kSortCells), 0, stream, s.sort_totals, s.sort_totals + kSortCells);
     hipLaunchKernelGGL(k_raysort_scatter, dim3(blocks), dim3(kSortThreads), 0, stream, s.sort_keys, n, s.sort_totals + kSortCells, s.sort_perm);
     hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, 32, false, 0>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)s.sort_perm);
-    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 
 int g_phased_min_rays = 4096 * kWave;           // rodent_hip_phased_min_rays()
@@ -828,7 +840,7 @@ template <bool ANY, int LDS_N, int CAPS, int LAST_RAYS = kWave> void L_phased(LA
     for (int p = 1; p < caps.count; p++)
         hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, true, true>), dim3(resume_grid(p)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.qcount, q[(p - 1) & 1], p, caps.cap[p], q[p & 1]);
     hipLaunchKernelGGL((k_bvh2_phase<ANY, LDS_N, true, false, LAST_RAYS>), dim3(resume_grid(caps.count) * (kWave / LAST_RAYS)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.qcount, q[(caps.count - 1) & 1], caps.count, 0, q[caps.count & 1]);
-    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.qcount);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.qcount);
 }
 
 #include "traversal_wide.h"          // BVH4 / BVH8 + Tri4: k_wide_single, k_wide_finish, L_wide_single
@@ -870,6 +882,9 @@ const Variant2 kVariants2[] = {
     K2("top63p4",            "k_bvh2_top_persist",   L_top_persist, 15, 63, 4, false),
     K2("top15p1",            "k_bvh2_top_persist",   L_top_persist, 15, 15, 1, false),
     K2("sorted-top255p16",   "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, true),
+    K2("top383p16-l13",      "k_bvh2_top_persist",   L_top_persist, 13, 383, 16, false),                // 13-entry stack windows: 128 more records
+    K2("top511p16-l11",      "k_bvh2_top_persist",   L_top_persist, 11, 511, 16, false),                // 11-entry windows: 256 more
+    K2("top639p16-l9",       "k_bvh2_top_persist",   L_top_persist, 9, 639, 16, false),
     K2("top255p16-o16",      "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 16),
     K2("top1023p16-o16",     "k_bvh2_top_persist",   L_top_persist, 15, 1023, 16, false, false, 16),
     K2("top255p8-o24",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 8, false, false, 24),

@@ -33,11 +33,12 @@ __global__ __launch_bounds__(kWave) void k_bvh2_top_finish(const Node2* __restri
                                                             const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
                                                             Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* tickets,
                                                             int4* __restrict__ image, int capacity) {
+    __shared__ int stack_lds[kStackCap * kWave];                     // (kStackCap x kWave >= kMaxTopNodes: also the image builder's slot table)
+    static_assert(kStackCap * kWave >= kMaxTopNodes, "slot table");
     const bool stale = ctl->reserved != 0;
-    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, tickets);
-    if (stale) {
-        __shared__ int slot_node[kMaxTopNodes];
-        build_top_image(nodes, image, capacity, (lds_int*)slot_node);
+    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)stack_lds, tickets);
+    if (stale && blockIdx.x == 0) {
+        build_top_image(nodes, image, capacity, (lds_int*)stack_lds);
         if (threadIdx.x == 0) ctl->reserved = 0;
     }
 }
@@ -105,11 +106,12 @@ __global__ __launch_bounds__(kHistoryThreads) void k_bvh2_top_finish_history(con
                                                                               Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* tickets,
                                                                               int4* __restrict__ image, int capacity, int total_chunks,
                                                                               const int* __restrict__ cost, int* __restrict__ order, int stride) {
-    __shared__ int keys[kMaxStripeChunks];
-    if (blockIdx.x == 0 && threadIdx.x < kWave) {
+    __shared__ int keys[kStackCap * kWave];                         // the deep rays' stack first, then the sort keys
+    static_assert(kStackCap * kWave >= kMaxStripeChunks && kStackCap * kWave >= kMaxTopNodes, "one LDS block for all three uses");
+    if (threadIdx.x < kWave) {
         const bool stale = ctl->reserved != 0;
-        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, tickets);
-        if (stale) {
+        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)keys, tickets);
+        if (stale && blockIdx.x == 0) {
             build_top_image(nodes, image, capacity, (lds_int*)keys);
             if (threadIdx.x == 0) ctl->reserved = 0;
         }
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
         if (!lds_raw[0] || wave != 0) return;
         __threadfence();
         const bool stale = __hip_atomic_load(&ctl->reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, deep_stack, tickets);
+        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)lds_raw, tickets);
         if (stale) {
             build_top_image(nodes, top_image, TOPN, (lds_int*)lds_raw);        // (the stacks are idle now)
             if (lane == 0) ctl->reserved = 0;

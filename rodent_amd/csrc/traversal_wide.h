@@ -209,9 +209,10 @@ template <bool ANY, int N>
 __global__ __launch_bounds__(kWave) void k_wide_finish(const char* __restrict__ nodes, const Tri4* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
                                                         Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack) {
+    __shared__ int stack_lds[kStackCap * kWave];                    // the reference's 64 entries per lane, in LDS (see DeepStack)
     const int count = ctl->deep_count;
     if (count > 0) {
-        GlobalStack st{deep_stack + threadIdx.x, &ctl->err};
+        DeepStack st{(lds_int*)stack_lds + threadIdx.x, &ctl->err};
         for (int k = threadIdx.x; k < count; k += kWave) {
             const int i = deep_list[k];
             const HitAcc hit = wide_ray_literal<ANY, N>(nodes, tris, load_ray(rays, i), st);
