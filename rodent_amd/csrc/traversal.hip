@@ -157,7 +157,8 @@ __device__ __forceinline__ void finish_launch(const Node2* __restrict__ nodes, c
     }
     if (threadIdx.x == 0) {
         // (every workgroup has read deep_count before it counts itself done, so the last one may zero it)
-        const bool last = gridDim.x == 1 || atomicAdd(&ctl->finish_done, 1) == (int)gridDim.x - 1;
+        // (with no deep rays -- the usual case -- nobody needs to wait for anybody: workgroup 0 rewrites the zeros)
+        const bool last = gridDim.x == 1 || (count == 0 ? blockIdx.x == 0 : atomicAdd(&ctl->finish_done, 1) == (int)gridDim.x - 1);
         if (last) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; ctl->finish_done = 0; }   // stats[7]: rays handed over (read by the tests); ready for the next launch
     }
 }
@@ -691,8 +692,8 @@ int mapped_node_ids(const Node2* nodes) {
 }
 
 int g_schedule_history = [] { const char* e = getenv("RODENT_HIP_SCHEDULE_HISTORY"); return e && atoi(e) ? 1 : 0; }();      // rodent_hip_schedule_history()
-// workgroups (of one wave) of the follow-up kernels in the shipped mappings: a launch's deep rays are restarted 64 x 64 at a time
-constexpr int kFinishGroups = 64;
+// workgroups (of one wave) of the follow-up kernels in the shipped mappings: a launch's deep rays are restarted 256 x 64 at a time
+constexpr int kFinishGroups = 256;
 #define LAUNCH_ARGS DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
 
 template <bool ANY, int LDS_N, int XCD, bool TR = false, int PRIO = 0> void L_single(LAUNCH_ARGS) {
