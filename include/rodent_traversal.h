@@ -136,8 +136,8 @@ int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2, 4 or 8 
  * every launch phased (tests). */
 void        rodent_hip_phased_min_rays(int32_t rays);
 /* The default BVH2 mapping ("top": top of the tree staged in LDS, persistent workgroups) takes the one-chunk-per-workgroup
- * kernel ("fast") for launches of fewer than this many rays (default 524 288 = one round of resident waves: the per-launch
- * image build does not pay below that); < 0 restores the default, 0 sends every launch through the LDS-image kernel (tests). */
+ * kernel ("fast") for launches of fewer than this many rays (default 589 824: the measured cross-over of the two kernels --
+ * staging and validating the image in every workgroup does not pay below that); < 0 restores the default, 0 sends every launch through the LDS-image kernel (tests). */
 void        rodent_hip_top_min_rays(int32_t rays);
 /* Schedule history of the default BVH2 mapping (off by default; RODENT_HIP_SCHEDULE_HISTORY=1): every launch records how many
  * wave iterations each 64-ray chunk took, and the next launch of the SAME ray count on that (device, stream) traces its chunks

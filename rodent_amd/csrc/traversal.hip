@@ -14,7 +14,7 @@
 //  * the default mapping (k_bvh2_top_persist): the top 255 nodes of the caller's hierarchy are staged in LDS as an image
 //    that every workgroup validates against the node array before using it (the ABI passes a pointer, not a handle); the
 //    grid is one resident generation of 16-wave workgroups whose waves draw chunks from 64 striped ticket counters;
-//    launches under 512 Ki rays take k_bvh2_single (64-lane workgroups = one wavefront, one chunk each);
+//    launches under 576 Ki rays take k_bvh2_single (64-lane workgroups = one wavefront, one chunk each);
 //  * the traversal stack is an LDS-only window of 15 / 16 entries, laid out [entry][lane] (bank = lane % 32 for
 //    ds_read/write_b32: conflict free whatever each lane's depth is) and walked with a cursor pointer; a ray that
 //    needs more is finished by the one-wave follow-up kernel (k_bvh2_finish / k_bvh2_top_finish) with the reference's
@@ -782,9 +782,11 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool S
 }
 
 // The default mapping: launches that fill the chip at least once take the persistent kernel with the LDS image, smaller ones
-// the single kernel (256 Ki rays: 0.098 ms against 0.122 ms -- staging and validating the image does not pay yet), and so do
+// the single kernel (256 Ki rays: 0.099 ms against 0.117 ms, 512 Ki: 0.138 against 0.144, 768 Ki: 0.181 against 0.155 --
+// staging and validating the image does not pay yet), and so do
 // launches whose node array the runtime cannot give a mapped range for (nothing bounds the ids of an older image then).
-int g_top_min_rays = 8192 * kWave;              // rodent_hip_top_min_rays()
+constexpr int kTopMinRays = 9216 * kWave;      // the measured cross-over lies between 512 Ki and 768 Ki rays (profiles/r02_threshold_sweep.txt)
+int g_top_min_rays = kTopMinRays;               // rodent_hip_top_min_rays()
 template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH> void L_default(LAUNCH_ARGS) {
     const int max_id = n < g_top_min_rays ? 0 : mapped_node_ids(nodes);
     if (max_id == 0) L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream);
@@ -1090,7 +1092,7 @@ const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t a
 void rodent_hip_phased_min_rays(int32_t rays) { g_phased_min_rays = rays < 0 ? 4096 * kWave : rays; }
 void rodent_hip_debug_set_perm(int32_t dev, const int32_t* device_perm) { device_state(dev).debug_perm = device_perm; }   // lab: see "top-userperm"
 void rodent_hip_schedule_history(int32_t enable) { g_schedule_history = enable ? 1 : 0; }
-void rodent_hip_top_min_rays(int32_t rays) { g_top_min_rays = rays < 0 ? 8192 * kWave : rays; }
+void rodent_hip_top_min_rays(int32_t rays) { g_top_min_rays = rays < 0 ? kTopMinRays : rays; }
 int32_t rodent_hip_is_lab_build(void) {
 #ifdef RODENT_HIP_LAB
     return 1;
