@@ -569,6 +569,7 @@ struct DeviceState {
     const Node2* top_image_nodes = nullptr; int top_image_n = 0;
     int*  chunk_cost = nullptr; int* chunk_order = nullptr;    // schedule history: wave iterations per chunk of the last launch, the order sorted from them
     int   order_rays = 0;                      // ray count of the launch chunk_order was sorted for (0: none)
+    int*  order_agree = nullptr;               // per stripe: {chunks the last two launches both found in their expensive half, half the stripe's chunks}
     const int* debug_perm = nullptr;           // lab: caller-supplied ray permutation of the "top-userperm" mapping (rodent_hip_debug_set_perm)
     int*  tickets = nullptr;                   // persistent "top*p" mappings: chunk tickets per XCD (zero between launches)
     Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
@@ -763,18 +764,21 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, 
             std::lock_guard<std::mutex> lock(g_mutex);
             HIP_CHECK(hipMalloc(&s.chunk_cost, sizeof(int) * kStripes * kMaxStripeChunks));
             HIP_CHECK(hipMalloc(&s.chunk_order, sizeof(int) * kStripes * kMaxStripeChunks));
+            HIP_CHECK(hipMalloc(&s.order_agree, sizeof(int) * 2 * kStripes));
+            HIP_CHECK(hipMemset(s.order_agree, 0xFF, sizeof(int) * 2 * kStripes));
         }
-        const History hist{s.order_rays == n ? s.chunk_order : nullptr, s.chunk_cost, stride};
+        const bool have_previous = s.order_rays == n;
+        const History hist{have_previous ? s.chunk_order : nullptr, s.chunk_cost, stride, s.order_agree};
         hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, false, OCC, false, 0, false, true>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(),
                            s.deep_list, perm, s.top_image, s.tickets, max_id, s.deep_stack, hist);
         hipLaunchKernelGGL((k_bvh2_top_finish_history<ANY>), dim3(kStripes), dim3(kHistoryThreads), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets,
-                           s.top_image, TOPN, total_chunks, (const int*)s.chunk_cost, s.chunk_order, stride);
+                           s.top_image, TOPN, total_chunks, (const int*)s.chunk_cost, s.chunk_order, stride, have_previous ? 1 : 0, s.order_agree);
         s.order_rays = n;
         return;
     }
     s.order_rays = 0;
     hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, OCC, TRACE, PRIO, FUSED>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                       perm, s.top_image, s.tickets, max_id, s.deep_stack, History{nullptr, nullptr, 0});
+                       perm, s.top_image, s.tickets, max_id, s.deep_stack, History{nullptr, nullptr, 0, nullptr});
     if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool SORTED = false, int OCC = 32, bool TRACE = false, int PRIO = 0, bool FUSED = false> void L_top_persist(LAUNCH_ARGS) {

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top(const No
 
 #endif
 
-struct History { const int* order; int* cost; int stride; };               // order[stripe * stride + ticket] = chunk; either may be null
+struct History { const int* order; int* cost; int stride; const int* agree; };   // order[stripe * stride + ticket] = chunk (may be null); cost may be null; agree: see below
 // chunks of stripe s under the default order: its complete 32-chunk groups plus, for one stripe, the ragged last group
 __device__ __forceinline__ int stripe_chunks(int total_chunks, int stripe) {
     const int full_groups = total_chunks / 32, rest = total_chunks % 32;
@@ -105,8 +105,11 @@ __global__ __launch_bounds__(kHistoryThreads) void k_bvh2_top_finish_history(con
                                                                               const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
                                                                               Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* tickets,
                                                                               int4* __restrict__ image, int capacity, int total_chunks,
-                                                                              const int* __restrict__ cost, int* __restrict__ order, int stride) {
-    __shared__ int keys[kStackCap * kWave];                         // the deep rays' stack first, then the sort keys
+                                                                              const int* __restrict__ cost, int* __restrict__ order, int stride,
+                                                                              int have_previous, int* __restrict__ agree) {
+    __shared__ __attribute__((aligned(16))) int keys[kStackCap * kWave];        // the deep rays' stack first, then the sort keys
+    __shared__ unsigned char previous_top[kMaxStripeChunks];        // default-order positions of the chunks the PREVIOUS launch found in its expensive half
+    __shared__ int agreeing;
     static_assert(kStackCap * kWave >= kMaxStripeChunks && kStackCap * kWave >= kMaxTopNodes, "one LDS block for all three uses");
     if (threadIdx.x < kWave) {
         const bool stale = ctl->reserved != 0;
@@ -121,9 +124,32 @@ __global__ __launch_bounds__(kHistoryThreads) void k_bvh2_top_finish_history(con
     int padded = 1;
     while (padded < count) padded *= 2;
     const auto chunk_of = [&](int t) { return ((t / 32) * kStripes + stripe) * 32 + t % 32; };
+    // How far may the order be trusted?  `order` still holds what the previous launch of this size sorted: the chunks of its
+    // expensive half are marked, and below the share of THIS launch's expensive half among them is counted.  The next launch
+    // draws by the new order only if the two launches agreed (k_bvh2_top_persist reads agree[]): unrelated ray sets of equal
+    // size fall back to the default order, which keeps neighbouring chunks together.
+    for (int i = threadIdx.x; i < count; i += kHistoryThreads) previous_top[i] = 0;
+    if (threadIdx.x == 0) agreeing = 0;
+    __syncthreads();
+    if (have_previous)
+        for (int t = threadIdx.x; t < count / 2; t += kHistoryThreads) {
+            const int chunk = order[stripe * stride + t];
+            previous_top[((chunk / 32) / kStripes) * 32 + chunk % 32] = 1;
+        }
     for (int i = threadIdx.x; i < padded; i += kHistoryThreads)
         keys[i] = i < count ? (min(cost[chunk_of(i)], 0x3FFFF) << 13) | (8191 - i) : -1;
     __syncthreads();
+    if (count <= kHistoryThreads) {
+        // one key per thread (1 Mi rays: 256 chunks per stripe): its rank is the number of larger keys -- count LDS broadcasts, no barrier
+        const int mine_key = threadIdx.x < count ? keys[threadIdx.x] : -1;
+        int rank = 0;
+        const int4* quads = reinterpret_cast<const int4*>(keys);            // (padded to a power of two with -1 keys: never larger than a real key)
+#pragma unroll 8
+        for (int j = 0; j < padded / 4; j++) { const int4 q = quads[j]; rank += (q.x > mine_key) + (q.y > mine_key) + (q.z > mine_key) + (q.w > mine_key); }
+        __syncthreads();
+        if (threadIdx.x < count) keys[rank] = mine_key;
+        __syncthreads();
+    } else
     for (int k = 2; k <= padded; k *= 2)
         for (int j = k / 2; j > 0; j /= 2) {
             for (int i = threadIdx.x; i < padded; i += kHistoryThreads) {
@@ -136,7 +162,12 @@ __global__ __launch_bounds__(kHistoryThreads) void k_bvh2_top_finish_history(con
             }
             __syncthreads();
         }
+    int mine = 0;
+    for (int i = threadIdx.x; i < count / 2; i += kHistoryThreads) mine += previous_top[8191 - (keys[i] & 8191)];
+    if (mine) atomicAdd(&agreeing, mine);
     for (int i = threadIdx.x; i < count; i += kHistoryThreads) order[stripe * stride + i] = chunk_of(8191 - (keys[i] & 8191));
+    __syncthreads();
+    if (threadIdx.x == 0) { agree[2 * stripe] = have_previous ? agreeing : -count; agree[2 * stripe + 1] = count / 2; }
 }
 
 // Stages the context's image into LDS and checks it against the caller's nodes: every record must equal the node whose id it
@@ -221,9 +252,16 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     lds_int* const sp_limit = col + LDS_N * kWave;
     const Bases base = make_bases(nodes, tris);
     const int my_chunks = HISTORY ? stripe_chunks(total_chunks, stripe) : 0;
+    static_assert(kStripes == kWave, "one stripe's agreement record per lane");
+    bool use_order = false;                                                  // HISTORY: an order exists and the last two launches agreed on what is expensive
+    if (HISTORY && hist.order) {
+        int a = hist.agree[2 * lane], h = hist.agree[2 * lane + 1];         // kStripes == kWave: one stripe per lane
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); h += __shfl_xor(h, off); }
+        use_order = 4 * (long long)a >= 3 * (long long)h;
+    }
     for (;;) {
         int chunk;
-        if (HISTORY && hist.order) {
+        if (HISTORY && use_order) {
             if (t >= my_chunks) break;
             chunk = hist.order[stripe * hist.stride + t];
         } else {
