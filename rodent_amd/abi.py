@@ -142,6 +142,18 @@ def traverse(bvh: DeviceBvh, rays: np.ndarray, any_hit=False, variant=None) -> n
     return from_device(hits_dev, F.HIT1)[:n]
 
 
+def schedule_history(enable: bool):
+    """rodent_hip_schedule_history: the default BVH2 mapping traces its chunks longest-first by the per-chunk cost the previous
+    launch of the same size recorded (off by default; per (device, stream); hit records do not depend on it)."""
+    lib().rodent_hip_schedule_history(int(bool(enable)))
+
+
+def top_min_rays(rays: int):
+    """rodent_hip_top_min_rays: launches of fewer rays take the one-chunk kernel instead of the persistent LDS-image kernel
+    (< 0: the shipped threshold, 0: every launch through the LDS-image kernel)."""
+    lib().rodent_hip_top_min_rays(int(rays))
+
+
 def check_errors(dev=0, stream=None):
     """The asynchronous entry points report a traversal-stack overflow (more than the reference's 64 entries,
     stack.impala:53) through a device-side flag: this waits for `stream`, reads and clears it, and raises."""
