@@ -571,6 +571,7 @@ struct DeviceState {
     int   order_rays = 0;                      // ray count of the launch chunk_order was sorted for (0: none)
     int*  order_agree = nullptr;               // per stripe: {chunks the last two launches both found in their expensive half, half the stripe's chunks}
     const int* debug_perm = nullptr;           // lab: caller-supplied ray permutation of the "top-userperm" mapping (rodent_hip_debug_set_perm)
+    int*  host_flags = nullptr;                // pinned: where the error flags are copied back to
     int*  tickets = nullptr;                   // persistent "top*p" mappings: chunk tickets per XCD (zero between launches)
     Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
 };
@@ -667,16 +668,19 @@ void ensure_deep_list(DeviceState& s, int n) {
 // Copies back and clears both stack-overflow flags (scratch[1]: the lab kernels' LaneStack; ctl->err: the follow-up
 // kernels' 64-entry global stack) after everything enqueued on `stream` has finished.
 bool read_and_clear_error_flags(DeviceState& s, hipStream_t stream) {
-    int flag[2] = {0, 0};
-    HIP_CHECK(hipMemcpyAsync(&flag[0], s.scratch + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipMemcpyAsync(&flag[1], &s.ctl()->err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    // one copy of the words that hold both flags (scratch[1] .. ctl->err) into pinned memory: the synchronous, reference-named
+    // entry points pay this on every call (two copies into pageable memory cost ~20 us of a 0.19 ms launch)
+    const size_t first = 1, last = (size_t)(&s.ctl()->err - s.scratch);
+    if (!s.host_flags) HIP_CHECK(hipHostMalloc(&s.host_flags, sizeof(int) * 32, hipHostMallocDefault));
+    HIP_CHECK(hipMemcpyAsync(s.host_flags, s.scratch + first, sizeof(int) * (last - first + 1), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    if (flag[0] || flag[1]) {
+    const bool raised = s.host_flags[0] != 0 || s.host_flags[last - first] != 0;
+    if (raised) {
         HIP_CHECK(hipMemsetAsync(s.scratch + 1, 0, sizeof(int), stream));
         HIP_CHECK(hipMemsetAsync(&s.ctl()->err, 0, sizeof(int), stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
-    return flag[0] || flag[1];
+    return raised;
 }
 // the reference's entry points have no return code (bench_traversal.impala:17-21: message + abort)
 void check_error_flag(DeviceState& s, hipStream_t stream) {
