@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""bench.py -- headline benchmark: Mrays/s of the HIP BVH traversal (BASELINE.json).
+"""bench.py -- headline benchmark: Mrays/s of the HIP BVH traversal (BASELINE.json), renderer frame rates beside it.
 
-  python bench.py --gpus N --steps K --warmup W [--strong]
+  python bench.py --gpus N --steps K --warmup W [--weak]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Step  = one closest-hit traversal pass over one 1 048 576-ray batch resident in HBM
@@ -11,16 +11,22 @@ Scene = "sponza" if data/sponza.{bvh,-primary.rays,-random.rays} were supplied, 
         regenerable procedural "atrium" (the reference checkout lacks the Sponza blobs).
 value = rays traced by all ranks per second / 1e6, kernel passes only (rays, BVH and hit
         buffers resident in HBM; H2D/D2H excluded like bench_traversal.cpp:124-135).
-N > 1 = no data-path collective: the BVH is replicated.
-        default (weak scaling): rank r traces sub-pixel sample r of N through the same 1024x1024 pixel grid (primary) /
-        seed 42 + r (random): 1 Mi rays per GPU per step;
-        --strong: ONE 1 Mi-ray set, rank r traces the contiguous range ray_range(n, r, N); after the timed
-        region one RCCL all-gather collects the Hit1 ranges and rank 0 compares the assembled array with its own trace
-        of the whole set.
-roofline: "bound: hbm" is SURVEY 8(d)'s algorithmic-bytes figure (it exceeds 1: the 22 MB BVH is served by L1 / L2 / MALL,
-        not by HBM).  The bounds that DO bind this kernel are reported next to it: the node-fetch rate of
-        the vector-memory pipeline (TA -> L1 -> L2) and the VALU issue rate, both against peaks measured on this chip by
-        the microbenchmarks under scripts/ubench (profiles/rNN_calibration.json), plus measured HBM traffic.
+N > 1 = no data-path collective: the BVH is replicated.  BOTH partitions are timed:
+        strong (`value`): ONE 1 Mi-ray set, rank r traces the contiguous range ray_range(n, r, N); after the
+        timed region one RCCL gather brings the Hit1 ranges to rank 0, which compares the assembled array with its own
+        trace of the whole set;
+        weak (`extra.weak_scaling`): rank r traces sub-pixel sample r of N through the same 1024 x 1024 pixel grid (primary) /
+        seed 42 + r (random): 1 Mi rays per GPU per step.  `--weak` makes this one `value` instead.
+roofline: the bound that binds this kernel: the larger of the VALU issue rate and the node-fetch rate of the
+        vector-memory pipeline (TA -> L1 -> L2), both against peaks measured on this chip by the microbenchmarks under
+        scripts/ubench (profiles/rNN_calibration.json).  SURVEY 8(d)'s algorithmic-HBM-bytes figure is kept as
+        `roofline.hbm_algorithmic` (it exceeds the HBM peak: the 22 MB BVH is served by L1 / L2 / MALL -- a count of cache
+        hits), the measured HBM traffic as `roofline.hbm_measured` / `roofline.traffic`.  Counter-derived figures come from
+        profiles committed under profiles/ and are only quoted while the profile's source hash matches the kernels'
+        sources (rodent_amd/provenance.py); a stale profile is reported as such, never used.
+render  (`extra.render`): BASELINE configs 4 and 5 through the renderer ABI -- Cornell 1920 x 1080, 64 spp, path length 4 and the
+        config-5 scene at 3840 x 2160, 256 spp, path length 8 (one GPU: the whole frame; N GPUs: row bands + one film gather
+        to rank 0), streaming and megakernel mappings, Msamples/s = spp * w * h / frame seconds / 1e6 (driver.cpp:300).
 """
 from __future__ import annotations
 
@@ -48,12 +54,18 @@ def parse_args():
     ap.add_argument("--scene", default=None)
     ap.add_argument("--bvh-width", type=int, default=int(os.environ.get("RODENT_BENCH_WIDTH", "2")), choices=(2, 4, 8))
     ap.add_argument("--variant", type=int, default=int(os.environ.get("RODENT_BENCH_VARIANT", "-1")))
-    ap.add_argument("--strong", action="store_true", help="N > 1: shard ONE ray set in contiguous ranges (strong scaling) and gather the Hit1 array")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weak", action="store_true", help="N > 1: report the weak-scaling figure as `value` (default: strong, SURVEY 8e)")
+    ap.add_argument("--strong", action="store_true", help="accepted for compatibility: strong scaling is the default for N > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="profiling aid: no oracle leg, no CPU baselines, no informational extras")
+    ap.add_argument("--no-render", action="store_true", help="skip the renderer section (extra.render)")
+    ap.add_argument("--render-spp5", type=int, default=256, help="samples per pixel of the config-5 frame (BASELINE: 256)")
     ap.add_argument("--only", choices=("primary", "random"), default=None, help="profiling aid: time only one ray set")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------
+# committed profiles (profiles/rNN_*.json) -- quoted only while they belong to the sources that are running
+# ------------------------------------------------------------------------------------------------
 def latest_json(pattern):
     best = None
     for f in sorted((ROOT / "profiles").glob(pattern)):
@@ -64,51 +76,63 @@ def latest_json(pattern):
     return best
 
 
+def current_profile(pattern, kind):
+    """(file name, data, None) of the newest committed profile matching `pattern` if it was taken on the present sources of
+    `kind`, else (name or None, None, reason)."""
+    from rodent_amd import provenance
+    found = latest_json(pattern)
+    if not found:
+        return None, None, f"no profiles/{pattern}"
+    name, data = found
+    if not provenance.is_current(data.get("_meta"), kind):
+        return name, None, f"profiles/{name} was taken on other {kind} sources (source_sha {data.get('_meta', {}).get('source_sha')} != {provenance.source_sha(kind)}): not quoted"
+    return name, data, None
+
+
 def kernel_counters(kernel, ray_set):
     """Per-launch counter means of `kernel` on the `ray_set` pass from the committed PMC passes (profiles/rNN_pmc_counters.json,
-    scripts/profile_pmc.sh: one small counter group per rocprofv3 --pmc run).  {} if this kernel was not profiled."""
-    found = latest_json("r*_pmc_counters.json")
+    scripts/profile_pmc.sh: one small counter group per rocprofv3 --pmc run).  ({}, reason) if there is no profile of this
+    kernel on the present sources."""
+    name, data, why = current_profile("r*_pmc_counters.json", "traversal")
+    if data is None:
+        return {}, why
     out = {}
-    if found:
-        name, data = found
-        key = kernel.replace(" ", "").rstrip(">")
-        for group, kernels in data.items():
-            if f"_{ray_set}_" not in group:
-                continue
-            for k, counters in kernels.items():
-                if k.replace(" ", "").startswith(key):
-                    out.update(counters)
-        if out:
-            out["source"] = name
-    return out
+    key = kernel.replace(" ", "").rstrip(">")
+    for group, kernels in data.items():
+        if group == "_meta" or f"_{ray_set}_" not in group:
+            continue
+        for k, counters in kernels.items():
+            if k.replace(" ", "").startswith(key):
+                out.update(counters)
+    if not out:
+        return {}, f"profiles/{name} holds no pass of kernel {kernel}"
+    out["source"] = name
+    return out, None
 
 
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` (primary pass): FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes
     (profiles/rNN_traffic.json, scripts/profile_round.sh); FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950."""
-    best = None
-    for f in sorted((ROOT / "profiles").glob("r*_traffic.json")):
-        try:
-            data = json.loads(f.read_text())
-        except ValueError:
-            continue
-        for name, t in data.items():
-            if name.replace(" ", "").startswith(kernel.replace(" ", "").rstrip(">")) and "hbm_bytes_fetch_x2" in t:
-                best = int(t["hbm_bytes_fetch_x2"])
-    return best
+    name, data, why = current_profile("r*_traffic.json", "traversal")
+    if data is None:
+        return None, why
+    for k, t in data.items():
+        if k != "_meta" and k.replace(" ", "").startswith(kernel.replace(" ", "").rstrip(">")) and "hbm_bytes_fetch_x2" in t:
+            return {"bytes": int(t["hbm_bytes_fetch_x2"]), "fetch_bytes_x2": int(2 * t["FETCH_SIZE"] * 1024), "write_bytes": int(t["WRITE_SIZE"] * 1024), "source": name}, None
+    return None, f"profiles/{name} holds no pass of kernel {kernel}"
 
 
 def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms, lds_steps_per_ray=0.0):
     """The bounds that bind the traversal kernel, against peaks MEASURED on this chip (profiles/rNN_calibration.json):
     node / triangle fetches per ns through the vector-memory pipeline (live: oracle visit counts x rays / HIP-event kernel
     time; `lds_steps_per_ray` of them are served from the LDS image of the default mapping instead and are reported against
-    the LDS rate) and VALU wave-instructions per us per SIMD (instruction count from the committed SQ counter pass / live
-    kernel time)."""
+    the LDS rate) and VALU wave-instructions per us per SIMD (instruction count from the committed SQ counter pass of THIS
+    kernel on THESE sources / live kernel time)."""
     cal = latest_json("r*_calibration.json")
     if not cal:
         return None
     cal_name, cal = cal
-    c = kernel_counters(kernel, ray_set)
+    c, stale = kernel_counters(kernel, ray_set)
     fetches_per_ns = (steps_per_ray - lds_steps_per_ray) * rays / (kernel_ms * 1e6)
     if ray_set == "primary":
         peak, peak_kind = cal["node_fetch_peak_coherent"], "64-byte node per lane, neighbouring lanes share nodes, L1/L2-resident (vmem_peak 'coherent')"
@@ -116,9 +140,9 @@ def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms, lds_steps_pe
         # incoherent rays: every lane its own node; blend of the scattered-L2 and scattered-MALL rates by the measured L2 hit rate
         hit = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if "TCC_HIT_sum" in c else 0.85
         peak = 1.0 / (hit / cal["node_fetch_peak_scattered_l2"] + (1.0 - hit) / cal["node_fetch_peak_scattered_mall"])
-        peak_kind = f"64-byte node per lane, scattered: L2 rate x {hit:.3f} + MALL rate x {1 - hit:.3f} (measured TCC hit rate; vmem_peak 'scattered')"
-    out = {"node_fetch": {"bound": "vector-memory pipeline (TA/L1/L2), node fetches", "unit": "fetches/ns", "achieved": round(fetches_per_ns, 2), "peak": round(peak, 2),
-                          "frac": round(fetches_per_ns / peak, 4), "peak_kind": peak_kind, "steps_per_ray": round(steps_per_ray - lds_steps_per_ray, 3), "peak_source": cal_name}}
+        peak_kind = f"64-byte node per lane, scattered: L2 rate x {hit:.3f} + MALL rate x {1 - hit:.3f} ({'measured' if 'TCC_HIT_sum' in c else 'assumed'} TCC hit rate; vmem_peak 'scattered')"
+    out = {"vmem_node_fetch": {"bound": "vector-memory pipeline (TA/L1/L2), node fetches", "unit": "fetches/ns", "achieved": round(fetches_per_ns, 2), "peak": round(peak, 2),
+                               "frac": round(fetches_per_ns / peak, 4), "peak_kind": peak_kind, "steps_per_ray": round(steps_per_ray - lds_steps_per_ray, 3), "peak_source": cal_name}}
     if lds_steps_per_ray:
         # MI355X_MICROARCH.md, LDS table: ds_read_b128 4 and ds_read_b64 2 LDS cycles per wave-instruction when conflict-free -> 3 x 4 + 2 per 64 node records
         lds_peak = LDS_CLOCK_GHZ * cal["cus"] * 64 / 14.0
@@ -126,6 +150,8 @@ def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms, lds_steps_pe
         out["lds_fetch"] = {"bound": "LDS (top-of-tree image: 3 x ds_read_b128 + ds_read_b64 per node)", "unit": "fetches/ns", "achieved": round(lds_per_ns, 2),
                             "peak": round(lds_peak, 1), "frac": round(lds_per_ns / lds_peak, 4), "steps_per_ray": round(lds_steps_per_ray, 3),
                             "peak_kind": "conflict-free rate of the guide's LDS table at 2.4 GHz; distinct records on one bank quarter serialise"}
+    if stale:
+        out["counters_not_quoted"] = stale
     if "SQ_INSTS_VALU" in c:
         per_simd_us = c["SQ_INSTS_VALU"] / (kernel_ms * 1e3) / cal["simds"]
         lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
@@ -140,6 +166,19 @@ def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms, lds_steps_pe
     return out
 
 
+def pick_bound(binding):
+    """The top-level roofline: whichever of the two throughput bounds of the kernel is closer to its peak."""
+    best = None
+    for key in ("valu_issue", "vmem_node_fetch"):
+        b = (binding or {}).get(key)
+        if b and (best is None or b["frac"] > best[1]["frac"]):
+            best = (key, b)
+    return best
+
+
+# ------------------------------------------------------------------------------------------------
+# timing
+# ------------------------------------------------------------------------------------------------
 def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, dist, any_hit=False):
     """W untimed + K timed launches.  Returns (wall seconds for K steps [max over ranks is taken by
     the caller], mean / median / min kernel ms from HIP events recorded on the launch stream)."""
@@ -166,6 +205,173 @@ def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, 
     return wall, float(np.mean(kernel_ms)), float(np.median(kernel_ms)), float(np.min(kernel_ms))
 
 
+def max_over_ranks(torch, dist, dev, values):
+    if dist is None:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device=f"cuda:{dev}")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t]
+
+
+def gather_scalars(torch, dist, dev, values):
+    """[[values of rank 0], [values of rank 1], ...] on every rank (bookkeeping, after the timed regions)."""
+    if dist is None:
+        return [list(values)]
+    t = torch.tensor(list(values), dtype=torch.float64, device=f"cuda:{dev}")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in g] for g in out]
+
+
+# ------------------------------------------------------------------------------------------------
+# renderer section (BASELINE configs 4 and 5)
+# ------------------------------------------------------------------------------------------------
+RENDER_CONFIGS = {
+    # name: (scene, width, height, spp, max path length)
+    "cfg4_cornell_1920x1080_64spp_len4": ("cornell", 1920, 1080, 64, 4),
+    "cfg5_atrium_3840x2160_256spp_len8": ("atrium", 3840, 2160, 256, 8),
+}
+
+
+def scene_file(scene_name):
+    """.rscene of a benchmark scene (converted once by rank 0; rodent_amd/bin/converter = the reference's converter as a
+    table emitter)."""
+    from rodent_amd import scene as S, scenes
+    if scene_name == "cornell":
+        obj = ROOT / "tests" / "golden" / "cornell_box.obj"
+    else:
+        scenes.scene_bvh(scene_name)                                  # generates data/<scene>.obj on the way
+        obj = scenes.DATA / f"{scene_name}.obj"
+    out = scenes.DATA / f"{scene_name}.bench.rscene"
+    if not out.exists():
+        scenes.DATA.mkdir(parents=True, exist_ok=True)
+        S.convert(obj, out)
+    return obj, out
+
+
+def render_profile(config_name):
+    """Per-kernel figures of the committed renderer profile of this configuration (profiles/rNN_render_profile_<cfg>.json,
+    scripts/render_profile.sh: rocprofv3 --kernel-trace --stats, then FETCH_SIZE and WRITE_SIZE in separate --pmc passes of the
+    same command), or the reason why none is quoted."""
+    short = config_name.split("_")[0]
+    name, data, why = current_profile(f"r*_render_profile_{short}.json", "render")
+    if data is None:
+        return {"not_quoted": why}
+    out = {"source": name, "command": data.get("_meta", {}).get("command")}
+    for mapping, kernels in data.items():
+        if mapping == "_meta":
+            continue
+        rows = {}
+        for k, v in kernels.items():
+            row = {"calls_per_frame": v.get("calls_per_frame"), "avg_ms": round(v["avg_us"] / 1e3, 4), "ms_per_frame": round(v["avg_us"] * v.get("calls_per_frame", 0) / 1e3, 3)}
+            if "hbm_TBps_fetch_x2" in v:
+                row["hbm_frac"] = round(v["hbm_TBps_fetch_x2"] * 1e3 / HBM_PEAK_GBPS, 4)
+                row["hbm_GBps"] = round(v["hbm_TBps_fetch_x2"] * 1e3, 1)
+            rows[k] = row
+        out[mapping] = rows
+    return out
+
+
+def render_section(args, torch, dist, rank, world, dev):
+    """Frame rates of BASELINE configs 4 and 5.  One GPU: whole frames, every mapping.  N GPUs: config 5 only, row bands
+    (parallel.row_band) + one film gather to rank 0, timed separately."""
+    from rodent_amd import parallel, render as R, scene as S, scenes
+    out = {}
+    for name, (scene_name, w, h, spp, max_len) in RENDER_CONFIGS.items():
+        if world > 1 and not name.startswith("cfg5"):
+            continue
+        if name.startswith("cfg5"):
+            spp = args.render_spp5
+        if rank == 0:
+            scene_file(scene_name)
+        if dist is not None:
+            dist.barrier()
+        obj, rscene = scene_file(scene_name)
+        sc = S.Scene(rscene)
+        eye, d, up, fov = scenes.CAMERAS[scene_name]
+        cam = S.camera_settings(eye, d, up, fov, w, h)
+        y0, y1 = parallel.row_band(h, rank, world)
+        frames = 3 if spp * w * h < (1 << 28) else 1
+        entry = {"scene": f"{scene_name} ({sc.num_tris} triangles, {len(sc.materials)} materials)", "width": w, "height": h, "spp": spp, "max_path_len": max_len,
+                 "samples_per_frame": spp * w * h, "timed_frames": frames, "rows_per_gpu": y1 - y0 if world > 1 else h}
+        mappings = ["auto", "streaming", "megakernel"]
+        chosen = None
+        for mapping in mappings:
+            r = R.Renderer(sc, w, h, spp=4, max_path_len=max_len, dev=dev, mapping=mapping)
+            if mapping == "auto":
+                chosen = r.mapping_name()
+            elif mapping == chosen and world == 1:
+                r.close()
+                entry[mapping] = {"same_as": "auto"}
+                continue
+            elif world > 1:                                            # N GPUs: only the mapping the library chooses
+                r.close()
+                continue
+            r.render_rows(cam, 0, y0, y1)                              # warm-up at 4 spp (allocations, code upload)
+            r.configure(spp, max_len)
+            r.clear()
+            secs = []
+            for it in range(frames):
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r.render_rows(cam, it, y0, y1)                         # synchronous: the band is in the device film when it returns
+                secs.append(time.perf_counter() - t0)
+            secs = [max_over_ranks(torch, dist, dev, [s])[0] for s in secs]
+            best = float(np.median(secs))
+            res = {"Msamples_s": round(spp * w * h / best / 1e6, 2), "frame_ms": round(best * 1e3, 2), "frame_ms_all": [round(s * 1e3, 2) for s in secs], "rays": r.counters()}
+            if world > 1:
+                # the one collective of the path (SURVEY 8e): every peer's rows into rank 0's device film, then the frame is complete there
+                film = parallel.device_film(dev)
+                torch.cuda.synchronize(); dist.barrier()
+                t0 = time.perf_counter()
+                full = parallel.gather_film_to_root(film, dist)
+                torch.cuda.synchronize()
+                g = max_over_ranks(torch, dist, dev, [time.perf_counter() - t0])[0]
+                res["film_gather_ms"] = round(g * 1e3, 3)
+                res["film_gather_MB"] = round((h - (y1 - y0)) * w * 12 / 1e6, 2) if rank == 0 else None
+                res["Msamples_s_including_gather"] = round(spp * w * h / (best + g) / 1e6, 2)
+                if rank == 0:
+                    res["film_complete_on_root"] = bool(torch.isfinite(full).all() and float(full[h - 1].abs().sum()) > 0 and float(full[0].abs().sum()) > 0)
+            r.close()
+            entry[mapping] = res
+            if mapping == "auto":
+                entry["auto_mapping"] = chosen
+        entry["per_kernel_profiled"] = render_profile(name)
+        out[name] = entry
+    return out
+
+
+def render_cpu_baseline(threads):
+    """The reference's CPU mapping restated (oracle/cpu_wavefront.inc: tile-parallel wavefront renderer, hybrid ray8 x BVH8
+    traversal, scalar shading) on this host: a bounded sample of each configuration (same scene, camera and path length,
+    fewer pixels and samples per pixel)."""
+    import subprocess
+    from oracle import binding as O
+    from rodent_amd import build, formats as F, scene as S, scenes
+    out = {}
+    for name, (scene_name, w, h, spp, max_len) in RENDER_CONFIGS.items():
+        obj, rscene = scene_file(scene_name)
+        sc = S.Scene(rscene)
+        bvh = scenes.DATA / f"{scene_name}.bench.bvh"
+        if not bvh.exists():
+            subprocess.run([str(build.BIN_DIR / "bvh_extractor"), "-obj", str(obj), "-o", str(bvh)], check=True, stdout=subprocess.DEVNULL)
+        n8, t8 = F.read_bvh(bvh, F.BVH8_TRI4)
+        sw, sh, sspp = (w // 2, h // 2, 4) if scene_name == "cornell" else (w // 4, h // 4, 4)
+        eye, d, up, fov = scenes.CAMERAS[scene_name]
+        cam = S.camera_settings(eye, d, up, fov, sw, sh)
+        O.render_wavefront(sc, n8, t8, cam, 0, 1, max_len, sw, sh, None, threads=threads)          # warm-up (thread start, page faults)
+        t0 = time.perf_counter()
+        O.render_wavefront(sc, n8, t8, cam, 0, sspp, max_len, sw, sh, None, threads=threads)
+        dt = time.perf_counter() - t0
+        out[name] = {"Msamples_s": round(sspp * sw * sh / dt / 1e6, 2), "cores": threads, "kind": "port",
+                     "sample": f"{sw}x{sh}, {sspp} spp, path length {max_len}: {sspp * sw * sh} samples in {dt:.2f} s; reference's CPU wavefront mapping restated "
+                               "(render/mapping_cpu.impala:352-473; scalar shading instead of RV-vectorised)"}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -191,7 +397,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP traversal has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = local_rank
-    strong = args.strong and world > 1
+    info = not args.no_cpu_baseline and args.only is None          # the informational extras (never in the profiling runs)
 
     # ---- inputs (rank 0 builds the files, the others wait) ----------------------------------
     scene = args.scene or scenes.default_scene()
@@ -204,36 +410,75 @@ def main():
     variant = args.variant if args.variant >= 0 else int(os.environ.get(f"RODENT_HIP_BVH{width}_VARIANT", "0"))
     bvh = abi.DeviceBvh.load(bvh_path, width, dev)
 
-    sample, samples = (0, 1) if strong else (rank, world)
-    if scene == "sponza":
-        prim_all = F.read_rays(scenes.DATA / "sponza-primary.rays", 0.0, scenes.PRIMARY_TMAX)
-        rnd_all = F.read_rays(scenes.DATA / "sponza-random.rays", 0.0, scenes.RANDOM_TMAX)
-    else:
+    def ray_sets(sample, samples):
+        if scene == "sponza":
+            return (F.read_rays(scenes.DATA / "sponza-primary.rays", 0.0, scenes.PRIMARY_TMAX), F.read_rays(scenes.DATA / "sponza-random.rays", 0.0, scenes.RANDOM_TMAX))
         eye, d, up, fov = scenes.CAMERAS[scene]
-        prim_all = raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, scenes.PRIMARY_TMAX, sample=sample, num_samples=samples)
+        p = raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, scenes.PRIMARY_TMAX, sample=sample, num_samples=samples)
         n4, _ = F.read_bvh(bvh_path, F.BVH4_TRI4)
         lo, hi = raygen.scene_bounds(n4)
-        rnd_all = raygen.random_rays(lo, hi, 1 << 20, 42 + sample, 0.0, scenes.RANDOM_TMAX)
-    if strong:                                                   # contiguous ranges keep coherent rays coherent
-        a, b = parallel.ray_range(len(prim_all), rank, world)
-        prim, rnd = prim_all[a:b], rnd_all[a:b]
-    else:
-        prim, rnd = prim_all, rnd_all
-    n = len(prim)
+        return p, raygen.random_rays(lo, hi, 1 << 20, 42 + sample, 0.0, scenes.RANDOM_TMAX)
 
-    prim_dev, rnd_dev = abi.to_device(prim, dev), abi.to_device(rnd, dev)
-    hits_dev = torch.zeros(n * F.HIT1.itemsize, dtype=torch.uint8, device=f"cuda:{dev}")
-    hits_rnd_dev = torch.zeros(len(rnd) * F.HIT1.itemsize, dtype=torch.uint8, device=f"cuda:{dev}")
-
-    # ---- timed region ------------------------------------------------------------------------
     steps_p, warm_p = (args.steps, args.warmup) if args.only != "random" else (1, 0)
     steps_r, warm_r = (args.steps, args.warmup) if args.only != "primary" else (1, 0)
-    wall, k_mean, k_med, k_min = time_passes(abi, torch, bvh, prim_dev, hits_dev, n, variant, steps_p, warm_p, dist)
-    wall_r, kr_mean, kr_med, kr_min = time_passes(abi, torch, bvh, rnd_dev, hits_rnd_dev, len(rnd), variant, steps_r, warm_r, dist)
+
+    def run_partition(prim, rnd):
+        """Times both sets on this rank's share; returns the per-partition record (times already max over ranks)."""
+        pd, rd = abi.to_device(prim, dev), abi.to_device(rnd, dev)
+        hp = torch.zeros(max(len(prim), 1) * F.HIT1.itemsize, dtype=torch.uint8, device=f"cuda:{dev}")
+        hr = torch.zeros(max(len(rnd), 1) * F.HIT1.itemsize, dtype=torch.uint8, device=f"cuda:{dev}")
+        wall, k_mean, k_med, k_min = time_passes(abi, torch, bvh, pd, hp, len(prim), variant, steps_p, warm_p, dist)
+        wall_r, kr_mean, kr_med, kr_min = time_passes(abi, torch, bvh, rd, hr, len(rnd), variant, steps_r, warm_r, dist)
+        abi.check_errors(dev)
+        wall, wall_r = max_over_ranks(torch, dist, dev, [wall, wall_r])
+        per_rank = gather_scalars(torch, dist, dev, [k_mean, kr_mean, float(len(prim)), float(len(rnd))])
+        total_p, total_r = int(sum(g[2] for g in per_rank)), int(sum(g[3] for g in per_rank))
+        return {"prim": prim, "rnd": rnd, "prim_dev": pd, "rnd_dev": rd, "hits_dev": hp, "hits_rnd_dev": hr, "wall": wall, "wall_r": wall_r,
+                "k": (k_mean, k_med, k_min), "kr": (kr_mean, kr_med, kr_min), "total": total_p, "total_rnd": total_r,
+                "value": total_p * steps_p / wall / 1e6, "value_rnd": total_r * steps_r / wall_r / 1e6,
+                "kernel_ms_per_rank": [[round(g[0], 5), round(g[1], 5)] for g in per_rank]}
+
+    # ---- timed regions ------------------------------------------------------------------------
+    prim_all, rnd_all = ray_sets(0, 1)
+    strong_check = weak = None
+    if world == 1:
+        main_part = run_partition(prim_all, rnd_all)
+        scaling = "weak"
+    else:
+        # strong (SURVEY 8e): ONE ray set in contiguous ranges -- contiguous keeps coherent rays coherent
+        a, b = parallel.ray_range(len(prim_all), rank, world)
+        strong = run_partition(prim_all[a:b], rnd_all[a:b])
+        # after the timed region: ONE gather of the Hit1 ranges to rank 0 (16 B/ray: 16 MiB in total), compared there with a
+        # single-GPU trace of the whole set
+        full = parallel.gather_hits_device(strong["hits_dev"], len(prim_all), dist, dev)
+        full_rnd = parallel.gather_hits_device(strong["hits_rnd_dev"], len(rnd_all), dist, dev)
+        if rank == 0:
+            whole = abi.traverse(bvh, prim_all, variant=variant)
+            whole_rnd = abi.traverse(bvh, rnd_all, variant=variant)
+            strong_check = {"primary_equal_to_single_gpu": bool(full.tobytes() == whole.tobytes()), "random_equal_to_single_gpu": bool(full_rnd.tobytes() == whole_rnd.tobytes())}
+        # weak: every rank its own 1 Mi rays (sub-pixel sample `rank` of `world`)
+        pw, rw = ray_sets(rank, world)
+        weak_part = run_partition(pw, rw)
+        counts = gather_scalars(torch, dist, dev, [float((abi.from_device(weak_part["hits_dev"], F.HIT1)["tri_id"] >= 0).sum()),
+                                                   float((abi.from_device(weak_part["hits_rnd_dev"], F.HIT1)["tri_id"] >= 0).sum())])
+        weak = {"Mrays_s": round(weak_part["value"], 3), "ms_per_step": round(1e3 * weak_part["wall"] / steps_p, 5), "random_Mrays_s": round(weak_part["value_rnd"], 3),
+                "rays_per_gpu_per_step": len(pw), "kernel_ms_per_rank[primary,random]": weak_part["kernel_ms_per_rank"],
+                "hit_counts_per_rank[primary,random]": [[int(c[0]), int(c[1])] for c in counts],
+                "what": "rank r traces sub-pixel sample r of N through the same 1024 x 1024 pixel grid (random: seed 42 + r): per-GPU work fixed"}
+        strong_rec = {"Mrays_s": round(strong["value"], 3), "ms_per_step": round(1e3 * strong["wall"] / steps_p, 5), "random_Mrays_s": round(strong["value_rnd"], 3),
+                      "rays_per_gpu_per_step": len(strong["prim"]), "kernel_ms_per_rank[primary,random]": strong["kernel_ms_per_rank"],
+                      "what": "ONE 1 Mi-ray set in contiguous ranges (SURVEY 8e), Hit1 gather to rank 0 after the timed region"}
+        main_part, scaling = (weak_part, "weak") if args.weak else (strong, "strong")
+    prim, rnd = main_part["prim"], main_part["rnd"]
+    n = len(prim)
+    prim_dev, rnd_dev, hits_dev, hits_rnd_dev = main_part["prim_dev"], main_part["rnd_dev"], main_part["hits_dev"], main_part["hits_rnd_dev"]
+    k_mean, k_med, k_min = main_part["k"]
+    kr_mean, kr_med, kr_min = main_part["kr"]
+
     # the same two sets with the schedule history on (rodent_hip_schedule_history: chunks traced longest first by the previous
     # launch's per-chunk cost -- state carried from step to step, therefore NOT the headline; same hit records)
     history = None
-    if width == 2 and abi.variants(2)[variant] == "top" and world == 1 and args.only is None:
+    if width == 2 and abi.variants(2)[variant] == "top" and world == 1 and info:
         abi.lib().rodent_hip_schedule_history(1)
         hits_h, hits_rnd_h = torch.zeros_like(hits_dev), torch.zeros_like(hits_rnd_dev)
         wall_h, kh_mean, _, _ = time_passes(abi, torch, bvh, prim_dev, hits_h, n, variant, steps_p, warm_p, None)
@@ -247,17 +492,19 @@ def main():
                            "chunks longest first; off by default, not the headline value"}
     # BASELINE config 3 ("ray compaction/sorting on"): the same random set through the "sorted" mapping -- the permutation by
     # origin cell is rebuilt inside every timed launch
-    sorted_variant = abi.variants(width).index("sorted") if "sorted" in abi.variants(width) else None
-    wall_s = ks_mean = None
-    hits_sorted_dev = None
-    if sorted_variant is not None and args.only != "primary":
+    sorted_rec = None
+    if world == 1 and "sorted" in abi.variants(width) and args.only != "primary":
+        sv = abi.variants(width).index("sorted")
         hits_sorted_dev = torch.zeros_like(hits_rnd_dev)
-        wall_s, ks_mean, _, _ = time_passes(abi, torch, bvh, rnd_dev, hits_sorted_dev, len(rnd), sorted_variant, steps_r, warm_r, dist)
+        wall_s, ks_mean, _, _ = time_passes(abi, torch, bvh, rnd_dev, hits_sorted_dev, len(rnd), sv, steps_r, warm_r, None)
+        sorted_rec = {"Mrays_s": round(len(rnd) * steps_r / wall_s / 1e6, 3), "ms_per_step": round(1e3 * wall_s / steps_r, 5), "kernels_ms": round(ks_mean, 5),
+                      "variant": "sorted: counting sort of the rays on 512 Morton cells of their origin inside every launch, then the default kernel through the permutation",
+                      "identical_to_unsorted": bool(torch.equal(hits_sorted_dev, hits_rnd_dev))}
     abi.check_errors(dev)                                         # the asynchronous entry points report stack overflows through a flag
     # for information only (never `value`): independent batches in flight on two streams -- the fill of one launch
     # overlaps the drain of the other (every (device, stream) has its own launch state)
-    overlapped = None
-    if args.only is None and not args.no_cpu_baseline and world == 1:      # not in the profiling runs: their per-kernel averages are the serial launches
+    overlapped = big = None
+    if info and world == 1:
         try:
             s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
             h2 = [hits_dev, torch.zeros_like(hits_dev)]
@@ -272,91 +519,62 @@ def main():
             overlapped = 2 * max(1, args.steps // 2) * n / (time.perf_counter() - t0) / 1e6
         except Exception as e:                                    # informational only: never lose the bench line over it
             print(f"bench.py: two-stream measurement skipped ({e})", file=sys.stderr)
-    # informational: the same camera at 4096 x 4096 = 16 Mi primary rays per launch -- the kernel's throughput regime (at 1 Mi rays
-    # the launch is bound by its schedule)
-    big = None
-    if args.only is None and not args.no_cpu_baseline and world == 1 and scene != "sponza":
-        try:
-            eye, d, up, fov = scenes.CAMERAS[scene]
-            big_rays = raygen.primary_rays(eye, d, up, fov, 4096, 4096, 0.0, scenes.PRIMARY_TMAX)
-            big_dev = abi.to_device(big_rays, dev)
-            big_hits = torch.zeros(len(big_rays) * F.HIT1.itemsize, dtype=torch.uint8, device=f"cuda:{dev}")
-            wall_b, kb_mean, _, _ = time_passes(abi, torch, bvh, big_dev, big_hits, len(big_rays), variant, 10, 3, None)
-            big = {"rays_per_launch": len(big_rays), "Mrays_s": round(len(big_rays) * 10 / wall_b / 1e6, 3), "ms_per_step": round(1e3 * wall_b / 10, 5), "kernels_ms": round(kb_mean, 5)}
-            del big_dev, big_hits, big_rays
-        except Exception as e:
-            print(f"bench.py: 16 Mi-ray measurement skipped ({e})", file=sys.stderr)
-    abi.lib()  # keep the handle alive
-    kernel_ms_ranks = [[k_mean, kr_mean]]
-    total_rays, total_rnd = n, len(rnd)
-    if dist is not None:
-        t = torch.tensor([wall, wall_r], dtype=torch.float64, device=f"cuda:{dev}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, wall_r = float(t[0]), float(t[1])
-        km = torch.tensor([k_mean, kr_mean, float(n), float(len(rnd))], dtype=torch.float64, device=f"cuda:{dev}")
-        gathered_km = [torch.zeros_like(km) for _ in range(world)]
-        dist.all_gather(gathered_km, km)
-        kernel_ms_ranks = [[round(float(g[0]), 5), round(float(g[1]), 5)] for g in gathered_km]
-        total_rays, total_rnd = int(sum(float(g[2]) for g in gathered_km)), int(sum(float(g[3]) for g in gathered_km))
-    value = total_rays * steps_p / wall / 1e6
-    value_rnd = total_rnd * steps_r / wall_r / 1e6
-    if wall_s is not None and dist is not None:
-        t = torch.tensor([wall_s], dtype=torch.float64, device=f"cuda:{dev}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall_s = float(t[0])
+        # the same camera at 4096 x 4096 = 16 Mi primary rays per launch -- the kernel's throughput regime (at 1 Mi rays
+        # the launch is bound by its schedule)
+        if scene != "sponza":
+            try:
+                eye, d, up, fov = scenes.CAMERAS[scene]
+                big_rays = raygen.primary_rays(eye, d, up, fov, 4096, 4096, 0.0, scenes.PRIMARY_TMAX)
+                big_dev = abi.to_device(big_rays, dev)
+                big_hits = torch.zeros(len(big_rays) * F.HIT1.itemsize, dtype=torch.uint8, device=f"cuda:{dev}")
+                wall_b, kb_mean, _, _ = time_passes(abi, torch, bvh, big_dev, big_hits, len(big_rays), variant, 10, 3, None)
+                big = {"rays_per_launch": len(big_rays), "Mrays_s": round(len(big_rays) * 10 / wall_b / 1e6, 3), "ms_per_step": round(1e3 * wall_b / 10, 5), "kernels_ms": round(kb_mean, 5)}
+                del big_dev, big_hits, big_rays
+            except Exception as e:
+                print(f"bench.py: 16 Mi-ray measurement skipped ({e})", file=sys.stderr)
 
-    # ---- after the timed region: ONE gather --------------------------------------------------
-    hits = abi.from_device(hits_dev, F.HIT1)
-    hits_rnd = abi.from_device(hits_rnd_dev, F.HIT1)
-    strong_check = None
-    if strong:
-        # the Hit1 ranges of all ranks, one RCCL all-gather (16 B/ray: 16 MiB in total), assembled in ray order on every rank
-        full = parallel.gather_hits_device(hits_dev, len(prim_all), dist, dev)
-        full_rnd = parallel.gather_hits_device(hits_rnd_dev, len(rnd_all), dist, dev)
-        if rank == 0:
-            whole = abi.traverse(bvh, prim_all, variant=variant)
-            whole_rnd = abi.traverse(bvh, rnd_all, variant=variant)
-            strong_check = {"primary_equal_to_single_gpu": bool(full.tobytes() == whole.tobytes()), "random_equal_to_single_gpu": bool(full_rnd.tobytes() == whole_rnd.tobytes())}
-        counts_all = None
-    else:
-        counts = torch.tensor([int((hits["tri_id"] >= 0).sum()), int((hits_rnd["tri_id"] >= 0).sum())], device=f"cuda:{dev}")
-        if dist is not None:
-            gathered = [torch.zeros_like(counts) for _ in range(world)]
-            dist.all_gather(gathered, counts)
-            counts_all = [g.tolist() for g in gathered]
-        else:
-            counts_all = [counts.tolist()]
+    hits = abi.from_device(hits_dev, F.HIT1)[:n]
+    hits_rnd = abi.from_device(hits_rnd_dev, F.HIT1)[:len(rnd)]
+
+    # ---- renderer (BASELINE configs 4 / 5): after the traversal's timed regions, own timed frames ----
+    render = None
+    if info and not args.no_render and width == 2:
+        render = render_section(args, torch, dist, rank, world, dev)
 
     if rank != 0:
         if dist is not None:
             dist.barrier(); dist.destroy_process_group()
         return
 
-    # ---- rank 0: algorithmic bytes (oracle visit counts), rooflines, CPU baseline ---------------
+    # ---- rank 0: the JSON line -----------------------------------------------------------------
     kname = abi.kernel_name(width, variant)
-    sharding = "ONE ray set in contiguous ranges (strong scaling), Hit1 all-gather after the timed region" if strong else "rays sharded by sub-pixel sample (weak scaling)"
+    sharding = {"strong": "ONE ray set in contiguous ranges (strong scaling), Hit1 gather to rank 0 after the timed region", "weak": "rays sharded by sub-pixel sample (weak scaling)"}[scaling]
     out = {
-        "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * wall / steps_p, 5), "higher_is_better": True,
-        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{scene}.bvh + {scene}-primary.rays (1024x1024 primary rays, tmax 5000, closest hit)" + ("" if strong else " per GPU"),
+        "metric": "Mrays/s", "value": round(main_part["value"], 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * main_part["wall"] / steps_p, 5), "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{scene}.bvh + {scene}-primary.rays (1024x1024 primary rays, tmax 5000, closest hit)" + (" per GPU" if scaling == "weak" and world > 1 else ""),
                    "rays_per_gpu_per_step": n, "bvh_layout": f"BVH{width}", "kernel": kname,
-                   "variant": abi.variants(width)[variant], "parallelism": f"replicated BVH x {world}, {sharding}",
+                   "variant": abi.variants(width)[variant], "parallelism": f"replicated BVH x {world}" + (f", {sharding}" if world > 1 else ""),
                    "world_size": world, "collective_backend": "nccl (RCCL)" if world > 1 else None},
-        "extra": {"random_Mrays_s": round(value_rnd, 3), "random_ms_per_step": round(1e3 * wall_r / steps_r, 5),
+        "extra": {"random_Mrays_s": round(main_part["value_rnd"], 3), "random_ms_per_step": round(1e3 * main_part["wall_r"] / steps_r, 5),
                   "primary_kernel_ms": {"mean": round(k_mean, 5), "median": round(k_med, 5), "min": round(k_min, 5)},
                   "random_kernel_ms": {"mean": round(kr_mean, 5), "median": round(kr_med, 5), "min": round(kr_min, 5)},
-                  "kernel_ms_per_rank[primary,random]": kernel_ms_ranks,
-                  "hit_counts_per_rank[primary,random]": counts_all, "strong_scaling_check": strong_check,
+                  "kernel_ms_per_rank[primary,random]": main_part["kernel_ms_per_rank"],
+                  "hit_counts[primary,random]": [int((hits["tri_id"] >= 0).sum()), int((hits_rnd["tri_id"] >= 0).sum())],
                   "two_streams_Mrays_s_per_gpu": None if overlapped is None else round(overlapped, 3),
                   "primary_16Mi_rays_per_launch": big},
     }
+    if world > 1:
+        out["extra"]["strong_scaling"] = strong_rec
+        out["extra"]["weak_scaling"] = weak
+        out["extra"]["strong_scaling_check"] = strong_check
     if history is not None:
         out["extra"]["with_schedule_history"] = history
-    if wall_s is not None:
-        out["extra"]["random_sorted"] = {"Mrays_s": round(total_rnd * steps_r / wall_s / 1e6, 3), "ms_per_step": round(1e3 * wall_s / steps_r, 5), "kernels_ms": round(ks_mean, 5),
-                                         "variant": "sorted: counting sort of the rays on 512 Morton cells of their origin inside every launch, then the default kernel through the permutation",
-                                         "identical_to_unsorted": bool(abi.from_device(hits_sorted_dev, F.HIT1).tobytes() == hits_rnd.tobytes())}
+    if sorted_rec is not None:
+        out["extra"]["random_sorted"] = sorted_rec
+    if render is not None:
+        out["extra"]["render"] = render
     if not args.no_cpu_baseline:
         from oracle import binding as O      # checker / CPU baseline only: never on the measured path
         # (1) visit counts of the reference algorithm for THIS layout over ALL rays -> algorithmic bytes per ray; full parity check
@@ -374,17 +592,30 @@ def main():
             lds_r = float(O.node_visits(nodes, tris, rnd)[ids].sum()) / len(rnd)
         bytes_per_ray = 32 + 16 + node_b * st["inner_per_ray"] + prim_b * st["prims_per_ray"]
         achieved = bytes_per_ray * n / (k_mean * 1e-3) / 1e9
-        traffic = measured_traffic(kname)
-        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                           "note": "frac > 1: SURVEY 8(d)'s algorithmic bytes count every node / triangle visit, and the BVH is served by L1 / L2 / MALL -- HBM does not bind this kernel; see hbm_measured and binding",
-                           "bytes_per_ray": round(bytes_per_ray, 2),
-                           "visits_per_ray": {"inner": round(st["inner_per_ray"], 3), "prim": round(st["prims_per_ray"], 3)},
-                           "compulsory_bytes_per_ray": 48, "kernel_ms": round(k_mean, 5),
-                           "hbm_measured": None if traffic is None else {"bytes_per_launch": traffic, "GBps": round(traffic / (k_mean * 1e-3) / 1e9, 1), "frac": round(traffic / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-                           "binding": binding_bounds(kname, "primary", n, st["inner_per_ray"] + st["prims_per_ray"], k_mean, lds_p),
-                           "random": {"kernel_ms": round(kr_mean, 5), "visits_per_ray": {"inner": round(st_r["inner_per_ray"], 3), "prim": round(st_r["prims_per_ray"], 3)},
-                                      "binding": binding_bounds(kname, "random", len(rnd), st_r["inner_per_ray"] + st_r["prims_per_ray"], kr_mean, lds_r)}}
+        traffic, traffic_why = measured_traffic(kname)
+        binding = binding_bounds(kname, "primary", n, st["inner_per_ray"] + st["prims_per_ray"], k_mean, lds_p)
+        binding_r = binding_bounds(kname, "random", len(rnd), st_r["inner_per_ray"] + st_r["prims_per_ray"], kr_mean, lds_r)
+        top = pick_bound(binding)
+        roof = {"bound": top[0], "achieved": top[1]["achieved"], "peak": top[1]["peak"], "unit": top[1]["unit"], "frac": top[1]["frac"]} if top else \
+               {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "note": "no calibration under profiles/"}
+        compulsory = 48 * n + nodes.nbytes + tris.nbytes
+        roof.update({
+            "traffic": None if traffic is None else traffic["bytes"],
+            "kernel": kname, "kernel_ms": round(k_mean, 5),
+            "what": "the larger of the kernel's two throughput bounds (VALU issue, node fetches through the vector-memory pipeline), peaks measured on this chip; "
+                    "at 1 Mi rays per launch neither is near 1: the launch is a tail (DESIGN.md 3.1.1), the same kernel at 16 Mi rays is in extra.primary_16Mi_rays_per_launch",
+            "hbm_algorithmic": {"bound": "hbm", "GBps": round(achieved, 2), "peak_GBps": HBM_PEAK_GBPS, "frac": round(achieved / HBM_PEAK_GBPS, 5), "bytes_per_ray": round(bytes_per_ray, 2),
+                                "visits_per_ray": {"inner": round(st["inner_per_ray"], 3), "prim": round(st["prims_per_ray"], 3)},
+                                "note": "SURVEY 8(d): 32 + 16 + 64 N_inner + 48 N_tri bytes per ray x rays / kernel time.  Every node / triangle visit is counted although the BVH "
+                                        "is served by L1 / L2 / MALL: a count of cache hits, not a fraction of anything (> 1 is expected)"},
+            "hbm_measured": {"not_quoted": traffic_why} if traffic is None else
+                            {"bytes_per_launch": traffic["bytes"], "GBps": round(traffic["bytes"] / (k_mean * 1e-3) / 1e9, 1), "frac": round(traffic["bytes"] / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "compulsory_bytes_per_launch": int(compulsory), "over_compulsory": round(traffic["bytes"] / compulsory, 3),
+                             "write_bytes": traffic["write_bytes"], "write_over_hit1_array": round(traffic["write_bytes"] / (16.0 * n), 3), "source": traffic["source"]},
+            "binding": binding,
+            "random": {"kernel_ms": round(kr_mean, 5), "visits_per_ray": {"inner": round(st_r["inner_per_ray"], 3), "prim": round(st_r["prims_per_ray"], 3)},
+                       "bound": (pick_bound(binding_r) or [None])[0], "frac": (pick_bound(binding_r) or [None, {"frac": None}])[1]["frac"], "binding": binding_r}})
+        out["roofline"] = roof
         # parity on every ray of both sets (bit-exact for the order-preserving kernels)
         out["extra"]["all_rays_bit_exact_vs_oracle"] = {"primary": bool(hits.tobytes() == ref_hits.tobytes()), "random": bool(hits_rnd.tobytes() == ref_rnd.tobytes())}
     if world == 1 and not args.no_cpu_baseline:
@@ -404,6 +635,11 @@ def main():
         out["extra"]["cpu_baseline_1core_Mrays_s"] = round(n / float(np.median(secs1)) / 1e6, 3)
         out["extra"]["cpu_baseline_random_Mrays_s"] = round(len(rnd) / float(np.median(secs_rnd)) / 1e6, 3)
         out["extra"]["cpu_vs_gpu_hit_mismatch"] = int(((cpu_hits["tri_id"] >= 0) != (hits[:len(cpu_hits)]["tri_id"] >= 0)).sum())
+        if render is not None:
+            try:
+                out["extra"]["render"]["cpu_baseline"] = render_cpu_baseline(threads)
+            except Exception as e:                                # informational: never lose the bench line over it
+                out["extra"]["render"]["cpu_baseline"] = {"skipped": str(e)}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()

@@ -72,11 +72,19 @@ struct RodentSceneDesc {           /* HOST pointers; copied to HBM by rodent_hip
 void    rodent_hip_scene_create(int32_t dev, const struct RodentSceneDesc* desc);   /* replaces the device's current scene */
 void    rodent_hip_scene_destroy(int32_t dev);
 void    rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len);   /* defaults 4 / 64 (converter.cpp:1007-1012) */
-/* 0 = streaming wavefront loop (src/render/mapping_gpu.impala:308-369, the default), 1 = persistent-threads megakernel
+/* 0 = streaming wavefront loop (src/render/mapping_gpu.impala:308-369), 1 = persistent-threads megakernel
  * (mapping_gpu.impala:371-474; the reference selects it at configure time with the converter target
- * amdgpu-megakernel / nvvm-megakernel, converter.cpp:30-35,1032-1037; `rodent --target amdgpu-megakernel` here).
- * The initial value can also be set with the environment variable RODENT_HIP_MAPPING=streaming|mega. */
+ * amdgpu-megakernel / nvvm-megakernel, converter.cpp:30-35,1032-1037; `rodent --target amdgpu-megakernel` here),
+ * -1 (default) = chosen per scene when the scene is created: the megakernel for hierarchies of at most
+ * RODENT_HIP_AUTO_MEGA_MAX_NODES inner nodes (default 4096: the whole BVH stays in the L1s / L2s and the wavefront
+ * formulation's stream traffic is all that is left to save; the Cornell box renders 1.45 x faster that way), the streaming
+ * loop for larger scenes (the atrium: 1.25 x faster).  The initial value can also be set with the environment variable
+ * RODENT_HIP_MAPPING=auto|streaming|mega.  rodent_hip_render_mapping_in_effect: 0 / 1, what the next frame will use. */
 void    rodent_hip_render_mapping(int32_t dev, int32_t mapping);
+int32_t rodent_hip_render_mapping_in_effect(int32_t dev);
+/* Every rodent_hip_render_* option of the device back to its default, or to what its RODENT_HIP_* environment variable says
+ * (the values a fresh process starts with); spp / max_path_len and the scene are kept. */
+void    rodent_hip_render_defaults(int32_t dev);
 /* Rays per ray stream of the streaming mapping: the reference's constant 1 Mi (mapping_gpu.impala:319) is 8 Mi here
  * by default (larger launches amortise their fill and drain on a 256-CU chip; 0 restores the default). */
 void    rodent_hip_render_capacity(int32_t dev, int32_t rays);
@@ -92,6 +100,11 @@ void    rodent_hip_render_overlap(int32_t dev, int32_t enable);
  * 18-word stream per bounce less, but a gathering shader: measured 3 % slower on the Cornell box, equal on the atrium).
  * Same paths and film.  RODENT_HIP_FUSED_SORT=0|1. */
 void    rodent_hip_render_fused_sort(int32_t dev, int32_t enable);
+/* 1 (default): compaction is part of the shader -- every ray that goes on is written straight to its compacted slot of the
+ * other stream (single-pass block scan with decoupled look-back: the same stable order gpu_compact_primary,
+ * mapping_gpu.impala:267-300, produces), one read + write of the 15-word stream per bounce less.  0: shade in place, then
+ * the separate compaction pass.  Same stream contents either way.  RODENT_HIP_FUSED_COMPACT=0|1. */
+void    rodent_hip_render_fused_compact(int32_t dev, int32_t enable);
 /* 1 (default): the stream traversal kernels run as 2-wave workgroups that stage the first 31 inner nodes of the scene's BVH
  * (breadth first, built at scene creation) in LDS and fetch those with ds_read instead of through the vector-memory pipeline.
  * 0: one wave per workgroup, every node from memory (rounds 1-2).  Same per-ray visit order, same film.  RODENT_HIP_LDS_IMAGE=0|1. */

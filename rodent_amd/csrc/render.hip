@@ -503,22 +503,63 @@ __device__ __forceinline__ ShadeOut shade_vertex(const SceneDev& sc, const PathV
     return o;
 }
 
+// Block-wide exclusive prefix over all EARLIER blocks of a launch, single pass ("decoupled look-back"): every block publishes
+// its own total as soon as it knows it (flag A), then adds up its predecessors' words -- 64 at a time, one per lane -- back to
+// the nearest block that already knows its inclusive prefix (flag P), and publishes its own.  A word is (flag << 30) | value;
+// the array is zeroed before the launch (flag 0 = nothing yet: wait).  Blocks are dispatched in index order and a block never
+// waits for a LATER one, so the chain always ends; the values are all that travels (relaxed agent-scope atomics, no fences).
+// Called by the first wave of the block; returns the prefix in every lane.
+constexpr unsigned kScanA = 1u << 30, kScanP = 2u << 30, kScanValue = (1u << 30) - 1u;
+__device__ __forceinline__ unsigned lookback_exclusive(unsigned* status, int block, unsigned total) {
+    const int lane = threadIdx.x;                                        // 0..63
+    if (lane == 0) __hip_atomic_store(&status[block], (block == 0 ? kScanP : kScanA) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (block == 0) return 0u;
+    unsigned excl = 0u;
+    for (int j = block - 1;; j -= kWave) {
+        unsigned long long upto, is_p;
+        unsigned w;
+        int first_p;
+        for (;;) {
+            const int idx = j - lane;
+            w = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanP;     // in front of block 0: prefix 0
+            is_p = __ballot((w >> 30) == 2u);
+            first_p = is_p ? __ffsll((long long)is_p) - 1 : kWave - 1;
+            upto = first_p >= 63 ? ~0ull : ((2ull << first_p) - 1ull);
+            if (!(__ballot((w >> 30) == 0u) & upto)) break;              // every word up to the nearest prefix is there
+            __builtin_amdgcn_s_sleep(2);
+        }
+        unsigned v = ((upto >> lane) & 1ull) ? (w & kScanValue) : 0u;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        excl += v;
+        if (is_p) break;
+    }
+    if (lane == 0) __hip_atomic_store(&status[block], kScanP | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
 // `perm` != nullptr: the sort did not move the rays, it only computed where each would go (perm[sorted position] = stream
-// index); thread i then shades ray perm[i] of `p` and writes the ray that goes on to slot i of `q` (all 15 words a ray
-// carries) -- the sorted stream exists only as the shader's output.  One full read + write of the 18-word stream per bounce
-// less than sorting physically first (copy_primary_ray, mapping_gpu.impala:136-164) and shading in place.  `perm` ==
-// nullptr: in place, q == p.
+// index); thread i then shades ray perm[i] of `p`.  `perm` == nullptr: thread i shades ray i.
+// `scan` == nullptr (the stage-level hip_shade, mapping_gpu.impala:82-134 as it stands): the ray that goes on is written to
+// slot i of `q` (q == p: in place), a path that ends leaves id -1 behind and gpu_compact_primary (:267-300) squeezes the
+// stream afterwards.  `scan` != nullptr (the renderer's loop): COMPACTION IS PART OF THE SHADER -- the ray that goes on is
+// written straight to its compacted slot of `q` (another stream than `p`): slot = rays that go on in earlier blocks
+// (lookback_exclusive over the blocks' totals) + those in earlier waves of the block + those in lower lanes.  That is the
+// stable order the separate compaction produced, without reading and writing the 15-word stream once more per bounce (the
+// compaction's copy was 38 % of the summed kernel time of BASELINE config 4, profiles/r02_render_pmc_digest.txt); the
+// new stream size goes to *alive_total.
 __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, PrimaryStream q, const int* __restrict__ perm, SecondaryStream s, const int* size_ptr, int n_value, float* film,
-                                                   float inv_spp, int max_path_len, int unsorted) {
+                                                   float inv_spp, int max_path_len, int unsorted, unsigned* scan, int* alive_total) {
+    __shared__ unsigned wave_total[kBlock / kWave + 1];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int n_valid = stream_size(size_ptr, n_value);
-    if ((int)(blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave) >= n_valid) return;     // whole wave beyond the stream
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    if (scan ? (int)(blockIdx.x * kBlock) >= n_valid : (int)(blockIdx.x * kBlock + wave * kWave) >= n_valid) return;     // whole block (whole wave) beyond the stream
     // Every lane of the wave reaches the ONE film_add_wave call below (it reduces across lanes with shuffles, which must
     // not read lanes that took another path): lanes beyond the stream and rays that missed take part with nothing to add.
     const bool in_range = i < n_valid;
     const int src = (perm && in_range) ? perm[i] : i;
     const bool live = in_range && !(unsorted && p.geom_id[src] >= sc.num_materials);
-    if (in_range && !live) { q.rays.id[i] = -1; s.rays.id[i] = -1; }                       // unsorted stream: a ray that missed ends here
+    if (in_range && !live) { if (!scan) q.rays.id[i] = -1; s.rays.id[i] = -1; }            // unsorted stream: a ray that missed ends here
     PathVertex pv; pv.pixel = -1; pv.depth = 0;
     ShadeOut o; o.emits = false; o.shadow = false; o.bounce = false; o.emitted = V(0, 0, 0);
     if (live) {
@@ -531,24 +572,43 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, 
         o = shade_vertex(sc, pv, max_path_len);
     }
     film_add_wave(film, pv.pixel, live && o.emits, o.emitted.x * inv_spp, o.emitted.y * inv_spp, o.emitted.z * inv_spp);
-    if (!live) return;
 
     // the secondary ray is written at the SAME index (mapping_gpu.impala:111-115)
-    if (o.shadow) {
-        s.rays.org_x[i] = o.s_org.x; s.rays.org_y[i] = o.s_org.y; s.rays.org_z[i] = o.s_org.z;
-        s.rays.dir_x[i] = o.s_dir.x; s.rays.dir_y[i] = o.s_dir.y; s.rays.dir_z[i] = o.s_dir.z;
-        s.rays.tmin[i] = kRayOffset; s.rays.tmax[i] = 1.0f - kRayOffset;
-        s.color_r[i] = o.s_color.x; s.color_g[i] = o.s_color.y; s.color_b[i] = o.s_color.z;
+    if (live) {
+        if (o.shadow) {
+            s.rays.org_x[i] = o.s_org.x; s.rays.org_y[i] = o.s_org.y; s.rays.org_z[i] = o.s_org.z;
+            s.rays.dir_x[i] = o.s_dir.x; s.rays.dir_y[i] = o.s_dir.y; s.rays.dir_z[i] = o.s_dir.z;
+            s.rays.tmin[i] = kRayOffset; s.rays.tmax[i] = 1.0f - kRayOffset;
+            s.color_r[i] = o.s_color.x; s.color_g[i] = o.s_color.y; s.color_b[i] = o.s_color.z;
+        }
+        s.rays.id[i] = o.shadow ? pv.pixel : -1;
     }
-    s.rays.id[i] = o.shadow ? pv.pixel : -1;
 
-    if (!o.bounce) { q.rays.id[i] = -1; return; }
-    if (perm) q.rays.id[i] = pv.pixel;                                                     // (in place the id is there already)
-    q.rays.org_x[i] = o.b_org.x; q.rays.org_y[i] = o.b_org.y; q.rays.org_z[i] = o.b_org.z;
-    q.rays.dir_x[i] = o.b_dir.x; q.rays.dir_y[i] = o.b_dir.y; q.rays.dir_z[i] = o.b_dir.z;
-    q.rays.tmin[i] = kRayOffset; q.rays.tmax[i] = FLT_MAX_REF;
-    q.rnd[i] = o.rnd; q.mis[i] = o.mis;
-    q.contrib_r[i] = o.contrib.x; q.contrib_g[i] = o.contrib.y; q.contrib_b[i] = o.contrib.z; q.depth[i] = pv.depth + 1;
+    const bool goes_on = live && o.bounce;
+    int d = i;
+    if (scan) {
+        const unsigned long long on = __ballot(goes_on);
+        if (lane == 0) wave_total[wave] = (unsigned)__popcll(on);
+        __syncthreads();
+        unsigned before = 0u, total = 0u;
+        for (int w = 0; w < kBlock / kWave; w++) { const unsigned c = wave_total[w]; if (w < wave) before += c; total += c; }
+        if (wave == 0) {
+            const unsigned excl = lookback_exclusive(scan, blockIdx.x, total);
+            if (lane == 0) {
+                wave_total[kBlock / kWave] = excl;
+                if ((int)blockIdx.x == (n_valid - 1) / kBlock) *alive_total = (int)(excl + total);      // the stream's last block: the new size
+            }
+        }
+        __syncthreads();
+        d = (int)(wave_total[kBlock / kWave] + before) + __popcll(on & ((1ull << lane) - 1ull));
+    } else if (live && !goes_on) q.rays.id[i] = -1;
+    if (!goes_on) return;
+    if (perm || scan) q.rays.id[d] = pv.pixel;                                             // (in place the id is there already)
+    q.rays.org_x[d] = o.b_org.x; q.rays.org_y[d] = o.b_org.y; q.rays.org_z[d] = o.b_org.z;
+    q.rays.dir_x[d] = o.b_dir.x; q.rays.dir_y[d] = o.b_dir.y; q.rays.dir_z[d] = o.b_dir.z;
+    q.rays.tmin[d] = kRayOffset; q.rays.tmax[d] = FLT_MAX_REF;
+    q.rnd[d] = o.rnd; q.mis[d] = o.mis;
+    q.contrib_r[d] = o.contrib.x; q.contrib_g[d] = o.contrib.y; q.contrib_b[d] = o.contrib.z; q.depth[d] = pv.depth + 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -775,6 +835,7 @@ __global__ __launch_bounds__(kBinBlock) void k_scatter(PrimaryStream p, PrimaryS
 // ---------------------------------------------------------------------------------------------
 struct DevScene {
     bool loaded = false;
+    int num_nodes = 0;
     SceneDev dev{};
     std::vector<void*> allocs;
 };
@@ -790,8 +851,11 @@ struct RenderDevice {
     int* tickets[2] = {nullptr, nullptr}; int num_cus = 0;
     int lds_image = 1;                         // 1 = the stream traversal kernels stage the scene's top-of-tree image in LDS (2-wave workgroups); 0 = every node from memory
     int fused_sort = 0;                        // 0 = rays are moved by the sort (copy_primary_ray), then shaded in place; 1 = the sort only computes the permutation and the shader gathers through it
+    int fused_compact = 1;                     // 1 = the shader writes every continuing ray to its compacted slot (k_shade + lookback_exclusive); 0 = shade in place, then the separate compaction pass (mapping_gpu.impala:267-300 as it stands)
+    unsigned* scan = nullptr; int scan_cap = 0;    // per-block words of the shader's look-back scan (zero before every launch)
     int* perm = nullptr; int perm_cap = 0;     // sorted position -> stream index
-    int mapping = 0;                           // 0 = streaming wavefront (mapping_gpu.impala:308-369), 1 = megakernel (:371-474)
+    int mapping = 0;                           // in effect: 0 = streaming wavefront (mapping_gpu.impala:308-369), 1 = megakernel (:371-474)
+    int mapping_request = -1;                  // -1 = chosen per scene (auto_mapping), 0 / 1 = the caller's choice
     float* film = nullptr; int film_w = 0, film_h = 0;
     float* slab[3] = {nullptr, nullptr, nullptr}; int slab_cap[3] = {0, 0, 0};       // first primary, second primary, secondary
     int* tmp = nullptr; int tmp_cap = 0;
@@ -810,6 +874,23 @@ std::mutex g_rmutex;
 int g_current_dev = 0;
 std::vector<float> g_host_film; size_t g_host_w = 0, g_host_h = 0;
 
+// every option of the renderer at its default, or at what its environment variable says (rodent_hip_render_defaults)
+void render_defaults(RenderDevice& r) {
+    r.sort = 1; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 1; r.lds_image = 1; r.trace_persistent = 0; r.mapping_request = -1; r.capacity = 0;
+    if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("RODENT_HIP_FUSED_SORT")) r.fused_sort = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("RODENT_HIP_FUSED_COMPACT")) r.fused_compact = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("RODENT_HIP_LDS_IMAGE")) r.lds_image = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("RODENT_HIP_TRACE_PERSISTENT")) r.trace_persistent = atoi(e) ? 1 : 0;
+    if (const char* m = getenv("RODENT_HIP_MAPPING")) {
+        if (!strcmp(m, "mega") || !strcmp(m, "megakernel") || !strcmp(m, "1")) r.mapping_request = 1;
+        else if (!strcmp(m, "streaming") || !strcmp(m, "0")) r.mapping_request = 0;
+        else if (strcmp(m, "auto") && strcmp(m, "-1")) { fprintf(stderr, "rodent_hip: RODENT_HIP_MAPPING must be 'auto', 'streaming' or 'mega'\n"); abort(); }
+    }
+    r.mapping = r.mapping_request == 1 ? 1 : 0;
+}
+
 RenderDevice& rdev(int dev) {
     if (dev < 0 || dev >= 16) { fprintf(stderr, "rodent_hip: invalid device index %d\n", dev); abort(); }
     std::lock_guard<std::mutex> lock(g_rmutex);
@@ -824,15 +905,7 @@ RenderDevice& rdev(int dev) {
         HIP_CHECK(hipMalloc(&r.counters, sizeof(unsigned long long) * kNumCounters));
         HIP_CHECK(hipMemset(r.counters, 0, sizeof(unsigned long long) * kNumCounters));
         HIP_CHECK(hipHostMalloc(&r.host_pinned, sizeof(int) * (8 + kMaxBins)));
-        if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
-        if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
-        if (const char* e = getenv("RODENT_HIP_FUSED_SORT")) r.fused_sort = atoi(e) ? 1 : 0;
-        if (const char* e = getenv("RODENT_HIP_LDS_IMAGE")) r.lds_image = atoi(e) ? 1 : 0;
-        if (const char* e = getenv("RODENT_HIP_TRACE_PERSISTENT")) r.trace_persistent = atoi(e) ? 1 : 0;
-        if (const char* m = getenv("RODENT_HIP_MAPPING")) {
-            if (!strcmp(m, "mega") || !strcmp(m, "megakernel") || !strcmp(m, "1")) r.mapping = 1;
-            else if (strcmp(m, "streaming") && strcmp(m, "0")) { fprintf(stderr, "rodent_hip: RODENT_HIP_MAPPING must be 'streaming' or 'mega'\n"); abort(); }
-        }
+        render_defaults(r);
         r.init = true;
     }
     return r;
@@ -1005,6 +1078,23 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
         r.perm_cap = round_cap(kCapacity);
     }
     hipStream_t sstream = overlap ? r.aux : stream;
+    const bool fused = r.fused_compact != 0;
+    int* d_alive = r.ctl + 6;                            // fused compaction: the shader's last block leaves the new stream size here
+    if (fused && r.scan_cap < (kCapacity + kBlock - 1) / kBlock) {
+        HIP_CHECK(hipDeviceSynchronize());
+        if (r.scan) HIP_CHECK(hipFree(r.scan));
+        r.scan_cap = (kCapacity + kBlock - 1) / kBlock;
+        HIP_CHECK(hipMalloc(&r.scan, sizeof(unsigned) * (size_t)r.scan_cap));
+    }
+    // the shader, either in place (then the compaction pass follows) or compacting into the other stream itself
+    const auto shade = [&](const PrimaryStream& from, const PrimaryStream& to, const int* perm, const int* size_ptr, int n_value, int unsorted, int blocks) {
+        if (fused) {
+            HIP_CHECK(hipMemsetAsync(r.scan, 0, sizeof(unsigned) * (size_t)blocks, stream));
+            HIP_CHECK(hipMemsetAsync(d_alive, 0, sizeof(int), stream));
+        }
+        hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, from, to, perm, sec, size_ptr, n_value, r.film, inv_spp, r.max_path_len, unsorted,
+                           fused ? r.scan : (unsigned*)nullptr, d_alive);
+    };
     while (id < num_rays || size > 0) {
         if (size < kCapacity && id < num_rays) {                                         // regenerate (mapping_gpu.impala:332-336)
             const int n = (int)std::min<long long>(num_rays - id, kCapacity - size);
@@ -1021,13 +1111,14 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
                 // through it and writes the sorted, shaded stream (misses, bin G, are not in the permutation: dropped, :347-357)
                 bin_stream(r, 0, *primary, *other, nullptr, size, KEY_GEOM, G + 1, 1, G, stream, 0, r.perm);
                 if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));   // the previous shadow rays have been traced
-                hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, *other, (const int*)r.perm, sec, d_valid, 0, r.film, inv_spp, r.max_path_len, 0);
+                shade(*primary, *other, r.perm, d_valid, 0, 0, blocks);
                 std::swap(primary, other);
             } else {
                 bin_stream(r, 0, *primary, *other, nullptr, size, KEY_GEOM, G + 1, 1, G, stream, 0);    // misses (bin G) are dropped (:347-357); tmin / tmax stay behind
                 std::swap(primary, other);
                 if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));       // the previous shadow rays have been traced
-                hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, *primary, (const int*)nullptr, sec, d_valid, 0, r.film, inv_spp, r.max_path_len, 0);
+                if (fused) { shade(*primary, *other, nullptr, d_valid, 0, 0, blocks); std::swap(primary, other); }
+                else shade(*primary, *primary, nullptr, d_valid, 0, 0, blocks);
             }
             if (overlap) {
                 HIP_CHECK(hipEventRecord(r.ev_shade, stream));
@@ -1037,20 +1128,21 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
                 launch_trace_secondary(r, r.aux, sec, r.ctl + 5, size, inv_spp);
                 HIP_CHECK(hipEventRecord(r.ev_sec, r.aux));
             } else launch_trace_secondary(r, stream, sec, d_valid, size, inv_spp);
-            bin_stream(r, 1, *primary, *other, d_valid, size, KEY_ALIVE, 2, 0, 1, stream);       // compaction (:267-300)
+            if (!fused) bin_stream(r, 1, *primary, *other, d_valid, size, KEY_ALIVE, 2, 0, 1, stream);       // compaction (:267-300)
         } else {                                     // option: no sort by material -- shade in stream order, misses end in the shader
             if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));
-            hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, *primary, *primary, (const int*)nullptr, sec, (const int*)nullptr, size, r.film, inv_spp, r.max_path_len, 1);
+            if (fused) { shade(*primary, *other, nullptr, nullptr, size, 1, blocks); std::swap(primary, other); }
+            else shade(*primary, *primary, nullptr, nullptr, size, 1, blocks);
             if (overlap) {
                 HIP_CHECK(hipEventRecord(r.ev_shade, stream));
                 HIP_CHECK(hipStreamWaitEvent(r.aux, r.ev_shade, 0));
             }
             launch_trace_secondary(r, sstream, sec, nullptr, size, inv_spp);
             if (overlap) HIP_CHECK(hipEventRecord(r.ev_sec, r.aux));
-            bin_stream(r, 1, *primary, *other, nullptr, size, KEY_ALIVE, 2, 0, 1, stream);
+            if (!fused) bin_stream(r, 1, *primary, *other, nullptr, size, KEY_ALIVE, 2, 0, 1, stream);
         }
-        std::swap(primary, other);
-        HIP_CHECK(hipMemcpyAsync(r.host_pinned, bin_end(r, 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (!fused) std::swap(primary, other);
+        HIP_CHECK(hipMemcpyAsync(r.host_pinned, fused ? d_alive : bin_end(r, 1), sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         size = r.host_pinned[0];
         iterations++;
@@ -1089,6 +1181,21 @@ void render_rows_mega(RenderDevice& r, const Settings* settings, int iter, int y
 void render_rows_any(RenderDevice& r, const Settings* settings, int iter, int y0, int y1, hipStream_t stream) {
     if (r.mapping == 1) render_rows_mega(r, settings, iter, y0, y1, stream);
     else render_rows(r, settings, iter, y0, y1, stream);
+}
+
+// Which mapping renders a scene when the caller leaves the choice to the library (rodent_hip_render_mapping(dev, -1), the
+// default).  What separates the two on this chip is whether the hierarchy stays in the caches next to the CUs: then a path's
+// traversal steps cost little, the streaming loop's per-bounce stream traffic (sort + shade + regenerate, ~500 bytes per
+// ray and bounce) is the frame, and the megakernel -- which keeps a path in registers -- wins (Cornell box, 22 nodes:
+// 3.2 against 2.2 Gsamples/s); once traversal dominates, the streaming loop's coherent, sorted wavefronts win (atrium,
+// 142 444 nodes: 0.74 against 0.59; profiles/r02_render_rates.txt, r03_mapping_sweep.txt for the sizes in between).
+int auto_mega_max_nodes() {
+    static const int v = [] { const char* e = getenv("RODENT_HIP_AUTO_MEGA_MAX_NODES"); return e ? atoi(e) : 4096; }();
+    return v;
+}
+int resolve_mapping(const RenderDevice& r) {
+    if (r.mapping_request >= 0) return r.mapping_request;
+    return r.scene.loaded && r.scene.num_nodes <= auto_mega_max_nodes() ? 1 : 0;
 }
 
 template <typename T> T* upload(DevScene& s, const T* host, size_t count) {
@@ -1179,7 +1286,9 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
     };
     s.dev.top_image = build_image(kSceneTopNodes);
     s.dev.top_image_large = build_image(kPersistTopNodes);
+    s.num_nodes = d->num_nodes;
     s.loaded = true;
+    r.mapping = resolve_mapping(r);
 }
 
 void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
@@ -1190,6 +1299,7 @@ void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
 void rodent_hip_render_sort(int32_t dev, int32_t enable) { rdev(dev).sort = enable ? 1 : 0; }
 void rodent_hip_render_overlap(int32_t dev, int32_t enable) { rdev(dev).overlap = enable ? 1 : 0; }
 void rodent_hip_render_fused_sort(int32_t dev, int32_t enable) { rdev(dev).fused_sort = enable ? 1 : 0; }
+void rodent_hip_render_fused_compact(int32_t dev, int32_t enable) { rdev(dev).fused_compact = enable ? 1 : 0; }
 void rodent_hip_render_lds_image(int32_t dev, int32_t enable) { rdev(dev).lds_image = enable ? 1 : 0; }
 void rodent_hip_render_trace_persistent(int32_t dev, int32_t enable) { rdev(dev).trace_persistent = enable ? 1 : 0; }
 
@@ -1199,9 +1309,13 @@ void rodent_hip_render_capacity(int32_t dev, int32_t rays) {
 }
 
 void rodent_hip_render_mapping(int32_t dev, int32_t mapping) {
-    if (mapping != 0 && mapping != 1) { fprintf(stderr, "rodent_hip: unknown mapping %d (0 = streaming, 1 = megakernel)\n", mapping); abort(); }
-    rdev(dev).mapping = mapping;
+    if (mapping < -1 || mapping > 1) { fprintf(stderr, "rodent_hip: unknown mapping %d (-1 = per scene, 0 = streaming, 1 = megakernel)\n", mapping); abort(); }
+    RenderDevice& r = rdev(dev);
+    r.mapping_request = mapping;
+    r.mapping = resolve_mapping(r);
 }
+int32_t rodent_hip_render_mapping_in_effect(int32_t dev) { return rdev(dev).mapping; }
+void rodent_hip_render_defaults(int32_t dev) { RenderDevice& r = rdev(dev); render_defaults(r); r.mapping = resolve_mapping(r); }
 
 int32_t get_spp(void) { return rdev(g_current_dev).spp; }
 
@@ -1307,7 +1421,7 @@ void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, 
     primary->size = num_rays; secondary->size = num_rays;
     if (num_rays <= 0) return;
     hipLaunchKernelGGL(k_shade, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, r.scene.dev, *primary, *primary, (const int*)nullptr, *secondary, (const int*)nullptr, num_rays, r.film,
-                       1.0f / (float)r.spp, r.max_path_len, 0);
+                       1.0f / (float)r.spp, r.max_path_len, 0, (unsigned*)nullptr, (int*)nullptr);
     HIP_CHECK(hipGetLastError());
 }
 

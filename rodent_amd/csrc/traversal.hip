@@ -129,16 +129,18 @@ struct DeepStack {
 // The deep rays of a launch, restarted from the root with the 64-entry stack; `stack_lds`: kStackCap x kWave ints of LDS.  Run by
 // ONE wave per workgroup (threads 0..63); with a grid of several workgroups each takes every gridDim.x-th batch of 64 rays and
 // the last one to finish resets the launch's control words (with a grid of one this is the old one-wave kernel).
+// `group` of `groups`: the calling workgroup's share (the follow-up kernels pass blockIdx.x / gridDim.x; the persistent kernel's
+// last workgroup, which does this work inside the launch, passes 0 / 1).
 template <bool ANY>
 __device__ __forceinline__ void finish_launch(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                               const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
-                                              Ctl* ctl, const int* __restrict__ deep_list, lds_int* stack_lds, int* phase_counters) {
+                                              Ctl* ctl, const int* __restrict__ deep_list, lds_int* stack_lds, int* phase_counters, int group, int groups, int known_count = -1) {
     // behind the last phase of a phased launch: the stripe counters are zero again for the next launch on this stream
-    if (phase_counters && blockIdx.x == 0) for (int k = threadIdx.x; k < 4 * 64; k += kWave) phase_counters[k * 16] = 0;
-    const int count = ctl->deep_count;
+    if (phase_counters && group == 0) for (int k = threadIdx.x; k < 4 * 64; k += kWave) phase_counters[k * 16] = 0;
+    const int count = known_count >= 0 ? known_count : ctl->deep_count;
     if (count > 0) {
         DeepStack st{stack_lds + threadIdx.x, &ctl->err};
-        for (int k = blockIdx.x * kWave + threadIdx.x; k < count; k += gridDim.x * kWave) {
+        for (int k = group * kWave + threadIdx.x; k < count; k += groups * kWave) {
             const int i = deep_list[k];
             RayX ray = load_ray(rays, i);
             HitAcc hit{-1, ray.tmax, 0.0f, 0.0f};
@@ -158,7 +160,7 @@ __device__ __forceinline__ void finish_launch(const Node2* __restrict__ nodes, c
     if (threadIdx.x == 0) {
         // (every workgroup has read deep_count before it counts itself done, so the last one may zero it)
         // (with no deep rays -- the usual case -- nobody needs to wait for anybody: workgroup 0 rewrites the zeros)
-        const bool last = gridDim.x == 1 || (count == 0 ? blockIdx.x == 0 : atomicAdd(&ctl->finish_done, 1) == (int)gridDim.x - 1);
+        const bool last = groups == 1 || (count == 0 ? group == 0 : atomicAdd(&ctl->finish_done, 1) == groups - 1);
         if (last) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; ctl->finish_done = 0; }   // stats[7]: rays handed over (read by the tests); ready for the next launch
     }
 }
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(kWave) void k_bvh2_finish(const Node2* __restrict__
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
                                                         Ctl* ctl, const int* __restrict__ deep_list, int* /* unused since the stack moved to LDS */, int* phase_counters) {
     __shared__ int stack_lds[kStackCap * kWave];
-    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)stack_lds, phase_counters);
+    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)stack_lds, phase_counters, blockIdx.x, gridDim.x);
 }
 
 // Single-step schedule (the default "fast" variant).  Every lane advances by ONE step per wave iteration,
@@ -192,6 +194,7 @@ struct Lane {
     int top;                   // 0 = done, > 0 inner node id, < 0 ~(triangle index)
     lds_int* sp;               // the stack entry under the top (entry `ptr` of the other kernels)
     int ray_id;
+    bool found;                // LAZY kernels only: a triangle has been accepted (lives in an SGPR lane mask, not in a VGPR)
 };
 typedef const __attribute__((address_space(1))) char* gptr;
 // Both array bases as 64-bit integers in VGPRs (the per-lane select in the step would otherwise copy them from SGPRs in
@@ -213,7 +216,11 @@ __device__ __forceinline__ Bases make_bases(const Node2* nodes, const Tri1* tris
 // TOP: the launch's top-of-tree image is staged in LDS (k_bvh2_top): a node id >= kLdsTag is the byte offset of a 64-byte
 // record inside `image` (same layout as Node2, child ids of resident children rewritten the same way), fetched with
 // ds_read_b128 instead of through the texture path.
-template <bool ANY, bool PF = false, bool TOP = false>
+// LAZY: the miss record is not stored up front (start_lane<true>); the step notes in L.found that the ray has a hit record
+// and the kernel stores the miss record of the rays that never got one when their chunk ends (finish_lane).
+// FENCE (kernels that finish the launch themselves, k_bvh2_top_persist<.., FUSED = 2>): a lane that hands its ray to the deep list
+// publishes the list entry and everything it stored for that ray before its workgroup counts itself done.
+template <bool ANY, bool PF = false, bool TOP = false, bool LAZY = false, bool FENCE = false>
 __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __restrict__ hits, lds_int* sp_limit, Ctl* ctl, int* __restrict__ deep_list,
                                           bool prefetch = false, lds_int* pf_row = nullptr, lds_int* image = nullptr) {
     const bool is_node = L.top > 0;
@@ -262,6 +269,8 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
         if (both && L.sp >= sp_limit) {                                 // (`both`: popping the sentinel moves sp below col, which wraps)                                           // deeper than the LDS window: k_bvh2_finish redoes this ray
             deep_list[atomicAdd(&ctl->deep_count, 1)] = L.ray_id;
             L.top = 0;
+            if (LAZY) L.found = true;                                   // its record is the follow-up pass's business
+            if (FENCE) __threadfence();
         }
     } else {
         const int prim_id = __float_as_int(q2.w);
@@ -273,6 +282,7 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
         if (intersect_tri(L.ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v)) {
             store_hit(hits, L.ray_id, prim_id & 0x7FFFFFFF, t, u, v);
             L.ray.tmax = t; found = true;
+            if (LAZY) L.found = true;
         }
         const bool leave = prim_id < 0;                               // sentinel: the leaf is done
         L.top = (ANY && found) ? 0 : (leave ? popped : L.top - 1);    // top - 1 == ~(j + 1)
@@ -281,16 +291,27 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
 }
 
 // A fresh ray: loads it, stores the miss record, empty stack (col[0] = the 0 that ends the traversal when popped).
+// LAZY: no miss record yet -- nearly every primary ray of a closed scene finds a triangle, and the record then was 16 of the
+// 28 bytes the launch wrote per ray (profiles/r02_pmc_counters.json: WRITE_SIZE 1.73 x the Hit1 array); finish_lane stores
+// it for the rays that end without a hit.
+template <bool LAZY = false>
 __device__ __forceinline__ Lane start_lane(const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int ray_id, int any_valid_ray, lds_int* col) {
     Lane L;
     L.ray_id = ray_id;
+    L.found = false;
     L.ray = load_ray(rays, ray_id >= 0 ? ray_id : any_valid_ray);
-    if (ray_id >= 0) store_hit(hits, ray_id, -1, L.ray.tmax, 0.0f, 0.0f);
+    if (!LAZY && ray_id >= 0) store_hit(hits, ray_id, -1, L.ray.tmax, 0.0f, 0.0f);
     L.ray.tmin = canonical(L.ray.tmin); L.ray.tmax = canonical(L.ray.tmax);      // see slab_canonical (after the miss record: it keeps the file's bits)
     L.top = ray_id >= 0 ? 1 : 0;
     L.sp = col;
     col[0] = 0;
     return L;
+}
+// LAZY kernels, when a chunk's loop has ended: the miss record (tri_id -1, t = the ray's tmax as the caller wrote it -- re-read,
+// the register copy is canonicalised) of every ray that no triangle was accepted for.  (A ray that went to the deep list gets
+// one too; the follow-up pass traces it again and stores its final record afterwards.)
+__device__ __forceinline__ void finish_lane(const Lane& L, const Ray1* __restrict__ rays, Hit1* __restrict__ hits) {
+    if (L.ray_id >= 0 && !L.found) store_hit(hits, L.ray_id, -1, rays[L.ray_id].tmax, 0.0f, 0.0f);
 }
 
 // PRIO (lab): 0 = none; 1 = a wave raises its issue priority as it ages (48 / 96 / 144 iterations -> s_setprio 1 / 2 / 3);
@@ -738,7 +759,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool SORTED = false, bool KE
 }
 #endif
 
-template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, int OCC, bool TRACE = false, int PRIO = 0, bool FUSED = false> void launch_top_persist(LAUNCH_ARGS, int max_id) {
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, int OCC, bool TRACE = false, int PRIO = 0, int FUSED = 0, bool LAZY = false> void launch_top_persist(LAUNCH_ARGS, int max_id) {
     ensure_deep_list(s, n);
     if (!s.top_image || !s.tickets) {
         std::lock_guard<std::mutex> lock(g_mutex);
@@ -781,12 +802,12 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, 
         return;
     }
     s.order_rays = 0;
-    hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, OCC, TRACE, PRIO, FUSED>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+    hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, OCC, TRACE, PRIO, FUSED, false, LAZY>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
                        perm, s.top_image, s.tickets, max_id, s.deep_stack, History{nullptr, nullptr, 0, nullptr});
     if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
-template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool SORTED = false, int OCC = 32, bool TRACE = false, int PRIO = 0, bool FUSED = false> void L_top_persist(LAUNCH_ARGS) {
-    launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, SORTED, OCC, TRACE, PRIO, FUSED>(s, nodes, tris, rays, hits, n, stream, mapped_node_ids(nodes));
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool SORTED = false, int OCC = 32, bool TRACE = false, int PRIO = 0, int FUSED = 0, bool LAZY = false> void L_top_persist(LAUNCH_ARGS) {
+    launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, SORTED, OCC, TRACE, PRIO, FUSED, LAZY>(s, nodes, tris, rays, hits, n, stream, mapped_node_ids(nodes));
 }
 
 // The default mapping: launches that fill the chip at least once take the persistent kernel with the LDS image, smaller ones
@@ -901,7 +922,11 @@ const Variant2 kVariants2[] = {
     K2("top255p8-o24",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 8, false, false, 24),
     K2("top63p4-o28",        "k_bvh2_top_persist",   L_top_persist, 15, 63, 4, false, false, 28),
     //                                                                    LDS_N TOPN WAVES REFILL (idle lanes that trigger a refill)
-    K2("top-fused",          "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, true),   // the last workgroup does the follow-up kernel's work
+    K2("top-fused",          "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 1),   // the last workgroup does the follow-up kernel's work (every workgroup fences)
+    K2("top-one",            "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 2),   // the same, fences on the rare paths only
+    K2("top-lazy",           "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 0, true),   // miss records stored at chunk end
+    K2("top-lazy-one",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 2, true),
+    K2("top-userperm-lazy-one", "k_bvh2_top_persist", L_top_persist, 15, 255, 16, false, false, 32, false, -1, 2, true),
     K2("top-userperm",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, -1),    // lane j traces ray perm[j] of a caller-supplied permutation (scheduling experiments)
     K2("top-prio64",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 64),    // s_setprio 3 once a chunk has run 64 / 96 / 128 iterations
     K2("top-prio96",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 96),

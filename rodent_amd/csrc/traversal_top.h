@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kWave) void k_bvh2_top_finish(const Node2* __restri
     __shared__ int stack_lds[kStackCap * kWave];                     // (kStackCap x kWave >= kMaxTopNodes: also the image builder's slot table)
     static_assert(kStackCap * kWave >= kMaxTopNodes, "slot table");
     const bool stale = ctl->reserved != 0;
-    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)stack_lds, tickets);
+    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)stack_lds, tickets, blockIdx.x, gridDim.x);
     if (stale && blockIdx.x == 0) {
         build_top_image(nodes, image, capacity, (lds_int*)stack_lds);
         if (threadIdx.x == 0) ctl->reserved = 0;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kHistoryThreads) void k_bvh2_top_finish_history(con
     static_assert(kStackCap * kWave >= kMaxStripeChunks && kStackCap * kWave >= kMaxTopNodes, "one LDS block for all three uses");
     if (threadIdx.x < kWave) {
         const bool stale = ctl->reserved != 0;
-        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)keys, tickets);
+        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)keys, tickets, blockIdx.x, gridDim.x);
         if (stale && blockIdx.x == 0) {
             build_top_image(nodes, image, capacity, (lds_int*)keys);
             if (threadIdx.x == 0) ctl->reserved = 0;
@@ -217,7 +217,7 @@ __device__ __forceinline__ bool stage_top_image(const Node2* __restrict__ nodes,
     __syncthreads();
     const bool all_ok = *flag != 0;
     __syncthreads();
-    if (!all_ok && threadIdx.x == 0) ctl->reserved = 1;
+    if (!all_ok && threadIdx.x == 0) __hip_atomic_store(&ctl->reserved, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (atomic: read by the launch's last workgroup, behind another XCD's L2)
     return all_ok;
 }
 
@@ -231,7 +231,12 @@ __device__ __forceinline__ bool stage_top_image(const Node2* __restrict__ nodes,
 // sorts each stripe's chunks by them, and the next launch of the same size draws its chunks in that order -- longest first
 // (frame-to-frame cost feedback, as renderers balance tiles by the previous frame's cost).  The order only decides WHEN a chunk
 // is traced; a launch without usable history (first launch, other size) takes the default order.
-template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int OCC = 32, bool TRACE = false, int PRIO = 0, bool FUSED = false, bool HISTORY = false>
+// FUSED: 0 = a follow-up kernel finishes the launch (deep rays, counters, stale image); 1 (lab) = the last workgroup to end does,
+// every workgroup releasing what it wrote; 2 = the last workgroup does, and only the rare paths pay for a fence: a lane that
+// hands its ray to the deep list publishes it on the spot (bvh2_step<FENCE>), the stale-image flag is an atomic, and a launch
+// without deep rays and with a valid image -- every launch but the first on a hierarchy -- costs one relaxed atomic per workgroup.
+// LAZY: miss records are stored when a chunk ends, for the rays that found nothing (start_lane<LAZY>, finish_lane).
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int OCC = 32, bool TRACE = false, int PRIO = 0, int FUSED = 0, bool HISTORY = false, bool LAZY = false>
 __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_persist(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                      const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                                      Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm,
@@ -273,16 +278,17 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
         if (PREFETCH && lane == 0) t_next = atomicAdd(counter, 1);           // in flight while this chunk is traced
         if (chunk < total_chunks) {
             const int first_ray = chunk * kWave, lane_ray = first_ray + lane;
-            Lane L = start_lane(rays, hits, lane_ray < n ? (perm ? perm[lane_ray] : lane_ray) : -1, perm ? perm[first_ray] : first_ray, col);
+            Lane L = start_lane<LAZY>(rays, hits, lane_ray < n ? (perm ? perm[lane_ray] : lane_ray) : -1, perm ? perm[first_ray] : first_ray, col);
             if (L.top != 0) L.top = root;
             const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
             int iterations = 0;
             if (PRIO > 0) __builtin_amdgcn_s_setprio(0);
             while (__ballot(L.top != 0)) {
-                if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+                if (L.top != 0) bvh2_step<ANY, false, true, LAZY, FUSED == 2>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
                 if (TRACE || PRIO > 0 || HISTORY) iterations++;
                 if (PRIO > 0 && iterations == PRIO) __builtin_amdgcn_s_setprio(3);          // lab: a chunk that is still running after PRIO iterations is on the critical path
             }
+            if (LAZY) finish_lane(L, rays, hits);
             if (HISTORY && hist.cost && lane == 0) hist.cost[chunk] = iterations;
             if (TRACE && lane == 0 && ctl->trace && chunk < 16384) {        // lab: per chunk start / end (100 MHz), iterations, wave << 32 | ticket
                 unsigned long long* tr = ctl->trace + 4 * (size_t)chunk;
@@ -295,19 +301,23 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     }
     if (FUSED) {
         // The workgroup that finishes last does the follow-up kernel's work (deep rays, counters, a new image if this launch found
-        // none or a stale one): one launch instead of two.  Every workgroup publishes what it wrote (agent-scope release: its
-        // XCD's L2 is written back) before it counts itself done; the last one acquires before it reads the deep list.
+        // none or a stale one): one launch instead of two.  FUSED == 1: every workgroup publishes what it wrote (agent-scope
+        // release: its XCD's L2 is written back) before it counts itself done, the last one acquires.  FUSED == 2: the counting
+        // is a relaxed atomic; the rays of the deep list were published by the lanes that put them there, and the last
+        // workgroup acquires only if there are any.
         __syncthreads();
         if (threadIdx.x == 0) {
-            __threadfence();
-            const int done = __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (FUSED == 1) __threadfence();
+            const int done = FUSED == 1 ? __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                                        : __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lds_raw[0] = done == (int)gridDim.x - 1;
         }
         __syncthreads();
         if (!lds_raw[0] || wave != 0) return;
-        __threadfence();
+        const int deep = __hip_atomic_load(&ctl->deep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (FUSED == 1 || deep > 0) __threadfence();
         const bool stale = __hip_atomic_load(&ctl->reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)lds_raw, tickets);
+        finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)lds_raw, tickets, 0, 1, deep);
         if (stale) {
             build_top_image(nodes, top_image, TOPN, (lds_int*)lds_raw);        // (the stacks are idle now)
             if (lane == 0) ctl->reserved = 0;

@@ -1,10 +1,15 @@
 """Multi-GPU partitioning: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on
 the GPU box, "gloo" in the CPU tests).  The path shards without any data-path collective:
-the BVH / scene is replicated, rays or image rows are partitioned, and ONE gather collects the results.
+the BVH / scene is replicated, rays or image rows are partitioned, and ONE gather to the root collects the results.
 
   traversal : rank r gets its own ray batch (sub-pixel sample r of N, or a contiguous ray range)
   frames    : rank r renders the row band row_band(height, r, N); seeds depend on absolute
               (sample, iter, x, y) only (src/render/renderer.impala:28-33), so bands reproduce the frame
+
+The gather is a grouped send / receive (what ncclGather is made of): the root posts one receive per peer straight into that
+peer's rows of ITS film (or its range of the Hit1 array), every peer posts one send of its own part -- each byte crosses one
+xGMI link once, nothing is padded, nobody but the root receives anything (12.4 MB per peer at 3840 x 2160).  The C++ hosts do
+the same with ncclSend / ncclRecv between ncclGroupStart / ncclGroupEnd (rodent_amd/host/multi_gpu.cpp).
 """
 from __future__ import annotations
 
@@ -25,32 +30,56 @@ def ray_range(num_rays: int, rank: int, world: int):
     return a, a + base + (1 if rank < extra else 0)
 
 
-def _gather_slabs(slab, counts, dist):
-    """ONE all_gather of equal-size slabs (RCCL has no gatherv: every rank pads to the largest share); returns the list of
-    per-rank tensors cut back to their true length.  `slab` lives where the collective runs (GPU for RCCL, CPU for gloo)."""
-    import torch
-    world = dist.get_world_size()
-    longest = max(counts)
-    padded = slab if slab.shape[0] == longest else torch.cat([slab, torch.zeros((longest - slab.shape[0],) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)])
-    out = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(out, padded.contiguous())
-    return [out[r][: counts[r]] for r in range(world)]
+def _active(dist):
+    return dist is not None and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def gather_film_tensor(band, height: int, dist=None):
-    """Row bands -> full film, as torch tensors on the device the collective runs on: band [rows_r, width, 3] float32 of
-    this rank -> [height, width, 3] on every rank.  One all_gather, no host bounce (12.4 MB per GPU at 3840x2160)."""
-    import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return band
+def gather_parts_to_root(full, part_of, dist, root: int = 0):
+    """ONE gather to `root`, in place: `full` is a tensor of the whole result on every rank (only the rank's own part
+    `full[part_of(rank)]` holds data); afterwards `full` is complete on the root.  `part_of(r)` -> slice of dim 0.
+    Grouped point-to-point: root receives every peer's part into its place, peers send theirs."""
+    if not _active(dist):
+        return full
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ops = []
+    if rank == root:
+        for r in range(world):
+            if r != root and part_of(r).stop > part_of(r).start:
+                ops.append(dist.P2POp(dist.irecv, full[part_of(r)], r))
+    elif part_of(rank).stop > part_of(rank).start:
+        ops.append(dist.P2POp(dist.isend, full[part_of(rank)], root))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return full if rank == root else None
+
+
+def gather_film_to_root(film, dist=None, root: int = 0):
+    """Row bands -> the frame on the root.  `film`: [height, width, 3] float32 tensor on the device the collective runs on, the
+    rank's band row_band(height, rank, world) rendered into it (parallel.device_film is such a tensor: a view of the library's
+    film).  Returns the complete film on the root (the same tensor, completed in place), None on the other ranks."""
+    if not _active(dist):
+        return film
+    height, world = film.shape[0], dist.get_world_size()
+    return gather_parts_to_root(film, lambda r: slice(*row_band(height, r, world)), dist, root)
+
+
+def gather_hits_to_root(hits_bytes, num_rays: int, dist=None, root: int = 0):
+    """Hit1 ranges -> the whole Hit1 array on the root.  `hits_bytes`: uint8 tensor of 16 x num_rays bytes on every rank, the
+    rank's own ray_range filled in.  Completed in place on the root; None on the other ranks."""
+    if not _active(dist):
+        return hits_bytes
     world = dist.get_world_size()
-    rows = [row_band(height, r, world)[1] - row_band(height, r, world)[0] for r in range(world)]
-    return torch.cat(_gather_slabs(band, rows, dist), dim=0)
+
+    def part(r):
+        a, b = ray_range(num_rays, r, world)
+        return slice(a * 16, b * 16)
+    return gather_parts_to_root(hits_bytes, part, dist, root)
 
 
 def device_film(dev: int):
     """The renderer's DEVICE film (rodent_get_film_data, interface.cpp:565-581) as a torch tensor [height, width, 3] that
-    aliases the library's memory (no copy): what gather_film_tensor hands to RCCL."""
+    aliases the library's memory (no copy): what gather_film_to_root hands to RCCL."""
     import ctypes as C
     import torch
     from . import render
@@ -63,38 +92,41 @@ def device_film(dev: int):
     return torch.as_tensor(_Alias(), device=f"cuda:{dev}")
 
 
-def gather_film(band: np.ndarray, height: int, dist=None, device="cpu"):
-    """Host-array form of gather_film_tensor (the CPU tests run it over gloo): band [rows_r, width, 3] float32 -> the
-    assembled [height, width, 3] array on every rank."""
+def gather_film(band: np.ndarray, height: int, dist=None, device="cpu", root: int = 0):
+    """Host-array form (the CPU tests run it over gloo): this rank's band [rows_r, width, 3] float32 -> the assembled
+    [height, width, 3] array on the root, None elsewhere."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active(dist):
         return band
-    return gather_film_tensor(torch.from_numpy(np.ascontiguousarray(band)).to(device), height, dist).cpu().numpy()
+    y0, y1 = row_band(height, dist.get_rank(), dist.get_world_size())
+    full = torch.zeros((height,) + tuple(band.shape[1:]), dtype=torch.float32, device=device)
+    full[y0:y1] = torch.from_numpy(np.ascontiguousarray(band)).to(device)
+    out = gather_film_to_root(full, dist, root)
+    return None if out is None else out.cpu().numpy()
 
 
-def gather_hits_tensor(hits_bytes, num_rays: int, dist=None):
-    """Hit1 ranges (uint8 tensor, 16 B/ray, this rank's ray_range) -> the whole array in ray order on every rank; one
-    all_gather on the device the tensor lives on."""
-    import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return hits_bytes
-    world = dist.get_world_size()
-    counts = [(ray_range(num_rays, r, world)[1] - ray_range(num_rays, r, world)[0]) * 16 for r in range(world)]
-    return torch.cat(_gather_slabs(hits_bytes[: counts[dist.get_rank()]], counts, dist), dim=0)
-
-
-def gather_hits_device(hits_dev, num_rays: int, dist, dev: int):
-    """bench.py --strong: device Hit1 ranges -> host Hit1 array of all rays (the D2H copy follows the collective, outside
-    the timed region like the reference's, bench_traversal.cpp:337-339)."""
-    from . import formats as F
-    return gather_hits_tensor(hits_dev, num_rays, dist).cpu().numpy().view(F.HIT1).copy()
-
-
-def gather_hits(hits: np.ndarray, num_rays: int, dist=None, device="cpu"):
-    """Host-array form of gather_hits_tensor (CPU tests over gloo)."""
+def gather_hits_device(hits_dev, num_rays: int, dist, dev: int, root: int = 0):
+    """bench.py (strong scaling): the rank's device Hit1 range -> host Hit1 array of all rays on the root (the D2H copy
+    follows the collective, outside the timed region like the reference's, bench_traversal.cpp:337-339)."""
     import torch
     from . import formats as F
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active(dist):
+        return hits_dev.cpu().numpy().view(F.HIT1).copy()
+    a, b = ray_range(num_rays, dist.get_rank(), dist.get_world_size())
+    full = torch.zeros(num_rays * 16, dtype=torch.uint8, device=f"cuda:{dev}")
+    full[a * 16: b * 16] = hits_dev[: (b - a) * 16]
+    out = gather_hits_to_root(full, num_rays, dist, root)
+    return None if out is None else out.cpu().numpy().view(F.HIT1).copy()
+
+
+def gather_hits(hits: np.ndarray, num_rays: int, dist=None, device="cpu", root: int = 0):
+    """Host-array form of gather_hits_to_root (CPU tests over gloo): the root gets the whole array, the others None."""
+    import torch
+    from . import formats as F
+    if not _active(dist):
         return hits
-    raw = torch.from_numpy(np.ascontiguousarray(hits).view(np.uint8).reshape(-1).copy()).to(device)
-    return gather_hits_tensor(raw, num_rays, dist).cpu().numpy().view(F.HIT1).copy()
+    a, b = ray_range(num_rays, dist.get_rank(), dist.get_world_size())
+    full = torch.zeros(num_rays * 16, dtype=torch.uint8, device=device)
+    full[a * 16: b * 16] = torch.from_numpy(np.ascontiguousarray(hits).view(np.uint8).reshape(-1).copy()).to(device)
+    out = gather_hits_to_root(full, num_rays, dist, root)
+    return None if out is None else out.cpu().numpy().view(F.HIT1).copy()

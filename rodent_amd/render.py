@@ -27,7 +27,7 @@ class SceneDesc(C.Structure):
                [(n, vp) for n in ("texcoords", "textures", "texels")] + [("num_textures", i32), ("num_texels", C.c_uint32)]
 
 
-RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_lds_image", "rodent_hip_render_trace_persistent", "get_spp", "render",
+RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_fused_compact", "rodent_hip_render_mapping_in_effect", "rodent_hip_render_defaults", "rodent_hip_render_lds_image", "rodent_hip_render_trace_persistent", "get_spp", "render",
                   "setup_interface", "get_pixels", "clear_pixels", "cleanup_interface", "rodent_get_film_data",
                   "rodent_gpu_get_first_primary_stream", "rodent_gpu_get_second_primary_stream", "rodent_gpu_get_secondary_stream",
                   "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows",
@@ -52,6 +52,9 @@ def lib():
         l.rodent_hip_render_overlap.argtypes = [i32, i32]; l.rodent_hip_render_overlap.restype = None
         l.rodent_hip_render_fused_sort.argtypes = [i32, i32]; l.rodent_hip_render_fused_sort.restype = None
         l.rodent_hip_render_lds_image.argtypes = [i32, i32]; l.rodent_hip_render_lds_image.restype = None
+        l.rodent_hip_render_fused_compact.argtypes = [i32, i32]; l.rodent_hip_render_fused_compact.restype = None
+        l.rodent_hip_render_mapping_in_effect.argtypes = [i32]; l.rodent_hip_render_mapping_in_effect.restype = i32
+        l.rodent_hip_render_defaults.argtypes = [i32]; l.rodent_hip_render_defaults.restype = None
         l.rodent_hip_render_trace_persistent.argtypes = [i32, i32]; l.rodent_hip_render_trace_persistent.restype = None
         l.get_spp.argtypes = []; l.get_spp.restype = i32
         l.render.argtypes = [C.POINTER(Settings), i32]; l.render.restype = None
@@ -83,9 +86,11 @@ def make_settings(cam) -> Settings:
 class Renderer:
     """One scene on one GPU.  render(cam, iter) accumulates `spp` samples per pixel into the film."""
 
-    MAPPINGS = {"streaming": 0, "megakernel": 1}       # mapping_gpu.impala:308-369 / :371-474
+    MAPPINGS = {"auto": -1, "streaming": 0, "megakernel": 1}       # per scene / mapping_gpu.impala:308-369 / :371-474
 
-    def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming", capacity=0, sort=True, overlap=True, fused_sort=False, lds_image=True, trace_persistent=None):
+    def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming", capacity=0, sort=None, overlap=None, fused_sort=None, lds_image=None,
+                 trace_persistent=None, fused_compact=None):
+        """Options left at None take the library's default, or what the option's RODENT_HIP_* environment variable says."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("rodent_amd: no GPU visible (the renderer has no CPU fallback)")
@@ -96,18 +101,29 @@ class Renderer:
         desc = SceneDesc(*[a.ctypes.data_as(vp) for a in keep], len(scene.vertices), scene.num_tris, len(scene.nodes), len(scene.tris),
                          len(scene.materials), len(scene.lights), *[a.ctypes.data_as(vp) for a in tex], len(scene.textures), len(scene.texels))
         l.rodent_hip_set_device(dev)
+        l.rodent_hip_render_defaults(dev)                    # options of an earlier Renderer in this process do not leak into this one
         l.rodent_hip_scene_create(dev, C.byref(desc))
         l.rodent_hip_render_config(dev, spp, max_path_len)
         l.rodent_hip_render_mapping(dev, self.MAPPINGS[mapping])
         l.rodent_hip_render_capacity(dev, capacity)          # rays per stream, 0 = default (8 Mi)
-        l.rodent_hip_render_sort(dev, int(bool(sort)))       # sort hit rays by material before shading (reference behaviour)
-        l.rodent_hip_render_overlap(dev, int(bool(overlap)))  # shadow rays on a second HIP stream
-        l.rodent_hip_render_fused_sort(dev, int(bool(fused_sort)))   # the sort computes a permutation, the shader gathers through it
-        l.rodent_hip_render_lds_image(dev, int(bool(lds_image)))     # stream traversal kernels stage the top of the BVH in LDS (default)
-        if trace_persistent is not None:
-            l.rodent_hip_render_trace_persistent(dev, int(bool(trace_persistent)))    # persistent form of those kernels for streams of >= 512 Ki rays
+        for value, setter in ((sort, l.rodent_hip_render_sort),                    # sort hit rays by material before shading (reference behaviour)
+                              (overlap, l.rodent_hip_render_overlap),              # shadow rays on a second HIP stream
+                              (fused_sort, l.rodent_hip_render_fused_sort),        # the sort computes a permutation, the shader gathers through it
+                              (lds_image, l.rodent_hip_render_lds_image),          # stream traversal kernels stage the top of the BVH in LDS
+                              (trace_persistent, l.rodent_hip_render_trace_persistent),   # persistent form of those kernels for streams of >= 512 Ki rays
+                              (fused_compact, l.rodent_hip_render_fused_compact)):        # the shader writes continuing rays to their compacted slots
+            if value is not None:
+                setter(dev, int(bool(value)))
         l.setup_interface(width, height)
         l.clear_pixels()
+
+    def configure(self, spp, max_path_len):
+        self.spp = spp
+        lib().rodent_hip_render_config(self.dev, spp, max_path_len)
+
+    def mapping_name(self):
+        """The mapping the next frame uses ("streaming" / "megakernel"): the caller's choice, or the library's for this scene."""
+        return {0: "streaming", 1: "megakernel"}[lib().rodent_hip_render_mapping_in_effect(self.dev)]
 
     def clear(self):
         lib().clear_pixels()

@@ -1,10 +1,13 @@
 #!/usr/bin/env python
 """Mean per dispatch of every counter in the rocprofv3 --pmc passes <dir>/<prefix>*/ (scripts/profile_pmc.sh), for the
 kernels whose name contains one of the given substrings (default: the traversal and renderer kernels).  Also writes
-<dir>/<prefix>_counters.json.  usage: python scripts/pmc_digest.py gpurun_out/profiles r02_pmc [k_bvh2 ...]"""
+<dir>/<prefix>_counters.json.  The JSON carries the hash of the kernel sources it was taken on (rodent_amd/provenance.py).
+usage: python scripts/pmc_digest.py gpurun_out/profiles r02_pmc [k_bvh2 ...]"""
 import csv, json, sys
 from collections import defaultdict
 from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from rodent_amd import provenance
 
 out, prefix = Path(sys.argv[1]), sys.argv[2]
 want = sys.argv[3:] or ["k_bvh2", "k_wide", "k_trace", "k_shade", "k_scatter", "k_bin", "k_mega", "k_generate"]
@@ -22,4 +25,5 @@ for d in sorted(p for p in out.glob(prefix + "*") if p.is_dir()):
     for (k, name), v in sorted(agg.items()):
         print(f"   {k[:58]:58s} {name:40s} n={len(v):3d} {sum(v) / len(v):18.1f}")
         result.setdefault(d.name, {}).setdefault(k, {})[name] = sum(v) / len(v)
+result["_meta"] = provenance.stamp("render" if any(w.startswith(("k_trace", "k_shade", "k_scatter", "k_bin", "k_mega", "k_generate")) for w in sys.argv[3:]) else "traversal")   # bench.py quotes the counters only while this hash holds
 json.dump(result, open(out / f"{prefix}_counters.json", "w"), indent=1)

@@ -4,6 +4,8 @@ the per-launch HBM traffic of the dominant traversal kernel (read by bench.py fo
 import csv, json, sys
 from collections import defaultdict
 from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from rodent_amd import provenance
 
 out, tag = Path(sys.argv[1]), sys.argv[2]
 
@@ -51,4 +53,5 @@ for k, t in traffic.items():
         t["hbm_bytes_raw"] = (t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024
         t["hbm_bytes_fetch_x2"] = (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024
         print(f"== traffic per launch [{k}]: raw {(t['hbm_bytes_raw']) / 1e6:.1f} MB, with x2 FETCH correction {t['hbm_bytes_fetch_x2'] / 1e6:.1f} MB")
+traffic["_meta"] = provenance.stamp("traversal")      # bench.py quotes the traffic only while this hash holds
 json.dump(traffic, open(out / f"{tag}_traffic.json", "w"), indent=1)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Frames across the GPUs of one node (SURVEY 8e / BASELINE config 5): one process per GPU, every rank holds the whole
-scene and renders its band of image rows with `rodent_hip_render_rows`, one RCCL all-gather completes the film.
+scene and renders its band of image rows with `rodent_hip_render_rows`, one RCCL gather to rank 0 completes the film
+(the C++ host does the same without Python: `rodent --ngpu N`).
 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
       scripts/render_multi_gpu.py [--scene tests/golden/cornell_box.obj] [--width 3840 --height 2160 --spp 64
@@ -63,10 +64,9 @@ def main():
         if dist is not None:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         rates.append(a.spp * a.width * a.height / float(dt[0]) / 1e6)
-    # the one collective of the path, on the DEVICE film (no host bounce): a view of the library's film memory, this rank's
-    # rows, one RCCL all-gather; the assembled frame comes to the host once, on rank 0
-    band = parallel.device_film(local)[y0:y1]
-    film = parallel.gather_film_tensor(band, a.height, dist)
+    # the one collective of the path, on the DEVICE film (no host bounce): a view of the library's film memory; rank 0 receives
+    # every peer's rows straight into its own film (grouped send / receive), then copies the frame to the host once
+    film = parallel.gather_film_to_root(parallel.device_film(local), dist)
     film = film.cpu().numpy() if rank == 0 else None
     r.close()
     if rank == 0:

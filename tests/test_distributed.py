@@ -35,19 +35,28 @@ rays = F.read_rays(sys.argv[3], 0.0, 1.0)
 a, b = parallel.ray_range(len(rays), rank, world)
 hits, _ = O.traverse(2, sc.nodes, sc.tris, rays[a:b])
 allhits = parallel.gather_hits(hits, len(rays), dist)
-# the tensor forms the GPU path uses (device film / device Hit1 ranges), with uneven shares: 7 rows, 1001 rays
-t = torch.arange(7 * 5 * 3, dtype=torch.float32).reshape(7, 5, 3)
-y0t, y1t = parallel.row_band(7, rank, world)
-assert torch.equal(parallel.gather_film_tensor(t[y0t:y1t].clone(), 7, dist), t)
-hb = torch.arange(1001 * 16, dtype=torch.int64).to(torch.uint8)
-at, bt = parallel.ray_range(1001, rank, world)
-assert torch.equal(parallel.gather_hits_tensor(hb[at * 16: bt * 16].clone(), 1001, dist), hb)
+# the tensor forms the GPU path uses (device film / device Hit1 array, completed in place on the root), with uneven
+# shares: 7 rows, 1001 rays; and a root other than 0
+for root in (0, world - 1):
+    t = torch.arange(7 * 5 * 3, dtype=torch.float32).reshape(7, 5, 3)
+    y0t, y1t = parallel.row_band(7, rank, world)
+    mine = torch.full_like(t, -1.0); mine[y0t:y1t] = t[y0t:y1t]
+    got = parallel.gather_film_to_root(mine, dist, root)
+    assert (got is None) == (rank != root) and (got is None or torch.equal(got, t))
+    hb = torch.arange(1001 * 16, dtype=torch.int64).to(torch.uint8)
+    at, bt = parallel.ray_range(1001, rank, world)
+    mineh = torch.zeros_like(hb); mineh[at * 16: bt * 16] = hb[at * 16: bt * 16]
+    goth = parallel.gather_hits_to_root(mineh, 1001, dist, root)
+    assert (goth is None) == (rank != root) and (goth is None or torch.equal(goth, hb))
 if rank == 0:
     ref, _ = O.render(sc, cam, 2, 2, 8, W, H, threads=1)
     refh, _ = O.traverse(2, sc.nodes, sc.tris, rays)
+    assert full is not None and allhits is not None
     assert np.array_equal(full, ref), "band films do not reproduce the frame"
     assert allhits.tobytes() == refh.tobytes(), "gathered hits differ"
     print("DIST_OK", world)
+else:
+    assert full is None and allhits is None, "only the root receives the gathered film / hits"
 dist.barrier(); dist.destroy_process_group()
 '''
 

@@ -329,7 +329,7 @@ def test_every_bsdf_matches_oracle(R, oracle, materials_scene, mapping, sort, ov
 
 def test_device_film_view_aliases_the_library_film(R, cornell_scene):
     """parallel.device_film: a zero-copy torch view of the DEVICE film (rodent_get_film_data) -- what the multi-GPU path hands
-    to RCCL (gather_film_tensor) instead of bouncing the band through the host."""
+    to RCCL (gather_film_to_root) instead of bouncing the band through the host."""
     import torch
     from rodent_amd import parallel
     W, H = 64, 40
@@ -341,5 +341,5 @@ def test_device_film_view_aliases_the_library_film(R, cornell_scene):
     assert np.array_equal(view.cpu().numpy(), r.film())
     r.render(cam, 1)                                             # the view follows the film: it is the same memory
     assert np.array_equal(view.cpu().numpy(), r.film())
-    assert torch.equal(parallel.gather_film_tensor(view[10:20], H, None), view[10:20])     # single process: no collective
+    assert parallel.gather_film_to_root(view, None) is view                                   # single process: no collective
     r.close()
