@@ -76,9 +76,9 @@ void    rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len)
  * (mapping_gpu.impala:371-474; the reference selects it at configure time with the converter target
  * amdgpu-megakernel / nvvm-megakernel, converter.cpp:30-35,1032-1037; `rodent --target amdgpu-megakernel` here),
  * -1 (default) = chosen per scene when the scene is created: the megakernel for hierarchies of at most
- * RODENT_HIP_AUTO_MEGA_MAX_NODES inner nodes (default 4096: the whole BVH stays in the L1s / L2s and the wavefront
- * formulation's stream traffic is all that is left to save; the Cornell box renders 1.45 x faster that way), the streaming
- * loop for larger scenes (the atrium: 1.25 x faster).  The initial value can also be set with the environment variable
+ * RODENT_HIP_AUTO_MEGA_MAX_NODES inner nodes (default 128: the whole tree sits in the traversal kernels' LDS image and the
+ * wavefront formulation's stream traffic is all that is left to save; the Cornell box renders 1.45 x faster that way), the
+ * streaming loop for larger scenes (1.05 x faster at 306 nodes, 1.4-1.5 x from 5 000 nodes on: profiles/r03_mapping_sweep.txt).  The initial value can also be set with the environment variable
  * RODENT_HIP_MAPPING=auto|streaming|mega.  rodent_hip_render_mapping_in_effect: 0 / 1, what the next frame will use. */
 void    rodent_hip_render_mapping(int32_t dev, int32_t mapping);
 int32_t rodent_hip_render_mapping_in_effect(int32_t dev);
@@ -100,10 +100,14 @@ void    rodent_hip_render_overlap(int32_t dev, int32_t enable);
  * 18-word stream per bounce less, but a gathering shader: measured 3 % slower on the Cornell box, equal on the atrium).
  * Same paths and film.  RODENT_HIP_FUSED_SORT=0|1. */
 void    rodent_hip_render_fused_sort(int32_t dev, int32_t enable);
-/* 1 (default): compaction is part of the shader -- every ray that goes on is written straight to its compacted slot of the
- * other stream (single-pass block scan with decoupled look-back: the same stable order gpu_compact_primary,
- * mapping_gpu.impala:267-300, produces), one read + write of the 15-word stream per bounce less.  0: shade in place, then
- * the separate compaction pass.  Same stream contents either way.  RODENT_HIP_FUSED_COMPACT=0|1. */
+/* Compaction as part of the shader: every ray that goes on is written straight to its compacted slot of the other stream, one
+ * read + write of the 15-word stream per bounce less than shading in place and compacting afterwards.
+ * 2 (default): a block of 256 rays takes its slots from one atomic counter (order of the blocks in the new stream = order
+ * of arrival; inside a block stream order; the reference's own compaction takes one atomic per RAY, mapping_gpu.impala:293).
+ * 1: slots from a single-pass block scan with decoupled look-back -- the stable order of the separate pass, reproducible
+ * from run to run, but every block waits for its 64 predecessors (measured: the shader 290 -> 535 us per 8 Mi rays).
+ * 0: shade in place, then the separate compaction pass (gpu_compact_primary, mapping_gpu.impala:267-300).
+ * Same rays in the stream either way, same film up to the order of the atomic adds.  RODENT_HIP_FUSED_COMPACT=0|1|2. */
 void    rodent_hip_render_fused_compact(int32_t dev, int32_t enable);
 /* 1 (default): the stream traversal kernels run as 2-wave workgroups that stage the first 31 inner nodes of the scene's BVH
  * (breadth first, built at scene creation) in LDS and fetch those with ds_read instead of through the vector-memory pipeline.

@@ -402,9 +402,10 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, SecondaryStream s, const int*
 // 64-entry stack in global memory; one wave, enqueued behind every stream traversal launch; resets the list.
 template <bool SECONDARY>
 __global__ __launch_bounds__(kWave) void k_trace_deep(SceneDev sc, PrimaryStream p, SecondaryStream s, float* film, float inv_spp, int* err, int* deep_count,
-                                                      const int* deep_list, int* deep_stack, int* tickets) {
+                                                      const int* deep_list, int* deep_stack, int* tickets, int* zero_word) {
     __shared__ int stack_lds[kStackCap * kWave];
     if (tickets) tickets[threadIdx.x * kTraceCounterStride] = 0;            // the persistent kernel's 64 ticket counters, ready for its next launch
+    if (zero_word && threadIdx.x == 0) *zero_word = 0;                      // primary pass: the slot counter of the shader that follows (fused compaction)
     const int count = *deep_count;
     DeepStack st{(lds_int*)stack_lds + threadIdx.x, err};
     for (int k = threadIdx.x; k < count; k += kWave) {
@@ -510,6 +511,7 @@ __device__ __forceinline__ ShadeOut shade_vertex(const SceneDev& sc, const PathV
 // waits for a LATER one, so the chain always ends; the values are all that travels (relaxed agent-scope atomics, no fences).
 // Called by the first wave of the block; returns the prefix in every lane.
 constexpr unsigned kScanA = 1u << 30, kScanP = 2u << 30, kScanValue = (1u << 30) - 1u;
+unsigned* const kScanAtomic = reinterpret_cast<unsigned*>(8);          // k_shade's `scan` argument for "slots from one atomic counter" (rodent_hip_render_fused_compact(dev, 2))
 __device__ __forceinline__ unsigned lookback_exclusive(unsigned* status, int block, unsigned total) {
     const int lane = threadIdx.x;                                        // 0..63
     if (lane == 0) __hip_atomic_store(&status[block], (block == 0 ? kScanP : kScanA) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -593,10 +595,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, 
         unsigned before = 0u, total = 0u;
         for (int w = 0; w < kBlock / kWave; w++) { const unsigned c = wave_total[w]; if (w < wave) before += c; total += c; }
         if (wave == 0) {
-            const unsigned excl = lookback_exclusive(scan, blockIdx.x, total);
-            if (lane == 0) {
-                wave_total[kBlock / kWave] = excl;
-                if ((int)blockIdx.x == (n_valid - 1) / kBlock) *alive_total = (int)(excl + total);      // the stream's last block: the new size
+            if (scan == kScanAtomic) {                                     // experiment: one returning atomic per block (order of the blocks = order of arrival)
+                if (lane == 0) wave_total[kBlock / kWave] = total ? (unsigned)atomicAdd(alive_total, (int)total) : 0u;
+            } else {
+                const unsigned excl = lookback_exclusive(scan, blockIdx.x, total);
+                if (lane == 0) {
+                    wave_total[kBlock / kWave] = excl;
+                    if ((int)blockIdx.x == (n_valid - 1) / kBlock) *alive_total = (int)(excl + total);      // the stream's last block: the new size
+                }
             }
         }
         __syncthreads();
@@ -851,7 +857,8 @@ struct RenderDevice {
     int* tickets[2] = {nullptr, nullptr}; int num_cus = 0;
     int lds_image = 1;                         // 1 = the stream traversal kernels stage the scene's top-of-tree image in LDS (2-wave workgroups); 0 = every node from memory
     int fused_sort = 0;                        // 0 = rays are moved by the sort (copy_primary_ray), then shaded in place; 1 = the sort only computes the permutation and the shader gathers through it
-    int fused_compact = 1;                     // 1 = the shader writes every continuing ray to its compacted slot (k_shade + lookback_exclusive); 0 = shade in place, then the separate compaction pass (mapping_gpu.impala:267-300 as it stands)
+    int fused_compact = 2;                     // the shader writes every continuing ray to its compacted slot: 2 = slots from one atomic per block (default), 1 = from a look-back scan
+                                               // (deterministic stream order; measured slower); 0 = shade in place, then the separate compaction pass (mapping_gpu.impala:267-300 as it stands)
     unsigned* scan = nullptr; int scan_cap = 0;    // per-block words of the shader's look-back scan (zero before every launch)
     int* perm = nullptr; int perm_cap = 0;     // sorted position -> stream index
     int mapping = 0;                           // in effect: 0 = streaming wavefront (mapping_gpu.impala:308-369), 1 = megakernel (:371-474)
@@ -876,11 +883,11 @@ std::vector<float> g_host_film; size_t g_host_w = 0, g_host_h = 0;
 
 // every option of the renderer at its default, or at what its environment variable says (rodent_hip_render_defaults)
 void render_defaults(RenderDevice& r) {
-    r.sort = 1; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 1; r.lds_image = 1; r.trace_persistent = 0; r.mapping_request = -1; r.capacity = 0;
+    r.sort = 1; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 2; r.lds_image = 1; r.trace_persistent = 0; r.mapping_request = -1; r.capacity = 0;
     if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_FUSED_SORT")) r.fused_sort = atoi(e) ? 1 : 0;
-    if (const char* e = getenv("RODENT_HIP_FUSED_COMPACT")) r.fused_compact = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("RODENT_HIP_FUSED_COMPACT")) r.fused_compact = std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("RODENT_HIP_LDS_IMAGE")) r.lds_image = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_TRACE_PERSISTENT")) r.trace_persistent = atoi(e) ? 1 : 0;
     if (const char* m = getenv("RODENT_HIP_MAPPING")) {
@@ -906,6 +913,9 @@ RenderDevice& rdev(int dev) {
         HIP_CHECK(hipMemset(r.counters, 0, sizeof(unsigned long long) * kNumCounters));
         HIP_CHECK(hipHostMalloc(&r.host_pinned, sizeof(int) * (8 + kMaxBins)));
         render_defaults(r);
+        // k_scatter ranks inside 1024-ray blocks with one counter row per wave: 16 x num_bins ints of dynamic LDS, 65 600 bytes at the
+        // 1025 bins kMaxBins allows -- more than the 64 KB a launch gets without asking
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * (kBinBlock / kWave) * kMaxBins)));
         r.init = true;
     }
     return r;
@@ -973,7 +983,7 @@ void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStre
                            r.ctl + 3, r.counters, r.deep_list[0], tickets);
     } else if (r.lds_image) hipLaunchKernelGGL((k_trace_primary<kTraceWaves, kSceneTopNodes>), dim3((n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
     else hipLaunchKernelGGL((k_trace_primary<1, 0>), dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
-    hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_stack[0], tickets);
+    hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_stack[0], tickets, r.ctl + 6);
 }
 void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const SecondaryStream& s, const int* size_ptr, int max_n, float inv_spp) {
     ensure_deep(r, 1, max_n);
@@ -984,7 +994,7 @@ void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const Secondary
                            r.ctl + 4, r.counters, r.deep_list[1], tickets);
     } else if (r.lds_image) hipLaunchKernelGGL((k_trace_secondary<kTraceWaves, kSceneTopNodes>), dim3((max_n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
     else hipLaunchKernelGGL((k_trace_secondary<1, 0>), dim3((max_n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
-    hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_stack[1], tickets);
+    hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_stack[1], tickets, (int*)nullptr);
 }
 
 void ensure_hist(RenderDevice& r, size_t ints) {
@@ -1089,11 +1099,11 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     // the shader, either in place (then the compaction pass follows) or compacting into the other stream itself
     const auto shade = [&](const PrimaryStream& from, const PrimaryStream& to, const int* perm, const int* size_ptr, int n_value, int unsorted, int blocks) {
         if (fused) {
-            HIP_CHECK(hipMemsetAsync(r.scan, 0, sizeof(unsigned) * (size_t)blocks, stream));
-            HIP_CHECK(hipMemsetAsync(d_alive, 0, sizeof(int), stream));
+            if (r.fused_compact != 2) HIP_CHECK(hipMemsetAsync(r.scan, 0, sizeof(unsigned) * (size_t)blocks, stream));
+            // (d_alive was zeroed by the primary pass's follow-up kernel, k_trace_deep<false>)
         }
         hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, from, to, perm, sec, size_ptr, n_value, r.film, inv_spp, r.max_path_len, unsorted,
-                           fused ? r.scan : (unsigned*)nullptr, d_alive);
+                           fused ? (r.fused_compact == 2 ? kScanAtomic : r.scan) : (unsigned*)nullptr, d_alive);
     };
     while (id < num_rays || size > 0) {
         if (size < kCapacity && id < num_rays) {                                         // regenerate (mapping_gpu.impala:332-336)
@@ -1188,9 +1198,11 @@ void render_rows_any(RenderDevice& r, const Settings* settings, int iter, int y0
 // traversal steps cost little, the streaming loop's per-bounce stream traffic (sort + shade + regenerate, ~500 bytes per
 // ray and bounce) is the frame, and the megakernel -- which keeps a path in registers -- wins (Cornell box, 22 nodes:
 // 3.2 against 2.2 Gsamples/s); once traversal dominates, the streaming loop's coherent, sorted wavefronts win (atrium,
-// 142 444 nodes: 0.74 against 0.59; profiles/r02_render_rates.txt, r03_mapping_sweep.txt for the sizes in between).
+// 142 444 nodes: 0.74 against 0.59).  Measured in between (profiles/r03_mapping_sweep.txt: the atrium with every 2nd ... 512th
+// face, 76 494 ... 306 nodes): the streaming loop wins all of them, by 5 % at 306 nodes and by 40-50 % from 5 000 nodes on;
+// only hierarchies of a few dozen nodes (the whole tree inside the traversal kernels' LDS image) go to the megakernel.
 int auto_mega_max_nodes() {
-    static const int v = [] { const char* e = getenv("RODENT_HIP_AUTO_MEGA_MAX_NODES"); return e ? atoi(e) : 4096; }();
+    static const int v = [] { const char* e = getenv("RODENT_HIP_AUTO_MEGA_MAX_NODES"); return e ? atoi(e) : 128; }();
     return v;
 }
 int resolve_mapping(const RenderDevice& r) {
@@ -1255,6 +1267,8 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
         for (int k = 0; k < 3; k++) if ((uint32_t)d->indices[4 * t + k] >= (uint32_t)d->num_vertices) invalid("vertex index out of range");
         if ((uint32_t)d->indices[4 * t + 3] >= (uint32_t)d->num_materials) invalid("material index out of range");
         if (d->light_ids[t] < 0 || (d->light_ids[t] > 0 && d->light_ids[t] >= d->num_lights)) invalid("light id out of range");
+        // an emitter's triangles are looked up in the light table by the shader (on_hit: sc.lights[light_ids[prim]]): the entry must exist
+        if (d->materials[d->indices[4 * t + 3]].emissive && d->light_ids[t] >= d->num_lights) invalid("emissive triangle without an entry in the light table");
     }
     for (int32_t k = 0; k < d->num_nodes; k++)
         for (int j = 0; j < 2; j++) {
@@ -1299,7 +1313,7 @@ void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
 void rodent_hip_render_sort(int32_t dev, int32_t enable) { rdev(dev).sort = enable ? 1 : 0; }
 void rodent_hip_render_overlap(int32_t dev, int32_t enable) { rdev(dev).overlap = enable ? 1 : 0; }
 void rodent_hip_render_fused_sort(int32_t dev, int32_t enable) { rdev(dev).fused_sort = enable ? 1 : 0; }
-void rodent_hip_render_fused_compact(int32_t dev, int32_t enable) { rdev(dev).fused_compact = enable ? 1 : 0; }
+void rodent_hip_render_fused_compact(int32_t dev, int32_t enable) { rdev(dev).fused_compact = std::min(2, std::max(0, (int)enable)); }
 void rodent_hip_render_lds_image(int32_t dev, int32_t enable) { rdev(dev).lds_image = enable ? 1 : 0; }
 void rodent_hip_render_trace_persistent(int32_t dev, int32_t enable) { rdev(dev).trace_persistent = enable ? 1 : 0; }
 

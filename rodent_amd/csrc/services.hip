@@ -58,16 +58,23 @@ void select_device(int dev) {
     HIP_CHECK(hipSetDevice(dev));
 }
 
+// The calling thread's current device is left as it was (the reference's copy_to_device does not touch it either).
 DeviceBlock copy_to_device(int dev, const void* host, size_t bytes) {           // interface.cpp:413-430
+    int previous = 0;
+    HIP_CHECK(hipGetDevice(&previous));
     select_device(dev);
     DeviceBlock b; b.bytes = bytes;
     HIP_CHECK(hipMalloc(&b.ptr, bytes ? bytes : 16));
     if (bytes) HIP_CHECK(hipMemcpy(b.ptr, host, bytes, hipMemcpyHostToDevice));
+    HIP_CHECK(hipSetDevice(previous));
     return b;
 }
 
+// The loaders return COPIES of the cache entries, made while the lock is held: a concurrent cleanup_interface() may erase the
+// map node, the pointers in the copy stay what the caller was promised ("valid until cleanup_interface()").  The cache is
+// keyed by (device, file name) like the reference's (interface.cpp:432-468): a file rewritten between two calls is NOT reloaded.
 template <typename Node, typename Tri>
-const DeviceBvh& load_bvh(int dev, const char* file) {                         // interface.cpp:395-423,432-454
+DeviceBvh load_bvh(int dev, const char* file) {                                // interface.cpp:395-423,432-454
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     const auto key = std::make_tuple(dev, (int)sizeof(Node), std::string(file));
     auto it = g_cache.bvhs.find(key);
@@ -83,7 +90,7 @@ const DeviceBvh& load_bvh(int dev, const char* file) {                         /
     return g_cache.bvhs[key] = b;
 }
 
-const DeviceImage& load_image(int dev, const char* file, bool png) {           // interface.cpp:470-492
+DeviceImage load_image(int dev, const char* file, bool png) {                  // interface.cpp:470-492
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     const auto key = std::make_pair(dev, std::string(file));
     auto it = g_cache.images.find(key);
@@ -103,9 +110,12 @@ const DeviceImage& load_image(int dev, const char* file, bool png) {           /
 // called by cleanup_interface() (render.hip): the reference frees these with its Interface singleton (interface.cpp:516-518)
 void rodent_services_cleanup() {
     std::lock_guard<std::mutex> lock(g_cache_mutex);
-    for (auto& kv : g_cache.buffers) { hipSetDevice(kv.first.first); hipFree(kv.second.ptr); }
-    for (auto& kv : g_cache.bvhs) { hipSetDevice(std::get<0>(kv.first)); hipFree(kv.second.nodes.ptr); hipFree(kv.second.tris.ptr); }
-    for (auto& kv : g_cache.images) { hipSetDevice(kv.first.first); hipFree(kv.second.pixels.ptr); }
+    int previous = 0;
+    const bool have_device = hipGetDevice(&previous) == hipSuccess;
+    for (auto& kv : g_cache.buffers) { (void)hipSetDevice(kv.first.first); (void)hipFree(kv.second.ptr); }
+    for (auto& kv : g_cache.bvhs) { (void)hipSetDevice(std::get<0>(kv.first)); (void)hipFree(kv.second.nodes.ptr); (void)hipFree(kv.second.tris.ptr); }
+    for (auto& kv : g_cache.images) { (void)hipSetDevice(kv.first.first); (void)hipFree(kv.second.pixels.ptr); }
+    if (have_device) (void)hipSetDevice(previous);
     g_cache = Cache();
 }
 
@@ -132,15 +142,15 @@ int64_t rodent_hip_buffer_size(int32_t dev, const char* file) {
 }
 
 void rodent_load_bvh2_tri1(int32_t dev, const char* file, Node2** nodes, Tri1** tris) {     // interface.cpp:601-605
-    const DeviceBvh& b = load_bvh<Node2, Tri1>(dev, file);
+    const DeviceBvh b = load_bvh<Node2, Tri1>(dev, file);
     *nodes = (Node2*)b.nodes.ptr; *tris = (Tri1*)b.tris.ptr;
 }
 void rodent_load_bvh4_tri4(int32_t dev, const char* file, Node4** nodes, Tri4** tris) {     // interface.cpp:607-611
-    const DeviceBvh& b = load_bvh<Node4, Tri4>(dev, file);
+    const DeviceBvh b = load_bvh<Node4, Tri4>(dev, file);
     *nodes = (Node4*)b.nodes.ptr; *tris = (Tri4*)b.tris.ptr;
 }
 void rodent_load_bvh8_tri4(int32_t dev, const char* file, Node8** nodes, Tri4** tris) {     // interface.cpp:613-617
-    const DeviceBvh& b = load_bvh<Node8, Tri4>(dev, file);
+    const DeviceBvh b = load_bvh<Node8, Tri4>(dev, file);
     *nodes = (Node8*)b.nodes.ptr; *tris = (Tri4*)b.tris.ptr;
 }
 void rodent_hip_bvh_counts(int32_t dev, const char* file, int32_t bvh_width, int32_t* num_nodes, int32_t* num_tris) {
@@ -154,11 +164,11 @@ void rodent_hip_bvh_counts(int32_t dev, const char* file, int32_t bvh_width, int
 }
 
 void rodent_load_png(int32_t dev, const char* file, uint8_t** pixels, int32_t* width, int32_t* height) {   // interface.cpp:584-589
-    const DeviceImage& img = load_image(dev, file, true);
+    const DeviceImage img = load_image(dev, file, true);
     *pixels = (uint8_t*)img.pixels.ptr; *width = img.width; *height = img.height;
 }
 void rodent_load_jpg(int32_t dev, const char* file, uint8_t** pixels, int32_t* width, int32_t* height) {   // interface.cpp:591-595
-    const DeviceImage& img = load_image(dev, file, false);
+    const DeviceImage img = load_image(dev, file, false);
     *pixels = (uint8_t*)img.pixels.ptr; *width = img.width; *height = img.height;
 }
 

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kHistoryThreads) void k_bvh2_top_finish_history(con
             const int chunk = order[stripe * stride + t];
             previous_top[((chunk / 32) / kStripes) * 32 + chunk % 32] = 1;
         }
-    for (int i = threadIdx.x; i < padded; i += kHistoryThreads)
+    for (int i = threadIdx.x; i < max(padded, 4); i += kHistoryThreads)           // (at least one whole quad: the rank count below reads the keys four at a time)
         keys[i] = i < count ? (min(cost[chunk_of(i)], 0x3FFFF) << 13) | (8191 - i) : -1;
     __syncthreads();
     if (count <= kHistoryThreads) {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kHistoryThreads) void k_bvh2_top_finish_history(con
         int rank = 0;
         const int4* quads = reinterpret_cast<const int4*>(keys);            // (padded to a power of two with -1 keys: never larger than a real key)
 #pragma unroll 8
-        for (int j = 0; j < padded / 4; j++) { const int4 q = quads[j]; rank += (q.x > mine_key) + (q.y > mine_key) + (q.z > mine_key) + (q.w > mine_key); }
+        for (int j = 0; j < (padded + 3) / 4; j++) { const int4 q = quads[j]; rank += (q.x > mine_key) + (q.y > mine_key) + (q.z > mine_key) + (q.w > mine_key); }
         __syncthreads();
         if (threadIdx.x < count) keys[rank] = mine_key;
         __syncthreads();

@@ -184,6 +184,8 @@ bool validate_scene(const SceneData& s, std::string* why) {
         for (int k = 0; k < 3; k++) if ((uint32_t)s.indices[4 * t + k] >= nv) return bad("vertex index out of range");
         if ((uint32_t)s.indices[4 * t + 3] >= s.materials.size()) return bad("material index out of range");
         if (s.light_ids[t] < 0 || (s.light_ids[t] > 0 && (size_t)s.light_ids[t] >= s.lights.size())) return bad("light id out of range");
+        // the shader looks an emitter's triangle up in the light table (light id 0 included): the entry must exist
+        if (s.materials[s.indices[4 * t + 3]].emissive && (size_t)s.light_ids[t] >= s.lights.size()) return bad("emissive triangle without an entry in the light table");
     }
     for (const Node2& n : s.nodes)
         for (int k = 0; k < 2; k++) {

@@ -113,7 +113,7 @@ class Renderer:
                               (trace_persistent, l.rodent_hip_render_trace_persistent),   # persistent form of those kernels for streams of >= 512 Ki rays
                               (fused_compact, l.rodent_hip_render_fused_compact)):        # the shader writes continuing rays to their compacted slots
             if value is not None:
-                setter(dev, int(bool(value)))
+                setter(dev, int(value))
         l.setup_interface(width, height)
         l.clear_pixels()
 

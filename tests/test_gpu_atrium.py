@@ -117,6 +117,29 @@ def test_atrium_fused_sort_matches_oracle(R, atrium_scene, atrium_reference):
     assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
 
 
+@pytest.mark.parametrize("mode,sort,fused_sort,capacity", [(0, True, False, 0), (1, True, False, 0), (2, True, False, 60_000), (1, False, False, 45_000), (2, False, False, 0),
+                                                           (1, True, True, 0), (2, True, True, 50_000)])
+def test_atrium_compaction_modes_match_oracle(R, atrium_scene, atrium_reference, mode, sort, fused_sort, capacity):
+    """rodent_hip_render_fused_compact: 0 = shade in place, then gpu_compact_primary (mapping_gpu.impala:267-300) as a pass of its
+    own; 1 = the shader writes every continuing ray to its compacted slot, slots from a look-back block scan (the separate
+    pass's stable order); 2 (default) = slots from one atomic per 256-ray block.  With and without the sort by material, with
+    the gathering shader, with regeneration into a small stream: same ray counts, same film."""
+    f = ATRIUM_FRAME
+    film_o, counts = atrium_reference
+    r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], sort=sort, fused_sort=fused_sort, fused_compact=mode, capacity=capacity)
+    r.render(atrium_camera(f["W"], f["H"]), f["IT"])
+    c = r.counters(); film_g = r.film(); r.close()
+    assert (c["primary_rays"], c["shadow_rays"], c["generated"]) == (counts[0], counts[1], f["W"] * f["H"] * f["SPP"])     # exact
+    assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
+
+
+def test_atrium_takes_the_streaming_mapping_by_default(R, atrium_scene):
+    f = ATRIUM_FRAME
+    r = R.Renderer(atrium_scene, f["W"], f["H"], 1, 2, mapping="auto")
+    name = r.mapping_name(); r.close()
+    assert name == "streaming"
+
+
 def test_atrium_without_the_lds_image_matches_oracle(R, atrium_scene, atrium_reference):
     """rodent_hip_render_lds_image(0): one-wave traversal workgroups that fetch every node from memory (the default stages the
     top 31 nodes of the BVH in LDS; every other test here runs on that); same paths, same film."""

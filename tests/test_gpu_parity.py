@@ -357,8 +357,23 @@ def test_bench_py_contract(native_build):
         assert k in d, k
     assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["peak"] == 8000.0
-    assert 0 < rf["binding"]["node_fetch"]["frac"] < 1.2 and 0 < rf["random"]["binding"]["node_fetch"]["frac"] < 1.2
+    # the top-level roofline is the bound that binds (VALU issue or node fetches through the vector-memory pipeline): a fraction of a
+    # peak measured on the chip, never above 1; SURVEY 8(d)'s algorithmic-HBM figure rides along, flagged
+    assert rf["bound"] in ("valu_issue", "vmem_node_fetch") and 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3
+    assert rf["hbm_algorithmic"]["bound"] == "hbm" and rf["hbm_algorithmic"]["peak_GBps"] == 8000.0 and rf["hbm_algorithmic"]["bytes_per_ray"] > 48
+    assert 0 < rf["binding"]["vmem_node_fetch"]["frac"] < 1.0 and 0 < rf["random"]["binding"]["vmem_node_fetch"]["frac"] < 1.2
+    # counter-derived figures are quoted only from a profile of THESE kernel sources (rodent_amd/provenance.py)
+    from rodent_amd import provenance
+    import glob
+    pmc = sorted(glob.glob(str(ROOT / "profiles" / "r*_pmc_counters.json")))
+    current = bool(pmc) and provenance.is_current(json.load(open(pmc[-1])).get("_meta"), "traversal")
+    assert ("valu_issue" in rf["binding"]) == current and ("counters_not_quoted" in rf["binding"]) == (not current)
+    rd = d["extra"]["render"]
+    for cfg, (w, h, spp) in (("cfg4_cornell_1920x1080_64spp_len4", (1920, 1080, 64)), ("cfg5_atrium_3840x2160_256spp_len8", (3840, 2160, 256))):
+        e = rd[cfg]
+        assert (e["width"], e["height"], e["spp"]) == (w, h, spp) and e["auto"]["Msamples_s"] > 100 and e["auto"]["rays"]["generated"] == w * h * spp
+        assert e["auto_mapping"] in ("streaming", "megakernel") and all(m in e for m in ("streaming", "megakernel"))
+    assert rd["cpu_baseline"]["cfg4_cornell_1920x1080_64spp_len4"]["Msamples_s"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["passes"] >= 10 and "sample" in cb
     assert d["value"] > 1000 and d["extra"]["all_rays_bit_exact_vs_oracle"] == {"primary": True, "random": True}
@@ -397,7 +412,8 @@ def test_schedule_history_only_reorders_the_chunks(gpu, oracle, cornell, cornell
     st = torch.cuda.Stream()
     gpu.lib().rodent_hip_schedule_history(1)
     try:
-        for k, n in enumerate((100_000, 100_000, 100_000, 70_001, 70_001, 100_000, 4096 * 64 + 7, 4096 * 64 + 7)):
+        # (100 rays and 34 x 64 rays: stripes of exactly two chunks -- the follow-up kernel's rank count reads its keys four at a time)
+        for k, n in enumerate((100_000, 100_000, 100_000, 70_001, 70_001, 100_000, 4096 * 64 + 7, 4096 * 64 + 7, 100, 100, 100, 34 * 64, 34 * 64, 34 * 64)):
             rays = np.tile(base, (n + len(base) - 1) // len(base))[:n].copy()
             rays["org"][:, 0] += (np.arange(n, dtype=np.float32) % 977) * 1e-4
             if k == 2:

@@ -46,6 +46,25 @@ def test_film_matches_oracle(R, oracle, cornell_scene, spp, max_len, iters):
     assert film_g.mean() > 0.02
 
 
+def test_a_thousand_materials_and_the_per_scene_mapping(R, oracle, cornell_scene):
+    """The sort by material with the most bins the reference allows (1024 geometries + the miss bin, mapping_gpu.impala:200,342):
+    k_scatter's in-block ranking then asks for 65 600 bytes of dynamic LDS.  And the library's own choice of mapping
+    (rodent_hip_render_mapping(dev, -1)): the megakernel for a hierarchy of a few dozen nodes."""
+    import copy
+    sc = copy.copy(cornell_scene)
+    sc.materials = np.ascontiguousarray(np.tile(cornell_scene.materials, 1024 // len(cornell_scene.materials) + 1)[:1024])
+    W, H = 150, 90
+    cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
+    film_o, counts = oracle.render(cornell_scene, cam, 0, 3, 5, W, H)
+    for mapping in ("streaming", "auto"):
+        r = R.Renderer(sc, W, H, 3, 5, mapping=mapping)
+        assert r.mapping_name() == ("streaming" if mapping == "streaming" else "megakernel")
+        r.render(cam, 0)
+        c = r.counters(); film_g = r.film(); r.close()
+        assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1])
+        assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
+
+
 @pytest.mark.parametrize("scene_name", ["cornell", "textured"])
 def test_unsorted_shading_traces_the_same_paths(R, oracle, cornell_scene, textured_scene, scene_name):
     """rodent_hip_render_sort(0): no sort by material, the shader ends the rays that missed -- same paths as the oracle."""

@@ -132,6 +132,10 @@ def test_corrupt_scene_files_are_rejected(native_build, cornell_scene, tmp_path)
         "child out of range": good[:nodes_at + 48] + struct.pack("<i", nn + 5) + good[nodes_at + 52:],
         "vertex index out of range": good[:48 + 32 * nv + 16 * nt] + struct.pack("<i", nv + 1) + good[48 + 32 * nv + 16 * nt + 4:],
     }
+    # an emissive material but an empty light table (every light id 0): the shader would read lights[0]
+    nbt, nm, nl = struct.unpack_from("<3I", good, 28)
+    lights_at = nodes_at + 64 * nn + 48 * nbt + 64 * nm
+    cases["emitter without a light table"] = good[:36] + struct.pack("<I", 0) + good[40:lights_at] + bytes(4 * nt) + good[lights_at + 80 * nl + 4 * nt:]
     tool = native_build.BIN_DIR / "rodent"
     for label, data in cases.items():
         (tmp_path / "bad.rscene").write_bytes(data)
