@@ -43,7 +43,7 @@ ORACLE_FLAGS = ["-O2", "-std=c11", "-Wall", "-fPIC", "-ffp-contract=off", "-fno-
 HIP_SOURCES = ["traversal.hip", "render.hip", "services.hip"]
 HIP_LIB_HOST_SOURCES = ["image.cpp"]             # host code the library links: texture decoders of rodent_load_png / _jpg
 HOST_LIB_SOURCES = ["mesh.cpp", "bvh_build.cpp", "atrium.cpp", "scene.cpp", "image.cpp"]
-HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png", "converter", "tex_dump", "buffer_tool"]
+HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png", "converter", "tex_dump", "buffer_tool", "partition_check"]
 HIP_TOOLS = {"bench_traversal": [], "rodent": ["mesh.o", "bvh_build.o", "scene.o", "image.o"]}   # tool -> host objects it links
 
 
@@ -112,7 +112,7 @@ def build_hip_tools(force: bool = False) -> list[Path]:
             # plain g++: host code only uses the HIP runtime API (hipcc mistakes .o inputs for sources)
             _run([CXX, "-O2", "-std=c++17", "-Wall", "-Wno-unused-result", "-D__HIP_PLATFORM_AMD__",
                   f"-I{ROOT / 'include'}", f"-I{ROCM / 'include'}", src, *objs,
-                  f"-L{LIB_DIR}", "-lrodent_hip", f"-L{ROCM / 'lib'}", "-lamdhip64",
+                  f"-L{LIB_DIR}", "-lrodent_hip", f"-L{ROCM / 'lib'}", "-lamdhip64", "-lrccl",
                   "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{ROCM / 'lib'}", "-pthread", "-lz", "-o", out])
         outs.append(out)
     return outs

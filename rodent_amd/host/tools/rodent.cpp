@@ -8,6 +8,10 @@
 //   --spp n             samples per pixel per frame        (default: the scene file's, 4)
 //   --max-path-len n    maximum path length                (default: the scene file's, 64)
 //   -dev n              HIP device                          (default 0)
+//   --ngpu K            K GPUs of this node (devices -dev .. -dev + K - 1; BASELINE config 5): every GPU holds the scene and renders
+//                       the row band split_range(height, r, K) of every frame (rodent_hip_render_rows; one host thread per
+//                       device), a frame takes as long as the slowest band; after the last frame ONE RCCL gather (grouped
+//                       ncclSend / ncclRecv, host/multi_gpu.h) brings the bands to the first device's film
 //   --target t          amdgpu-streaming (default) or amdgpu-megakernel (converter.cpp:30-35,1032-1037)
 //   --no-sort           streaming target: shade in stream order instead of sorting hit rays by material first
 // Without --bench the reference opens an SDL window and renders until it is closed; this build is
@@ -19,6 +23,7 @@
 #include <iostream>
 #include <vector>
 
+#include "../multi_gpu.h"
 #include "../png_write.h"
 #include "../scene.h"
 
@@ -32,6 +37,7 @@ static void usage() {
               << "   --spp    n          Samples per pixel per frame\n"
               << "   --max-path-len n    Maximum path length\n"
               << "   -dev     n          GPU device index\n"
+              << "   --ngpu   K          Renders on K GPUs (row bands, one film gather to the first device)\n"
               << "   --target t          amdgpu-streaming (default) or amdgpu-megakernel\n"
               << "   --no-sort           Do not sort rays by material before shading (streaming target)\n"
               << "   --width  pixels     Sets the viewport horizontal dimension (in pixels)\n"
@@ -51,7 +57,7 @@ int main(int argc, char** argv) {
     size_t bench_iter = 0, width = 1080, height = 720;
     float fov = 60.0f;
     V3 eye(0.0f), dir(0.0f, 0.0f, 1.0f), up(0.0f, 1.0f, 0.0f);
-    int spp = 0, max_path_len = -1, dev = 0, mapping = -1;
+    int spp = 0, max_path_len = -1, dev = 0, mapping = -1, ngpu = 1;
     bool no_sort = false;
 
     for (int i = 1; i < argc; ++i) {
@@ -69,6 +75,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--spp")) { need(1); spp = strtol(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "--max-path-len")) { need(1); max_path_len = strtol(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "-dev")) { need(1); dev = strtol(argv[++i], nullptr, 10); }
+        else if (!strcmp(argv[i], "--ngpu")) { need(1); ngpu = strtol(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "--no-sort")) no_sort = true;
         else if (!strcmp(argv[i], "--target")) {
             need(1); ++i;
@@ -95,22 +102,53 @@ int main(int argc, char** argv) {
     const float w = std::tan(fov * 3.14159265359f / 360.0f), h = w / ((float)width / (float)height);
     const Settings settings{{eye.x, eye.y, eye.z}, {d.x, d.y, d.z}, {u.x, u.y, u.z}, {r.x, r.y, r.z}, w, h};
 
-    rodent_hip_set_device(dev);
+    if (ngpu < 1) fail("Invalid GPU count");
+    DeviceGroup group;
+    {
+        std::string err;
+        if (!group.init(dev, ngpu, &err)) fail("No such GPU device(s): " + err);
+    }
     const RodentSceneDesc desc = scene.desc();
-    rodent_hip_scene_create(dev, &desc);
-    rodent_hip_render_config(dev, spp, max_path_len);
-    if (mapping >= 0) rodent_hip_render_mapping(dev, mapping);
-    if (no_sort) rodent_hip_render_sort(dev, 0);
     setup_interface(width, height);
+    for (int r = ngpu - 1; r >= 0; r--) {                                // (the first device last: it stays the current one of render() / get_spp())
+        const int d = group.device(r);
+        rodent_hip_set_device(d);
+        rodent_hip_scene_create(d, &desc);
+        rodent_hip_render_config(d, spp, max_path_len);
+        if (mapping >= 0) rodent_hip_render_mapping(d, mapping);
+        if (no_sort) rodent_hip_render_sort(d, 0);
+    }
     clear_pixels();
 
     std::vector<double> samples_sec;
     uint32_t iter = 0;
     while (samples_sec.size() < bench_iter) {
         const auto ticks = std::chrono::high_resolution_clock::now();
-        render(&settings, iter++);
+        if (ngpu == 1) render(&settings, iter++);
+        else {
+            // every GPU its band of this frame, all at once; the call returns when the band is in the device's film
+            group.run([&](int r) { const Part band = split_range((int)height, r, ngpu); rodent_hip_render_rows(group.device(r), &settings, (int32_t)iter, band.begin, band.end, nullptr); });
+            iter++;
+        }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - ticks).count();
         samples_sec.emplace_back(1000.0 * double(get_spp() * width * height) / ms);
+    }
+    double gather_s = 0.0;
+    if (ngpu > 1) {
+        // the one collective: every peer's rows straight into the first device's film, then that film to the host
+        std::vector<const void*> src(ngpu); std::vector<void*> dst(ngpu); std::vector<size_t> bytes(ngpu);
+        float* root_film = nullptr; int32_t fw = 0, fh = 0;
+        rodent_get_film_data(group.device(0), &root_film, &fw, &fh);
+        for (int r = 0; r < ngpu; r++) {
+            const Part band = split_range((int)height, r, ngpu);
+            float* film = nullptr;
+            rodent_get_film_data(group.device(r), &film, &fw, &fh);
+            src[r] = film + (size_t)band.begin * width * 3; dst[r] = root_film + (size_t)band.begin * width * 3; bytes[r] = (size_t)band.size() * width * 3 * sizeof(float);
+        }
+        std::string err;
+        gather_s = group.gather_to_root(src, dst, bytes, &err);
+        if (gather_s < 0) fail(err);
+        rodent_present(group.device(0));
     }
 
     if (!out_file.empty()) {                                             // driver.cpp:138-162
@@ -125,10 +163,13 @@ int main(int argc, char** argv) {
         std::cout << "Image saved to '" << out_file << "'" << std::endl;
     }
     cleanup_interface();
-    rodent_hip_scene_destroy(dev);
+    for (int r = 0; r < ngpu; r++) rodent_hip_scene_destroy(group.device(r));
 
     std::sort(samples_sec.begin(), samples_sec.end());
     std::cout << "# " << samples_sec.front() * 1e-6 << "/" << samples_sec[samples_sec.size() / 2] * 1e-6 << "/" << samples_sec.back() * 1e-6
               << " (min/med/max Msamples/s)" << std::endl;
+    if (ngpu > 1)
+        std::cout << "# GPUs: " << ngpu << " (devices " << dev << ".." << dev + ngpu - 1 << "), bands of " << split_range((int)height, 0, ngpu).size() << " row(s); film gather to device " << dev << ": "
+                  << double(height - split_range((int)height, 0, ngpu).size()) * width * 12 / 1e6 << " MB in " << gather_s * 1e3 << " ms (RCCL)" << std::endl;
     return 0;
 }

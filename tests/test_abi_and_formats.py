@@ -151,8 +151,11 @@ def test_cli_errors(native_build, cornell):
     assert r.returncode == 1 and "Unknown option" in r.stderr
     r = subprocess.run([bt, "-bvh", "x", "-ray", "y", "-gpu", "cuda"], capture_output=True, text=True)
     assert r.returncode == 1 and "Unknown GPU platform" in r.stderr
-    r = subprocess.run([bt, "-bvh", "x", "-ray", "y", "-s", "-gpu", "hip"], capture_output=True, text=True)
-    assert r.returncode == 1 and "incompatible" in r.stderr
+    for flag in ("-s", "--single", "-p", "--packet"):                          # the reference's CPU variants are not options of this tool: it says where they live
+        r = subprocess.run([bt, "-bvh", "x", "-ray", "y", flag, "-gpu", "hip"], capture_output=True, text=True)
+        assert r.returncode == 1 and "CPU traversal variants" in r.stderr and "oracle/cpu_bench_traversal.py" in r.stderr
+    r = subprocess.run([bt, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--single" not in r.stdout and "-ngpu" in r.stdout
     r = subprocess.run([bt, "-bvh", str(cornell.bvh_path), "-ray", "y"], capture_output=True, text=True)
     assert r.returncode == 1 and "disabled at compile-time" in r.stderr       # no CPU path in the product
 

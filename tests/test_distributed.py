@@ -70,6 +70,15 @@ def test_partitions_cover_exactly():
     assert parallel.row_band(2160, 3, 8) == (810, 1080)                       # cfg5: 270 rows per GPU
 
 
+def test_cpp_hosts_partition_like_the_python_hosts(native_build):
+    """host/partition.h (what `rodent --ngpu K` / `bench_traversal -ngpu K` shard by) against parallel.row_band / ray_range."""
+    tool = native_build.BIN_DIR / "partition_check"
+    for n, w in ((2160, 8), (720, 7), (5, 8), (1 << 20, 3), (1001, 2), (0, 4), (64, 1)):
+        out = subprocess.run([str(tool), str(n), str(w)], check=True, capture_output=True, text=True).stdout.split()
+        got = [(int(out[3 * r + 1]), int(out[3 * r + 2])) for r in range(w)]
+        assert got == [parallel.row_band(n, r, w) for r in range(w)] == [parallel.ray_range(n, r, w) for r in range(w)], (n, w)
+
+
 @pytest.mark.parametrize("world", [2])
 def test_two_rank_gloo_bands_and_hits(native_build, tmp_path, world):
     from rodent_amd import scene as S

@@ -342,6 +342,16 @@ def test_bench_traversal_cli(gpu, native_build, oracle, cornell, tmp_path):
         assert np.array_equal(F.read_fbuf(out), exp["t"])
     r = subprocess.run(cmd + ["-gpu", "amdgpu", "-any"], capture_output=True, text=True, check=True)
     assert "4096 intersection(s)" in r.stdout
+    # -ngpu K: contiguous ray ranges, one Hit1 gather to the first device; K = 1 and every GPU the box has give the same file
+    have = gpu.lib().rodent_hip_device_count()
+    for k in sorted({1, min(have, 2), have}):
+        r = subprocess.run(cmd + ["-gpu", "hip", "-ngpu", str(k), "--hits", tmp_path / "h.bin"], capture_output=True, text=True, check=True)
+        assert "4096 intersection(s)" in r.stdout and (k == 1 or f"# GPUs: {k}" in r.stdout)
+        assert np.array_equal(F.read_fbuf(out), cornell.expected["bvh2_gpu.primary_tmin.closest"]["t"])
+        hits = np.fromfile(tmp_path / "h.bin", F.HIT1)
+        assert np.array_equal(hits["t"], cornell.expected["bvh2_gpu.primary_tmin.closest"]["t"]) and (hits["tri_id"] >= 0).all()
+    r = subprocess.run(cmd + ["-gpu", "hip", "-ngpu", str(have + 1)], capture_output=True, text=True)
+    assert r.returncode != 0 and "No such GPU device(s)" in r.stderr
 
 
 def test_bench_py_contract(native_build):

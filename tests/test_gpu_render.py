@@ -141,6 +141,26 @@ def test_rodent_cli(native_build, tmp_path):
     assert (im[:80, 100:220, :3].min(axis=2) > 250).sum() > 50                     # the ceiling light (top centre) is saturated
 
 
+def test_rodent_cli_ngpu(native_build, tmp_path):
+    """`rodent --ngpu K` (BASELINE config 5's partition in the C++ host): K = 1 is the single-GPU renderer; with as many GPUs
+    as the box has, row bands + one RCCL gather reproduce the single-GPU image; more GPUs than the box has is an error, not a crash."""
+    import torch
+    have = torch.cuda.device_count()           # (torch first: it brings its own HIP runtime, and that one has to initialise before the library's)
+    imgs = {}
+    for k in sorted({1, min(have, 2), have}):
+        out = tmp_path / f"n{k}.png"
+        cmd = [str(native_build.BIN_DIR / "rodent"), "--scene", str(GOLDEN / "cornell_box.obj"), "--eye", "0", "1", "2.7", "--dir", "0", "0", "-1", "--up", "0", "1", "0",
+               "--width", "200", "--height", "123", "--spp", "4", "--bench", "3", "--target", "amdgpu-streaming", "--ngpu", str(k), "-o", str(out)]
+        res = subprocess.run(cmd, capture_output=True, text=True, check=True)
+        assert "(min/med/max Msamples/s)" in res.stdout and (k == 1 or f"# GPUs: {k}" in res.stdout)
+        imgs[k] = np.asarray(Image.open(out).convert("RGB"), dtype=np.int32)
+        assert imgs[k].mean() > 40
+    for k, im in imgs.items():
+        assert np.abs(im - imgs[1]).max() <= 1, k
+    bad = subprocess.run(cmd[:-4] + ["--ngpu", str(have + 1), "-o", str(out)], capture_output=True, text=True)
+    assert bad.returncode != 0 and "No such GPU device(s)" in bad.stderr
+
+
 def test_stage_level_api_reproduces_render(R, oracle, cornell_scene):
     """Drive the wavefront loop from the host through the stage entry points exactly like the reference's
     gpu_streaming_trace (mapping_gpu.impala:308-369) and check stream invariants after every stage:
