@@ -875,7 +875,8 @@ template <bool ANY, int LDS_N, int CAPS, int LAST_RAYS = kWave> void L_phased(LA
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.qcount);
 }
 
-#include "traversal_wide.h"          // BVH4 / BVH8 + Tri4: k_wide_single, k_wide_finish, L_wide_single
+#include "traversal_wide.h"          // BVH4 / BVH8 + Tri4: k_wide_single, k_wide_top_persist, k_wide_finish, L_wide_single, L_wide_top
+int wide_top_min_rays() { return g_top_min_rays; }
 #ifdef RODENT_HIP_LAB
 #include "traversal_variants.h"      // lab build only: the kernels that were measured and lost, instrumented builds
 #endif
@@ -1003,13 +1004,16 @@ struct VariantW { const char* name; const char* kernel[2]; LaunchW launch[2]; };
 #define KW(name, kname, fn, ...) {name, {kname "<false," #__VA_ARGS__ ">", kname "<true," #__VA_ARGS__ ">"}, {&fn<false, __VA_ARGS__>, &fn<true, __VA_ARGS__>}}
 const VariantW kVariants4[] = {
     //                                                   N LDS_N XCD_GROUP
-    KW("single",             "k_wide_single",        L_wide_single, 4, 16, 32),
+    //                                                N LDS_N
+    KW("top",                "k_wide_top_persist",   L_wide_top, 4, 16),               // default: persistent 16-wave workgroups, the top 85 nodes staged in LDS by every workgroup (launches under rodent_hip_top_min_rays: k_wide_single)
+    KW("single",             "k_wide_single",        L_wide_single, 4, 16, 32),        // one 64-ray chunk per workgroup, every node from memory (default of round 2)
     KW("single-noxcd",       "k_wide_single",        L_wide_single, 4, 16, 0),
 #ifdef RODENT_HIP_LAB
     KW("lane",               "k_wide_lane",          L_wide_lane, 4, 16),              // literal reference mapping
 #endif
 };
 const VariantW kVariants8[] = {
+    KW("top",                "k_wide_top_persist",   L_wide_top, 8, 24),               // default: ... the top 73 nodes
     KW("single",             "k_wide_single",        L_wide_single, 8, 24, 32),
     KW("single-noxcd",       "k_wide_single",        L_wide_single, 8, 24, 0),
 #ifdef RODENT_HIP_LAB

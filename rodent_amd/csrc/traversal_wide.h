@@ -48,16 +48,20 @@ __device__ __forceinline__ bool tri_pre(const RayX& r, float v0x, float v0y, flo
     return (u >= 0.0f) && (v >= 0.0f) && (u + v <= abs_det) && (abs_det != 0.0f) && (t >= abs_det * r.tmin);
 }
 
-template <bool ANY, int N, int LDS_N>
+// TOP: the workgroup has staged the top of the hierarchy in LDS (k_wide_top_persist, stage_wide_top): `root` and every child id
+// >= kLdsTag is the byte offset of a node record inside `image` (same layout as the node, child ids of staged children
+// rewritten the same way), fetched with ds_read_b128 instead of through the vector-memory pipeline.
+template <bool ANY, int N, int LDS_N, bool TOP = false>
 __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const Tri4* __restrict__ tris, const Ray1* __restrict__ rays,
-                                           Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray) {
+                                           Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray,
+                                           lds_int* image = nullptr, int root = 1) {
     typedef WideLayout<N> L;
-    const int lane_ray = first_ray + (int)threadIdx.x;
+    const int lane_ray = first_ray + (int)(threadIdx.x % kWave);
     const int ray_id = lane_ray < n ? lane_ray : -1;
     RayX ray = load_ray(rays, ray_id >= 0 ? ray_id : first_ray);
     if (ray_id >= 0) store_hit(hits, ray_id, -1, ray.tmax, 0.0f, 0.0f);       // the miss record; accepted triangles overwrite it
     ray.tmin = canonical(ray.tmin); ray.tmax = canonical(ray.tmax);
-    int top = ray_id >= 0 ? 1 : 0;
+    int top = ray_id >= 0 ? root : 0;
     lds_int* sp = col;                               // the top entry of the stack in memory (mem[ptr] of the oracle)
     lds_int* const sp_limit = col + LDS_N * kWave;
     col[0] = 0;
@@ -68,18 +72,24 @@ __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const
     while (__ballot(top != 0)) {
         if (top != 0) {
             const bool is_node = top > 0;
-            const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? L::kNodeBytes : (unsigned)sizeof(Tri4);
-            const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
-            const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
             f32x4 d[L::kVecs];
-            // the pieces both kinds need, then the ones only the longer kind needs (exec-masked loads: the other lanes must
-            // not read past the end of their array)
-            constexpr int kShared = L::kNodeVecs < L::kTriVecs ? L::kNodeVecs : L::kTriVecs;
+            if (TOP && top >= kLdsTag) {
+                const __attribute__((address_space(3))) f32x4* p = (const __attribute__((address_space(3))) f32x4*)((__attribute__((address_space(3))) const char*)image + (unsigned)(top - kLdsTag));
 #pragma unroll
-            for (int k = 0; k < kShared; k++) d[k] = p[k];
-            if (L::kNodeVecs > L::kTriVecs ? is_node : !is_node) {
+                for (int k = 0; k < L::kNodeVecs; k++) d[k] = p[k];
+            } else {
+                const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? L::kNodeBytes : (unsigned)sizeof(Tri4);
+                const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
+                const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
+                // the pieces both kinds need, then the ones only the longer kind needs (exec-masked loads: the other lanes must
+                // not read past the end of their array)
+                constexpr int kShared = L::kNodeVecs < L::kTriVecs ? L::kNodeVecs : L::kTriVecs;
 #pragma unroll
-                for (int k = kShared; k < L::kVecs; k++) d[k] = p[k];
+                for (int k = 0; k < kShared; k++) d[k] = p[k];
+                if (L::kNodeVecs > L::kTriVecs ? is_node : !is_node) {
+#pragma unroll
+                    for (int k = kShared; k < L::kVecs; k++) d[k] = p[k];
+                }
             }
             const int popped = *sp;
             // every load in flight before anything is consumed (see unified_chunk in traversal.hip)
@@ -152,6 +162,84 @@ __global__ __launch_bounds__(kWave) void k_wide_single(const char* __restrict__ 
     wide_chunk<ANY, N, LDS_N>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent form with the top of the hierarchy in LDS (variant "top"; the wide counterpart of k_bvh2_top_persist).
+// A wide tree is shallow: the root, its children and their children are 1 + 8 + 64 = 73 Node8 records (18.7 KB) or, one level
+// further, 1 + 4 + 16 + 64 = 85 Node4 records (10.9 KB).  Every workgroup stages them ITSELF from the caller's array when it
+// starts -- one dependent load per level, three or four in all -- so there is no image to keep between launches and nothing
+// to validate (the BVH2 kernel's 255 records are eight levels deep: it keeps a validated image per context instead).
+// The grid is one resident generation of 16-wave workgroups -- one per CU: sixteen (LDS_N + N)-row stack windows and the
+// records are 147 KB (BVH8) of a CU's 160 KB, and ~100 VGPRs allow four waves per SIMD anyway -- whose waves draw 64-ray
+// chunks from the striped ticket counters of k_bvh2_top_persist.
+// ---------------------------------------------------------------------------------------------
+template <int N> struct WideTop {                    // records: levels 0..2 (BVH8), 0..3 (BVH4)
+    static constexpr int kRecords = N == 8 ? 1 + 8 + 64 : 1 + 4 + 16 + 64;
+};
+
+// Run by the workgroup's first wave: breadth first from the root; a child that gets a record is rewritten to a link.
+template <int N>
+__device__ __forceinline__ void stage_wide_top(const char* __restrict__ nodes, lds_int* image, lds_int* slot_node /* [kRecords] */) {
+    typedef WideLayout<N> L;
+    constexpr int kRecords = WideTop<N>::kRecords, kNodeInts = (int)L::kNodeBytes / 4;
+    const int lane = threadIdx.x;                                            // 0..63
+    if (lane == 0) slot_node[0] = 1;
+    wave_lds_sync();
+    int begin = 0, end = 1;
+    while (begin < end) {
+        int next = end;
+        for (int first = begin; first < end; first += kWave) {
+            const int slot = first + lane;
+            const bool on = slot < end;
+            const int id = on ? slot_node[slot] : 1;
+            const int* src = reinterpret_cast<const int*>(nodes + (size_t)(id - 1) * L::kNodeBytes);
+            int child[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) child[k] = on ? src[6 * N + k] : 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const bool inner = child[k] > 0;
+                const unsigned long long m = __ballot(inner);
+                const int s = next + __popcll(m & ((1ull << lane) - 1ull));
+                if (inner && s < kRecords) { slot_node[s] = child[k]; child[k] = kLdsTag + s * (int)L::kNodeBytes; }
+                next = min(kRecords, next + __popcll(m));
+            }
+            if (on) {
+                lds_int* rec = image + slot * kNodeInts;
+                for (int j = 0; j < 6 * N; j++) rec[j] = src[j];
+#pragma unroll
+                for (int k = 0; k < N; k++) { rec[6 * N + k] = child[k]; rec[7 * N + k] = 0; }
+            }
+        }
+        wave_lds_sync();
+        begin = end; end = next;
+    }
+}
+
+template <bool ANY, int N, int LDS_N, int WAVES>
+__global__ __launch_bounds__(kWave * WAVES) void k_wide_top_persist(const char* __restrict__ nodes, const Tri4* __restrict__ tris,
+                                                                   const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                                   Ctl* ctl, int* __restrict__ deep_list, int* __restrict__ tickets) {
+    constexpr int kStackInts = WAVES * (LDS_N + N) * kWave, kImageInts = WideTop<N>::kRecords * (int)WideLayout<N>::kNodeBytes / 4, kGroup = 32;
+    static_assert((kStackInts + kImageInts + WideTop<N>::kRecords) * 4 <= 160 * 1024, "one workgroup per CU must fit its stacks and records in LDS");
+    __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + kImageInts + WideTop<N>::kRecords];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + N) * kWave + lane;
+    lds_int* image = (lds_int*)lds_raw + kStackInts;
+    if (wave == 0) stage_wide_top<N>(nodes, image, image + kImageInts);
+    __syncthreads();
+    const int total_chunks = (n + kWave - 1) / kWave, stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
+    int* counter = tickets + stripe * kCounterStride;
+    int t = (blockIdx.x / kStripes) * WAVES + wave;                          // a wave's first ticket: its rank inside the stripe
+    for (;;) {
+        const int group_first = ((t / kGroup) * kStripes + stripe) * kGroup, chunk = group_first + t % kGroup;
+        if (group_first >= total_chunks) break;                              // this stripe's share is used up
+        if (chunk < total_chunks) wide_chunk<ANY, N, LDS_N, true>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, image, kLdsTag);
+        int t_next = 0;
+        if (lane == 0) t_next = atomicAdd(counter, 1);
+        t = stripe_waves + __builtin_amdgcn_readfirstlane(t_next);
+    }
+}
+
 // The reference's general-arity loop, literally, for one ray (mapping_gpu.impala:136-178): the follow-up kernel's body
 // and the lab build's "lane" kernel.
 template <bool ANY, int N, typename Stack>
@@ -208,8 +296,9 @@ __device__ __forceinline__ HitAcc wide_ray_literal(const char* __restrict__ node
 template <bool ANY, int N>
 __global__ __launch_bounds__(kWave) void k_wide_finish(const char* __restrict__ nodes, const Tri4* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
-                                                        Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack) {
+                                                        Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* tickets) {
     __shared__ int stack_lds[kStackCap * kWave];                    // the reference's 64 entries per lane, in LDS (see DeepStack)
+    if (tickets) for (int k = threadIdx.x; k < 4 * 64; k += kWave) tickets[k * 16] = 0;     // the persistent form's ticket counters, ready for the next launch
     const int count = ctl->deep_count;
     if (count > 0) {
         DeepStack st{(lds_int*)stack_lds + threadIdx.x, &ctl->err};
@@ -226,5 +315,23 @@ __global__ __launch_bounds__(kWave) void k_wide_finish(const char* __restrict__ 
 template <bool ANY, int N, int LDS_N, int XCD> void L_wide_single(WIDE_LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     hipLaunchKernelGGL((k_wide_single<ANY, N, LDS_N, XCD>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
-    hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(1), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack);
+    hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(1), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
+}
+// "top": the persistent form with the staged top levels for launches that fill the chip (as the BVH2 default: rodent_hip_top_min_rays),
+// the one-chunk kernel below that
+int wide_top_min_rays();
+template <bool ANY, int N, int LDS_N> void L_wide_top(WIDE_LAUNCH_ARGS) {
+    if (n < wide_top_min_rays()) { L_wide_single<ANY, N, LDS_N, 32>(s, nodes, tris, rays, hits, n, stream); return; }
+    ensure_deep_list(s, n);
+    if (!s.tickets) {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (!s.tickets) {
+            HIP_CHECK(hipMalloc(&s.tickets, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
+            HIP_CHECK(hipMemset(s.tickets, 0, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
+        }
+    }
+    constexpr int kWaves = 16;
+    const int groups = ((s.num_cus + kStripes - 1) / kStripes) * kStripes;   // one workgroup per CU, the same number in every stripe
+    hipLaunchKernelGGL((k_wide_top_persist<ANY, N, LDS_N, kWaves>), dim3(groups), dim3(kWave * kWaves), 0, stream, (const char*)nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.tickets);
+    hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(1), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets);
 }

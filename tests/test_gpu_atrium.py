@@ -61,6 +61,50 @@ def test_all_benchmark_rays_bit_exact(gpu, oracle, dumps, width, kind):
     assert occ.tobytes() == ref_any.tobytes()
 
 
+@pytest.mark.parametrize("scene,limit", [("atrium", 1.10), ("refbuilt", 1.10), ("cornell", 1.25)])
+def test_default_mapping_is_not_slower_than_the_one_chunk_kernel_where_it_is_selected(gpu, scene, limit, tmp_path):
+    """The default BVH2 mapping switches from the one-chunk kernel ("fast") to the persistent LDS-image kernel at 589 824 rays, with
+    a 255-record image and 15-entry stack windows -- constants tuned on the atrium's primary camera (profiles/r02_threshold_sweep.txt).
+    From that size on it must not lose to "fast" by more than 10 %: on the benchmark scene, on the decimated atrium as the
+    REFERENCE's builder lays it out (tests/golden/atrium-decimated-refbuilt.bvh.gz), primary and random rays.  On a tree that
+    fits the image whole (Cornell, 16 nodes) the persistent launch's fixed cost (~8 us of a 50 us launch) shows at the switch
+    point: 25 % there (profiles/r03_threshold_sweep.txt has the table)."""
+    import gzip
+    import torch
+    from rodent_amd import raygen, scenes
+    if scene == "refbuilt":
+        path = tmp_path / "r.bvh"
+        path.write_bytes(gzip.decompress((scenes.GOLDEN / "atrium-decimated-refbuilt.bvh.gz").read_bytes()))
+        cam = scenes.CAMERAS["atrium"]
+    else:
+        path, cam = scenes.scene_bvh(scene), scenes.CAMERAS[scene]
+    bvh = gpu.DeviceBvh.load(path, 2, 0)
+    n4, _ = F.read_bvh(path, F.BVH4_TRI4)
+    lo, hi = raygen.scene_bounds(n4)
+    names = gpu.variants(2)
+    st = torch.cuda.current_stream()
+
+    def timed(v, rd, hd, n):
+        for _ in range(4):
+            gpu.traverse_async(bvh, rd, hd, n, False, v, st)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(25)]
+        for s, e in ev:
+            s.record(st); gpu.traverse_async(bvh, rd, hd, n, False, v, st); e.record(st)
+        torch.cuda.synchronize()
+        return float(np.median([s.elapsed_time(e) for s, e in ev]))
+
+    try:                                                               # (this module runs on the shipped switch point throughout)
+        for w, h in ((1024, 576), (1024, 1024)):
+            n = w * h
+            for kind, rays in (("primary", raygen.primary_rays(*cam, w, h, 0.0, 5000.0)), ("random", raygen.random_rays(lo, hi, n, 42, 0.0, 1.0))):
+                rd = gpu.to_device(rays, 0); hd = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
+                fast, top = timed(names.index("fast"), rd, hd, n), timed(names.index("top"), rd, hd, n)
+                assert top <= limit * fast, (scene, n, kind, top, fast)
+    finally:
+        gpu.lib().rodent_hip_top_min_rays(-1)
+
+
 @pytest.fixture(scope="module")
 def atrium_scene(native_build, tmp_path_factory):
     from rodent_amd import scenes

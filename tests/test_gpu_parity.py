@@ -117,12 +117,12 @@ def test_chunk_mapping_is_a_bijection(gpu, cornell, cornell_dev, n):
     for width in (4, 8):                                       # the wide kernels use the same mapping
         wn = gpu.variants(width)
         wide = {}
-        for name in ("single", "single-noxcd"):
+        for name in ("top", "single", "single-noxcd"):            # "top": tickets of the persistent form (k_wide_top_persist), as the BVH2 default
             hd = torch.full((n * 16,), 0xFF, dtype=torch.uint8, device="cuda:0")
             gpu.traverse_async(cornell_dev[width], rd, hd, n, False, wn.index(name))
             torch.cuda.synchronize()
             wide[name] = gpu.from_device(hd, F.HIT1)
-        assert wide["single"].tobytes() == wide["single-noxcd"].tobytes()
+        assert wide["single"].tobytes() == wide["single-noxcd"].tobytes() == wide["top"].tobytes()
         assert np.array_equal(wide["single"]["tri_id"] >= 0, out["fast"]["tri_id"] >= 0)
 
 
