@@ -358,7 +358,8 @@ def render_cpu_baseline(threads):
         if not bvh.exists():
             subprocess.run([str(build.BIN_DIR / "bvh_extractor"), "-obj", str(obj), "-o", str(bvh)], check=True, stdout=subprocess.DEVNULL)
         n8, t8 = F.read_bvh(bvh, F.BVH8_TRI4)
-        sw, sh, sspp = (w // 2, h // 2, 4) if scene_name == "cornell" else (w // 4, h // 4, 4)
+        # bounded samples (seconds, not minutes, of CPU work): config 4 whole (133 M samples), config 5 at a quarter of the pixels and 8 spp
+        sw, sh, sspp = (w, h, spp) if scene_name == "cornell" else (w // 2, h // 2, 8)
         eye, d, up, fov = scenes.CAMERAS[scene_name]
         cam = S.camera_settings(eye, d, up, fov, sw, sh)
         O.render_wavefront(sc, n8, t8, cam, 0, 1, max_len, sw, sh, None, threads=threads)          # warm-up (thread start, page faults)

@@ -816,10 +816,12 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool S
 // launches whose node array the runtime cannot give a mapped range for (nothing bounds the ids of an older image then).
 constexpr int kTopMinRays = 9216 * kWave;      // the measured cross-over lies between 512 Ki and 768 Ki rays (profiles/r02_threshold_sweep.txt)
 int g_top_min_rays = kTopMinRays;               // rodent_hip_top_min_rays()
-template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH> void L_default(LAUNCH_ARGS) {
+// FUSED = 2: the launch finishes itself (its last workgroup does the follow-up kernel's work; fences on the rare paths only): one
+// kernel per call instead of two, +1.1 % / +1.8 % on the benchmark's primary / random set in wall-clock terms (bench.py, 100 steps).
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int FUSED = 2> void L_default(LAUNCH_ARGS) {
     const int max_id = n < g_top_min_rays ? 0 : mapped_node_ids(nodes);
     if (max_id == 0) L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream);
-    else launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, false, 32>(s, nodes, tris, rays, hits, n, stream, max_id);
+    else launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, false, 32, false, 0, FUSED>(s, nodes, tris, rays, hits, n, stream, max_id);
 }
 
 #ifdef RODENT_HIP_LAB
@@ -888,7 +890,7 @@ const Variant2 kVariants2[] = {
     // 0 = default (used by the reference-named entry points).  All variants keep the reference's per-ray
     // visit order and are bit-identical; they differ in how a wavefront schedules its 64 rays.
     //                                                              LDS_N TOPN WAVES PREFETCH
-    K2("top",                "k_bvh2_top_persist",   L_default, 15, 255, 16, false),   // default: LDS-staged top of the tree (255 nodes), persistent 16-wave workgroups
+    K2("top",                "k_bvh2_top_persist",   L_default, 15, 255, 16, false),   // default: LDS-staged top of the tree (255 nodes), persistent 16-wave workgroups, the last one finishes the launch
                                                                                        // (launches under rodent_hip_top_min_rays: k_bvh2_single)
     //                                                        LDS_N XCD_GROUP
     K2("fast",               "k_bvh2_single",        L_single, 16, 32),                // single-step schedule, one 64-ray chunk per workgroup, XCD-aware 32-chunk groups (default of rounds 1-2)
@@ -924,7 +926,8 @@ const Variant2 kVariants2[] = {
     K2("top63p4-o28",        "k_bvh2_top_persist",   L_top_persist, 15, 63, 4, false, false, 28),
     //                                                                    LDS_N TOPN WAVES REFILL (idle lanes that trigger a refill)
     K2("top-fused",          "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 1),   // the last workgroup does the follow-up kernel's work (every workgroup fences)
-    K2("top-one",            "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 2),   // the same, fences on the rare paths only
+    K2("top-one",            "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 2),   // the same, fences on the rare paths only (= the default from 576 Ki rays on)
+    K2("top-two",            "k_bvh2_top_persist",   L_default, 15, 255, 16, false, 0),                          // the default with a follow-up kernel instead (rounds 2's form)
     K2("top-lazy",           "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 0, true),   // miss records stored at chunk end
     K2("top-lazy-one",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 2, true),
     K2("top-userperm-lazy-one", "k_bvh2_top_persist", L_top_persist, 15, 255, 16, false, false, 32, false, -1, 2, true),

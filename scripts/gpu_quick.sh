@@ -1,3 +1,7 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out/r03
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_atrium.py tests/test_refbuilt.py -m gpu -x -q 2>&1 | tail -6
-timeout 900 python scripts/sweep_widths.py --widths 2,4,8 --all-variants --big --only fast,single,top 2>&1 | tee gpurun_out/r03/sweep_widths.log | cut -c1-200
+export RODENT_HIP_LAB=1
+for v in top top-one top-lazy-one; do
+  idx=$(python -c "from rodent_amd import abi; print(abi.variants(2).index('$v'))")
+  for rep in 1 2; do python bench.py --variant $idx --no-cpu-baseline --steps 100 --warmup 10 | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'], d['extra']['primary_kernel_ms']['mean'], d['extra']['random_Mrays_s'])"; done
+done
