@@ -294,10 +294,12 @@ def render_section(args, torch, dist, rank, world, dev):
         frames = 3 if spp * w * h < (1 << 28) else 1
         entry = {"scene": f"{scene_name} ({sc.num_tris} triangles, {len(sc.materials)} materials)", "width": w, "height": h, "spp": spp, "max_path_len": max_len,
                  "samples_per_frame": spp * w * h, "timed_frames": frames, "rows_per_gpu": y1 - y0 if world > 1 else h}
-        mappings = ["auto", "streaming", "megakernel"]
+        # auto = what the library chooses for this scene; streaming = the wavefront loop with the library's defaults (shading in stream
+        # order); streaming_sorted = the same with the reference's sort by material in front of the shader (rodent_hip_render_sort)
+        mappings = ["auto", "streaming", "streaming_sorted", "megakernel"]
         chosen = None
         for mapping in mappings:
-            r = R.Renderer(sc, w, h, spp=4, max_path_len=max_len, dev=dev, mapping=mapping)
+            r = R.Renderer(sc, w, h, spp=4, max_path_len=max_len, dev=dev, mapping=mapping.split("_")[0], sort=True if mapping.endswith("_sorted") else None)
             if mapping == "auto":
                 chosen = r.mapping_name()
             elif mapping == chosen and world == 1:

@@ -88,9 +88,12 @@ void    rodent_hip_render_defaults(int32_t dev);
 /* Rays per ray stream of the streaming mapping: the reference's constant 1 Mi (mapping_gpu.impala:319) is 8 Mi here
  * by default (larger launches amortise their fill and drain on a 256-CU chip; 0 restores the default). */
 void    rodent_hip_render_capacity(int32_t dev, int32_t rays);
-/* 1 (default): hit rays are sorted by material before shading and misses dropped, as in the reference
- * (mapping_gpu.impala:166-221,347-357).  0: no sort -- the table-driven shader runs in stream order and ends the rays that
- * missed; one stream copy less per bounce.  Same paths, same ray counts; RODENT_HIP_SORT=0|1 sets the initial value. */
+/* 1: hit rays are sorted by material before shading and misses dropped, as in the reference (mapping_gpu.impala:166-221,347-357:
+ * there every material is its own generated shader and the sort is what makes a launch per material possible).
+ * 0 (default): no sort -- the shader here is ONE table-driven kernel; it runs in stream order and ends the rays that missed; one
+ * stream copy less per bounce.  Measured on every scene at hand (profiles/r03_sort_sweep.txt: Cornell, the atrium, a room with
+ * every BSDF kind on neighbouring walls, a textured room) the unsorted loop is 5 ... 22 % faster, so it is the default; the sort
+ * stays one call away.  Same paths, same ray counts; RODENT_HIP_SORT=0|1 sets the initial value, `rodent --sort` / `--no-sort`. */
 void    rodent_hip_render_sort(int32_t dev, int32_t enable);
 /* 1 (default): the shadow rays of a bounce are traced on a second HIP stream beside the compaction, regeneration and the
  * next closest-hit pass; 0: one stream.  Same film up to the order of the atomic adds.  RODENT_HIP_OVERLAP=0|1. */

@@ -852,7 +852,8 @@ struct RenderDevice {
     DevScene scene;
     int spp = 4, max_path_len = 64;
     int capacity = 0;                          // rays per stream; 0 = default (env_capacity())
-    int sort = 1;                              // 1 = sort hit rays by material before shading (mapping_gpu.impala:166-221), 0 = shade in stream order
+    int sort = 0;                              // 1 = sort hit rays by material before shading (mapping_gpu.impala:166-221), 0 = shade in stream order (default: the shader is ONE table-driven
+                                               // kernel, not a kernel per material, and the sort costs more than the divergence it removes -- 5 ... 22 % of the frame on every scene of profiles/r03_sort_sweep.txt)
     int trace_persistent = 0;                  // 1 = persistent stream traversal kernels (k_trace_persist: 16-wave workgroups, 255-record image, ticket counters)
     int* tickets[2] = {nullptr, nullptr}; int num_cus = 0;
     int lds_image = 1;                         // 1 = the stream traversal kernels stage the scene's top-of-tree image in LDS (2-wave workgroups); 0 = every node from memory
@@ -883,7 +884,7 @@ std::vector<float> g_host_film; size_t g_host_w = 0, g_host_h = 0;
 
 // every option of the renderer at its default, or at what its environment variable says (rodent_hip_render_defaults)
 void render_defaults(RenderDevice& r) {
-    r.sort = 1; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 2; r.lds_image = 1; r.trace_persistent = 0; r.mapping_request = -1; r.capacity = 0;
+    r.sort = 0; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 2; r.lds_image = 1; r.trace_persistent = 0; r.mapping_request = -1; r.capacity = 0;
     if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_FUSED_SORT")) r.fused_sort = atoi(e) ? 1 : 0;

@@ -13,7 +13,7 @@
 //                       device), a frame takes as long as the slowest band; after the last frame ONE RCCL gather (grouped
 //                       ncclSend / ncclRecv, host/multi_gpu.h) brings the bands to the first device's film
 //   --target t          amdgpu-streaming (default) or amdgpu-megakernel (converter.cpp:30-35,1032-1037)
-//   --no-sort           streaming target: shade in stream order instead of sorting hit rays by material first
+//   --sort / --no-sort  streaming target: sort hit rays by material before shading (the reference's loop) / shade in stream order (default)
 // Without --bench the reference opens an SDL window and renders until it is closed; this build is
 // headless (DISABLE_GUI, driver.cpp:236-242), so --bench or -o is required.
 #include <algorithm>
@@ -39,7 +39,8 @@ static void usage() {
               << "   -dev     n          GPU device index\n"
               << "   --ngpu   K          Renders on K GPUs (row bands, one film gather to the first device)\n"
               << "   --target t          amdgpu-streaming (default) or amdgpu-megakernel\n"
-              << "   --no-sort           Do not sort rays by material before shading (streaming target)\n"
+              << "   --sort              Sort rays by material before shading (streaming target; default: stream order)\n"
+              << "   --no-sort           Do not sort rays by material before shading\n"
               << "   --width  pixels     Sets the viewport horizontal dimension (in pixels)\n"
               << "   --height pixels     Sets the viewport vertical dimension (in pixels)\n"
               << "   --eye    x y z      Sets the position of the camera\n"
@@ -58,7 +59,7 @@ int main(int argc, char** argv) {
     float fov = 60.0f;
     V3 eye(0.0f), dir(0.0f, 0.0f, 1.0f), up(0.0f, 1.0f, 0.0f);
     int spp = 0, max_path_len = -1, dev = 0, mapping = -1, ngpu = 1;
-    bool no_sort = false;
+    int sort = -1;                                                        // -1: the library's default
 
     for (int i = 1; i < argc; ++i) {
         if (argv[i][0] != '-') fail(std::string("Unexpected argument '") + argv[i] + "'");
@@ -76,7 +77,8 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--max-path-len")) { need(1); max_path_len = strtol(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "-dev")) { need(1); dev = strtol(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "--ngpu")) { need(1); ngpu = strtol(argv[++i], nullptr, 10); }
-        else if (!strcmp(argv[i], "--no-sort")) no_sort = true;
+        else if (!strcmp(argv[i], "--no-sort")) sort = 0;
+        else if (!strcmp(argv[i], "--sort")) sort = 1;
         else if (!strcmp(argv[i], "--target")) {
             need(1); ++i;
             if (!strcmp(argv[i], "amdgpu-streaming") || !strcmp(argv[i], "amdgpu")) mapping = 0;
@@ -116,7 +118,7 @@ int main(int argc, char** argv) {
         rodent_hip_scene_create(d, &desc);
         rodent_hip_render_config(d, spp, max_path_len);
         if (mapping >= 0) rodent_hip_render_mapping(d, mapping);
-        if (no_sort) rodent_hip_render_sort(d, 0);
+        if (sort >= 0) rodent_hip_render_sort(d, sort);
     }
     clear_pixels();
 

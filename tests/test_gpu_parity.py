@@ -382,7 +382,7 @@ def test_bench_py_contract(native_build):
     for cfg, (w, h, spp) in (("cfg4_cornell_1920x1080_64spp_len4", (1920, 1080, 64)), ("cfg5_atrium_3840x2160_256spp_len8", (3840, 2160, 256))):
         e = rd[cfg]
         assert (e["width"], e["height"], e["spp"]) == (w, h, spp) and e["auto"]["Msamples_s"] > 100 and e["auto"]["rays"]["generated"] == w * h * spp
-        assert e["auto_mapping"] in ("streaming", "megakernel") and all(m in e for m in ("streaming", "megakernel"))
+        assert e["auto_mapping"] in ("streaming", "megakernel") and all(m in e for m in ("streaming", "streaming_sorted", "megakernel")) and e["streaming_sorted"]["Msamples_s"] > 100
     assert rd["cpu_baseline"]["cfg4_cornell_1920x1080_64spp_len4"]["Msamples_s"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["passes"] >= 10 and "sample" in cb

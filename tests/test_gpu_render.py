@@ -33,7 +33,7 @@ def R(native_build):
 def test_film_matches_oracle(R, oracle, cornell_scene, spp, max_len, iters):
     W, H = 200, 120
     cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
-    r = R.Renderer(cornell_scene, W, H, spp, max_len)
+    r = R.Renderer(cornell_scene, W, H, spp, max_len, sort=bool(iters % 2))     # with the sort by material (the reference's loop) and without (the default)
     film_o = None
     for it in range(iters):
         r.render(cam, it)
@@ -57,7 +57,7 @@ def test_a_thousand_materials_and_the_per_scene_mapping(R, oracle, cornell_scene
     cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
     film_o, counts = oracle.render(cornell_scene, cam, 0, 3, 5, W, H)
     for mapping in ("streaming", "auto"):
-        r = R.Renderer(sc, W, H, 3, 5, mapping=mapping)
+        r = R.Renderer(sc, W, H, 3, 5, mapping=mapping, sort=True)
         assert r.mapping_name() == ("streaming" if mapping == "streaming" else "megakernel")
         r.render(cam, 0)
         c = r.counters(); film_g = r.film(); r.close()
