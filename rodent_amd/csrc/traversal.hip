@@ -782,7 +782,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, 
     if (!SORTED && PRIO == -1) perm = s.debug_perm;                          // lab "top-userperm"
     const int groups = ((s.num_cus * (OCC / WAVES) + kStripes - 1) / kStripes) * kStripes;   // one resident generation, the same number in every stripe
     const int total_chunks = blocks_for(n), stride = ((total_chunks + 31) / 32 + kStripes - 1) / kStripes * 32;       // chunks of the fullest stripe
-    if (g_schedule_history && !SORTED && !TRACE && PRIO == 0 && !FUSED && !PREFETCH && stride <= kMaxStripeChunks) {
+    if (g_schedule_history && !SORTED && !TRACE && PRIO == 0 && FUSED != 1 && !PREFETCH && stride <= kMaxStripeChunks) {      // (with the history on, the launch is followed by k_bvh2_top_finish_history whatever FUSED says)
         // schedule history: this launch records its chunks' costs; it draws them in the order the previous launch of the same
         // size left behind, if there is one (all on `stream`: the follow-up kernel writes the order before the next launch reads it)
         if (!s.chunk_cost) {
