@@ -89,7 +89,9 @@ void amdgpu_occluded_single_ray1_bvh2_tri1(int32_t dev,
 
 /* BVH4/Tri4 and BVH8/Tri4 on the GPU (the reference only has these layouts on the CPU,
  * cpu_{intersect,occluded}_single_ray1_bvh{4,8}_tri4, bench_traversal.impala:399-455).  Per-ray visit order: the
- * reference GPU kernel's branch for arity != 2 (src/traversal/mapping_gpu.impala:136-153,160-169). */
+ * reference GPU kernel's branch for arity != 2 (src/traversal/mapping_gpu.impala:136-153,160-169).
+ * Which layout for what (one MI355X, profiles/r03_sweep_widths.log): closest hits and any query about incoherent rays are
+ * fastest on BVH2 / Tri1; visibility (occluded_*) of COHERENT rays is fastest on BVH8 / Tri4 -- 24-33 % ahead of BVH2. */
 void hip_intersect_single_ray1_bvh4_tri4(int32_t dev,
         const struct Node4* nodes, const struct Tri4* tris,
         const struct Ray1* rays, struct Hit1* hits, int32_t num_rays);
@@ -108,7 +110,8 @@ void hip_occluded_single_ray1_bvh8_tri4(int32_t dev,
  * caller can bracket launches with its own HIP events.  `variant` selects the
  * kernel mapping (see rodent_hip_variant_name); 0 is the default shipped one.
  * Every (device, stream) pair has its own control words and deep-ray list (rays whose stack outgrows the LDS window
- * are finished by a follow-up kernel enqueued behind each launch), so launches on different streams may overlap;
+ * are traced again with the reference's 64-entry stack: by the launch's last workgroup in the default BVH2 mapping, by a
+ * follow-up kernel enqueued behind the launch in the others), so launches on different streams may overlap;
  * up to 64 streams per device. */
 void hip_traverse_bvh2_tri1_async(int32_t dev,
         const struct Node2* nodes, const struct Tri1* tris,
@@ -137,7 +140,9 @@ int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2, 4 or 8 
 void        rodent_hip_phased_min_rays(int32_t rays);
 /* The default BVH2 mapping ("top": top of the tree staged in LDS, persistent workgroups) takes the one-chunk-per-workgroup
  * kernel ("fast") for launches of fewer than this many rays (default 589 824: the measured cross-over of the two kernels --
- * staging and validating the image in every workgroup does not pay below that); < 0 restores the default, 0 sends every launch through the LDS-image kernel (tests). */
+ * staging and validating the image in every workgroup does not pay below that); < 0 restores the default, 0 sends every launch through the LDS-image kernel (tests).
+ * The default BVH4 / BVH8 mapping ("top": persistent workgroups that stage the top 85 / 73 nodes themselves) switches to ITS one-chunk kernel
+ * ("single") at the same size. */
 void        rodent_hip_top_min_rays(int32_t rays);
 /* Schedule history of the default BVH2 mapping (off by default; RODENT_HIP_SCHEDULE_HISTORY=1): every launch records how many
  * wave iterations each 64-ray chunk took, and the next launch of the SAME ray count on that (device, stream) traces its chunks
