@@ -299,15 +299,14 @@ def render_section(args, torch, dist, rank, world, dev):
         mappings = ["auto", "streaming", "streaming_sorted", "megakernel"]
         chosen = None
         for mapping in mappings:
+            if world > 1 and mapping != "auto":                        # N GPUs: only the mapping the library chooses
+                continue
             r = R.Renderer(sc, w, h, spp=4, max_path_len=max_len, dev=dev, mapping=mapping.split("_")[0], sort=True if mapping.endswith("_sorted") else None)
             if mapping == "auto":
                 chosen = r.mapping_name()
-            elif mapping == chosen and world == 1:
+            elif mapping == chosen:
                 r.close()
                 entry[mapping] = {"same_as": "auto"}
-                continue
-            elif world > 1:                                            # N GPUs: only the mapping the library chooses
-                r.close()
                 continue
             r.render_rows(cam, 0, y0, y1)                              # warm-up at 4 spp (allocations, code upload)
             r.configure(spp, max_len)
