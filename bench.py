@@ -205,10 +205,14 @@ def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, 
     return wall, float(np.mean(kernel_ms)), float(np.median(kernel_ms)), float(np.min(kernel_ms))
 
 
+def _collective_device(dist, dev):
+    return "cpu" if dist.get_backend() == "gloo" else f"cuda:{dev}"
+
+
 def max_over_ranks(torch, dist, dev, values):
     if dist is None:
         return list(values)
-    t = torch.tensor(list(values), dtype=torch.float64, device=f"cuda:{dev}")
+    t = torch.tensor(list(values), dtype=torch.float64, device=_collective_device(dist, dev))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(x) for x in t]
 
@@ -217,7 +221,7 @@ def gather_scalars(torch, dist, dev, values):
     """[[values of rank 0], [values of rank 1], ...] on every rank (bookkeeping, after the timed regions)."""
     if dist is None:
         return [list(values)]
-    t = torch.tensor(list(values), dtype=torch.float64, device=f"cuda:{dev}")
+    t = torch.tensor(list(values), dtype=torch.float64, device=_collective_device(dist, dev))
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [[float(x) for x in g] for g in out]
@@ -392,8 +396,16 @@ def main():
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RODENT_BENCH_BACKEND=gloo RODENT_BENCH_SHARE_GPUS=1 (test mode: the N-rank code path on a box with fewer GPUs than ranks --
+        # ranks share devices, collectives go through the host); the driver's runs use RCCL, one rank per GPU
+        backend = os.environ.get("RODENT_BENCH_BACKEND", "nccl")
+        if os.environ.get("RODENT_BENCH_SHARE_GPUS", "0") not in ("", "0"):
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP traversal has no CPU fallback)")
@@ -558,7 +570,7 @@ def main():
         "config": {"workload": f"{scene}.bvh + {scene}-primary.rays (1024x1024 primary rays, tmax 5000, closest hit)" + (" per GPU" if scaling == "weak" and world > 1 else ""),
                    "rays_per_gpu_per_step": n, "bvh_layout": f"BVH{width}", "kernel": kname,
                    "variant": abi.variants(width)[variant], "parallelism": f"replicated BVH x {world}" + (f", {sharding}" if world > 1 else ""),
-                   "world_size": world, "collective_backend": "nccl (RCCL)" if world > 1 else None},
+                   "world_size": world, "collective_backend": (None if dist is None else ("nccl (RCCL)" if dist.get_backend() == "nccl" else dist.get_backend() + " (test mode)"))},
         "extra": {"random_Mrays_s": round(main_part["value_rnd"], 3), "random_ms_per_step": round(1e3 * main_part["wall_r"] / steps_r, 5),
                   "primary_kernel_ms": {"mean": round(k_mean, 5), "median": round(k_med, 5), "min": round(k_min, 5)},
                   "random_kernel_ms": {"mean": round(kr_mean, 5), "median": round(kr_med, 5), "min": round(kr_min, 5)},

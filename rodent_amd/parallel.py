@@ -9,7 +9,7 @@ the BVH / scene is replicated, rays or image rows are partitioned, and ONE gathe
 The gather is a grouped send / receive (what ncclGather is made of): the root posts one receive per peer straight into that
 peer's rows of ITS film (or its range of the Hit1 array), every peer posts one send of its own part -- each byte crosses one
 xGMI link once, nothing is padded, nobody but the root receives anything (12.4 MB per peer at 3840 x 2160).  The C++ hosts do
-the same with ncclSend / ncclRecv between ncclGroupStart / ncclGroupEnd (rodent_amd/host/multi_gpu.cpp).
+the same with ncclSend / ncclRecv between ncclGroupStart / ncclGroupEnd (rodent_amd/host/multi_gpu.h).
 """
 from __future__ import annotations
 
@@ -41,6 +41,13 @@ def gather_parts_to_root(full, part_of, dist, root: int = 0):
     if not _active(dist):
         return full
     rank, world = dist.get_rank(), dist.get_world_size()
+    if dist.get_backend() == "gloo" and full.is_cuda:
+        # gloo moves host memory only (CPU tests; bench.py's shared-GPU test mode): bounce the parts through the host
+        host = gather_parts_to_root(full.cpu(), part_of, dist, root)
+        if host is None:
+            return None
+        full.copy_(host)
+        return full
     ops = []
     if rank == root:
         for r in range(world):

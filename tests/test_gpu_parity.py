@@ -390,6 +390,32 @@ def test_bench_py_contract(native_build):
     assert d["extra"]["random_sorted"]["identical_to_unsorted"] is True
 
 
+def test_bench_py_with_two_ranks(native_build):
+    """The N > 1 code path of bench.py -- strong partition as `value` (one ray set in contiguous ranges, Hit1 gather to rank 0,
+    assembled array equal to a single-GPU trace), weak partition beside it, config 5 as row bands with a film gather -- with two
+    ranks.  On a box with one GPU the ranks share it and the collectives go through gloo (RODENT_BENCH_SHARE_GPUS / _BACKEND);
+    with two or more GPUs this is the driver's RCCL launch."""
+    import json, os, sys
+    import torch
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_PORT="29541")
+    if torch.cuda.device_count() < 2:
+        env.update(RODENT_BENCH_BACKEND="gloo", RODENT_BENCH_SHARE_GPUS="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--render-spp5", "2"], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rays_per_gpu_per_step"] == (1 << 19) and d["value"] > 1000
+    e = d["extra"]
+    assert e["strong_scaling_check"] == {"primary_equal_to_single_gpu": True, "random_equal_to_single_gpu": True}
+    assert e["weak_scaling"]["rays_per_gpu_per_step"] == (1 << 20) and e["weak_scaling"]["Mrays_s"] > 1000 and len(e["weak_scaling"]["kernel_ms_per_rank[primary,random]"]) == 2
+    assert e["all_rays_bit_exact_vs_oracle"] == {"primary": True, "random": True}          # rank 0's range against the oracle
+    c5 = e["render"]["cfg5_atrium_3840x2160_256spp_len8"]
+    assert c5["rows_per_gpu"] == 1080 and c5["auto"]["film_complete_on_root"] is True and c5["auto"]["film_gather_ms"] > 0 and "cfg4_cornell_1920x1080_64spp_len4" not in e["render"]
+    assert "cpu_baseline" not in d                                                          # rank 0, N = 1 only
+
+
 def test_stack_overflow_is_reported_not_silent(gpu, oracle):
     """The reference's stack holds 64 entries, unchecked (stack.impala:53-54).  A ray that needs more raises a device flag:
     rodent_hip_check_errors reports it once and clears it (the synchronous entry points abort on it); launches that stay
