@@ -116,9 +116,15 @@ void    rodent_hip_render_fused_compact(int32_t dev, int32_t enable);
  * (breadth first, built at scene creation) in LDS and fetch those with ds_read instead of through the vector-memory pipeline.
  * 0: one wave per workgroup, every node from memory (rounds 1-2).  Same per-ray visit order, same film.  RODENT_HIP_LDS_IMAGE=0|1. */
 void    rodent_hip_render_lds_image(int32_t dev, int32_t enable);
-/* 1: the stream traversal kernels run in their persistent form (one resident generation of 16-wave workgroups, the first 255
- * inner nodes in LDS, 64-ray chunks drawn from striped ticket counters -- traversal.hip's default mapping) for streams of at
- * least 524 288 rays.  0 (default): the 2-wave form above.  Same film.  RODENT_HIP_TRACE_PERSISTENT=0|1. */
+/* The stream traversal launches of the streaming loop.
+ * 0: 2-wave workgroups with a 31-node image (rodent_hip_render_lds_image), the shadow pass on a second stream (rodent_hip_render_overlap).
+ * 1: persistent form (one resident generation of 16-wave workgroups, the first 255 inner nodes in LDS, 64-ray chunks drawn from
+ *    striped ticket counters -- traversal.hip's default mapping) for streams of at least 524 288 rays.
+ * 2: joint -- the shadow pass of an iteration rides in the NEXT iteration's closest-hit launch: one persistent kernel works through
+ *    both ray lists (they depend on the same shader run and on nothing else), one stream, no pass waits for the other's tail.
+ * -1 (default): per scene -- 2 for every hierarchy the per-scene mapping rule sends to the streaming loop (+3 ... +9 % on the atrium at
+ *    306 ... 142 444 nodes, profiles/r03_joint_sweep.txt), 0 for a tree of a few dozen nodes (Cornell box: 2 is 5 % slower).
+ * Same film.  RODENT_HIP_TRACE_PERSISTENT=-1|0|1|2. */
 void    rodent_hip_render_trace_persistent(int32_t dev, int32_t enable);
 
 /* ---- the reference's renderer ABI ---- */

@@ -350,10 +350,15 @@ __global__ __launch_bounds__(kWave * WAVES) void k_trace_secondary(SceneDev sc, 
 // striped ticket counters (ticket t of stripe s = chunk ((t / 32) * 64 + s) * 32 + t % 32; a wave's first ticket is its rank in
 // the stripe).  The stream size may live on the device: the grid does not depend on it.  k_trace_deep zeroes the counters.
 constexpr int kPersistWaves = 16, kPersistTopNodes = 255, kTraceStripes = 64, kTraceCounterStride = 16;
-template <bool SECONDARY>
+// MODE 0: the closest-hit pass over `p`; 1: the shadow pass over `s`; 2 ("joint", rodent_hip_render_trace_persistent(dev, 2)): BOTH in
+// one launch -- the closest-hit pass of an iteration and the shadow pass of the iteration before it depend on the same shader
+// run and on nothing else, so their chunks go through one ticket sequence (the closest-hit chunks first): one resident
+// generation works through both lists, no pass waits for the other's tail, and there is no second stream whose kernels a
+// persistent grid would shut out.
+template <int MODE>
 __global__ __launch_bounds__(kWave * kPersistWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_trace_persist(SceneDev sc, PrimaryStream p, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
-                     int* deep_count, unsigned long long* counters, int* deep_list, int* tickets) {
+void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
+                     int* deep_count_primary, int* deep_count_secondary, unsigned long long* counters, int* deep_list_primary, int* deep_list_secondary, int* tickets) {
     constexpr int kStackInts = kPersistWaves * (kTopStack + 1) * kWave;
     __shared__ __attribute__((aligned(16))) int lds[kStackInts + kPersistTopNodes * 16];
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
@@ -361,36 +366,36 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, SecondaryStream s, const int*
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     for (int j = threadIdx.x; j < kPersistTopNodes * 4; j += kWave * kPersistWaves)
         reinterpret_cast<__attribute__((address_space(3))) i32x4*>(image)[j] = reinterpret_cast<const i32x4*>(sc.top_image_large)[j];
-    const int n = stream_size(size_ptr, n_value), total_chunks = (n + kWave - 1) / kWave;
+    const int np = MODE == 1 ? 0 : n_primary, ns = MODE == 0 ? 0 : stream_size(size_ptr, n_value);
+    const int chunks_p = (np + kWave - 1) / kWave, total_chunks = chunks_p + (ns + kWave - 1) / kWave;
     const int stripe = blockIdx.x % kTraceStripes, stripe_waves = (gridDim.x / kTraceStripes) * kPersistWaves;
     int* counter = tickets + stripe * kTraceCounterStride;
     int t = (blockIdx.x / kTraceStripes) * kPersistWaves + wave;
     lds_int* col = (lds_int*)lds + wave * (kTopStack + 1) * kWave + lane;
     __syncthreads();
-    if (!SECONDARY && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)n);
+    if (MODE != 1 && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)np);
     for (;;) {
         const int group_first = ((t / 32) * kTraceStripes + stripe) * 32, chunk = group_first + t % 32;
         if (group_first >= total_chunks) break;
-        if (chunk < total_chunks) {
+        if (chunk < chunks_p) {
             const int i = chunk * kWave + lane;
-            if (!SECONDARY) {
-                if (i < n) {
-                    CursorStack st; st.init(col, kTopStack);
-                    trace_primary_ray<true>(sc, p, i, &st, nullptr, image);
-                    if (st.overflow) deep_list[atomicAdd(deep_count, 1)] = i;
-                }
-            } else {
-                const int pixel = i < n ? s.rays.id[i] : -1;
-                const unsigned long long live = __ballot(pixel >= 0);
-                if (lane == 0 && live) atomicAdd(&counters[4 + (chunk & 63)], (unsigned long long)__popcll(live));
-                bool lit = false;
-                if (pixel >= 0) {
-                    CursorStack st; st.init(col, kTopStack);
-                    lit = !trace_one<true, true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {}, image);
-                    if (st.overflow) { deep_list[atomicAdd(deep_count, 1)] = i; lit = false; }      // k_trace_deep decides
-                }
-                film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
+            if (i < np) {
+                CursorStack st; st.init(col, kTopStack);
+                trace_primary_ray<true>(sc, p, i, &st, nullptr, image);
+                if (st.overflow) deep_list_primary[atomicAdd(deep_count_primary, 1)] = i;
             }
+        } else if (chunk < total_chunks) {
+            const int c = chunk - chunks_p, i = c * kWave + lane;
+            const int pixel = i < ns ? s.rays.id[i] : -1;
+            const unsigned long long live = __ballot(pixel >= 0);
+            if (lane == 0 && live) atomicAdd(&counters[4 + (c & 63)], (unsigned long long)__popcll(live));
+            bool lit = false;
+            if (pixel >= 0) {
+                CursorStack st; st.init(col, kTopStack);
+                lit = !trace_one<true, true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {}, image);
+                if (st.overflow) { deep_list_secondary[atomicAdd(deep_count_secondary, 1)] = i; lit = false; }      // k_trace_deep decides
+            }
+            film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
         }
         int t_next = 0;
         if (lane == 0) t_next = atomicAdd(counter, 1);
@@ -854,7 +859,9 @@ struct RenderDevice {
     int capacity = 0;                          // rays per stream; 0 = default (env_capacity())
     int sort = 0;                              // 1 = sort hit rays by material before shading (mapping_gpu.impala:166-221), 0 = shade in stream order (default: the shader is ONE table-driven
                                                // kernel, not a kernel per material, and the sort costs more than the divergence it removes -- 5 ... 22 % of the frame on every scene of profiles/r03_sort_sweep.txt)
-    int trace_persistent = 0;                  // 1 = persistent stream traversal kernels (k_trace_persist: 16-wave workgroups, 255-record image, ticket counters)
+    int trace_persistent = 0;                  // in effect: 0 = 2-wave traversal workgroups (31-record image), shadow pass on the second stream; 1 = persistent stream traversal kernels
+                                               // (k_trace_persist: 16-wave workgroups, 255-record image, ticket counters); 2 = joint: both passes of a bounce in ONE persistent launch
+    int trace_persistent_request = -1;         // -1 = per scene (joint for every scene the per-scene mapping rule sends to the streaming loop), 0 / 1 / 2 = the caller's choice
     int* tickets[2] = {nullptr, nullptr}; int num_cus = 0;
     int lds_image = 1;                         // 1 = the stream traversal kernels stage the scene's top-of-tree image in LDS (2-wave workgroups); 0 = every node from memory
     int fused_sort = 0;                        // 0 = rays are moved by the sort (copy_primary_ray), then shaded in place; 1 = the sort only computes the permutation and the shader gathers through it
@@ -884,19 +891,20 @@ std::vector<float> g_host_film; size_t g_host_w = 0, g_host_h = 0;
 
 // every option of the renderer at its default, or at what its environment variable says (rodent_hip_render_defaults)
 void render_defaults(RenderDevice& r) {
-    r.sort = 0; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 2; r.lds_image = 1; r.trace_persistent = 0; r.mapping_request = -1; r.capacity = 0;
+    r.sort = 0; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 2; r.lds_image = 1; r.trace_persistent_request = -1; r.mapping_request = -1; r.capacity = 0;
     if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_FUSED_SORT")) r.fused_sort = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_FUSED_COMPACT")) r.fused_compact = std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("RODENT_HIP_LDS_IMAGE")) r.lds_image = atoi(e) ? 1 : 0;
-    if (const char* e = getenv("RODENT_HIP_TRACE_PERSISTENT")) r.trace_persistent = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("RODENT_HIP_TRACE_PERSISTENT")) r.trace_persistent_request = std::min(2, std::max(-1, atoi(e)));
     if (const char* m = getenv("RODENT_HIP_MAPPING")) {
         if (!strcmp(m, "mega") || !strcmp(m, "megakernel") || !strcmp(m, "1")) r.mapping_request = 1;
         else if (!strcmp(m, "streaming") || !strcmp(m, "0")) r.mapping_request = 0;
         else if (strcmp(m, "auto") && strcmp(m, "-1")) { fprintf(stderr, "rodent_hip: RODENT_HIP_MAPPING must be 'auto', 'streaming' or 'mega'\n"); abort(); }
     }
     r.mapping = r.mapping_request == 1 ? 1 : 0;
+    r.trace_persistent = std::max(0, r.trace_persistent_request);
 }
 
 RenderDevice& rdev(int dev) {
@@ -980,8 +988,8 @@ void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStre
     int* tickets = nullptr;
     if (r.trace_persistent && n >= kPersistMinRays) {
         ensure_tickets(r); tickets = r.tickets[0];
-        hipLaunchKernelGGL(k_trace_persist<false>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, SecondaryStream{}, (const int*)nullptr, n, (float*)nullptr, 0.0f,
-                           r.ctl + 3, r.counters, r.deep_list[0], tickets);
+        hipLaunchKernelGGL(k_trace_persist<0>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
+                           r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets);
     } else if (r.lds_image) hipLaunchKernelGGL((k_trace_primary<kTraceWaves, kSceneTopNodes>), dim3((n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
     else hipLaunchKernelGGL((k_trace_primary<1, 0>), dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
     hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_stack[0], tickets, r.ctl + 6);
@@ -991,11 +999,22 @@ void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const Secondary
     int* tickets = nullptr;
     if (r.trace_persistent && max_n >= kPersistMinRays) {
         ensure_tickets(r); tickets = r.tickets[1];
-        hipLaunchKernelGGL(k_trace_persist<true>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, s, size_ptr, max_n, r.film, inv_spp,
-                           r.ctl + 4, r.counters, r.deep_list[1], tickets);
+        hipLaunchKernelGGL(k_trace_persist<1>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, s, size_ptr, max_n, r.film, inv_spp,
+                           r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets);
     } else if (r.lds_image) hipLaunchKernelGGL((k_trace_secondary<kTraceWaves, kSceneTopNodes>), dim3((max_n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
     else hipLaunchKernelGGL((k_trace_secondary<1, 0>), dim3((max_n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
     hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_stack[1], tickets, (int*)nullptr);
+}
+
+// Joint form: the closest-hit pass over `p` (n rays) and the shadow pass over `s` (size *size_ptr, or max_n) in ONE persistent launch,
+// then the two follow-up kernels for the rays either pass abandoned.
+void launch_trace_joint(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n, const SecondaryStream& s, const int* size_ptr, int max_n, float inv_spp) {
+    ensure_deep(r, 0, n); ensure_deep(r, 1, max_n);
+    ensure_tickets(r);
+    hipLaunchKernelGGL(k_trace_persist<2>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, s, size_ptr, max_n, r.film, inv_spp,
+                       r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0]);
+    hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_stack[0], r.tickets[0], r.ctl + 6);
+    hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_stack[1], (int*)nullptr, (int*)nullptr);
 }
 
 void ensure_hist(RenderDevice& r, size_t ints) {
@@ -1075,7 +1094,9 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     // Shadow rays are independent of what follows the shader on the primary stream (compaction, regeneration, the next
     // closest-hit pass and sort): they are traced on a second HIP stream and joined again before the next shader run
     // overwrites the secondary stream.  The latency-bound traversal then shares the chip with the HBM-bound stream copies.
-    const bool overlap = r.overlap != 0;
+    const bool joint = r.trace_persistent == 2;          // the shadow pass of an iteration rides in the next iteration's closest-hit launch: one stream
+    const bool overlap = r.overlap != 0 && !joint;
+    bool shadow_pending = false; const int* shadow_size_ptr = nullptr; int shadow_n = 0;
     if (overlap && !r.aux) {
         HIP_CHECK(hipStreamCreateWithFlags(&r.aux, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&r.ev_shade, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&r.ev_sec, hipEventDisableTiming));
@@ -1088,7 +1109,6 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
         HIP_CHECK(hipMalloc(&r.perm, sizeof(int) * (size_t)round_cap(kCapacity)));
         r.perm_cap = round_cap(kCapacity);
     }
-    hipStream_t sstream = overlap ? r.aux : stream;
     const bool fused = r.fused_compact != 0;
     int* d_alive = r.ctl + 6;                            // fused compaction: the shader's last block leaves the new stream size here
     if (fused && r.scan_cap < (kCapacity + kBlock - 1) / kBlock) {
@@ -1114,7 +1134,17 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
             id += n; size += n; generated += n;
         }
         const int blocks = (size + kBlock - 1) / kBlock;
-        launch_trace_primary(r, stream, *primary, size);
+        if (joint && shadow_pending && size >= kPersistMinRays) launch_trace_joint(r, stream, *primary, size, sec, shadow_size_ptr, shadow_n, inv_spp);
+        else {
+            if (joint && shadow_pending) launch_trace_secondary(r, stream, sec, shadow_size_ptr, shadow_n, inv_spp);
+            launch_trace_primary(r, stream, *primary, size);
+        }
+        shadow_pending = false;
+        // the shadow pass of this iteration: on the second stream, behind the shader on this one, or (joint) inside the next closest-hit launch
+        const auto shadow_pass = [&](const int* size_ptr) {
+            if (joint) { shadow_pending = true; shadow_size_ptr = size_ptr; shadow_n = size; }
+            else launch_trace_secondary(r, overlap ? r.aux : stream, sec, size_ptr, size, inv_spp);
+        };
         if (r.sort) {
             if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_copy, 0));      // the aux stream has its copy of the previous valid count
             if (r.fused_sort) {
@@ -1136,9 +1166,9 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
                 HIP_CHECK(hipStreamWaitEvent(r.aux, r.ev_shade, 0));
                 hipLaunchKernelGGL(k_copy_int, dim3(1), dim3(1), 0, r.aux, d_valid, r.ctl + 5);
                 HIP_CHECK(hipEventRecord(r.ev_copy, r.aux));
-                launch_trace_secondary(r, r.aux, sec, r.ctl + 5, size, inv_spp);
+                shadow_pass(r.ctl + 5);
                 HIP_CHECK(hipEventRecord(r.ev_sec, r.aux));
-            } else launch_trace_secondary(r, stream, sec, d_valid, size, inv_spp);
+            } else shadow_pass(d_valid);
             if (!fused) bin_stream(r, 1, *primary, *other, d_valid, size, KEY_ALIVE, 2, 0, 1, stream);       // compaction (:267-300)
         } else {                                     // option: no sort by material -- shade in stream order, misses end in the shader
             if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));
@@ -1148,7 +1178,7 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
                 HIP_CHECK(hipEventRecord(r.ev_shade, stream));
                 HIP_CHECK(hipStreamWaitEvent(r.aux, r.ev_shade, 0));
             }
-            launch_trace_secondary(r, sstream, sec, nullptr, size, inv_spp);
+            shadow_pass(nullptr);
             if (overlap) HIP_CHECK(hipEventRecord(r.ev_sec, r.aux));
             if (!fused) bin_stream(r, 1, *primary, *other, nullptr, size, KEY_ALIVE, 2, 0, 1, stream);
         }
@@ -1158,6 +1188,7 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
         size = r.host_pinned[0];
         iterations++;
     }
+    if (shadow_pending) launch_trace_secondary(r, stream, sec, shadow_size_ptr, shadow_n, inv_spp);       // joint: the last iteration's shadow rays
     if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));           // the last shadow rays belong to this call
     const unsigned long long host_counts[2] = {iterations, generated};
     HIP_CHECK(hipMemcpyAsync(r.counters + 2, host_counts, sizeof(host_counts), hipMemcpyHostToDevice, stream));
@@ -1209,6 +1240,13 @@ int auto_mega_max_nodes() {
 int resolve_mapping(const RenderDevice& r) {
     if (r.mapping_request >= 0) return r.mapping_request;
     return r.scene.loaded && r.scene.num_nodes <= auto_mega_max_nodes() ? 1 : 0;
+}
+// The stream traversal launches of the streaming loop when the caller leaves the choice to the library: the joint persistent launch
+// for every hierarchy above the megakernel's size class (+3 ... +9 % on the atrium at 306 ... 142 444 nodes, profiles/r03_joint_sweep.txt),
+// the 2-wave kernels with the shadow pass on a second stream for a tree of a few dozen nodes (Cornell box: joint -5 %).
+int resolve_trace(const RenderDevice& r) {
+    if (r.trace_persistent_request >= 0) return r.trace_persistent_request;
+    return r.scene.loaded && r.scene.num_nodes > auto_mega_max_nodes() ? 2 : 0;
 }
 
 template <typename T> T* upload(DevScene& s, const T* host, size_t count) {
@@ -1304,6 +1342,7 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
     s.num_nodes = d->num_nodes;
     s.loaded = true;
     r.mapping = resolve_mapping(r);
+    r.trace_persistent = resolve_trace(r);
 }
 
 void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
@@ -1316,7 +1355,7 @@ void rodent_hip_render_overlap(int32_t dev, int32_t enable) { rdev(dev).overlap 
 void rodent_hip_render_fused_sort(int32_t dev, int32_t enable) { rdev(dev).fused_sort = enable ? 1 : 0; }
 void rodent_hip_render_fused_compact(int32_t dev, int32_t enable) { rdev(dev).fused_compact = std::min(2, std::max(0, (int)enable)); }
 void rodent_hip_render_lds_image(int32_t dev, int32_t enable) { rdev(dev).lds_image = enable ? 1 : 0; }
-void rodent_hip_render_trace_persistent(int32_t dev, int32_t enable) { rdev(dev).trace_persistent = enable ? 1 : 0; }
+void rodent_hip_render_trace_persistent(int32_t dev, int32_t enable) { RenderDevice& r = rdev(dev); r.trace_persistent_request = std::min(2, std::max(-1, (int)enable)); r.trace_persistent = resolve_trace(r); }
 
 void rodent_hip_render_capacity(int32_t dev, int32_t rays) {
     if (rays != 0 && (rays < 64 || rays > kMaxCapacity)) { fprintf(stderr, "rodent_hip: stream capacity must be 0 (default) or 64 .. %ld rays\n", kMaxCapacity); abort(); }
@@ -1330,7 +1369,7 @@ void rodent_hip_render_mapping(int32_t dev, int32_t mapping) {
     r.mapping = resolve_mapping(r);
 }
 int32_t rodent_hip_render_mapping_in_effect(int32_t dev) { return rdev(dev).mapping; }
-void rodent_hip_render_defaults(int32_t dev) { RenderDevice& r = rdev(dev); render_defaults(r); r.mapping = resolve_mapping(r); }
+void rodent_hip_render_defaults(int32_t dev) { RenderDevice& r = rdev(dev); render_defaults(r); r.mapping = resolve_mapping(r); r.trace_persistent = resolve_trace(r); }
 
 int32_t get_spp(void) { return rdev(g_current_dev).spp; }
 

@@ -110,7 +110,7 @@ class Renderer:
                               (overlap, l.rodent_hip_render_overlap),              # shadow rays on a second HIP stream
                               (fused_sort, l.rodent_hip_render_fused_sort),        # the sort computes a permutation, the shader gathers through it
                               (lds_image, l.rodent_hip_render_lds_image),          # stream traversal kernels stage the top of the BVH in LDS
-                              (trace_persistent, l.rodent_hip_render_trace_persistent),   # persistent form of those kernels for streams of >= 512 Ki rays
+                              (trace_persistent, l.rodent_hip_render_trace_persistent),   # 0 / 1 / 2: 2-wave kernels + second stream / persistent / joint persistent launch (default: per scene)
                               (fused_compact, l.rodent_hip_render_fused_compact)):        # the shader writes continuing rays to their compacted slots
             if value is not None:
                 setter(dev, int(value))

@@ -1,2 +1,2 @@
-export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "two_ranks" 2>&1 | tail -30
+export TMPDIR=/tmp; mkdir -p gpurun_out/r03
+timeout 900 python scripts/joint_sweep.py 2>&1 | tee gpurun_out/r03/joint_sweep.txt

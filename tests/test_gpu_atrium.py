@@ -177,6 +177,27 @@ def test_atrium_compaction_modes_match_oracle(R, atrium_scene, atrium_reference,
     assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
 
 
+@pytest.mark.parametrize("sort", [False, True])
+def test_atrium_joint_traversal_launch_renders_the_same_frame(R, atrium_scene, sort):
+    """rodent_hip_render_trace_persistent(dev, 2): the shadow pass of an iteration rides in the next iteration's closest-hit launch (one
+    persistent kernel over both ray lists, one stream).  Streams of more than 524 288 rays (below that the joint form is not
+    used), regeneration included: same ray counts as the default loop -- which the tests above hold against the oracle -- and
+    the same film up to the order of the atomic adds."""
+    W, H, SPP, MAXLEN = 640, 360, 8, 8                                    # 1.8 M paths, 700 000-ray streams: three refills
+    cam = atrium_camera(W, H)
+    out = {}
+    for mode in (0, 1, 2):                                                # 2-wave kernels + second stream / persistent kernels / joint (the default for this scene)
+        r = R.Renderer(atrium_scene, W, H, SPP, MAXLEN, mapping="streaming", sort=sort, trace_persistent=mode, capacity=700_000)
+        r.render(cam, 3)
+        out[mode] = (r.counters(), r.film()); r.close()
+    c0, f0 = out[0]
+    for mode in (1, 2):
+        c, f = out[mode]
+        assert (c["primary_rays"], c["shadow_rays"], c["generated"]) == (c0["primary_rays"], c0["shadow_rays"], W * H * SPP), mode
+        assert np.allclose(f, f0, rtol=FILM_RTOL, atol=FILM_ATOL), mode
+    assert f0.mean() > 1e-3
+
+
 def test_atrium_takes_the_streaming_mapping_by_default(R, atrium_scene):
     f = ATRIUM_FRAME
     r = R.Renderer(atrium_scene, f["W"], f["H"], 1, 2, mapping="auto")
