@@ -255,16 +255,21 @@ bool load_jpg(const std::string& path, ImageRgba8& img, std::string* error) {
     std::vector<uint8_t> file;
     if (!read_file(path, file)) return fail(error, "cannot read '" + path + "'");
     if (file.size() < 4 || file[0] != 0xFF || file[1] != 0xD8) return fail(error, "not a JPEG file");
+    // Baseline / extended sequential (SOF0 / SOF1) and PROGRESSIVE (SOF2) Huffman JPEG, any number of scans: every scan
+    // decodes into per-component coefficient arrays (ITU T.81 F.2 / G.2: spectral selection Ss..Se, successive approximation
+    // Ah / Al, end-of-band runs, refinement passes); dequantisation and the inverse DCT follow the last scan.  The reference
+    // reads its textures with libjpeg (src/driver/image.cpp:185-238), which decodes all of these.
     uint16_t qt[4][64] = {}; Huff dc[4], ac[4];
     std::vector<JpegComp> comps;
-    int width = 0, height = 0, restart_interval = 0, adobe_transform = -1;
+    std::vector<std::vector<int16_t>> coef;                               // per component: blocks in raster order over the padded grid x 64, natural order
+    int width = 0, height = 0, restart_interval = 0, adobe_transform = -1, hmax = 1, vmax = 1, mcux = 0, mcuy = 0;
+    bool progressive = false, any_scan = false;
     size_t pos = 2;
-    const uint8_t* scan = nullptr;
     while (pos + 4 <= file.size()) {
         if (file[pos] != 0xFF) { pos++; continue; }
         const int marker = file[pos + 1];
         if (marker == 0xFF) { pos++; continue; }
-        if (marker == 0xD8 || (marker >= 0xD0 && marker <= 0xD7) || marker == 0x01) { pos += 2; continue; }
+        if (marker == 0x00 || marker == 0xD8 || (marker >= 0xD0 && marker <= 0xD7) || marker == 0x01) { pos += 2; continue; }
         if (marker == 0xD9) break;
         const size_t len = ((size_t)file[pos + 2] << 8) | file[pos + 3];
         if (len < 2 || pos + 2 + len > file.size()) return fail(error, "truncated JPEG segment");
@@ -287,63 +292,154 @@ bool load_jpg(const std::string& path, ImageRgba8& img, std::string* error) {
                 memcpy(h.vals, d + i, total); i += total;
                 build_huff(h);
             }
-        } else if (marker == 0xC0 || marker == 0xC1) {                   // SOF0 / SOF1: sequential Huffman
+        } else if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2) { // SOF0 / SOF1: sequential Huffman; SOF2: progressive Huffman
+            if (!comps.empty()) return fail(error, "JPEG with more than one frame");
             if (n < 6 || d[0] != 8) return fail(error, "only 8-bit JPEG is supported");
+            progressive = marker == 0xC2;
             height = (d[1] << 8) | d[2]; width = (d[3] << 8) | d[4];
             const int nc = d[5];
-            if ((nc != 1 && nc != 3) || n < 6 + 3 * (size_t)nc) return fail(error, "unsupported JPEG component count");
+            if ((nc != 1 && nc != 3) || n < 6 + 3 * (size_t)nc || width <= 0 || height <= 0) return fail(error, "unsupported JPEG component count");
             comps.resize(nc);
             for (int c = 0; c < nc; c++) { comps[c].id = d[6 + 3 * c]; comps[c].h = d[7 + 3 * c] >> 4; comps[c].v = d[7 + 3 * c] & 15; comps[c].tq = d[8 + 3 * c] & 3; }
-        } else if (marker == 0xC2 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC)) {
-            return fail(error, "progressive / arithmetic / lossless JPEG is not supported");
+            // a frame with ONE component is never interleaved: its MCU is a single 8x8 block whatever the sampling factors say
+            // (ITU T.81 A.2.2; several encoders write greyscale files with 2x2 factors)
+            if (nc == 1) comps[0].h = comps[0].v = 1;
+            for (auto& c : comps) { if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4) return fail(error, "bad JPEG component"); hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+            mcux = (width + 8 * hmax - 1) / (8 * hmax); mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+            coef.resize(nc);
+            for (int c = 0; c < nc; c++) { comps[c].stride = (size_t)mcux * comps[c].h * 8; coef[c].assign((size_t)mcux * comps[c].h * mcuy * comps[c].v * 64, 0); }
+        } else if (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC) {
+            return fail(error, "arithmetic-coded / lossless / hierarchical JPEG is not supported");
         } else if (marker == 0xDD && n >= 2) restart_interval = (d[0] << 8) | d[1];
         else if (marker == 0xEE && n >= 12 && !memcmp(d, "Adobe", 5)) adobe_transform = d[11];
-        else if (marker == 0xDA) {                                       // SOS
-            if (comps.empty() || n < 1 + 2 * (size_t)d[0] + 3 || d[0] != comps.size()) return fail(error, "unsupported JPEG scan layout");
-            for (int s = 0; s < d[0]; s++)
-                for (auto& c : comps) if (c.id == d[1 + 2 * s]) { c.td = d[2 + 2 * s] >> 4; c.ta = d[2 + 2 * s] & 15; }
-            scan = &file[pos + 2 + len];
-            break;
+        else if (marker == 0xDA) {                                       // SOS: one scan
+            const int ns = n ? d[0] : 0;
+            if (comps.empty() || ns < 1 || ns > (int)comps.size() || n < 1 + 2 * (size_t)ns + 3) return fail(error, "unsupported JPEG scan layout");
+            std::vector<int> in_scan;
+            for (int k = 0; k < ns; k++) {
+                int found = -1;
+                for (size_t c = 0; c < comps.size(); c++) if (comps[c].id == d[1 + 2 * k]) found = (int)c;
+                if (found < 0) return fail(error, "JPEG scan refers to an unknown component");
+                comps[found].td = d[2 + 2 * k] >> 4; comps[found].ta = d[2 + 2 * k] & 15;
+                in_scan.push_back(found);
+            }
+            const int ss = d[1 + 2 * ns], se = d[2 + 2 * ns], ah = d[3 + 2 * ns] >> 4, al = d[3 + 2 * ns] & 15;
+            if (progressive ? (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13) : (ss != 0 || se != 63 || ah != 0 || al != 0))
+                return fail(error, "bad JPEG scan parameters");
+            for (int c : in_scan) {
+                if ((!progressive || ss == 0) && ah == 0 && !dc[comps[c].td & 3].defined) return fail(error, "JPEG scan without its DC table");
+                if ((!progressive || ss > 0) && !ac[comps[c].ta & 3].defined) return fail(error, "JPEG scan without its AC table");
+            }
+            BitReader br{&file[pos + 2 + len], file.data() + file.size()};
+            for (auto& c : comps) c.pred = 0;
+            int eobrun = 0, until_restart = restart_interval;
+            // an interleaved scan walks MCUs (h x v blocks of every component); a scan of one component walks that component's
+            // own blocks: ceil(its width / 8) x ceil(its height / 8) (A.2.2, A.2.3)
+            const bool interleaved = ns > 1;
+            const JpegComp& c0 = comps[in_scan[0]];
+            const int units_x = interleaved ? mcux : ((width * c0.h + hmax - 1) / hmax + 7) / 8, units_y = interleaved ? mcuy : ((height * c0.v + vmax - 1) / vmax + 7) / 8;
+            for (int uy = 0; uy < units_y; uy++) for (int ux = 0; ux < units_x; ux++) {
+                if (restart_interval && until_restart == 0) {            // RSTn: byte-align, skip the marker, reset predictors and the band run
+                    while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) br.p++;
+                    if (br.p + 1 < br.end) br.p += 2;
+                    br.restart();
+                    for (auto& c : comps) c.pred = 0;
+                    eobrun = 0; until_restart = restart_interval;
+                }
+                for (int ci : in_scan) {
+                    JpegComp& c = comps[ci];
+                    const int bw = interleaved ? c.h : 1, bh = interleaved ? c.v : 1;
+                    for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
+                        const size_t block_x = (size_t)ux * bw + bx, block_y = (size_t)uy * bh + by;
+                        int16_t* blk = &coef[ci][(block_y * ((size_t)mcux * c.h) + block_x) * 64];
+                        if (!progressive) {                              // F.2.2: the whole block
+                            const int t = decode_huff(br, dc[c.td & 3]);
+                            if (t < 0 || t > 11) return fail(error, "corrupt JPEG data (DC)");
+                            c.pred += extend(br.bits(t), t);
+                            blk[0] = (int16_t)c.pred;
+                            for (int k = 1; k < 64;) {
+                                const int rs = decode_huff(br, ac[c.ta & 3]);
+                                if (rs < 0) return fail(error, "corrupt JPEG data (AC)");
+                                const int r = rs >> 4, sz = rs & 15;
+                                if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                                k += r;
+                                if (k > 63) return fail(error, "corrupt JPEG data (run)");
+                                blk[kZigzag[k]] = (int16_t)extend(br.bits(sz), sz);
+                                k++;
+                            }
+                        } else if (ss == 0) {                            // G.1.2.1: DC, first pass / refinement bit
+                            if (ah == 0) {
+                                const int t = decode_huff(br, dc[c.td & 3]);
+                                if (t < 0 || t > 11) return fail(error, "corrupt JPEG data (DC)");
+                                c.pred += extend(br.bits(t), t);
+                                blk[0] = (int16_t)(c.pred * (1 << al));
+                            } else if (br.bit()) blk[0] = (int16_t)(blk[0] | (1 << al));
+                        } else if (ah == 0) {                            // G.1.2.2: AC band, first pass
+                            if (eobrun > 0) { eobrun--; continue; }
+                            for (int k = ss; k <= se;) {
+                                const int rs = decode_huff(br, ac[c.ta & 3]);
+                                if (rs < 0) return fail(error, "corrupt JPEG data (AC)");
+                                const int r = rs >> 4, sz = rs & 15;
+                                if (sz == 0) {
+                                    if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += br.bits(r); break; }
+                                    k += 16;
+                                } else {
+                                    k += r;
+                                    if (k > se) return fail(error, "corrupt JPEG data (run)");
+                                    blk[kZigzag[k]] = (int16_t)(extend(br.bits(sz), sz) * (1 << al));
+                                    k++;
+                                }
+                            }
+                        } else {                                         // G.1.2.3: AC band, refinement
+                            const int p1 = 1 << al, m1 = -(1 << al);
+                            const auto refine = [&](int16_t& v) { if (br.bit() && (v & p1) == 0) v = (int16_t)(v + (v >= 0 ? p1 : m1)); };
+                            int k = ss;
+                            if (eobrun == 0) {
+                                for (; k <= se; k++) {
+                                    const int rs = decode_huff(br, ac[c.ta & 3]);
+                                    if (rs < 0) return fail(error, "corrupt JPEG data (AC)");
+                                    int r = rs >> 4, val = 0;
+                                    if (rs & 15) val = br.bit() ? p1 : m1;                 // (the size is 1)
+                                    else if (r != 15) { eobrun = 1 << r; if (r) eobrun += br.bits(r); break; }
+                                    // pass over the coefficients that are non-zero already (one correction bit each) and over r zero ones
+                                    while (k <= se) {
+                                        int16_t& v = blk[kZigzag[k]];
+                                        if (v != 0) refine(v);
+                                        else if (--r < 0) break;
+                                        k++;
+                                    }
+                                    if (val && k <= se) blk[kZigzag[k]] = (int16_t)val;
+                                }
+                            }
+                            if (eobrun > 0) {
+                                for (; k <= se; k++) { int16_t& v = blk[kZigzag[k]]; if (v != 0) refine(v); }
+                                eobrun--;
+                            }
+                        }
+                    }
+                }
+                if (restart_interval) until_restart--;
+            }
+            any_scan = true;
+            pos = (size_t)(br.p - file.data());                           // the next marker follows the entropy-coded data
+            continue;
         }
         pos += 2 + len;
     }
-    if (!scan || width <= 0 || height <= 0) return fail(error, "JPEG without image data");
-    // a scan with ONE component is not interleaved: its MCU is a single 8x8 block whatever the sampling factors say
-    // (ITU T.81 A.2.2; several encoders write greyscale files with 2x2 factors)
-    if (comps.size() == 1) comps[0].h = comps[0].v = 1;
-    int hmax = 1, vmax = 1;
-    for (auto& c : comps) { if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || !dc[c.td & 3].defined || !ac[c.ta & 3].defined) return fail(error, "bad JPEG component"); hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
-    const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
-    for (auto& c : comps) { c.stride = (size_t)mcux * c.h * 8; c.plane.assign(c.stride * mcuy * c.v * 8, 0); }
-    BitReader br{scan, file.data() + file.size()};
-    int until_restart = restart_interval;
-    for (int my = 0; my < mcuy; my++) for (int mx = 0; mx < mcux; mx++) {
-        if (restart_interval && until_restart == 0) {                    // RSTn: byte-align, skip the marker, reset the predictors
-            while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) br.p++;
-            if (br.p + 1 < br.end) br.p += 2;
-            br.restart();
-            for (auto& c : comps) c.pred = 0;
-            until_restart = restart_interval;
+    if (!any_scan || width <= 0 || height <= 0) return fail(error, "JPEG without image data");
+    // dequantise (tables are in zigzag order) and transform every block
+    for (size_t ci = 0; ci < comps.size(); ci++) {
+        JpegComp& c = comps[ci];
+        c.plane.assign(c.stride * mcuy * c.v * 8, 0);
+        float dq[64];
+        for (int k = 0; k < 64; k++) dq[kZigzag[k]] = (float)qt[c.tq][k];
+        const size_t blocks_x = (size_t)mcux * c.h, blocks_y = (size_t)mcuy * c.v;
+        for (size_t by = 0; by < blocks_y; by++) for (size_t bx = 0; bx < blocks_x; bx++) {
+            const int16_t* blk = &coef[ci][(by * blocks_x + bx) * 64];
+            float block[64];
+            for (int k = 0; k < 64; k++) block[k] = (float)blk[k] * dq[k];
+            idct8x8(block, &c.plane[by * 8 * c.stride + bx * 8], c.stride);
         }
-        for (auto& c : comps) for (int by = 0; by < c.v; by++) for (int bx = 0; bx < c.h; bx++) {
-            float block[64] = {0};
-            const int t = decode_huff(br, dc[c.td & 3]);
-            if (t < 0 || t > 11) return fail(error, "corrupt JPEG data (DC)");
-            c.pred += extend(br.bits(t), t);
-            block[0] = (float)(c.pred * (int)qt[c.tq][0]);
-            for (int k = 1; k < 64;) {
-                const int rs = decode_huff(br, ac[c.ta & 3]);
-                if (rs < 0) return fail(error, "corrupt JPEG data (AC)");
-                const int r = rs >> 4, s = rs & 15;
-                if (s == 0) { if (r == 15) { k += 16; continue; } break; }
-                k += r;
-                if (k > 63) return fail(error, "corrupt JPEG data (run)");
-                block[kZigzag[k]] = (float)(extend(br.bits(s), s) * (int)qt[c.tq][k]);
-                k++;
-            }
-            idct8x8(block, &c.plane[((size_t)(my * c.v + by) * 8) * c.stride + (size_t)(mx * c.h + bx) * 8], c.stride);
-        }
-        if (restart_interval) until_restart--;
     }
     img.width = width; img.height = height;
     // Upsampling to full resolution: libjpeg's "fancy" triangle filters for the common 2x1 and 2x2 chroma layouts

@@ -6,9 +6,9 @@
 //
 // The reference links libpng and libjpeg; this image has no headers for them, so the decoders are written here:
 // PNG on top of zlib's inflate (all colour types and bit depths, non-interlaced and Adam7), baseline / extended
-// sequential Huffman JPEG (8-bit, any sampling factors, restart markers; 2x1 / 2x2 chroma is upsampled with libjpeg's
-// triangle filter and the IDCT is done in float, so texels can differ from libjpeg's by a level or two; progressive
-// files are rejected),
+// sequential AND progressive Huffman JPEG (8-bit, any sampling factors, any number of scans, restart markers; 2x1 / 2x2 chroma
+// is upsampled with libjpeg's triangle filter and the IDCT is done in float, so texels can differ from libjpeg's by a level
+// or two; arithmetic-coded, lossless and hierarchical files are rejected),
 // TGA types 2 / 3 / 10 / 11 (the reference's converter names a `load_tga` that its runtime never had).
 #pragma once
 #include <cstdint>

@@ -97,10 +97,43 @@ def test_jpeg_close_to_pil(native_build, tmp_path, subsampling, gray, restart):
     assert frac > 0.99, frac
 
 
-def test_progressive_jpeg_is_rejected(native_build, tmp_path):
-    Image.fromarray(picture(40, 40), "RGB").save(tmp_path / "p.jpg", progressive=True)
-    r = subprocess.run([native_build.BIN_DIR / "tex_dump", tmp_path / "p.jpg", tmp_path / "o"], capture_output=True, text=True)
-    assert r.returncode != 0 and "progressive" in r.stderr
+@pytest.mark.parametrize("subsampling,gray,restart,quality,size", [(0, False, 0, 92, (83, 61)), (2, False, 0, 92, (83, 61)), (1, False, 0, 75, (130, 47)), (0, True, 0, 92, (83, 61)),
+                                                                   (2, False, 3, 60, (200, 150)), (2, False, 0, 30, (64, 64))])
+def test_progressive_jpeg_close_to_pil(native_build, tmp_path, subsampling, gray, restart, quality, size):
+    """SOF2 files (spectral selection + successive approximation: DC first / refinement scans, AC bands with end-of-band runs,
+    AC refinement passes, several scans per component) decode like libjpeg's output -- the reference reads its textures with
+    libjpeg, which takes progressive files (src/driver/image.cpp:185-238)."""
+    w, h = size
+    rgb = picture(w, h, seed=11)
+    rgb[h // 2:, w // 2:] = np.clip(rgb[h // 2:, w // 2:].astype(int) // 2 + 60, 0, 255)          # smooth region
+    im = Image.fromarray(rgb, "RGB").convert("L" if gray else "RGB")
+    path = tmp_path / "p.jpg"
+    kw = {"quality": quality, "progressive": True}
+    if not gray:
+        kw["subsampling"] = subsampling
+    if restart:
+        kw["restart_marker_blocks"] = restart
+    try:
+        im.save(path, **kw)
+    except TypeError:
+        kw.pop("restart_marker_blocks", None); im.save(path, **kw)
+    assert b"\xff\xc2" in path.read_bytes()[:2000]                                                # really a progressive frame
+    got = decode(native_build, path, tmp_path).astype(int)
+    srgb = np.asarray(Image.open(path).convert("RGBA"), dtype=np.uint8)[::-1].astype(int)
+    lut = (np.power(np.arange(256, dtype=np.float32) * np.float32(1 / 255.0), np.float32(2.2)) * np.float32(255.0)).astype(int)
+    lo, hi = lut[np.clip(srgb[..., :3] - 3, 0, 255)], lut[np.clip(srgb[..., :3] + 3, 0, 255)]
+    inside = (got[..., :3] >= lo) & (got[..., :3] <= hi)
+    assert got.shape == srgb.shape and (got[..., 3] == 255).all()
+    assert inside.mean() > 0.99, inside.mean()
+
+
+def test_arithmetic_coded_jpeg_is_rejected(native_build, tmp_path):
+    Image.fromarray(picture(40, 40), "RGB").save(tmp_path / "p.jpg")
+    data = bytearray((tmp_path / "p.jpg").read_bytes())
+    i = data.index(b"\xff\xc0"); data[i + 1] = 0xC9                                               # SOF9: extended sequential, arithmetic coding
+    (tmp_path / "a.jpg").write_bytes(bytes(data))
+    r = subprocess.run([native_build.BIN_DIR / "tex_dump", tmp_path / "a.jpg", tmp_path / "o"], capture_output=True, text=True)
+    assert r.returncode != 0 and "arithmetic" in r.stderr
 
 
 @pytest.mark.parametrize("rle,alpha,gray", [(False, False, False), (True, False, False), (True, True, False), (False, False, True)])
