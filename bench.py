@@ -352,17 +352,13 @@ def render_cpu_baseline(threads):
     """The reference's CPU mapping restated (oracle/cpu_wavefront.inc: tile-parallel wavefront renderer, hybrid ray8 x BVH8
     traversal, scalar shading) on this host: a bounded sample of each configuration (same scene, camera and path length,
     fewer pixels and samples per pixel)."""
-    import subprocess
     from oracle import binding as O
-    from rodent_amd import build, formats as F, scene as S, scenes
+    from rodent_amd import formats as F, scene as S, scenes
     out = {}
     for name, (scene_name, w, h, spp, max_len) in RENDER_CONFIGS.items():
         obj, rscene = scene_file(scene_name)
         sc = S.Scene(rscene)
-        bvh = scenes.DATA / f"{scene_name}.bench.bvh"
-        if not bvh.exists():
-            subprocess.run([str(build.BIN_DIR / "bvh_extractor"), "-obj", str(obj), "-o", str(bvh)], check=True, stdout=subprocess.DEVNULL)
-        n8, t8 = F.read_bvh(bvh, F.BVH8_TRI4)
+        n8, t8 = F.read_bvh(scenes.scene_bvh(scene_name), F.BVH8_TRI4)      # the reference's CPU targets trace a BVH8 / Tri4 (converter.cpp:152-259)
         # bounded samples (seconds, not minutes, of CPU work): config 4 whole (133 M samples), config 5 at a quarter of the pixels and 8 spp
         sw, sh, sspp = (w, h, spp) if scene_name == "cornell" else (w // 2, h // 2, 8)
         eye, d, up, fov = scenes.CAMERAS[scene_name]
