@@ -1,5 +1,2 @@
-export TMPDIR=/tmp
-rm -rf data
-( time python bench.py > /tmp/b.json 2> /tmp/b.err ) 2>&1 | tail -3
-wc -l /tmp/b.json; tail -3 /tmp/b.err; python -c "
-import json; d=json.loads(open('/tmp/b.json').read()); print(d['value'], d['extra']['render']['cpu_baseline'])"
+export TMPDIR=/tmp; mkdir -p gpurun_out/r03
+timeout 600 python scripts/split_experiment.py 2>&1 | tee gpurun_out/r03/split_experiment.txt
