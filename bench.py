@@ -572,6 +572,8 @@ def main():
                   "random_kernel_ms": {"mean": round(kr_mean, 5), "median": round(kr_med, 5), "min": round(kr_min, 5)},
                   "kernel_ms_per_rank[primary,random]": main_part["kernel_ms_per_rank"],
                   "hit_counts[primary,random]": [int((hits["tri_id"] >= 0).sum()), int((hits_rnd["tri_id"] >= 0).sum())],
+                  "library": {"version": abi.lib().rodent_hip_version().decode(), "source_digest": abi.lib().rodent_hip_source_digest().decode(),
+                              "built_from_these_sources": abi.built_from_these_sources()},       # the prebuilt .so against the sources lying next to it
                   "two_streams_Mrays_s_per_gpu": None if overlapped is None else round(overlapped, 3),
                   "primary_16Mi_rays_per_launch": big},
     }

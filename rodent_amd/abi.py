@@ -29,7 +29,7 @@ SYNC_ENTRY_POINTS = [
 ASYNC_ENTRY_POINTS = ["hip_traverse_bvh2_tri1_async", "hip_traverse_bvh4_tri4_async", "hip_traverse_bvh8_tri4_async"]
 EXPORTS = SYNC_ENTRY_POINTS + ASYNC_ENTRY_POINTS + [
     "rodent_hip_check_errors", "rodent_hip_device_count", "rodent_hip_num_variants", "rodent_hip_variant_name",
-    "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_is_lab_build", "rodent_hip_phased_min_rays", "rodent_hip_top_min_rays", "rodent_hip_schedule_history", "rodent_hip_read_stats", "rodent_hip_read_trace", "rodent_hip_debug_set_perm",
+    "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_source_digest", "rodent_hip_is_lab_build", "rodent_hip_phased_min_rays", "rodent_hip_top_min_rays", "rodent_hip_schedule_history", "rodent_hip_read_stats", "rodent_hip_read_trace", "rodent_hip_debug_set_perm",
 ]
 BLOCK_OF_WIDTH = {2: F.BVH2_TRI1, 4: F.BVH4_TRI4, 8: F.BVH8_TRI4}
 
@@ -62,11 +62,18 @@ def lib():
         l.rodent_hip_variant_name.restype = C.c_char_p; l.rodent_hip_variant_name.argtypes = [i32, i32]
         l.rodent_hip_kernel_name.restype = C.c_char_p; l.rodent_hip_kernel_name.argtypes = [i32, i32, i32]
         l.rodent_hip_version.restype = C.c_char_p; l.rodent_hip_version.argtypes = []
+        l.rodent_hip_source_digest.restype = C.c_char_p; l.rodent_hip_source_digest.argtypes = []
         l.rodent_hip_read_trace.restype = None; l.rodent_hip_read_trace.argtypes = [i32, C.c_void_p]
         l.rodent_hip_debug_set_perm.restype = None; l.rodent_hip_debug_set_perm.argtypes = [i32, C.c_void_p]
         l.rodent_hip_read_stats.restype = None; l.rodent_hip_read_stats.argtypes = [i32, C.POINTER(C.c_uint64)]
         _lib = l
     return _lib
+
+
+def built_from_these_sources() -> bool:
+    """Whether the loaded library was compiled from the sources in this tree (its compiled-in digest against build.source_digest())."""
+    from . import build
+    return lib().rodent_hip_source_digest().decode() == build.source_digest()
 
 
 def variants(width):

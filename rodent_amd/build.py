@@ -63,16 +63,33 @@ def _headers():
     return list((ROOT / "include").glob("*.h")) + list(HOST.glob("*.h")) + list(CSRC.glob("*.h")) + list(CSRC.glob("*.hpp"))
 
 
+def _hip_lib_inputs():
+    return [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()] + [HOST / s for s in HIP_LIB_HOST_SOURCES]
+
+
+def source_digest() -> str:
+    """sha256 (16 hex digits) over everything librodent_hip.so is compiled from: its sources and every header they can include.
+    The build passes it to the compiler (-DRODENT_HIP_SOURCE_DIGEST) and the library returns it from rodent_hip_source_digest():
+    whoever loads a prebuilt .so can check that it was built from the sources lying next to it (tests, bench.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(_hip_lib_inputs() + _headers(), key=lambda p: str(p.relative_to(ROOT))):
+        h.update(str(f.relative_to(ROOT)).encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def build_hip_lib(force: bool = False) -> Path:
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     out = LIB_DIR / "librodent_hip.so"
-    srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()] + [HOST / s for s in HIP_LIB_HOST_SOURCES]
+    srcs = _hip_lib_inputs()
+    digest = f'-DRODENT_HIP_SOURCE_DIGEST="{source_digest()}"'
     if force or _newer(out, *srcs, *_headers()):
-        _run([HIPCC, *HIP_FLAGS, "-shared", *srcs, "-lz", "-o", out])
+        _run([HIPCC, *HIP_FLAGS, digest, "-shared", *srcs, "-lz", "-o", out])
     if os.environ.get("RODENT_HIP_LAB", "0") not in ("", "0"):
         lab = LIB_DIR / "librodent_hip_lab.so"
         if force or _newer(lab, *srcs, *_headers()):
-            _run([HIPCC, *HIP_FLAGS, "-DRODENT_HIP_LAB", "-shared", *srcs, "-lz", "-o", lab])
+            _run([HIPCC, *HIP_FLAGS, digest, "-DRODENT_HIP_LAB", "-shared", *srcs, "-lz", "-o", lab])
     return out
 
 

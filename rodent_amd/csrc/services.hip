@@ -172,6 +172,11 @@ void rodent_load_jpg(int32_t dev, const char* file, uint8_t** pixels, int32_t* w
     *pixels = (uint8_t*)img.pixels.ptr; *width = img.width; *height = img.height;
 }
 
+#ifndef RODENT_HIP_SOURCE_DIGEST
+#define RODENT_HIP_SOURCE_DIGEST "unknown"
+#endif
+const char* rodent_hip_source_digest(void) { return RODENT_HIP_SOURCE_DIGEST; }      // rodent_amd/build.py source_digest(), passed by the build
+
 int64_t clock_us(void) {                                                       // interface.cpp:665-673 (its non-x86 branch: a monotonic clock)
     return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }

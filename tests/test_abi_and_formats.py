@@ -160,6 +160,15 @@ def test_cli_errors(native_build, cornell):
     assert r.returncode == 1 and "disabled at compile-time" in r.stderr       # no CPU path in the product
 
 
+def test_library_was_built_from_the_sources_next_to_it(native_build):
+    """librodent_hip.so travels prebuilt (git-ignored, shipped to the GPU box with the snapshot): it carries the digest of the
+    sources it was compiled from (rodent_amd/build.py source_digest -> -DRODENT_HIP_SOURCE_DIGEST -> rodent_hip_source_digest()),
+    which must be the digest of the sources in this tree -- a stale binary cannot pass for the code under test."""
+    from rodent_amd import abi, build
+    assert abi.lib().rodent_hip_source_digest().decode() == build.source_digest() and abi.built_from_these_sources()
+    assert len(build.source_digest()) == 16 and build.source_digest() != "unknown"
+
+
 def test_fbuf2png(tmp_path, native_build):
     from PIL import Image
     t = np.linspace(0, 4, 16 * 8, dtype="<f4")

@@ -387,6 +387,7 @@ def test_bench_py_contract(native_build):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["passes"] >= 10 and "sample" in cb
     assert d["value"] > 1000 and d["extra"]["all_rays_bit_exact_vs_oracle"] == {"primary": True, "random": True}
+    assert d["extra"]["library"]["built_from_these_sources"] is True
     assert d["extra"]["random_sorted"]["identical_to_unsorted"] is True
 
 
