@@ -1,2 +1,2 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out/r03
-timeout 600 python scripts/split_experiment.py 2>&1 | tee gpurun_out/r03/split_experiment.txt
+timeout 900 python scripts/bounce_coherence_experiment.py 2>&1 | tee gpurun_out/r03/bounce_coherence_experiment.txt | tail -40
