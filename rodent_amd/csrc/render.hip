@@ -1475,7 +1475,7 @@ void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, 
     primary->size = num_rays; secondary->size = num_rays;
     if (num_rays <= 0) return;
     hipLaunchKernelGGL(k_shade, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, r.scene.dev, *primary, *primary, (const int*)nullptr, *secondary, (const int*)nullptr, num_rays, r.film,
-                       1.0f / (float)r.spp, r.max_path_len, 0, (unsigned*)nullptr, (int*)nullptr);
+                       1.0f / (float)r.spp, r.max_path_len, /* a ray that missed ends here instead of indexing the material table with the miss id: */ 1, (unsigned*)nullptr, (int*)nullptr);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -218,6 +218,30 @@ def test_stage_level_api_reproduces_render(R, oracle, cornell_scene):
     assert np.allclose(film, ref, rtol=FILM_RTOL, atol=FILM_ATOL)
 
 
+def test_stage_level_shader_ends_rays_that_missed(R, cornell_scene):
+    """hip_shade on a stream that was NOT sorted first (the reference's loop drops the misses in its sort, mapping_gpu.impala:347-357):
+    a ray that missed carries the miss id in geom_id; the shader must end it (id -1, no shadow ray), not index the material
+    table with it."""
+    import ctypes as C
+    W, H = 128, 96
+    cam = S.camera_settings((0, 1, 4.5), (0, 0, -1), (0, 1, 0), 80, W, H)          # from outside the box: many rays pass it
+    r = R.Renderer(cornell_scene, W, H, 1, 4)
+    l = R.stage_lib()
+    p, s = R.PrimaryStream(), R.SecondaryStream()
+    l.rodent_gpu_get_first_primary_stream(0, C.byref(p), W * H)
+    l.rodent_gpu_get_secondary_stream(0, C.byref(s), W * H)
+    st = R.make_settings(cam)
+    l.hip_generate_rays(0, C.byref(p), W * H, 0, W * H, C.byref(st), 0, W, H, 0, 1, None)
+    l.hip_traverse_primary(0, C.byref(p), None)
+    geom = R.read_stream_array(p.geom_id, W * H, "<i4")
+    missed = geom >= len(cornell_scene.materials)
+    assert 0.05 < missed.mean() < 0.95
+    l.hip_shade(0, C.byref(p), C.byref(s), W * H, None)
+    ids, sids = R.read_stream_array(p.rays.id, W * H, "<i4"), R.read_stream_array(s.rays.id, W * H, "<i4")
+    assert (ids[missed] == -1).all() and (sids[missed] == -1).all() and (ids[~missed] >= 0).sum() > 0
+    r.close()
+
+
 @pytest.mark.parametrize("spp,max_len,W,H", [(1, 64, 203, 121), (4, 64, 200, 120), (3, 2, 77, 50), (64, 4, 40, 30), (2048, 1, 5, 3)])
 def test_megakernel_matches_oracle(R, oracle, cornell_scene, spp, max_len, W, H):
     """The persistent-threads mapping (mapping_gpu.impala:371-474): same paths, same ray counts, per-path colour sums;
