@@ -154,7 +154,7 @@ int32_t     rodent_hip_is_lab_build(void);              /* 1 = librodent_hip_lab
 const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant);
 const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t any_hit);
 const char* rodent_hip_version(void);
-/* Digest of the sources this binary was compiled from (rodent_amd/build.py source_digest(): sha256 over csrc/*, the host code the
+/* Digest of the sources this binary was compiled from (rodent_amd/build.py source_digest(): sha256 over the files of csrc/, the host code the
  * library links and every header): a prebuilt library can be checked against the sources lying next to it. */
 const char* rodent_hip_source_digest(void);
 /* Debug aid: reads and clears the 8 phase counters of the instrumented "stats-*" variants

@@ -1377,7 +1377,7 @@ void setup_interface(size_t width, size_t height) { g_host_w = width; g_host_h =
 float* get_pixels(void) { return g_host_film.data(); }
 void cleanup_interface(void) {
     rodent_services_cleanup();                                               // buffers / BVHs / images loaded through rodent_load_* (services.hip)
-    for (auto& r : g_rdev) if (r.init && r.film) { hipSetDevice(r.dev); hipFree(r.film); r.film = nullptr; r.film_w = r.film_h = 0; }
+    for (auto& r : g_rdev) if (r.init && r.film) { (void)hipSetDevice(r.dev); (void)hipFree(r.film); r.film = nullptr; r.film_w = r.film_h = 0; }
     g_host_film.clear(); g_host_w = g_host_h = 0;
 }
 void clear_pixels(void) {                                                    // interface.cpp:498-505
