@@ -96,7 +96,8 @@ void    rodent_hip_render_capacity(int32_t dev, int32_t rays);
  * stays one call away.  Same paths, same ray counts; RODENT_HIP_SORT=0|1 sets the initial value, `rodent --sort` / `--no-sort`. */
 void    rodent_hip_render_sort(int32_t dev, int32_t enable);
 /* 1 (default): the shadow rays of a bounce are traced on a second HIP stream beside the compaction, regeneration and the
- * next closest-hit pass; 0: one stream.  Same film up to the order of the atomic adds.  RODENT_HIP_OVERLAP=0|1. */
+ * next closest-hit pass; 0: one stream.  Same film up to the order of the atomic adds.  RODENT_HIP_OVERLAP=0|1.
+ * (Without effect while the joint traversal launch is in use, rodent_hip_render_trace_persistent below: that loop has one stream.) */
 void    rodent_hip_render_overlap(int32_t dev, int32_t enable);
 /* 0 (default): rays are moved by the sort (copy_primary_ray, mapping_gpu.impala:136-164) and shaded in place.  1: the sort by
  * material only computes the permutation; the shader gathers its rays through it and writes the sorted stream (one copy of the
