@@ -117,6 +117,12 @@ void    rodent_hip_render_fused_compact(int32_t dev, int32_t enable);
  * (breadth first, built at scene creation) in LDS and fetch those with ds_read instead of through the vector-memory pipeline.
  * 0: one wave per workgroup, every node from memory (rounds 1-2).  Same per-ray visit order, same film.  RODENT_HIP_LDS_IMAGE=0|1. */
 void    rodent_hip_render_lds_image(int32_t dev, int32_t enable);
+/* Megakernel mapping.  0 (default): the reference's sequence of loops (closest hit, shade, shadow; mapping_gpu.impala:371-474).
+ * 1: a lane traces the shadow ray of its path vertex and the path's next ray back to back in ONE wave-level loop (a wave needs max
+ * over its lanes of the SUM of the two rays' steps instead of the sum of two maxima) -- measured 6 ... 14 % SLOWER (a path that ends
+ * with a shadow ray pending holds its lane for one more loop): an option, not the default.
+ * Same paths, same ray counts, same film up to the order of the atomic adds.  RODENT_HIP_MEGA_JOINT=0|1. */
+void    rodent_hip_render_mega_joint(int32_t dev, int32_t enable);
 /* The stream traversal launches of the streaming loop.
  * 0: 2-wave workgroups with a 31-node image (rodent_hip_render_lds_image), the shadow pass on a second stream (rodent_hip_render_overlap).
  * 1: persistent form (one resident generation of 16-wave workgroups, the first 255 inner nodes in LDS, 64-ray chunks drawn from

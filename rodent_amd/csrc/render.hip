@@ -261,6 +261,76 @@ __device__ __forceinline__ RayX make_rayx(float ox, float oy, float oz, float dx
     x.iox = -(x.ox * x.idx); x.ioy = -(x.oy * x.idy); x.ioz = -(x.oz * x.idz);
     return x;
 }
+// Two rays per lane, back to back, in ONE wave-level loop (the megakernel's joint form): first the shadow ray `a` (any hit:
+// the first accepted triangle ends it), then the path ray `b` (closest hit, on_hit_b for every accepted triangle), both from
+// the same origin.  A wave then needs max over its lanes of (steps of a + steps of b) iterations instead of the sum of the two
+// maxima of separate loops.  Per ray the visit order is trace_one's.  Returns {a was occluded, b hit something}.
+struct TwoHits { bool a_occluded, b_hit; };
+template <typename Stack, typename OnHit>
+__device__ __forceinline__ TwoHits trace_two(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, bool has_a, bool has_b,
+                                             float ox, float oy, float oz, float adx, float ady, float adz, float a_tmin, float a_tmax,
+                                             float bdx, float bdy, float bdz, float b_tmin, float b_tmax, Stack& st, OnHit on_hit_b) {
+    TwoHits out{false, false};
+    bool phase_a = has_a;
+    RayX ray = phase_a ? make_rayx(ox, oy, oz, adx, ady, adz, a_tmin, a_tmax) : make_rayx(ox, oy, oz, bdx, bdy, bdz, b_tmin, b_tmax);
+    ray.tmin = canonical(ray.tmin); ray.tmax = canonical(ray.tmax);
+    int ptr = 0, top = (has_a || has_b) ? 1 : 0;
+    st.put(0, 0);
+    typedef const __attribute__((address_space(1))) char* gptr;
+    unsigned long long node_bits = reinterpret_cast<unsigned long long>(nodes - 1), tri_bits = reinterpret_cast<unsigned long long>(tris);
+    asm volatile("" : "+v"(node_bits), "+v"(tri_bits));
+    const gptr node_base = (gptr)node_bits, tri_base = (gptr)tri_bits;
+    for (;;) {
+        // a lane whose shadow ray is finished goes on with its path ray (if it has one)
+        const bool next = top == 0 && phase_a;
+        if (__ballot(next)) {
+            if (next) {
+                phase_a = false;
+                if (has_b) {
+                    ray = make_rayx(ox, oy, oz, bdx, bdy, bdz, b_tmin, b_tmax);
+                    ray.tmin = canonical(ray.tmin); ray.tmax = canonical(ray.tmax);
+                    top = 1; ptr = 0; st.put(0, 0);
+                }
+            }
+        }
+        if (!__ballot(top != 0)) break;
+        if (top != 0) {
+            const bool is_node = top > 0;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            typedef int i32x2 __attribute__((ext_vector_type(2)));
+            const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
+            const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
+            const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
+            f32x4 q0 = p[0], q1 = p[1], q2 = p[2];
+            i32x2 ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
+            const int popped = st.get(ptr);
+            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
+            if (is_node) {
+                float te0, te1;
+                const bool h0 = slab_canonical(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
+                const bool h1 = slab_canonical(ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
+                const bool c0first = te0 < te1, both = h0 && h1;
+                top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
+                st.put(ptr + 1, c0first ? ch.y : ch.x);
+                ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
+            } else {
+                const int prim_id = __float_as_int(q2.w);
+                const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
+                float t, u, v;
+                bool ends = false;
+                if (intersect_tri(ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v)) {
+                    if (phase_a) { out.a_occluded = true; ends = true; }
+                    else { on_hit_b(prim_id & 0x7FFFFFFF, __float_as_int(q1.w), t, u, v); ray.tmax = t; out.b_hit = true; }
+                }
+                const bool leave = prim_id < 0;
+                top = ends ? 0 : (leave ? popped : top - 1);
+                ptr -= (leave && !ends) ? 1 : 0;
+            }
+        }
+    }
+    return out;
+}
+
 __device__ __forceinline__ RayX load_stream_ray(const RayStream& r, int i) {   // driver.impala:63-84
     return make_rayx(r.org_x[i], r.org_y[i], r.org_z[i], r.dir_x[i], r.dir_y[i], r.dir_z[i], r.tmin[i], r.tmax[i]);
 }
@@ -693,6 +763,74 @@ __global__ __launch_bounds__(kWave) void k_mega(SceneDev sc, CameraDev cam, floa
     }
 }
 
+// Joint form of the megakernel (rodent_hip_render_mega_joint(dev, 1); measured, NOT the default): the shadow ray of a path vertex and
+// the path's NEXT ray are traced back to back in one wave-level loop (trace_two) instead of in two loops that each wait for
+// their slowest lane; the shader runs between two such loops.  k_mega is issue-bound at 41 % lane utilisation
+// (profiles/r03_mega_pmc.txt), and the joint loop does save wave iterations inside a loop -- but a path whose last vertex still
+// has a shadow ray pending keeps its lane for one more loop in which it has no path ray to trace, and the phase switch builds
+// a second ray (three divisions) inside the loop: config 4 3 225 -> 2 786 Msamples/s, atrium 586 -> 550
+// (profiles/r03_render_rates_mega_joint.txt).  Per path the sequence is unchanged (ray, shade, shadow ray, next ray, ...); the
+// path's colour is added to the film when both its last ray and its last shadow ray are done.
+__global__ __launch_bounds__(kWave) void k_mega_joint(SceneDev sc, CameraDev cam, float* film, int film_w, int film_h, int y0, int y1, int iter, int spp,
+                                                      int max_path_len, int log2_tile, float inv_spp, int* err, unsigned long long* counters) {
+    __shared__ int lds[kLdsStack * kWave];
+    const int tile = 1 << log2_tile;
+    const int tile_x = blockIdx.x * tile, tile_y = y0 + blockIdx.y * tile;
+    const int tile_w = min(film_w - tile_x, tile), tile_h = min(y1 - tile_y, tile);
+    const int ray_count = tile_w * tile_h * spp;
+    StreamStack st; st.col = (lds_int*)lds + threadIdx.x; st.err = err;
+    int next = 0;                                   // wave-uniform
+    bool has_path = false, has_shadow = false, unpaid = false;      // unpaid: the path's colour has not gone to the film yet
+    PathVertex pv; pv.pixel = -1; pv.org = V(0, 0, 0); pv.dir = V(0, 0, 1); pv.rnd = 0; pv.mis = 0.0f; pv.contrib = V(0, 0, 0); pv.depth = 0;
+    float tmin = 0.0f;
+    v3 final_color = V(0, 0, 0), s_dir = V(0, 0, 1), s_color = V(0, 0, 0);
+    unsigned n_primary = 0, n_shadow = 0;
+    for (;;) {
+        const unsigned long long need = __ballot(!has_path && !has_shadow);
+        if (need && next < ray_count) {
+            const int id = next + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            next += __popcll(need);
+            if (!has_path && !has_shadow && id < ray_count) {
+                const int ray_id = id / spp, sample = id - ray_id * spp;
+                const int in_y = ray_id / tile_w, in_x = ray_id - in_y * tile_w;
+                const int x = tile_x + in_x, y = tile_y + in_y;
+                pv.dir = emit_sample(cam, iter, film_w, film_h, x, y, sample, &pv.rnd);
+                pv.org = LD3(cam.eye);
+                pv.pixel = y * film_w + x; pv.mis = 0.0f; pv.contrib = V(1, 1, 1); pv.depth = 0;
+                tmin = 0.0f; final_color = V(0, 0, 0);
+                has_path = true; unpaid = true;
+            }
+        }
+        if (!__ballot(has_path || has_shadow)) break;
+
+        n_primary += has_path ? 1u : 0u; n_shadow += has_shadow ? 1u : 0u;
+        const TwoHits hits = trace_two(sc.nodes, sc.tris, has_shadow, has_path, pv.org.x, pv.org.y, pv.org.z, s_dir.x, s_dir.y, s_dir.z, kRayOffset, 1.0f - kRayOffset,
+                                       pv.dir.x, pv.dir.y, pv.dir.z, tmin, FLT_MAX_REF, st,
+                                       [&](int prim, int geom, float t, float u, float v) { pv.prim = prim; pv.geom = geom; pv.t = t; pv.u = u; pv.v = v; });
+        if (has_shadow && !hits.a_occluded) final_color = add(final_color, s_color);
+        has_shadow = false;
+        if (has_path) {
+            if (!hits.b_hit) has_path = false;
+            else {
+                const ShadeOut o = shade_vertex(sc, pv, max_path_len);
+                if (o.emits) final_color = add(final_color, o.emitted);
+                if (o.shadow) { has_shadow = true; s_dir = o.s_dir; s_color = o.s_color; pv.org = o.s_org; }
+                if (o.bounce) { pv.org = o.b_org; pv.dir = o.b_dir; pv.rnd = o.rnd; pv.mis = o.mis; pv.contrib = o.contrib; pv.depth++; tmin = kRayOffset; }
+                else has_path = false;
+            }
+        }
+        const bool pay = unpaid && !has_path && !has_shadow;
+        film_add_wave(film, pv.pixel, pay, final_color.x * inv_spp, final_color.y * inv_spp, final_color.z * inv_spp);
+        if (pay) unpaid = false;
+    }
+    for (int off = 32; off > 0; off >>= 1) { n_primary += __shfl_xor(n_primary, off); n_shadow += __shfl_xor(n_shadow, off); }
+    if (threadIdx.x == 0) {
+        const int stripe = (blockIdx.y * gridDim.x + blockIdx.x) & 31;
+        atomicAdd(&counters[68 + stripe], (unsigned long long)n_primary);
+        atomicAdd(&counters[4 + stripe], (unsigned long long)n_shadow);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K4 / K7: deterministic, stable binning of a primary stream (sort by geometry id, or compaction
 // with key = dead ? 1 : 0).  dst(ray) = bin_begin[key] + (rays with that key in earlier blocks)
@@ -865,6 +1003,7 @@ struct RenderDevice {
     int* tickets[2] = {nullptr, nullptr}; int num_cus = 0;
     int lds_image = 1;                         // 1 = the stream traversal kernels stage the scene's top-of-tree image in LDS (2-wave workgroups); 0 = every node from memory
     int fused_sort = 0;                        // 0 = rays are moved by the sort (copy_primary_ray), then shaded in place; 1 = the sort only computes the permutation and the shader gathers through it
+    int mega_joint = 0;                        // megakernel: 1 = shadow ray and next path ray of a lane traced in one loop (k_mega_joint: measured slower), 0 = the reference's sequence of loops (k_mega)
     int fused_compact = 2;                     // the shader writes every continuing ray to its compacted slot: 2 = slots from one atomic per block (default), 1 = from a look-back scan
                                                // (deterministic stream order; measured slower); 0 = shade in place, then the separate compaction pass (mapping_gpu.impala:267-300 as it stands)
     unsigned* scan = nullptr; int scan_cap = 0;    // per-block words of the shader's look-back scan (zero before every launch)
@@ -891,12 +1030,13 @@ std::vector<float> g_host_film; size_t g_host_w = 0, g_host_h = 0;
 
 // every option of the renderer at its default, or at what its environment variable says (rodent_hip_render_defaults)
 void render_defaults(RenderDevice& r) {
-    r.sort = 0; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 2; r.lds_image = 1; r.trace_persistent_request = -1; r.mapping_request = -1; r.capacity = 0;
+    r.sort = 0; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 2; r.mega_joint = 0; r.lds_image = 1; r.trace_persistent_request = -1; r.mapping_request = -1; r.capacity = 0;
     if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_FUSED_SORT")) r.fused_sort = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_FUSED_COMPACT")) r.fused_compact = std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("RODENT_HIP_LDS_IMAGE")) r.lds_image = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("RODENT_HIP_MEGA_JOINT")) r.mega_joint = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_TRACE_PERSISTENT")) r.trace_persistent_request = std::min(2, std::max(-1, atoi(e)));
     if (const char* m = getenv("RODENT_HIP_MAPPING")) {
         if (!strcmp(m, "mega") || !strcmp(m, "megakernel") || !strcmp(m, "1")) r.mapping_request = 1;
@@ -1209,9 +1349,12 @@ void render_rows_mega(RenderDevice& r, const Settings* settings, int iter, int y
     int* err = r.ctl + 2;
     HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 3, stream));
     HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * kNumCounters, stream));
-    if (y1 > y0)
-        hipLaunchKernelGGL(k_mega, grid, dim3(kWave), 0, stream, r.scene.dev, to_cam(settings), r.film, r.film_w, r.film_h, y0, y1, iter, r.spp,
-                           r.max_path_len, log2_tile, 1.0f / (float)r.spp, err, r.counters);
+    if (y1 > y0) {
+        if (r.mega_joint) hipLaunchKernelGGL(k_mega_joint, grid, dim3(kWave), 0, stream, r.scene.dev, to_cam(settings), r.film, r.film_w, r.film_h, y0, y1, iter, r.spp,
+                                             r.max_path_len, log2_tile, 1.0f / (float)r.spp, err, r.counters);
+        else hipLaunchKernelGGL(k_mega, grid, dim3(kWave), 0, stream, r.scene.dev, to_cam(settings), r.film, r.film_w, r.film_h, y0, y1, iter, r.spp,
+                                r.max_path_len, log2_tile, 1.0f / (float)r.spp, err, r.counters);
+    }
     HIP_CHECK(hipGetLastError());
     const unsigned long long host_counts[2] = {1ull, (unsigned long long)r.spp * r.film_w * (unsigned long long)(y1 - y0)};
     HIP_CHECK(hipMemcpyAsync(r.counters + 2, host_counts, sizeof(host_counts), hipMemcpyHostToDevice, stream));
@@ -1355,6 +1498,7 @@ void rodent_hip_render_overlap(int32_t dev, int32_t enable) { rdev(dev).overlap 
 void rodent_hip_render_fused_sort(int32_t dev, int32_t enable) { rdev(dev).fused_sort = enable ? 1 : 0; }
 void rodent_hip_render_fused_compact(int32_t dev, int32_t enable) { rdev(dev).fused_compact = std::min(2, std::max(0, (int)enable)); }
 void rodent_hip_render_lds_image(int32_t dev, int32_t enable) { rdev(dev).lds_image = enable ? 1 : 0; }
+void rodent_hip_render_mega_joint(int32_t dev, int32_t enable) { rdev(dev).mega_joint = enable ? 1 : 0; }
 void rodent_hip_render_trace_persistent(int32_t dev, int32_t enable) { RenderDevice& r = rdev(dev); r.trace_persistent_request = std::min(2, std::max(-1, (int)enable)); r.trace_persistent = resolve_trace(r); }
 
 void rodent_hip_render_capacity(int32_t dev, int32_t rays) {

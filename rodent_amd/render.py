@@ -27,7 +27,7 @@ class SceneDesc(C.Structure):
                [(n, vp) for n in ("texcoords", "textures", "texels")] + [("num_textures", i32), ("num_texels", C.c_uint32)]
 
 
-RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_fused_compact", "rodent_hip_render_mapping_in_effect", "rodent_hip_render_defaults", "rodent_hip_render_lds_image", "rodent_hip_render_trace_persistent", "get_spp", "render",
+RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_fused_compact", "rodent_hip_render_mapping_in_effect", "rodent_hip_render_defaults", "rodent_hip_render_lds_image", "rodent_hip_render_mega_joint", "rodent_hip_render_trace_persistent", "get_spp", "render",
                   "setup_interface", "get_pixels", "clear_pixels", "cleanup_interface", "rodent_get_film_data",
                   "rodent_gpu_get_first_primary_stream", "rodent_gpu_get_second_primary_stream", "rodent_gpu_get_secondary_stream",
                   "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows",
@@ -56,6 +56,7 @@ def lib():
         l.rodent_hip_render_mapping_in_effect.argtypes = [i32]; l.rodent_hip_render_mapping_in_effect.restype = i32
         l.rodent_hip_render_defaults.argtypes = [i32]; l.rodent_hip_render_defaults.restype = None
         l.rodent_hip_render_trace_persistent.argtypes = [i32, i32]; l.rodent_hip_render_trace_persistent.restype = None
+        l.rodent_hip_render_mega_joint.argtypes = [i32, i32]; l.rodent_hip_render_mega_joint.restype = None
         l.get_spp.argtypes = []; l.get_spp.restype = i32
         l.render.argtypes = [C.POINTER(Settings), i32]; l.render.restype = None
         l.setup_interface.argtypes = [C.c_size_t, C.c_size_t]; l.setup_interface.restype = None
@@ -89,7 +90,7 @@ class Renderer:
     MAPPINGS = {"auto": -1, "streaming": 0, "megakernel": 1}       # per scene / mapping_gpu.impala:308-369 / :371-474
 
     def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming", capacity=0, sort=None, overlap=None, fused_sort=None, lds_image=None,
-                 trace_persistent=None, fused_compact=None):
+                 trace_persistent=None, fused_compact=None, mega_joint=None):
         """Options left at None take the library's default, or what the option's RODENT_HIP_* environment variable says."""
         import torch
         if not torch.cuda.is_available():
@@ -111,6 +112,7 @@ class Renderer:
                               (fused_sort, l.rodent_hip_render_fused_sort),        # the sort computes a permutation, the shader gathers through it
                               (lds_image, l.rodent_hip_render_lds_image),          # stream traversal kernels stage the top of the BVH in LDS
                               (trace_persistent, l.rodent_hip_render_trace_persistent),   # 0 / 1 / 2: 2-wave kernels + second stream / persistent / joint persistent launch (default: per scene)
+                              (mega_joint, l.rodent_hip_render_mega_joint),               # megakernel: shadow ray + next path ray of a lane in one loop (measured slower) / the reference's sequence of loops (default)
                               (fused_compact, l.rodent_hip_render_fused_compact)):        # the shader writes continuing rays to their compacted slots
             if value is not None:
                 setter(dev, int(value))

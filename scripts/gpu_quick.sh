@@ -1,8 +1,6 @@
-export TMPDIR=/tmp; mkdir -p gpurun_out/r03 gpurun_out/profiles
-C="rodent_amd/bin/rodent --scene tests/golden/cornell_box.obj --bench 2 --eye 0 1 2.7 --dir 0 0 -1 --up 0 1 0 --width 1920 --height 1080 --spp 64 --max-path-len 4 --target amdgpu-megakernel"
-run() { name=$1; shift; timeout -k 5 200 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/profiles/r03m_$name -o rodent -- $C > gpurun_out/profiles/r03m_$name.log 2>&1 || echo "pass $name failed"; }
-run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
-run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS
-run grbm GRBM_GUI_ACTIVE GRBM_TA_BUSY
-run ta TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum
-python scripts/pmc_digest.py gpurun_out/profiles r03m_ k_mega 2>&1 | grep -v "^\[" | tee gpurun_out/r03/mega_pmc.txt
+export TMPDIR=/tmp; mkdir -p gpurun_out/r03
+timeout 900 python -m pytest tests/test_gpu_render.py tests/test_gpu_atrium.py -m gpu -x -q -k "mega or bsdf or textured or row_bands or path_trace" 2>&1 | tail -5
+python -c "from rodent_amd import scenes; scenes.scene_bvh('atrium')"
+C="--scene tests/golden/cornell_box.obj --bench 5 --eye 0 1 2.7 --dir 0 0 -1 --up 0 1 0 --width 1920 --height 1080 --spp 64 --max-path-len 4 --target amdgpu-megakernel"
+A="--scene data/atrium.obj --bench 3 --eye -1150 350 30 --dir 1 0.12 -0.05 --up 0 1 0 --width 1920 --height 1080 --spp 16 --max-path-len 8 --target amdgpu-megakernel"
+for J in 0 1; do echo "RODENT_HIP_MEGA_JOINT=$J: cfg4 $(RODENT_HIP_MEGA_JOINT=$J rodent_amd/bin/rodent $C | tail -1)   atrium1080p16 $(RODENT_HIP_MEGA_JOINT=$J rodent_amd/bin/rodent $A | tail -1)"; done | tee gpurun_out/r03/render_rates_mega_joint.txt

@@ -247,7 +247,7 @@ def test_megakernel_matches_oracle(R, oracle, cornell_scene, spp, max_len, W, H)
     """The persistent-threads mapping (mapping_gpu.impala:371-474): same paths, same ray counts, per-path colour sums;
     ragged tiles (film not a multiple of the tile side), spp that is not a power of two, spp > 1024 (tile side 1)."""
     cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
-    r = R.Renderer(cornell_scene, W, H, spp, max_len, mapping="megakernel")
+    r = R.Renderer(cornell_scene, W, H, spp, max_len, mapping="megakernel", mega_joint=(W % 2 == 0))      # both loop structures: k_mega / k_mega_joint
     film_o = None
     for it in range(2):
         r.render(cam, it)
