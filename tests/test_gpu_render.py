@@ -218,6 +218,47 @@ def test_stage_level_api_reproduces_render(R, oracle, cornell_scene):
     assert np.allclose(film, ref, rtol=FILM_RTOL, atol=FILM_ATOL)
 
 
+@pytest.mark.parametrize("mapping", ["streaming", "megakernel"])
+def test_renderer_on_a_hierarchy_deeper_than_the_lds_window(R, oracle, cornell_scene, mapping):
+    """The Cornell box under a degenerate CHAIN hierarchy (node k = {triangle k, everything behind it}): rays whose nearer child is
+    the rest push a leaf per level, 30 and more entries deep -- past the 15 / 16-entry LDS windows of the stream traversal kernels
+    (rays handed to k_trace_deep) and of the megakernel (traced again with its 64-entry LDS + scratch stack).  Same frame as the
+    oracle on the same hierarchy."""
+    import copy
+    from rodent_amd import formats as F
+    sc = copy.copy(cornell_scene)
+    first = {}
+    for i, t in enumerate(cornell_scene.tris):
+        first.setdefault(int(t["prim_id"]) & 0x7FFFFFFF, i)
+    tris = cornell_scene.tris[sorted(first.values())].copy()
+    tris["prim_id"] = (tris["prim_id"].astype(np.int64) | 0x80000000).astype(np.uint32).view(np.int32) if tris["prim_id"].dtype.kind == "i" else tris["prim_id"] | 0x80000000
+    n = len(tris)
+    v0 = tris["v0"].astype(np.float64); v1 = v0 - tris["e1"]; v2 = v0 + tris["e2"]            # Tri1 stores e1 = v0 - v1, e2 = v2 - v0 (converter.cpp:365-380)
+    # every box is the scene's box (loose bounds are legal): each ray enters both children of every node at the same distance, the
+    # strict `<` sends it into the rest first and the leaf goes on the stack -- 35 entries at the bottom of the chain
+    lo = np.tile(np.minimum(np.minimum(v0, v1), v2).min(0) - 1e-3, (n, 1)); hi = np.tile(np.maximum(np.maximum(v0, v1), v2).max(0) + 1e-3, (n, 1))
+    rest_lo, rest_hi = lo, hi
+    nodes = np.zeros(n - 1, F.NODE2)
+    for k in range(n - 1):
+        b = nodes["bounds"][k]
+        b[0:6:2], b[1:6:2] = lo[k], hi[k]
+        last = k == n - 2
+        b[6:12:2], b[7:12:2] = (lo[k + 1], hi[k + 1]) if last else (rest_lo[k + 1], rest_hi[k + 1])
+        nodes["child"][k] = (~k, ~(k + 1) if last else k + 2)
+    sc.nodes, sc.tris = nodes, tris
+    W, H = 120, 80
+    cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
+    from rodent_amd import raygen
+    depth = oracle.ray_depths(nodes, tris, raygen.primary_rays((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H, 0.0, 1e9))
+    assert depth.max() >= 30 and (depth > 16).mean() > 0.5                  # really past every LDS window
+    film_o, counts = oracle.render(sc, cam, 0, 2, 6, W, H)
+    r = R.Renderer(sc, W, H, 2, 6, mapping=mapping)
+    r.render(cam, 0)
+    c = r.counters(); film_g = r.film(); r.close()
+    assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1])
+    assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL) and film_g.mean() > 0.02
+
+
 def test_stage_level_shader_ends_rays_that_missed(R, cornell_scene):
     """hip_shade on a stream that was NOT sorted first (the reference's loop drops the misses in its sort, mapping_gpu.impala:347-357):
     a ray that missed carries the miss id in geom_id; the shader must end it (id -1, no shadow ray), not index the material
