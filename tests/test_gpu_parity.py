@@ -378,6 +378,7 @@ def test_bench_py_contract(native_build):
     pmc = sorted(glob.glob(str(ROOT / "profiles" / "r*_pmc_counters.json")))
     current = bool(pmc) and provenance.is_current(json.load(open(pmc[-1])).get("_meta"), "traversal")
     assert ("valu_issue" in rf["binding"]) == current and ("counters_not_quoted" in rf["binding"]) == (not current)
+    assert not current or 1.0 < rf["binding"]["occupancy"]["resident_waves_per_simd_time_averaged_profiled"] <= 8.0
     rd = d["extra"]["render"]
     for cfg, (w, h, spp) in (("cfg4_cornell_1920x1080_64spp_len4", (1920, 1080, 64)), ("cfg5_atrium_3840x2160_256spp_len8", (3840, 2160, 256))):
         e = rd[cfg]
