@@ -928,6 +928,11 @@ const Variant2 kVariants2[] = {
     K2("top-fused",          "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 1),   // the last workgroup does the follow-up kernel's work (every workgroup fences)
     K2("top-one",            "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 2),   // the same, fences on the rare paths only (= the default from 576 Ki rays on)
     K2("top-two",            "k_bvh2_top_persist",   L_default, 15, 255, 16, false, 0),                          // the default with a follow-up kernel instead (rounds 2's form)
+    //                                                                     LDS_N TOPN WAVES HOT_ITER HOT_LANES
+    K2("top-partner-48-24",  "k_bvh2_top_partner",   L_top_partner, 15, 255, 16, 48, 24),   // stateless order attempt: second-generation chunks = vertical partners of the first generation, partners of chunks that look expensive first
+    K2("top-partner-32-40",  "k_bvh2_top_partner",   L_top_partner, 15, 255, 16, 32, 40),
+    K2("top-partner-64-16",  "k_bvh2_top_partner",   L_top_partner, 15, 255, 16, 64, 16),
+    K2("top-partner-999-64", "k_bvh2_top_partner",   L_top_partner, 15, 255, 16, 999, 64),  // the paired ticket map alone (nothing ever hot): what the even / odd row order is worth
     K2("top-lazy",           "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 0, true),   // miss records stored at chunk end
     K2("top-lazy-one",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 2, true),
     K2("top-userperm-lazy-one", "k_bvh2_top_persist", L_top_persist, 15, 255, 16, false, false, 32, false, -1, 2, true),

@@ -440,3 +440,106 @@ __global__ __launch_bounds__(kWave) void k_wide_lane(const char* __restrict__ no
 template <bool ANY, int N, int LDS_N> void L_wide_lane(WIDE_LAUNCH_ARGS) {
     hipLaunchKernelGGL((k_wide_lane<ANY, N, LDS_N>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, n, s.scratch + 1);
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// "top-partner" (round 3, lab): a STATELESS attempt at the chunk order the schedule history gets from the previous launch.
+// The persistent LDS-image kernel (k_bvh2_top_persist) with another ticket -> chunk map and another way to draw:
+//   * a stripe's first generation (one chunk per resident wave, tickets 0 .. W-1) takes the EVEN row of every pair of 16-chunk rows
+//     the stripe owns, the second generation (tickets W .. 2W-1) the odd rows: ticket t and ticket t + W are vertical neighbours
+//     in a scanline-ordered ray set (their costs correlate at 0.98 on the benchmark's primary rays);
+//   * a first-generation chunk that still has >= HOT_LANES rays alive after HOT_ITER iterations marks its partner HOT (one atomicOr into
+//     the stripe's 128-bit mask);
+//   * a wave that has finished a chunk claims (atomicOr on the stripe's claimed mask) the lowest hot partner that is not taken,
+//     or else the lowest partner that is not taken (= the default order).
+// Only for launches of exactly 2 x resident-waves chunks (1 Mi rays on 256 CUs); anything else takes the default order.
+// ---------------------------------------------------------------------------------------------
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int HOT_ITER, int HOT_LANES>
+__global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_partner(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                                     const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                                     Ctl* ctl, int* __restrict__ deep_list, int4* __restrict__ top_image, int* __restrict__ tickets, int max_id) {
+    constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave;
+    __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
+    lds_int* image = (lds_int*)lds_raw + kStackInts;
+    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, (const int4*)top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;
+    const int total_chunks = (n + kWave - 1) / kWave, stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
+    unsigned* state = reinterpret_cast<unsigned*>(tickets + stripe * kCounterStride);      // [1..4] hot mask, [5..8] claimed mask (word 0: the default order's counter)
+    const bool paired = total_chunks == 2 * stripe_waves * kStripes && stripe_waves == 128;
+    lds_int* const sp_limit = col + LDS_N * kWave;
+    const Bases base = make_bases(nodes, tris);
+    int t = (blockIdx.x / kStripes) * WAVES + wave;
+    for (;;) {
+        int chunk;
+        if (paired) {
+            if (t >= 2 * stripe_waves) break;
+            const int u = t % stripe_waves;                                   // first generation: even row of the pair; second: odd row
+            chunk = ((u / 16) * kStripes + stripe) * 32 + (t >= stripe_waves ? 16 : 0) + u % 16;
+        } else {
+            const int group_first = ((t / 32) * kStripes + stripe) * 32;
+            if (group_first >= total_chunks) break;
+            chunk = group_first + t % 32;
+        }
+        if (chunk < total_chunks) {
+            const int first_ray = chunk * kWave, lane_ray = first_ray + lane;
+            Lane L = start_lane(rays, hits, lane_ray < n ? lane_ray : -1, first_ray, col);
+            if (L.top != 0) L.top = root;
+            int iterations = 0;
+            for (;;) {
+                const unsigned long long live = __ballot(L.top != 0);
+                if (!live) break;
+                if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+                if (paired && ++iterations == HOT_ITER && t < stripe_waves && __popcll(live) >= HOT_LANES && lane == 0)
+                    atomicOr(&state[1 + (t >> 5)], 1u << (t & 31));              // the partner (ticket t + W) looks expensive
+            }
+        }
+        int t_next = 0;
+        if (paired) {
+            // the whole wave draws: lanes 0..3 read the hot words, 4..7 the claimed words (ONE round trip), lane 0 claims
+            t_next = 1 << 20;                                                 // nothing left
+            const int start = (int)(((blockIdx.x / kStripes) * WAVES + wave) >> 5) & 3;         // waves look for hot partners from different words: fewer collisions
+            for (;;) {
+                const unsigned word = lane < 8 ? __hip_atomic_load(&state[1 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                const unsigned free_hot = word & ~(unsigned)__shfl((int)word, (lane & 3) + 4);          // lanes 0..3: hot and not taken
+                const unsigned long long any = __ballot(lane < 4 && free_hot != 0u);
+                int pick = -1;
+                if (any) {
+                    const unsigned rot = (unsigned)(((any | (any << 4)) >> start) & 15ull);            // first non-empty word from `start` on
+                    const int w = (start + __ffs((int)rot) - 1) & 3;
+                    pick = 32 * w + __ffs(__shfl((int)free_hot, w)) - 1;
+                } else {
+                    // no hot partner left: the next one in the default order (one returning atomic, as the default kernel's draw)
+                    if (lane == 0) pick = atomicAdd(reinterpret_cast<int*>(state), 1);
+                    pick = __builtin_amdgcn_readfirstlane(pick);
+                    if (pick >= stripe_waves) break;
+                }
+                unsigned old = 0u;
+                if (lane == 0) old = atomicOr(&state[5 + (pick >> 5)], 1u << (pick & 31));
+                old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+                if (!(old & (1u << (pick & 31)))) { t_next = stripe_waves + pick; break; }
+            }
+        } else if (lane == 0) t_next = stripe_waves + atomicAdd(reinterpret_cast<int*>(state), 1);
+        t = __builtin_amdgcn_readfirstlane(t_next);
+    }
+}
+// the follow-up kernel's extra duty: the hot / claimed masks back to zero
+__global__ void k_partner_reset(int* tickets) { const int s = threadIdx.x; for (int w = 1; w <= 8; w++) tickets[s * kCounterStride + w] = 0; }
+
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int HOT_ITER, int HOT_LANES> void L_top_partner(LAUNCH_ARGS) {
+    ensure_deep_list(s, n);
+    if (!s.top_image || !s.tickets) {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (!s.top_image) { HIP_CHECK(hipMalloc(&s.top_image, kMaxTopNodes * sizeof(Node2))); HIP_CHECK(hipMemset(s.top_image, 0, kMaxTopNodes * sizeof(Node2))); }
+        if (!s.tickets) {
+            HIP_CHECK(hipMalloc(&s.tickets, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
+            HIP_CHECK(hipMemset(s.tickets, 0, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
+        }
+    }
+    s.top_image_nodes = nullptr;
+    const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;
+    hipLaunchKernelGGL((k_bvh2_top_partner<ANY, LDS_N, TOPN, WAVES, HOT_ITER, HOT_LANES>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+                       s.top_image, s.tickets, mapped_node_ids(nodes));
+    hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
+    hipLaunchKernelGGL(k_partner_reset, dim3(1), dim3(kStripes), 0, stream, s.tickets);
+}
