@@ -133,6 +133,16 @@ void    rodent_hip_render_mega_joint(int32_t dev, int32_t enable);
  *    306 ... 142 444 nodes, profiles/r03_joint_sweep.txt), 0 for a tree of a few dozen nodes (Cornell box: 2 is 5 % slower).
  * Same film.  RODENT_HIP_TRACE_PERSISTENT=-1|0|1|2. */
 void    rodent_hip_render_trace_persistent(int32_t dev, int32_t enable);
+/* Lane refill in the persistent traversal launches (1 and 2 above).  Thresholds 1 .. 64: a wave whose idle lanes reach that count
+ * retires their rays and draws as many new ones from its stripe's counter instead of waiting for the last ray of a 64-ray chunk
+ * (k_trace_refill) -- idle_bounce while it draws from the rays the last bounce left, idle_shadow while it draws shadow rays (64 =
+ * whole chunks for that kind); the camera rays a launch holds (the host knows where: the rays generated for it) always go chunk
+ * by chunk.  0, 0: whole chunks for everything (k_trace_persist).  -1, -1 (default): per scene -- 48, 48 for hierarchies of 16 384
+ * nodes and more (atrium: +8 % at 1920 x 1080 x 16 spp, +9 % at 3840 x 2160 x 32 spp; profiles/r03_refill_sweep.txt), off below
+ * (every ray is short there: -4 ... -11 %).  Same paths, same ray counts, same film up to the order of the atomic adds.
+ * RODENT_HIP_TRACE_REFILL=<both> or <bounce>,<shadow>. */
+void    rodent_hip_render_trace_refill(int32_t dev, int32_t idle_bounce, int32_t idle_shadow);
+int32_t rodent_hip_render_trace_refill_in_effect(int32_t dev);      /* idle_bounce | idle_shadow << 8 for the scene that is loaded (0 = whole chunks) */
 
 /* ---- the reference's renderer ABI ---- */
 int32_t get_spp(void);

@@ -473,6 +473,162 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStrea
     }
 }
 
+// Persistent form WITH LANE REFILL (rodent_hip_render_trace_refill): a wave does not wait for the last ray of a 64-ray chunk.
+// As soon as `refill_idle` of its lanes are idle it retires their rays (shadow rays: film contribution; abandoned rays: deep
+// list), draws that many rays from its stripe's counter (ONE atomic per refill) and starts them in the idle lanes; the rest
+// keep stepping.  Bounce and shadow rays are incoherent: their step counts inside a chunk differ by an order of magnitude
+// and a chunk runs at a quarter of its lanes (standalone, 8 Mi random segments: closest hit +15 %, any hit +22 %,
+// profiles/r03_sweep_refill_big_random.log) -- camera rays are not (the same kernel on 16 Mi primary rays: -18 %), and the
+// host knows where they are: the stream is [survivors of the last bounce | rays generated for this launch], so draws that
+// start inside [coherent_from, n_primary) wait for the whole wave like a chunk does.
+// One index space for both lists: g < P = the closest-hit ray g of `p` (P = n_primary rounded up to whole chunks), g >= P the
+// shadow ray g - P of `s`; ticket t of stripe s is index ((t / 2048) * 64 + s) * 2048 + t % 2048 (the same 32-chunk groups as
+// k_trace_persist); a wave's first 64 tickets are static.  Which rays share a wave changes, what a ray visits does not.
+// Lane state next to the ray: `g` = index in the joint space (low 28 bits; -1 = no ray) with bit kFoundBit = "an accepted triangle"
+// (what a shadow ray's film contribution depends on; a ray handed to the deep list sets it too: k_trace_deep decides for it).
+// Kept small on purpose: 64 VGPRs is the budget of 8 waves per SIMD, and a spill lands inside the step.
+struct RefillLane { RayX ray; int top; lds_int* sp; int g; };
+constexpr int kFoundBit = 1 << 29, kIndexMask = (1 << 28) - 1;
+__global__ __launch_bounds__(kWave * kPersistWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_from, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
+                    int* deep_count_primary, int* deep_count_secondary, unsigned long long* counters, int* deep_list_primary, int* deep_list_secondary, int* tickets,
+                    int idle_bounce, int idle_shadow) {
+    constexpr int kStackInts = kPersistWaves * (kTopStack + 1) * kWave, kGroupRays = 32 * kWave;
+    __shared__ __attribute__((aligned(16))) int lds[kStackInts + kPersistTopNodes * 16];
+    const int lane = threadIdx.x % kWave, wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    lds_int* image = (lds_int*)lds + kStackInts;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    for (int j = threadIdx.x; j < kPersistTopNodes * 4; j += kWave * kPersistWaves)
+        reinterpret_cast<__attribute__((address_space(3))) i32x4*>(image)[j] = reinterpret_cast<const i32x4*>(sc.top_image_large)[j];
+    const int np = n_primary, ns = s.rays.id ? stream_size(size_ptr, n_value) : 0;
+    const int P = (np + kWave - 1) / kWave * kWave, total = P + ns;
+    const int stripe = blockIdx.x % kTraceStripes, stripe_waves = (gridDim.x / kTraceStripes) * kPersistWaves;
+    int* counter = tickets + stripe * kTraceCounterStride;
+    const auto index_of = [&](int t) { return ((t / kGroupRays) * kTraceStripes + stripe) * kGroupRays + t % kGroupRays; };
+    lds_int* const wave_stack = (lds_int*)lds + wave * (kTopStack + 1) * kWave;        // wave-uniform; lane l's column starts at wave_stack + l
+    lds_int* const wave_limit = wave_stack + kTopStack * kWave;                        // sp >= wave_limit  <=>  the lane's cursor is at entry kTopStack (l < kWave)
+    __syncthreads();
+    if (np && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)np);
+    typedef const __attribute__((address_space(1))) char* gptr;
+    unsigned long long node_bits = reinterpret_cast<unsigned long long>(sc.nodes - 1), tri_bits = reinterpret_cast<unsigned long long>(sc.tris);   // node ids are 1-based
+    asm volatile("" : "+v"(node_bits), "+v"(tri_bits));
+    const gptr node_base = (gptr)node_bits, tri_base = (gptr)tri_bits;
+
+    RefillLane L; L.top = 0; L.g = -1; L.sp = wave_stack + lane;
+    // rays that ended since the last refill leave the wave: wave-uniform control flow (film_add_wave shuffles)
+    const auto retire = [&]() {
+        const bool done = L.g >= 0 && L.top == 0;
+        const int i = (L.g & kIndexMask) - P;
+        const bool lit = done && i >= 0 && !(L.g & kFoundBit);
+        if (__ballot(lit))
+            film_add_wave(film, lit ? s.rays.id[i] : -1, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
+        if (done) L.g = -1;
+    };
+    const auto start = [&](int g) {
+        RayX ray;
+        if (g < P) {
+            if (g >= np) return;
+            ray = load_stream_ray(p.rays, g);
+            p.geom_id[g] = sc.num_materials; p.prim_id[g] = -1; p.t[g] = ray.tmax; p.u[g] = 0.0f; p.v[g] = 0.0f;     // the miss record; hits overwrite it
+        } else {
+            const int i = g - P;
+            if (i >= ns || s.rays.id[i] < 0) return;
+            ray = load_stream_ray(s.rays, i);
+        }
+        ray.tmin = canonical(ray.tmin); ray.tmax = canonical(ray.tmax);
+        L.ray = ray; L.g = g;
+        L.sp = wave_stack + lane; *L.sp = 0; L.top = kLdsTag;
+    };
+
+    // (a prefetched ticket range per wave -- the atomic of the next refill issued at this one -- was measured: 3 % slower, the reserved rays are missing at the launch's end)
+    bool more = true, first_draw = true;
+    int need_idle = 0;
+    for (;;) {
+        const unsigned long long live = __ballot(L.top != 0);
+        const int idle = kWave - __popcll(live);
+        if (more && idle >= need_idle && idle > 0) {
+            retire();
+            int first;
+            if (first_draw) { first = ((blockIdx.x / kTraceStripes) * kPersistWaves + wave) * kWave; first_draw = false; }
+            else {
+                int f = 0;
+                if (lane == 0) f = atomicAdd(counter, idle);
+                first = stripe_waves * kWave + __builtin_amdgcn_readfirstlane(f);
+            }
+            const int g0 = index_of(first);
+            more = g0 < total;                                                   // index_of grows with the ticket: once past the end, always past the end
+            need_idle = (g0 >= coherent_from && g0 < P) ? kWave : (g0 < P ? idle_bounce : idle_shadow);   // camera rays: chunk by chunk
+            if (L.top == 0) {
+                const int g = index_of(first + __popcll(~live & ((1ull << lane) - 1ull)));
+                if (g < total) start(g);
+            }
+            const unsigned long long shadows = __ballot(L.top != 0 && L.g >= P && !((live >> lane) & 1ull));
+            if (lane == 0 && shadows) atomicAdd(&counters[4 + ((first / kWave) & 63)], (unsigned long long)__popcll(shadows));
+            continue;
+        }
+        if (live == 0) { retire(); break; }
+        if (L.top != 0) {
+            // one step of trace_one (the same visit order, the same arithmetic); any hit / closest hit is a property of the lane here
+            const int top = L.top;
+            const bool is_node = top > 0;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            typedef int i32x2 __attribute__((ext_vector_type(2)));
+            f32x4 q0, q1, q2;
+            i32x2 ch;
+            if (top >= kLdsTag) {
+                typedef __attribute__((address_space(3))) const char* lds_bytes;
+                const lds_bytes rec = (lds_bytes)image + (unsigned)(top - kLdsTag);
+                const __attribute__((address_space(3))) f32x4* q = (const __attribute__((address_space(3))) f32x4*)rec;
+                q0 = q[0]; q1 = q[1]; q2 = q[2];
+                ch = *(const __attribute__((address_space(3))) i32x2*)(rec + 48);
+            } else {
+                const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
+                const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
+                const __attribute__((address_space(1))) f32x4* q = (const __attribute__((address_space(1))) f32x4*)addr;
+                q0 = q[0]; q1 = q[1]; q2 = q[2];
+                ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
+            }
+            const int popped = *L.sp;
+            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
+            if (is_node) {
+                float te0, te1;
+                // -(o * 1/d) is computed here, not carried (make_rayx's product, the same value): three multiplications per node step for three
+                // registers -- with them in the lane state the register allocator puts three ray components into scratch and reloads them in every step
+                RayX rr = L.ray; rr.iox = -(rr.ox * rr.idx); rr.ioy = -(rr.oy * rr.idy); rr.ioz = -(rr.oz * rr.idz);
+                const bool h0 = slab_canonical(rr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
+                const bool h1 = slab_canonical(rr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
+                const bool c0first = te0 < te1, both = h0 && h1;
+                L.top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
+                L.sp[kWave] = c0first ? ch.y : ch.x;
+                L.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
+                if (both && L.sp >= wave_limit) {                                // abandoned: k_trace_deep traces it again with the 64-entry stack and decides
+                    const int g = L.g & kIndexMask;
+                    if (g >= P) deep_list_secondary[atomicAdd(deep_count_secondary, 1)] = g - P;
+                    else deep_list_primary[atomicAdd(deep_count_primary, 1)] = g;
+                    L.g |= kFoundBit; L.top = 0;
+                }
+            } else {
+                const int prim_id = __float_as_int(q2.w);
+                const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
+                float t, u, v;
+                const bool any = (L.g & kIndexMask) >= P;
+                bool found = false;
+                if (intersect_tri(L.ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v)) {
+                    if (!any) {
+                        unsigned k = (unsigned)L.g & (unsigned)kIndexMask;
+                        asm volatile("" : "+v"(k));
+                        p.geom_id[k] = __float_as_int(q1.w); p.prim_id[k] = prim_id & 0x7FFFFFFF; p.t[k] = t; p.u[k] = u; p.v[k] = v;
+                    }
+                    L.ray.tmax = t; found = true; L.g |= kFoundBit;
+                }
+                const bool leave = prim_id < 0, ends = any && found;
+                L.top = ends ? 0 : (leave ? popped : top - 1);
+                L.sp -= (leave && !ends) ? kWave : 0;
+            }
+        }
+    }
+}
+
 // The rays the two kernels above abandoned (stack deeper than the LDS window), traced again from the root with the
 // 64-entry stack in global memory; one wave, enqueued behind every stream traversal launch; resets the list.
 template <bool SECONDARY>
@@ -1016,6 +1172,8 @@ struct RenderDevice {
     int trace_persistent = 0;                  // in effect: 0 = 2-wave traversal workgroups (31-record image), shadow pass on the second stream; 1 = persistent stream traversal kernels
                                                // (k_trace_persist: 16-wave workgroups, 255-record image, ticket counters); 2 = joint: both passes of a bounce in ONE persistent launch
     int trace_persistent_request = -1;         // -1 = per scene (joint for every scene the per-scene mapping rule sends to the streaming loop), 0 / 1 / 2 = the caller's choice
+    int trace_refill = 0, trace_refill_shadow = 0;   // in effect, persistent traversal launches: > 0 = lane refill (k_trace_refill) once that many lanes of a wave are idle (bounce rays / shadow rays); 0 = whole chunks (k_trace_persist)
+    int trace_refill_request[2] = {-1, -1};    // -1 = per scene (resolve_refill), else the caller's thresholds
     int* tickets[2] = {nullptr, nullptr}; int num_cus = 0;
     int lds_image = 1;                         // 1 = the stream traversal kernels stage the scene's top-of-tree image in LDS (2-wave workgroups); 0 = every node from memory
     int fused_sort = 0;                        // 0 = rays are moved by the sort (copy_primary_ray), then shaded in place; 1 = the sort only computes the permutation and the shader gathers through it
@@ -1046,13 +1204,19 @@ std::vector<float> g_host_film; size_t g_host_w = 0, g_host_h = 0;
 
 // every option of the renderer at its default, or at what its environment variable says (rodent_hip_render_defaults)
 void render_defaults(RenderDevice& r) {
-    r.sort = 0; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 2; r.mega_joint = 0; r.lds_image = 1; r.trace_persistent_request = -1; r.mapping_request = -1; r.capacity = 0;
+    r.sort = 0; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 2; r.mega_joint = 0; r.lds_image = 1; r.trace_persistent_request = -1; r.mapping_request = -1; r.capacity = 0; r.trace_refill_request[0] = r.trace_refill_request[1] = -1;
     if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_FUSED_SORT")) r.fused_sort = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_FUSED_COMPACT")) r.fused_compact = std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("RODENT_HIP_LDS_IMAGE")) r.lds_image = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_MEGA_JOINT")) r.mega_joint = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("RODENT_HIP_TRACE_REFILL")) {                 // "48", "48,32" (bounce rays, shadow rays), "0" = off, "-1" = per scene
+        const char* c = strchr(e, ',');
+        const int a = std::min(kWave, std::max(-1, atoi(e))), b = c ? std::min(kWave, std::max(-1, atoi(c + 1))) : a;
+        if (a > 0 && b > 0) { r.trace_refill_request[0] = a; r.trace_refill_request[1] = b; }
+        else r.trace_refill_request[0] = r.trace_refill_request[1] = (a < 0 || b < 0) ? -1 : 0;
+    }
     if (const char* e = getenv("RODENT_HIP_TRACE_PERSISTENT")) r.trace_persistent_request = std::min(2, std::max(-1, atoi(e)));
     if (const char* m = getenv("RODENT_HIP_MAPPING")) {
         if (!strcmp(m, "mega") || !strcmp(m, "megakernel") || !strcmp(m, "1")) r.mapping_request = 1;
@@ -1139,12 +1303,16 @@ int persistent_grid(RenderDevice& r) {
     if (!r.num_cus) { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, r.dev)); r.num_cus = prop.multiProcessorCount; }
     return ((r.num_cus * (32 / kPersistWaves) + kTraceStripes - 1) / kTraceStripes) * kTraceStripes;
 }
-void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n) {
+// coherent_from: the rays [coherent_from, n) were generated for this launch (camera rays), the ones in front of them are what the last bounce left
+void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n, int coherent_from = 0) {
     ensure_deep(r, 0, n);
     int* tickets = nullptr;
     if (r.trace_persistent && n >= kPersistMinRays) {
         ensure_tickets(r); tickets = r.tickets[0];
-        hipLaunchKernelGGL(k_trace_persist<0>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
+        if (r.trace_refill > 0)
+            hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
+                               r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow);
+        else hipLaunchKernelGGL(k_trace_persist<0>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
                            r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets);
     } else if (r.lds_image) hipLaunchKernelGGL((k_trace_primary<kTraceWaves, kSceneTopNodes>), dim3((n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
     else hipLaunchKernelGGL((k_trace_primary<1, 0>), dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
@@ -1155,7 +1323,10 @@ void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const Secondary
     int* tickets = nullptr;
     if (r.trace_persistent && max_n >= kPersistMinRays) {
         ensure_tickets(r); tickets = r.tickets[1];
-        hipLaunchKernelGGL(k_trace_persist<1>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, s, size_ptr, max_n, r.film, inv_spp,
+        if (r.trace_refill > 0)
+            hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, 0, s, size_ptr, max_n, r.film, inv_spp,
+                               r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow);
+        else hipLaunchKernelGGL(k_trace_persist<1>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, s, size_ptr, max_n, r.film, inv_spp,
                            r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets);
     } else if (r.lds_image) hipLaunchKernelGGL((k_trace_secondary<kTraceWaves, kSceneTopNodes>), dim3((max_n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
     else hipLaunchKernelGGL((k_trace_secondary<1, 0>), dim3((max_n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
@@ -1164,10 +1335,13 @@ void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const Secondary
 
 // Joint form: the closest-hit pass over `p` (n rays) and the shadow pass over `s` (size *size_ptr, or max_n) in ONE persistent launch,
 // then the two follow-up kernels for the rays either pass abandoned.
-void launch_trace_joint(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n, const SecondaryStream& s, const int* size_ptr, int max_n, float inv_spp) {
+void launch_trace_joint(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n, int coherent_from, const SecondaryStream& s, const int* size_ptr, int max_n, float inv_spp) {
     ensure_deep(r, 0, n); ensure_deep(r, 1, max_n);
     ensure_tickets(r);
-    hipLaunchKernelGGL(k_trace_persist<2>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, s, size_ptr, max_n, r.film, inv_spp,
+    if (r.trace_refill > 0)
+        hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, s, size_ptr, max_n, r.film, inv_spp,
+                           r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0], r.trace_refill, r.trace_refill_shadow);
+    else hipLaunchKernelGGL(k_trace_persist<2>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, s, size_ptr, max_n, r.film, inv_spp,
                        r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0]);
     hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_stack[0], r.tickets[0], r.ctl + 6);
     hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_stack[1], (int*)nullptr, (int*)nullptr);
@@ -1283,6 +1457,7 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
                            fused ? (r.fused_compact == 2 ? kScanAtomic : r.scan) : (unsigned*)nullptr, d_alive);
     };
     while (id < num_rays || size > 0) {
+        const int survivors = size;                                                      // [0, survivors): what the last bounce left; behind them the rays generated now
         if (size < kCapacity && id < num_rays) {                                         // regenerate (mapping_gpu.impala:332-336)
             const int n = (int)std::min<long long>(num_rays - id, kCapacity - size);
             hipLaunchKernelGGL(k_generate, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, *primary, size, (int)id, n, cam, iter,
@@ -1290,10 +1465,10 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
             id += n; size += n; generated += n;
         }
         const int blocks = (size + kBlock - 1) / kBlock;
-        if (joint && shadow_pending && size >= kPersistMinRays) launch_trace_joint(r, stream, *primary, size, sec, shadow_size_ptr, shadow_n, inv_spp);
+        if (joint && shadow_pending && size >= kPersistMinRays) launch_trace_joint(r, stream, *primary, size, survivors, sec, shadow_size_ptr, shadow_n, inv_spp);
         else {
             if (joint && shadow_pending) launch_trace_secondary(r, stream, sec, shadow_size_ptr, shadow_n, inv_spp);
-            launch_trace_primary(r, stream, *primary, size);
+            launch_trace_primary(r, stream, *primary, size, survivors);
         }
         shadow_pending = false;
         // the shadow pass of this iteration: on the second stream, behind the shader on this one, or (joint) inside the next closest-hit launch
@@ -1407,6 +1582,16 @@ int resolve_trace(const RenderDevice& r) {
     if (r.trace_persistent_request >= 0) return r.trace_persistent_request;
     return r.scene.loaded && r.scene.num_nodes > auto_mega_max_nodes() ? 2 : 0;
 }
+// Lane refill in those launches when the caller leaves it to the library: on for hierarchies of 16 Ki nodes and more.  What it buys is the
+// spread of the rays' step counts inside a wave (a bounce or shadow ray of the atrium takes between 3 and 150 steps); in a small tree
+// every ray is short and the refill's own cost (one atomic, eight loads and a reciprocal per started ray, three more multiplications
+// per node step) is not paid back -- profiles/r03_refill_sweep.txt: +8 % at 142 444 nodes, +16 % at 76 494, +8 % at 19 862, +1 % at 9 870,
+// -4 ... -11 % from 4 951 nodes down.
+constexpr int kRefillMinNodes = 16384, kRefillIdleLanes = 48;
+void resolve_refill(RenderDevice& r) {
+    if (r.trace_refill_request[0] >= 0) { r.trace_refill = r.trace_refill_request[0]; r.trace_refill_shadow = r.trace_refill_request[1]; return; }
+    r.trace_refill = r.trace_refill_shadow = r.scene.loaded && r.scene.num_nodes >= kRefillMinNodes ? kRefillIdleLanes : 0;
+}
 
 template <typename T> T* upload(DevScene& s, const T* host, size_t count) {
     T* d = nullptr;
@@ -1502,6 +1687,7 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
     s.loaded = true;
     r.mapping = resolve_mapping(r);
     r.trace_persistent = resolve_trace(r);
+    resolve_refill(r);
 }
 
 void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
@@ -1517,6 +1703,18 @@ void rodent_hip_render_lds_image(int32_t dev, int32_t enable) { rdev(dev).lds_im
 void rodent_hip_render_mega_joint(int32_t dev, int32_t enable) { rdev(dev).mega_joint = enable ? 1 : 0; }
 void rodent_hip_render_trace_persistent(int32_t dev, int32_t enable) { RenderDevice& r = rdev(dev); r.trace_persistent_request = std::min(2, std::max(-1, (int)enable)); r.trace_persistent = resolve_trace(r); }
 
+void rodent_hip_render_trace_refill(int32_t dev, int32_t idle_bounce, int32_t idle_shadow) {
+    const bool per_scene = idle_bounce == -1 && idle_shadow == -1, off = idle_bounce == 0 && idle_shadow == 0;
+    if (!per_scene && !off && (idle_bounce < 1 || idle_bounce > kWave || idle_shadow < 1 || idle_shadow > kWave)) {
+        fprintf(stderr, "rodent_hip: lane refill thresholds must be -1, -1 (per scene), 0, 0 (off) or 1 .. 64 idle lanes each\n"); abort();
+    }
+    RenderDevice& r = rdev(dev);
+    r.trace_refill_request[0] = idle_bounce; r.trace_refill_request[1] = idle_shadow;
+    resolve_refill(r);
+}
+
+int32_t rodent_hip_render_trace_refill_in_effect(int32_t dev) { const RenderDevice& r = rdev(dev); return r.trace_refill | (r.trace_refill_shadow << 8); }
+
 void rodent_hip_render_capacity(int32_t dev, int32_t rays) {
     if (rays != 0 && (rays < 64 || rays > kMaxCapacity)) { fprintf(stderr, "rodent_hip: stream capacity must be 0 (default) or 64 .. %ld rays\n", kMaxCapacity); abort(); }
     rdev(dev).capacity = rays;
@@ -1529,7 +1727,7 @@ void rodent_hip_render_mapping(int32_t dev, int32_t mapping) {
     r.mapping = resolve_mapping(r);
 }
 int32_t rodent_hip_render_mapping_in_effect(int32_t dev) { return rdev(dev).mapping; }
-void rodent_hip_render_defaults(int32_t dev) { RenderDevice& r = rdev(dev); render_defaults(r); r.mapping = resolve_mapping(r); r.trace_persistent = resolve_trace(r); }
+void rodent_hip_render_defaults(int32_t dev) { RenderDevice& r = rdev(dev); render_defaults(r); r.mapping = resolve_mapping(r); r.trace_persistent = resolve_trace(r); resolve_refill(r); }
 
 int32_t get_spp(void) { return rdev(g_current_dev).spp; }
 

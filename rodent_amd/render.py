@@ -27,7 +27,7 @@ class SceneDesc(C.Structure):
                [(n, vp) for n in ("texcoords", "textures", "texels")] + [("num_textures", i32), ("num_texels", C.c_uint32)]
 
 
-RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_fused_compact", "rodent_hip_render_mapping_in_effect", "rodent_hip_render_defaults", "rodent_hip_render_lds_image", "rodent_hip_render_mega_joint", "rodent_hip_render_trace_persistent", "get_spp", "render",
+RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_fused_compact", "rodent_hip_render_mapping_in_effect", "rodent_hip_render_defaults", "rodent_hip_render_lds_image", "rodent_hip_render_mega_joint", "rodent_hip_render_trace_persistent", "rodent_hip_render_trace_refill", "rodent_hip_render_trace_refill_in_effect", "get_spp", "render",
                   "setup_interface", "get_pixels", "clear_pixels", "cleanup_interface", "rodent_get_film_data",
                   "rodent_gpu_get_first_primary_stream", "rodent_gpu_get_second_primary_stream", "rodent_gpu_get_secondary_stream",
                   "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows",
@@ -56,6 +56,8 @@ def lib():
         l.rodent_hip_render_mapping_in_effect.argtypes = [i32]; l.rodent_hip_render_mapping_in_effect.restype = i32
         l.rodent_hip_render_defaults.argtypes = [i32]; l.rodent_hip_render_defaults.restype = None
         l.rodent_hip_render_trace_persistent.argtypes = [i32, i32]; l.rodent_hip_render_trace_persistent.restype = None
+        l.rodent_hip_render_trace_refill.argtypes = [i32, i32, i32]; l.rodent_hip_render_trace_refill.restype = None
+        l.rodent_hip_render_trace_refill_in_effect.argtypes = [i32]; l.rodent_hip_render_trace_refill_in_effect.restype = i32
         l.rodent_hip_render_mega_joint.argtypes = [i32, i32]; l.rodent_hip_render_mega_joint.restype = None
         l.get_spp.argtypes = []; l.get_spp.restype = i32
         l.render.argtypes = [C.POINTER(Settings), i32]; l.render.restype = None
@@ -90,7 +92,7 @@ class Renderer:
     MAPPINGS = {"auto": -1, "streaming": 0, "megakernel": 1}       # per scene / mapping_gpu.impala:308-369 / :371-474
 
     def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming", capacity=0, sort=None, overlap=None, fused_sort=None, lds_image=None,
-                 trace_persistent=None, fused_compact=None, mega_joint=None):
+                 trace_persistent=None, fused_compact=None, mega_joint=None, trace_refill=None):
         """Options left at None take the library's default, or what the option's RODENT_HIP_* environment variable says."""
         import torch
         if not torch.cuda.is_available():
@@ -116,6 +118,9 @@ class Renderer:
                               (fused_compact, l.rodent_hip_render_fused_compact)):        # the shader writes continuing rays to their compacted slots
             if value is not None:
                 setter(dev, int(value))
+        if trace_refill is not None:                         # persistent traversal launches: lane refill once that many lanes of a wave are idle: n or (bounce rays, shadow rays); 0 = whole chunks
+            bounce, shadow = trace_refill if isinstance(trace_refill, (tuple, list)) else (trace_refill, trace_refill)
+            l.rodent_hip_render_trace_refill(dev, int(bounce), int(shadow))
         l.setup_interface(width, height)
         l.clear_pixels()
 
@@ -126,6 +131,11 @@ class Renderer:
     def mapping_name(self):
         """The mapping the next frame uses ("streaming" / "megakernel"): the caller's choice, or the library's for this scene."""
         return {0: "streaming", 1: "megakernel"}[lib().rodent_hip_render_mapping_in_effect(self.dev)]
+
+    def trace_refill(self):
+        """(idle lanes that trigger a refill while a wave draws bounce rays, ... shadow rays) of the persistent traversal launches; (0, 0) = whole chunks."""
+        v = lib().rodent_hip_render_trace_refill_in_effect(self.dev)
+        return v & 255, v >> 8
 
     def clear(self):
         lib().clear_pixels()

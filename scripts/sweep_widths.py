@@ -2,7 +2,7 @@
 """Times the shipped kernel of every BVH layout (BVH2/Tri1, BVH4/Tri4, BVH8/Tri4) on the benchmark ray sets at 1 Mi rays
 per launch and on 16 Mi primary rays per launch (HIP events on the launch stream, median of --steps), closest and any
 hit, and checks every result against variant 0 of its layout.
-usage: python scripts/sweep_widths.py [--steps 20] [--widths 2,4,8] [--all-variants] [--big]"""
+usage: python scripts/sweep_widths.py [--steps 20] [--widths 2,4,8] [--all-variants] [--big] [--big-random]"""
 import argparse, sys
 from pathlib import Path
 import numpy as np
@@ -16,6 +16,7 @@ ap.add_argument("--widths", default="2,4,8")
 ap.add_argument("--all-variants", action="store_true")
 ap.add_argument("--big", action="store_true", help="also 16 Mi primary rays per launch")
 ap.add_argument("--mid", action="store_true", help="also 256 Ki, 2 Mi and 4 Mi primary rays per launch")
+ap.add_argument("--big-random", action="store_true", help="also 8 Mi random segments per launch (what a renderer's bounce pass looks like)")
 ap.add_argument("--only", default=None, help="comma-separated variant names")
 ap.add_argument("--scene", default="atrium")
 a = ap.parse_args()
@@ -28,6 +29,8 @@ sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0)
         "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
 if a.big:
     sets["primary16Mi"] = raygen.primary_rays(eye, d, up, fov, 4096, 4096, 0.0, 5000.0)
+if a.big_random:
+    sets["random8Mi"] = raygen.random_rays(lo, hi, 1 << 23, 43, 0.0, 1.0)
 if a.mid:
     sets["primary256Ki"] = raygen.primary_rays(eye, d, up, fov, 512, 512, 0.0, 5000.0)
     sets["primary2Mi"] = raygen.primary_rays(eye, d, up, fov, 2048, 1024, 0.0, 5000.0)

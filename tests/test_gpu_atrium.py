@@ -198,6 +198,28 @@ def test_atrium_joint_traversal_launch_renders_the_same_frame(R, atrium_scene, s
     assert f0.mean() > 1e-3
 
 
+def test_atrium_lane_refill_renders_the_same_frame(R, atrium_scene):
+    """rodent_hip_render_trace_refill: waves of the persistent traversal launches replace finished rays instead of waiting for the
+    last ray of a 64-ray chunk (k_trace_refill; the per-scene default for a hierarchy of this size).  Separate launches (1) and the
+    joint launch (2), several thresholds (1 = a refill whenever a lane is idle, 64 = whole chunks through the refill kernel),
+    regeneration included: the ray counts of the chunked kernels exactly, the same film up to the order of the atomic adds."""
+    W, H, SPP, MAXLEN = 640, 360, 8, 8
+    cam = atrium_camera(W, H)
+    r = R.Renderer(atrium_scene, W, H, SPP, MAXLEN, mapping="streaming", trace_persistent=2, trace_refill=(0, 0), capacity=700_000)
+    assert r.trace_refill() == (0, 0)
+    r.render(cam, 3)
+    c0, f0 = r.counters(), r.film(); r.close()
+    for mode, refill in ((2, (48, 48)), (2, (1, 1)), (2, (64, 32)), (2, (24, 64)), (1, (48, 48)), (1, (8, 60))):
+        r = R.Renderer(atrium_scene, W, H, SPP, MAXLEN, mapping="streaming", trace_persistent=mode, trace_refill=refill, capacity=700_000)
+        assert r.trace_refill() == refill
+        r.render(cam, 3)
+        c, f = r.counters(), r.film(); r.close()
+        assert (c["primary_rays"], c["shadow_rays"], c["generated"]) == (c0["primary_rays"], c0["shadow_rays"], W * H * SPP), (mode, refill)
+        assert np.allclose(f, f0, rtol=FILM_RTOL, atol=FILM_ATOL), (mode, refill)
+    r = R.Renderer(atrium_scene, W, H, SPP, MAXLEN, mapping="streaming")          # left to the library: on for 142 444 nodes
+    assert r.trace_refill() == (48, 48); r.close()
+
+
 def test_atrium_takes_the_streaming_mapping_by_default(R, atrium_scene):
     f = ATRIUM_FRAME
     r = R.Renderer(atrium_scene, f["W"], f["H"], 1, 2, mapping="auto")

@@ -115,6 +115,23 @@ def test_capacity_regeneration(R, oracle, cornell_scene, capacity):
     assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
 
 
+def test_lane_refill_on_a_small_tree_matches_oracle(R, oracle, cornell_scene):
+    """k_trace_refill where the library would not use it (a 22-node tree: every ray is short, refills follow each other closely):
+    640 x 480 x 3 spp in streams of 600 000 rays (the persistent launches need 524 288), joint launch and separate launches, against
+    the oracle's film and exact ray counts."""
+    W, H, SPP = 640, 480, 3
+    cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
+    film_o, counts = oracle.render(cornell_scene, cam, 1, SPP, 5, W, H)
+    r = R.Renderer(cornell_scene, W, H, SPP, 5, mapping="streaming")
+    assert r.trace_refill() == (0, 0); r.close()                             # per scene: off for this one
+    for mode, refill in ((2, (32, 32)), (1, (4, 48))):
+        r = R.Renderer(cornell_scene, W, H, SPP, 5, mapping="streaming", trace_persistent=mode, trace_refill=refill, capacity=600_000)
+        r.render(cam, 1)
+        c = r.counters(); film_g = r.film(); r.close()
+        assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1]) and c["generated"] == W * H * SPP, (mode, refill)
+        assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL), (mode, refill)
+
+
 def test_cornell_matches_reference_image_full_size(R, cornell_scene):
     """The reference's own CTest (src/CMakeLists.txt:131-134): 1080x720, 50 frames x 4 spp, vs testing/ref-cornell.png."""
     W, H = 1080, 720
