@@ -315,6 +315,7 @@ def render_section(args, torch, dist, rank, world, dev):
             r = R.Renderer(sc, w, h, spp=4, max_path_len=max_len, dev=dev, mapping=mapping.split("_")[0], sort=True if mapping.endswith("_sorted") else None)
             if mapping == "auto":
                 chosen = r.mapping_name()
+                entry["auto_trace_refill_idle_lanes[bounce,shadow]"] = list(r.trace_refill())      # lane refill in the persistent traversal launches (0 = whole chunks)
             elif mapping == chosen:
                 r.close()
                 entry[mapping] = {"same_as": "auto"}
@@ -517,6 +518,16 @@ def main():
         sorted_rec = {"Mrays_s": round(len(rnd) * steps_r / wall_s / 1e6, 3), "ms_per_step": round(1e3 * wall_s / steps_r, 5), "kernels_ms": round(ks_mean, 5),
                       "variant": "sorted: counting sort of the rays on 512 Morton cells of their origin inside every launch, then the default kernel through the permutation",
                       "identical_to_unsorted": bool(torch.equal(hits_sorted_dev, hits_rnd_dev))}
+    # ... and through "refill": continuous compaction inside the persistent kernel (a wave replaces finished rays instead of waiting for
+    # the last ray of a 64-ray chunk) -- the mapping for incoherent ray sets; the renderer's bounce and shadow passes use the same scheme
+    refill_rec = None
+    if world == 1 and "refill" in abi.variants(width) and args.only != "primary":
+        rv = abi.variants(width).index("refill")
+        hits_refill_dev = torch.zeros_like(hits_rnd_dev)
+        wall_f, kf_mean, _, _ = time_passes(abi, torch, bvh, rnd_dev, hits_refill_dev, len(rnd), rv, steps_r, warm_r, None)
+        refill_rec = {"Mrays_s": round(len(rnd) * steps_r / wall_f / 1e6, 3), "ms_per_step": round(1e3 * wall_f / steps_r, 5), "kernels_ms": round(kf_mean, 5),
+                      "variant": "refill: the default's persistent workgroups; a wave whose idle lanes reach 32 draws that many new rays from its stripe's counter",
+                      "identical_to_default": bool(torch.equal(hits_refill_dev, hits_rnd_dev))}
     abi.check_errors(dev)                                         # the asynchronous entry points report stack overflows through a flag
     # for information only (never `value`): independent batches in flight on two streams -- the fill of one launch
     # overlaps the drain of the other (every (device, stream) has its own launch state)
@@ -592,6 +603,8 @@ def main():
         out["extra"]["with_schedule_history"] = history
     if sorted_rec is not None:
         out["extra"]["random_sorted"] = sorted_rec
+    if refill_rec:
+        out["extra"]["random_refill"] = refill_rec
     if render is not None:
         out["extra"]["render"] = render
     if not args.no_cpu_baseline:

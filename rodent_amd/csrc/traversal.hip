@@ -824,8 +824,11 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int FUSED = 2
     else launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, false, 32, false, 0, FUSED>(s, nodes, tris, rays, hits, n, stream, max_id);
 }
 
-#ifdef RODENT_HIP_LAB
+// "refill": the persistent kernel with lane refill (traversal_top.h), for ray sets whose rays differ widely in cost -- incoherent ones: the
+// benchmark's random segments +5 % at 1 Mi rays per launch, +13 % (closest hit) / +18 % (any hit) at 8 Mi, profiles/r03_sweep_refill_big_random.log;
+// coherent camera rays LOSE 13 ... 18 % (neighbouring rays stop being in step), which is why it is a variant the caller asks for and not the default.
 template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL> void L_top_refill(LAUNCH_ARGS) {
+    if (n < g_top_min_rays || mapped_node_ids(nodes) == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }      // (as L_default)
     ensure_deep_list(s, n);
     if (!s.top_image || !s.tickets) {
         std::lock_guard<std::mutex> lock(g_mutex);
@@ -841,7 +844,6 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL> void L_top_refil
                        (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes));
     hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
-#endif
 
 // Phased traversal: caps of the capped phases (the last, uncapped phase follows).  Launches too small to fill the chip
 // once take the single kernel.
@@ -898,6 +900,8 @@ const Variant2 kVariants2[] = {
     //                                                       LDS_N CAPS (index into kPhaseCaps) [LAST_RAYS]
     K2("phased",             "k_bvh2_phase",         L_phased, 16, 2),                 // phased traversal with ray compaction: one capped phase of 40 iterations, then the rest
     K2("sorted",             "k_bvh2_single",        L_sorted, 16),                    // rays grouped by the Morton cell of their origin first (for incoherent ray sets)
+    //                                                                    LDS_N TOPN WAVES REFILL (idle lanes that trigger a refill)
+    K2("refill",             "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 32),   // the default's persistent workgroups, but a wave replaces finished rays instead of waiting for the last ray of a chunk (for incoherent ray sets)
 #ifdef RODENT_HIP_LAB
     // LDS-staged top of the tree, what was swept (profiles/r02_sweep_top_*.log): image size x workgroup shape, one chunk per
     // workgroup wave (L_top) or persistent (L_top_persist), ticket prefetch, waves per CU, lane refill
@@ -940,7 +944,6 @@ const Variant2 kVariants2[] = {
     K2("top-prio64",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 64),    // s_setprio 3 once a chunk has run 64 / 96 / 128 iterations
     K2("top-prio96",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 96),
     K2("top-prio128",        "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 128),
-    K2("top255r16-32",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 32),
     K2("top255r16-48",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 48),
     // what was swept on the way (profiles/r02_sweep_phased*.log, r02_sweep_prio.log): other phase caps, fewer rays per wave in
     // the last phase, issue priorities by wave age / dispatch round

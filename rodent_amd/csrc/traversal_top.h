@@ -5,7 +5,8 @@
 //   stage_top_image                                            a workgroup stages the image and VALIDATES it against the caller's nodes
 //   k_bvh2_top_persist                                         the kernel: one resident generation of workgroups, chunks from striped tickets
 //   k_bvh2_top_finish, k_bvh2_top_finish_history               follow-up kernels (deep rays, stale image, schedule history)
-//   k_bvh2_top, k_bvh2_top_refill                              lab build: one chunk per workgroup wave; lane refill
+//   k_bvh2_top_refill                                          variant "refill": persistent, idle lanes are refilled (for incoherent ray sets)
+//   k_bvh2_top                                                 lab build: one chunk per workgroup wave
 #pragma once
 
 // ---------------------------------------------------------------------------------------------
@@ -325,8 +326,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     }
 }
 
-#ifdef RODENT_HIP_LAB
-// Persistent form with lane refill: a wave does not wait for the last ray of a 64-ray chunk.  As soon as REFILL of its lanes
+// Persistent form with lane refill (variant "refill"): a wave does not wait for the last ray of a 64-ray chunk.  As soon as REFILL of its lanes
 // are idle it draws that many rays from its stripe's counter (one atomic per refill) and starts them in the idle lanes; the
 // rest keep stepping.  Ticket t of stripe s is ray ((t / 2048) * 64 + s) * 2048 + t % 2048 (the same 32-chunk groups), the first
 // 64 tickets of a wave are static.  Which rays share a wave changes, what a ray visits does not.
@@ -374,5 +374,4 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(c
         if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
     }
 }
-#endif
 

@@ -41,7 +41,7 @@ def test_introspection_without_gpu(native_build):
     # are in the lab build (RODENT_HIP_LAB=1)
     if not abi.LAB:
         assert abi.lib().rodent_hip_is_lab_build() == 0
-        assert len(abi.variants(2)) <= 5 and not any(n.startswith(("stats-", "trace-")) for w in (2, 4, 8) for n in abi.variants(w))
+        assert abi.variants(2) == ["top", "fast", "fast-noxcd", "phased", "sorted", "refill"] and not any(n.startswith(("stats-", "trace-")) for w in (2, 4, 8) for n in abi.variants(w))
 
 
 def test_no_cpu_fallback(native_build):

@@ -390,6 +390,7 @@ def test_bench_py_contract(native_build):
     assert d["value"] > 1000 and d["extra"]["all_rays_bit_exact_vs_oracle"] == {"primary": True, "random": True}
     assert d["extra"]["library"]["built_from_these_sources"] is True
     assert d["extra"]["random_sorted"]["identical_to_unsorted"] is True
+    assert d["extra"]["random_refill"]["identical_to_default"] is True
 
 
 def test_bench_py_with_two_ranks(native_build):
