@@ -85,8 +85,8 @@ int32_t rodent_hip_render_mapping_in_effect(int32_t dev);
 /* Every rodent_hip_render_* option of the device back to its default, or to what its RODENT_HIP_* environment variable says
  * (the values a fresh process starts with); spp / max_path_len and the scene are kept. */
 void    rodent_hip_render_defaults(int32_t dev);
-/* Rays per ray stream of the streaming mapping: the reference's constant 1 Mi (mapping_gpu.impala:319) is 8 Mi here
- * by default (larger launches amortise their fill and drain on a 256-CU chip; 0 restores the default). */
+/* Rays per ray stream of the streaming mapping: the reference's constant 1 Mi (mapping_gpu.impala:319) is 32 Mi here
+ * by default (larger launches amortise their fill and drain on a 256-CU chip: 7.1 GB of streams out of 288 GB; 0 restores the default). */
 void    rodent_hip_render_capacity(int32_t dev, int32_t rays);
 /* 1: hit rays are sorted by material before shading and misses dropped, as in the reference (mapping_gpu.impala:166-221,347-357:
  * there every material is its own generated shader and the sort is what makes a launch per material possible).
@@ -137,7 +137,7 @@ void    rodent_hip_render_trace_persistent(int32_t dev, int32_t enable);
  * retires their rays and draws as many new ones from its stripe's counter instead of waiting for the last ray of a 64-ray chunk
  * (k_trace_refill) -- idle_bounce while it draws from the rays the last bounce left, idle_shadow while it draws shadow rays (64 =
  * whole chunks for that kind); the camera rays a launch holds (the host knows where: the rays generated for it) always go chunk
- * by chunk.  0, 0: whole chunks for everything (k_trace_persist).  -1, -1 (default): per scene -- 48, 48 for hierarchies of 16 384
+ * by chunk.  0, 0: whole chunks for everything (k_trace_persist).  -1, -1 (default): per scene -- 40, 40 for hierarchies of 16 384
  * nodes and more (atrium: +8 % at 1920 x 1080 x 16 spp, +9 % at 3840 x 2160 x 32 spp; profiles/r03_refill_sweep.txt), off below
  * (every ray is short there: -4 ... -11 %).  Same paths, same ray counts, same film up to the order of the atomic adds.
  * RODENT_HIP_TRACE_REFILL=<both> or <bounce>,<shadow>. */

@@ -52,10 +52,10 @@ constexpr int kBlock = 256;                    // workgroup of the streaming (no
 constexpr int kBinBlock = 1024;
 constexpr int kMaxBins = 1025;                 // mapping_gpu.impala:200,342 (1024 geometries + the "miss" bin)
 // Rays per stream.  The reference uses 1 Mi (mapping_gpu.impala:319, sized for ~12 GB boards).  On this chip a 1 Mi-ray
-// launch is two rounds of resident waves, all fill and drain; 8 Mi-ray streams (1.8 GB of streams +
-// 1.5 GB of stack slab out of 288 GB) render the atrium 25 % faster and the Cornell box 9 % faster.  Results do not
-// depend on it.  rodent_hip_render_capacity() / RODENT_HIP_STREAM_CAPACITY override it.
-constexpr int kDefaultCapacity = 8 * 1024 * 1024;
+// launch is two rounds of resident waves, all fill and drain; 8 Mi-ray streams render the atrium 25 % faster and the
+// Cornell box 9 % faster (round 1), 32 Mi-ray streams another 4.6 % / 4.6 % (profiles/r03_capacity_sweep.txt; 64 Mi: no further gain):
+// 7.1 GB of streams out of 288 GB.  Results do not depend on it.  rodent_hip_render_capacity() / RODENT_HIP_STREAM_CAPACITY override it.
+constexpr int kDefaultCapacity = 32 * 1024 * 1024;
 constexpr long kMaxCapacity = 64l << 20;
 static int env_capacity() {
     static const int v = [] { const char* e = getenv("RODENT_HIP_STREAM_CAPACITY"); const long c = e ? atol(e) : 0; return c >= 64 && c <= kMaxCapacity ? (int)c : kDefaultCapacity; }();
@@ -1587,7 +1587,7 @@ int resolve_trace(const RenderDevice& r) {
 // every ray is short and the refill's own cost (one atomic, eight loads and a reciprocal per started ray, three more multiplications
 // per node step) is not paid back -- profiles/r03_refill_sweep.txt: +8 % at 142 444 nodes, +16 % at 76 494, +8 % at 19 862, +1 % at 9 870,
 // -4 ... -11 % from 4 951 nodes down.
-constexpr int kRefillMinNodes = 16384, kRefillIdleLanes = 48;
+constexpr int kRefillMinNodes = 16384, kRefillIdleLanes = 40;
 void resolve_refill(RenderDevice& r) {
     if (r.trace_refill_request[0] >= 0) { r.trace_refill = r.trace_refill_request[0]; r.trace_refill_shadow = r.trace_refill_request[1]; return; }
     r.trace_refill = r.trace_refill_shadow = r.scene.loaded && r.scene.num_nodes >= kRefillMinNodes ? kRefillIdleLanes : 0;

@@ -108,7 +108,7 @@ class Renderer:
         l.rodent_hip_scene_create(dev, C.byref(desc))
         l.rodent_hip_render_config(dev, spp, max_path_len)
         l.rodent_hip_render_mapping(dev, self.MAPPINGS[mapping])
-        l.rodent_hip_render_capacity(dev, capacity)          # rays per stream, 0 = default (8 Mi)
+        l.rodent_hip_render_capacity(dev, capacity)          # rays per stream, 0 = default (32 Mi)
         for value, setter in ((sort, l.rodent_hip_render_sort),                    # sort hit rays by material before shading (reference behaviour)
                               (overlap, l.rodent_hip_render_overlap),              # shadow rays on a second HIP stream
                               (fused_sort, l.rodent_hip_render_fused_sort),        # the sort computes a permutation, the shader gathers through it

@@ -217,7 +217,7 @@ def test_atrium_lane_refill_renders_the_same_frame(R, atrium_scene):
         assert (c["primary_rays"], c["shadow_rays"], c["generated"]) == (c0["primary_rays"], c0["shadow_rays"], W * H * SPP), (mode, refill)
         assert np.allclose(f, f0, rtol=FILM_RTOL, atol=FILM_ATOL), (mode, refill)
     r = R.Renderer(atrium_scene, W, H, SPP, MAXLEN, mapping="streaming")          # left to the library: on for 142 444 nodes
-    assert r.trace_refill() == (48, 48); r.close()
+    assert r.trace_refill() == (40, 40); r.close()
 
 
 def test_atrium_takes_the_streaming_mapping_by_default(R, atrium_scene):

@@ -104,7 +104,7 @@ def test_row_bands_reproduce_the_frame(R, oracle, cornell_scene):
 @pytest.mark.parametrize("capacity", [1 << 20, 100_000, 4096])
 def test_capacity_regeneration(R, oracle, cornell_scene, capacity):
     """More paths per frame than a stream holds: the stream is refilled while it drains (mapping_gpu.impala:332-336).
-    The reference's capacity (1 Mi), an odd one and a tiny one; the default (8 Mi) is what the other tests run with."""
+    The reference's capacity (1 Mi), an odd one and a tiny one; the default (32 Mi) is what the other tests run with."""
     W, H, SPP = (640, 480, 5) if capacity == 1 << 20 else (200, 150, 3)       # 1 536 000 / 90 000 paths > capacity
     cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
     r = R.Renderer(cornell_scene, W, H, SPP, 6, capacity=capacity)
