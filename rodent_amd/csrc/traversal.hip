@@ -827,7 +827,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int FUSED = 2
 // "refill": the persistent kernel with lane refill (traversal_top.h), for ray sets whose rays differ widely in cost -- incoherent ones: the
 // benchmark's random segments +5 % at 1 Mi rays per launch, +13 % (closest hit) / +18 % (any hit) at 8 Mi, profiles/r03_sweep_refill_big_random.log;
 // coherent camera rays LOSE 13 ... 18 % (neighbouring rays stop being in step), which is why it is a variant the caller asks for and not the default.
-template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL> void L_top_refill(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = false> void L_top_refill(LAUNCH_ARGS) {
     if (n < g_top_min_rays || mapped_node_ids(nodes) == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }      // (as L_default)
     ensure_deep_list(s, n);
     if (!s.top_image || !s.tickets) {
@@ -840,7 +840,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL> void L_top_refil
     }
     s.top_image_nodes = nullptr;
     const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;
-    hipLaunchKernelGGL((k_bvh2_top_refill<ANY, LDS_N, TOPN, WAVES, REFILL>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+    hipLaunchKernelGGL((k_bvh2_top_refill<ANY, LDS_N, TOPN, WAVES, REFILL, ADAPT>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
                        (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes));
     hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
@@ -945,6 +945,9 @@ const Variant2 kVariants2[] = {
     K2("top-prio96",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 96),
     K2("top-prio128",        "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 128),
     K2("top255r16-48",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 48),
+    K2("top-adaptive-32",    "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 32, true),     // refill unless the rays a draw started share an origin (then: whole chunks)
+    K2("top-adaptive-48",    "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 48, true),
+    K2("top255r16-64",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 64),           // whole chunks through the refill kernel: what its loop costs
     // what was swept on the way (profiles/r02_sweep_phased*.log, r02_sweep_prio.log): other phase caps, fewer rays per wave in
     // the last phase, issue priorities by wave age / dispatch round
     K2("phased-40-24",       "k_bvh2_phase",         L_phased, 16, 0),

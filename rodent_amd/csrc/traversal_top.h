@@ -330,7 +330,9 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
 // are idle it draws that many rays from its stripe's counter (one atomic per refill) and starts them in the idle lanes; the
 // rest keep stepping.  Ticket t of stripe s is ray ((t / 2048) * 64 + s) * 2048 + t % 2048 (the same 32-chunk groups), the first
 // 64 tickets of a wave are static.  Which rays share a wave changes, what a ray visits does not.
-template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL>
+// ADAPT: the threshold is chosen at every draw from the rays just drawn -- rays that share an origin (a camera's) wait for the whole
+// wave like a chunk (their neighbours are in step, a refill would take that away), anything else refills at REFILL idle lanes.
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = false>
 __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                     const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                                     Ctl* ctl, int* __restrict__ deep_list, const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id) {
@@ -352,10 +354,24 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(c
         L = start_lane(rays, hits, r < n ? r : -1, 0, col);
         if (L.top != 0) L.top = root;
     }
+    // the rays a draw started: one origin for all of them?  (readlane: the leader is wave-uniform)
+    const auto one_origin = [&](unsigned long long started) {
+        if (!started) return false;
+        const int leader = __ffsll((long long)started) - 1;
+        const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.ray.ox), leader));
+        const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.ray.oy), leader));
+        const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.ray.oz), leader));
+        const bool mine = (started >> lane) & 1ull;
+        return __ballot(mine && !(L.ray.ox == ox && L.ray.oy == oy && L.ray.oz == oz)) == 0ull;
+    };
+    int need = REFILL;                                                       // wave-uniform: idle lanes that trigger the next draw
+    if (ADAPT) need = one_origin(__ballot(L.top != 0)) ? kWave : REFILL;
+    // One flat loop, deliberately: with the steps in an inner loop of their own whole chunks run 8 % faster through this kernel and
+    // refilled waves 8 % slower (8 Mi random segments 1.27 -> 1.37 ms, and 66 VGPRs unless capped) -- profiles/r03_sweep_adaptive.log.
     bool more = true;                                                        // wave-uniform: the stripe may have rays left
     for (;;) {
         const unsigned long long live = __ballot(L.top != 0);
-        if (more && __popcll(live) <= kWave - REFILL) {
+        if (more && __popcll(live) <= kWave - need) {
             const int want = kWave - __popcll(live);
             int first = 0;
             if (lane == 0) first = atomicAdd(counter, want);
@@ -368,6 +384,7 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(c
                     L.top = root;
                 }
             }
+            if (ADAPT) need = one_origin(__ballot(L.top != 0) & ~live) ? kWave : REFILL;
             continue;
         }
         if (live == 0) break;
