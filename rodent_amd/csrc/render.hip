@@ -1404,7 +1404,8 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     const int G = r.scene.dev.num_materials;
     if (G + 1 > kMaxBins) { fprintf(stderr, "rodent_hip: too many geometries (%d)\n", G); abort(); }
     PrimaryStream a, b; SecondaryStream sec;
-    const int kCapacity = r.capacity > 0 ? r.capacity : env_capacity();
+    // rays per stream: the configured capacity, but no more than this call can ever have in flight (a 256 x 144 frame does not reserve 7 GB)
+    const int kCapacity = (int)std::min<long long>(r.capacity > 0 ? r.capacity : env_capacity(), std::max<long long>(64, ((long long)r.spp * r.film_w * std::max(0, y1 - y0) + 63) / 64 * 64));
     carve_primary(a, ensure_slab(r, 0, kCapacity, 20), round_cap(kCapacity));
     carve_primary(b, ensure_slab(r, 1, kCapacity, 20), round_cap(kCapacity));
     carve_secondary(sec, ensure_slab(r, 2, kCapacity, 13), round_cap(kCapacity));
