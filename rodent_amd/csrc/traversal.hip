@@ -941,6 +941,7 @@ const Variant2 kVariants2[] = {
     K2("top-lazy-one",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 2, true),
     K2("top-userperm-lazy-one", "k_bvh2_top_persist", L_top_persist, 15, 255, 16, false, false, 32, false, -1, 2, true),
     K2("top-userperm",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, -1),    // lane j traces ray perm[j] of a caller-supplied permutation (scheduling experiments)
+    K2("top-double",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, -2, 2),   // two image levels per iteration (a lane whose next node is in LDS visits it at once)
     K2("top-prio64",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 64),    // s_setprio 3 once a chunk has run 64 / 96 / 128 iterations
     K2("top-prio96",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 96),
     K2("top-prio128",        "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 128),

@@ -286,6 +286,9 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
             if (PRIO > 0) __builtin_amdgcn_s_setprio(0);
             while (__ballot(L.top != 0)) {
                 if (L.top != 0) bvh2_step<ANY, false, true, LAZY, FUSED == 2>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+                // lab (PRIO == -2, "top-double"): a lane whose next node is in the LDS image visits it in the same iteration -- two levels of the top
+                // of the tree per dependent step where the fetch is a ds_read (VERDICT r2 item 2's "BVH4-collapsed image", without a second layout)
+                if (PRIO == -2 && L.top >= kLdsTag) bvh2_step<ANY, false, true, LAZY, FUSED == 2>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
                 if (TRACE || PRIO > 0 || HISTORY) iterations++;
                 if (PRIO > 0 && iterations == PRIO) __builtin_amdgcn_s_setprio(3);          // lab: a chunk that is still running after PRIO iterations is on the critical path
             }
