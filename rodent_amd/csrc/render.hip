@@ -780,7 +780,7 @@ __device__ __forceinline__ unsigned lookback_exclusive(unsigned* status, int blo
 // stable order the separate compaction produced, without reading and writing the 15-word stream once more per bounce (the
 // compaction's copy was 38 % of the summed kernel time of BASELINE config 4, profiles/r02_render_pmc_digest.txt); the
 // new stream size goes to *alive_total.
-__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, PrimaryStream p, PrimaryStream q, const int* __restrict__ perm, SecondaryStream s, const int* size_ptr, int n_value, float* film,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shade(SceneDev sc, PrimaryStream p, PrimaryStream q, const int* __restrict__ perm, SecondaryStream s, const int* size_ptr, int n_value, float* film,
                                                    float inv_spp, int max_path_len, int unsorted, unsigned* scan, int* alive_total) {
     __shared__ unsigned wave_total[kBlock / kWave + 1];
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -1303,13 +1303,16 @@ int persistent_grid(RenderDevice& r) {
     if (!r.num_cus) { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, r.dev)); r.num_cus = prop.multiProcessorCount; }
     return ((r.num_cus * (32 / kPersistWaves) + kTraceStripes - 1) / kTraceStripes) * kTraceStripes;
 }
+// k_trace_refill keeps a ray's index in 28 bits of a lane register (the renderer's own streams hold at most 64 Mi rays each; a caller's stage-level
+// streams may be larger: those go through k_trace_persist)
+bool refill_indexable(long long n_primary, long long n_secondary) { return n_primary + kWave + n_secondary <= (long long)kIndexMask; }
 // coherent_from: the rays [coherent_from, n) were generated for this launch (camera rays), the ones in front of them are what the last bounce left
 void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n, int coherent_from = 0) {
     ensure_deep(r, 0, n);
     int* tickets = nullptr;
     if (r.trace_persistent && n >= kPersistMinRays) {
         ensure_tickets(r); tickets = r.tickets[0];
-        if (r.trace_refill > 0)
+        if (r.trace_refill > 0 && refill_indexable(n, 0))
             hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
                                r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow);
         else hipLaunchKernelGGL(k_trace_persist<0>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
@@ -1323,7 +1326,7 @@ void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const Secondary
     int* tickets = nullptr;
     if (r.trace_persistent && max_n >= kPersistMinRays) {
         ensure_tickets(r); tickets = r.tickets[1];
-        if (r.trace_refill > 0)
+        if (r.trace_refill > 0 && refill_indexable(0, max_n))
             hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, 0, s, size_ptr, max_n, r.film, inv_spp,
                                r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow);
         else hipLaunchKernelGGL(k_trace_persist<1>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, s, size_ptr, max_n, r.film, inv_spp,
@@ -1338,7 +1341,7 @@ void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const Secondary
 void launch_trace_joint(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n, int coherent_from, const SecondaryStream& s, const int* size_ptr, int max_n, float inv_spp) {
     ensure_deep(r, 0, n); ensure_deep(r, 1, max_n);
     ensure_tickets(r);
-    if (r.trace_refill > 0)
+    if (r.trace_refill > 0 && refill_indexable(n, max_n))
         hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, s, size_ptr, max_n, r.film, inv_spp,
                            r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0], r.trace_refill, r.trace_refill_shadow);
     else hipLaunchKernelGGL(k_trace_persist<2>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, s, size_ptr, max_n, r.film, inv_spp,
