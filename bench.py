@@ -531,7 +531,7 @@ def main():
     abi.check_errors(dev)                                         # the asynchronous entry points report stack overflows through a flag
     # for information only (never `value`): independent batches in flight on two streams -- the fill of one launch
     # overlaps the drain of the other (every (device, stream) has its own launch state)
-    overlapped = big = None
+    overlapped = big = big_random = None
     if info and world == 1:
         try:
             s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -560,6 +560,20 @@ def main():
                 del big_dev, big_hits, big_rays
             except Exception as e:
                 print(f"bench.py: 16 Mi-ray measurement skipped ({e})", file=sys.stderr)
+            # ... and 8 Mi random segments per launch (what a renderer's bounce pass looks like): the default mapping and "refill"
+            try:
+                if width == 2 and "refill" in abi.variants(width):
+                    lo8, hi8 = raygen.scene_bounds(F.read_bvh(bvh_path, F.BVH4_TRI4)[0])
+                    rnd8 = raygen.random_rays(lo8, hi8, 1 << 23, 43, 0.0, scenes.RANDOM_TMAX)
+                    rnd8_dev = abi.to_device(rnd8, dev)
+                    h8 = [torch.zeros(len(rnd8) * F.HIT1.itemsize, dtype=torch.uint8, device=f"cuda:{dev}") for _ in range(2)]
+                    wall_d, kd, _, _ = time_passes(abi, torch, bvh, rnd8_dev, h8[0], len(rnd8), variant, 10, 3, None)
+                    wall_f8, kf8, _, _ = time_passes(abi, torch, bvh, rnd8_dev, h8[1], len(rnd8), abi.variants(width).index("refill"), 10, 3, None)
+                    big_random = {"rays_per_launch": len(rnd8), "default_Mrays_s": round(len(rnd8) * 10 / wall_d / 1e6, 3), "default_kernels_ms": round(kd, 5),
+                                  "refill_Mrays_s": round(len(rnd8) * 10 / wall_f8 / 1e6, 3), "refill_kernels_ms": round(kf8, 5), "identical_hits": bool(torch.equal(h8[0], h8[1]))}
+                    del rnd8_dev, h8, rnd8
+            except Exception as e:
+                print(f"bench.py: 8 Mi random-ray measurement skipped ({e})", file=sys.stderr)
 
     hits = abi.from_device(hits_dev, F.HIT1)[:n]
     hits_rnd = abi.from_device(hits_rnd_dev, F.HIT1)[:len(rnd)]
@@ -593,7 +607,7 @@ def main():
                   "library": {"version": abi.lib().rodent_hip_version().decode(), "source_digest": abi.lib().rodent_hip_source_digest().decode(),
                               "built_from_these_sources": abi.built_from_these_sources()},       # the prebuilt .so against the sources lying next to it
                   "two_streams_Mrays_s_per_gpu": None if overlapped is None else round(overlapped, 3),
-                  "primary_16Mi_rays_per_launch": big},
+                  "primary_16Mi_rays_per_launch": big, "random_8Mi_rays_per_launch": big_random},
     }
     if world > 1:
         out["extra"]["strong_scaling"] = strong_rec

@@ -391,6 +391,7 @@ def test_bench_py_contract(native_build):
     assert d["extra"]["library"]["built_from_these_sources"] is True
     assert d["extra"]["random_sorted"]["identical_to_unsorted"] is True
     assert d["extra"]["random_refill"]["identical_to_default"] is True
+    assert d["extra"]["random_8Mi_rays_per_launch"]["identical_hits"] is True
 
 
 def test_bench_py_with_two_ranks(native_build):
