@@ -14,7 +14,7 @@
  * (oracle_brute_force below; closest t must equal the minimum over every
  * triangle), (2) an independent float64 Moeller-Trumbore in tests/, (3) fixtures generated on this side
  * (tests/golden/), and (4) hierarchies the REFERENCE'S OWN BUILDER made (oracle/_ref/ref_bvh_builder = the reference's
- * obj.cpp + bvh.h compiled where they lie; tests/golden/*-refbuilt.bvh, tests/test_refbuilt.py): B1 / B1g / B2 on those against
+ * obj.cpp + bvh.h compiled where they lie; tests/golden/<name>-refbuilt.bvh, tests/test_refbuilt.py): B1 / B1g / B2 on those against
  * the exhaustive checker.  Indirectly, the reference does hold it: the renderer
  * oracle (render_oracle.c) traces every ray with oracle_bvh2_tri1 below and reproduces the reference's own
  * golden image testing/ref-cornell.png.
