@@ -13,6 +13,7 @@ from rodent_amd import abi, formats as F, raygen, scenes
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--cameras", action="store_true", help="also four other views of the scene and a 4 Mi-ray image")
 a = ap.parse_args()
 path = scenes.scene_bvh("atrium")
 bvh = abi.DeviceBvh.load(path, 2, 0)
@@ -61,6 +62,14 @@ orders = {"default (top half of the image first)": lambda k, m: k,
           "middle out": lambda k, m: (m // 2 + (k + 1) // 2 * (1 if k % 2 else -1)) % m}
 sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0), "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0),
         "primary 2048x1024": raygen.primary_rays(eye, d, up, fov, 2048, 1024, 0.0, 5000.0)}
+if a.cameras:                                        # other views of the same scene: from the far end, looking up, looking down, from a corner
+    c = 0.5 * (lo + hi); e = np.asarray(eye, np.float32)
+    for label, (e2, d2) in {"from the other end": (2 * c - e + np.array([0, 2 * (e[1] - c[1]), 0], np.float32), -np.asarray(d, np.float32)),
+                            "looking up": (e, np.asarray(d, np.float32) + np.array([0, 0.6, 0], np.float32)),
+                            "looking down": (e, np.asarray(d, np.float32) + np.array([0, -0.6, 0], np.float32)),
+                            "across": (c + np.array([0, 0, 0.4 * (hi[2] - lo[2])], np.float32), np.array([0.3, -0.1, -1], np.float32))}.items():
+        sets["primary, " + label] = raygen.primary_rays(tuple(float(x) for x in e2), tuple(float(x) for x in d2), up, fov, 1024, 1024, 0.0, 5000.0)
+    sets["primary 2048x2048"] = raygen.primary_rays(eye, d, up, fov, 2048, 2048, 0.0, 5000.0)
 v = names.index("top-userperm")
 for sname, rays in sets.items():
     n = len(rays)
