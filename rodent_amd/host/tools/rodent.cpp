@@ -12,7 +12,7 @@
 //                       the row band split_range(height, r, K) of every frame (rodent_hip_render_rows; one host thread per
 //                       device), a frame takes as long as the slowest band; after the last frame ONE RCCL gather (grouped
 //                       ncclSend / ncclRecv, host/multi_gpu.h) brings the bands to the first device's film
-//   --target t          amdgpu-streaming (default) or amdgpu-megakernel (converter.cpp:30-35,1032-1037)
+//   --target t          amdgpu-streaming or amdgpu-megakernel (default: chosen per scene) (converter.cpp:30-35,1032-1037)
 //   --sort / --no-sort  streaming target: sort hit rays by material before shading (the reference's loop) / shade in stream order (default)
 // Without --bench the reference opens an SDL window and renders until it is closed; this build is
 // headless (DISABLE_GUI, driver.cpp:236-242), so --bench or -o is required.
@@ -38,7 +38,7 @@ static void usage() {
               << "   --max-path-len n    Maximum path length\n"
               << "   -dev     n          GPU device index\n"
               << "   --ngpu   K          Renders on K GPUs (row bands, one film gather to the first device)\n"
-              << "   --target t          amdgpu-streaming (default) or amdgpu-megakernel\n"
+              << "   --target t          amdgpu-streaming or amdgpu-megakernel (default: chosen per scene)\n"
               << "   --sort              Sort rays by material before shading (streaming target; default: stream order)\n"
               << "   --no-sort           Do not sort rays by material before shading\n"
               << "   --width  pixels     Sets the viewport horizontal dimension (in pixels)\n"
