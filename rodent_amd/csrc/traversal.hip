@@ -593,6 +593,9 @@ struct DeviceState {
     int*  order_agree = nullptr;               // per stripe: {chunks the last two launches both found in their expensive half, half the stripe's chunks}
     const int* debug_perm = nullptr;           // lab: caller-supplied ray permutation of the "top-userperm" mapping (rodent_hip_debug_set_perm)
     int*  host_flags = nullptr;                // pinned: where the error flags are copied back to
+    // Ray-kind hint of the default mapping (L_default): host_kinds[0] / [1] = id of the last launch whose rays some workgroup found coherent / incoherent
+    // (pinned host memory the kernels store into); hint_* = the ray list the hint is about and the first launch that traced it.
+    int*  host_kinds = nullptr; int launch_id = 0; const void* hint_rays = nullptr; int hint_n = 0, hint_first_id = 0;
     int*  tickets = nullptr;                   // persistent "top*p" mappings: chunk tickets per XCD (zero between launches)
     Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
 };
@@ -816,18 +819,62 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool S
 // launches whose node array the runtime cannot give a mapped range for (nothing bounds the ids of an older image then).
 constexpr int kTopMinRays = 9216 * kWave;      // the measured cross-over lies between 512 Ki and 768 Ki rays (profiles/r02_threshold_sweep.txt)
 int g_top_min_rays = kTopMinRays;               // rodent_hip_top_min_rays()
+int g_kind_hint = [] { const char* e = getenv("RODENT_HIP_KIND_HINT"); return e && !atoi(e) ? 0 : 1; }();      // rodent_hip_ray_kind_hint(): 0 = the default mapping never remembers what a ray list was
 // FUSED = 2: the launch finishes itself (its last workgroup does the follow-up kernel's work; fences on the rare paths only): one
 // kernel per call instead of two, +1.1 % / +1.8 % on the benchmark's primary / random set in wall-clock terms (bench.py, 100 steps).
-template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int FUSED = 2> void L_default(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int FUSED = 2> void L_chunks(LAUNCH_ARGS) {
     const int max_id = n < g_top_min_rays ? 0 : mapped_node_ids(nodes);
     if (max_id == 0) L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream);
     else launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, false, 32, false, 0, FUSED>(s, nodes, tris, rays, hits, n, stream, max_id);
+}
+// Round 4: the persistent kernel chooses per wave and per draw between whole chunks (rays that share an origin or a direction) and lane
+// refill (anything else): k_bvh2_top_auto, traversal_top.h.  With the schedule history on, launches keep the chunk kernel (the history
+// orders CHUNKS).
+void ensure_top_buffers(DeviceState& s) {
+    if (s.top_image && s.tickets) return;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (!s.top_image) { HIP_CHECK(hipMalloc(&s.top_image, kMaxTopNodes * sizeof(Node2))); HIP_CHECK(hipMemset(s.top_image, 0, kMaxTopNodes * sizeof(Node2))); }
+    if (!s.tickets) {
+        HIP_CHECK(hipMalloc(&s.tickets, sizeof(int) * kMaxPhases * kStripes * kCounterStride));      // the size k_bvh2_finish clears
+        HIP_CHECK(hipMemset(s.tickets, 0, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
+    }
+}
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0, bool FUSED = true> void L_default(LAUNCH_ARGS) {
+    const int max_id = n < g_top_min_rays ? 0 : mapped_node_ids(nodes);
+    if (max_id == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }
+    if (g_schedule_history) { launch_top_persist<ANY, LDS_N, TOPN, WAVES, false, false, 32, false, 0, 2>(s, nodes, tris, rays, hits, n, stream, max_id); return; }
+    ensure_deep_list(s, n);
+    ensure_top_buffers(s);
+    s.top_image_nodes = nullptr; s.order_rays = 0;
+    const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;   // one resident generation, the same number in every stripe
+    // Which kernel?  k_bvh2_top_auto decides per wave and is right for any list; but its refill loop, compiled under the chunk loop's
+    // register budget, runs 7 % behind k_bvh2_top_refill's (profiles/r04_sweep_auto.log).  So the kernels report what they saw
+    // (report_ray_kind) and a list that earlier launches found incoherent throughout goes to k_bvh2_top_refill -- from the second launch
+    // on the same (pointer, count); a stale or missing hint costs speed, never correctness, and either kernel corrects it.
+    if (!s.host_kinds) {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (!s.host_kinds) { HIP_CHECK(hipHostMalloc(&s.host_kinds, sizeof(int) * 16, hipHostMallocDefault)); s.host_kinds[0] = s.host_kinds[1] = 0; }
+    }
+    if (s.hint_rays != rays || s.hint_n != n) { s.hint_rays = rays; s.hint_n = n; s.hint_first_id = s.launch_id + 1; }
+    const int id = ++s.launch_id;
+    const volatile int* kinds = s.host_kinds;
+    // incoherent: the newest report of "incoherent" is about this list and newer than the newest report of "coherent" (a list of both kinds reports both in one launch)
+    const bool incoherent = MODE == 0 && g_kind_hint && kinds[1] >= s.hint_first_id && kinds[0] < kinds[1];
+    if (incoherent) {
+        hipLaunchKernelGGL((k_bvh2_top_refill<ANY, LDS_N, TOPN, WAVES, REFILL, false, false>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+                           (const int4*)s.top_image, s.tickets, max_id, s.host_kinds, id);
+        hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
+        return;
+    }
+    hipLaunchKernelGGL((k_bvh2_top_auto<ANY, LDS_N, TOPN, WAVES, REFILL, MODE, FUSED>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+                       s.top_image, s.tickets, max_id, s.host_kinds, id);
+    if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 
 // "refill": the persistent kernel with lane refill (traversal_top.h), for ray sets whose rays differ widely in cost -- incoherent ones: the
 // benchmark's random segments +5 % at 1 Mi rays per launch, +13 % (closest hit) / +18 % (any hit) at 8 Mi, profiles/r03_sweep_refill_big_random.log;
 // coherent camera rays LOSE 13 ... 18 % (neighbouring rays stop being in step), which is why it is a variant the caller asks for and not the default.
-template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = false> void L_top_refill(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = false, bool FENCE = false> void L_top_refill(LAUNCH_ARGS) {
     if (n < g_top_min_rays || mapped_node_ids(nodes) == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }      // (as L_default)
     ensure_deep_list(s, n);
     if (!s.top_image || !s.tickets) {
@@ -840,10 +887,22 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = fal
     }
     s.top_image_nodes = nullptr;
     const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;
-    hipLaunchKernelGGL((k_bvh2_top_refill<ANY, LDS_N, TOPN, WAVES, REFILL, ADAPT>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+    hipLaunchKernelGGL((k_bvh2_top_refill<ANY, LDS_N, TOPN, WAVES, REFILL, ADAPT, FENCE>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+                       (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes), (int*)nullptr, 0);
+    hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
+}
+
+#ifdef RODENT_HIP_LAB
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL> void L_top_refill_wpe(LAUNCH_ARGS) {
+    ensure_deep_list(s, n);
+    ensure_top_buffers(s);
+    s.top_image_nodes = nullptr;
+    const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;
+    hipLaunchKernelGGL((k_bvh2_top_refill_wpe<ANY, LDS_N, TOPN, WAVES, REFILL>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
                        (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes));
     hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
+#endif
 
 // Phased traversal: caps of the capped phases (the last, uncapped phase follows).  Launches too small to fill the chip
 // once take the single kernel.
@@ -892,7 +951,9 @@ const Variant2 kVariants2[] = {
     // 0 = default (used by the reference-named entry points).  All variants keep the reference's per-ray
     // visit order and are bit-identical; they differ in how a wavefront schedules its 64 rays.
     //                                                              LDS_N TOPN WAVES PREFETCH
-    K2("top",                "k_bvh2_top_persist",   L_default, 15, 255, 16, false),   // default: LDS-staged top of the tree (255 nodes), persistent 16-wave workgroups, the last one finishes the launch
+    //                                                              LDS_N TOPN WAVES REFILL
+    K2("top",                "k_bvh2_top_auto",      L_default, 15, 255, 16, 32),      // default: LDS-staged top of the tree (255 nodes), persistent 16-wave workgroups, the last one finishes the launch;
+                                                                                       // a wave traces rays that share an origin or a direction as whole chunks and refills idle lanes otherwise
                                                                                        // (launches under rodent_hip_top_min_rays: k_bvh2_single)
     //                                                        LDS_N XCD_GROUP
     K2("fast",               "k_bvh2_single",        L_single, 16, 32),                // single-step schedule, one 64-ray chunk per workgroup, XCD-aware 32-chunk groups (default of rounds 1-2)
@@ -931,7 +992,13 @@ const Variant2 kVariants2[] = {
     //                                                                    LDS_N TOPN WAVES REFILL (idle lanes that trigger a refill)
     K2("top-fused",          "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 1),   // the last workgroup does the follow-up kernel's work (every workgroup fences)
     K2("top-one",            "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 2),   // the same, fences on the rare paths only (= the default from 576 Ki rays on)
-    K2("top-two",            "k_bvh2_top_persist",   L_default, 15, 255, 16, false, 0),                          // the default with a follow-up kernel instead (rounds 2's form)
+    K2("top-two",            "k_bvh2_top_persist",   L_chunks, 15, 255, 16, false, 0),                           // whole chunks only, with a follow-up kernel (round 2's default)
+    K2("auto-chunks-only",   "k_bvh2_top_auto",      L_default, 15, 255, 16, 32, 1),
+    K2("auto-refill-only",   "k_bvh2_top_auto",      L_default, 15, 255, 16, 32, 2),
+    K2("refill-fence",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 32, false, true),
+    K2("auto-refill-only-two", "k_bvh2_top_auto",    L_default, 15, 255, 16, 32, 2, false),
+    K2("refill-wpe",         "k_bvh2_top_refill_wpe", L_top_refill_wpe, 15, 255, 16, 32),
+    K2("top-chunks",         "k_bvh2_top_persist",   L_chunks, 15, 255, 16, false, 2),                           // whole chunks only, the launch finishes itself (round 3's default)
     //                                                                     LDS_N TOPN WAVES HOT_ITER HOT_LANES
     K2("top-partner-48-24",  "k_bvh2_top_partner",   L_top_partner, 15, 255, 16, 48, 24),   // stateless order attempt: second-generation chunks = vertical partners of the first generation, partners of chunks that look expensive first
     K2("top-partner-32-40",  "k_bvh2_top_partner",   L_top_partner, 15, 255, 16, 32, 40),
@@ -1145,6 +1212,7 @@ void rodent_hip_phased_min_rays(int32_t rays) { g_phased_min_rays = rays < 0 ? 4
 void rodent_hip_debug_set_perm(int32_t dev, const int32_t* device_perm) { device_state(dev).debug_perm = device_perm; }   // lab: see "top-userperm"
 void rodent_hip_schedule_history(int32_t enable) { g_schedule_history = enable ? 1 : 0; }
 void rodent_hip_top_min_rays(int32_t rays) { g_top_min_rays = rays < 0 ? kTopMinRays : rays; }
+void rodent_hip_ray_kind_hint(int32_t enable) { g_kind_hint = enable ? 1 : 0; }
 int32_t rodent_hip_is_lab_build(void) {
 #ifdef RODENT_HIP_LAB
     return 1;

@@ -329,16 +329,29 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     }
 }
 
+// Do the rays held by the lanes of `valid` share an origin (a camera's) or a direction (parallel rays)?  Wave-uniform; call in uniform control flow.
+__device__ __forceinline__ bool wave_rays_coherent(float ox, float oy, float oz, float dx, float dy, float dz, bool valid) {
+    const auto differs = [&](float x) { return x != __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+    const bool o = differs(ox) | differs(oy) | differs(oz), d = differs(dx) | differs(dy) | differs(dz);
+    return __ballot(valid && o) == 0ull || __ballot(valid && d) == 0ull;      // (lane 0 is valid whenever any lane is: rays are handed out in lane order)
+}
+// What the default mapping remembers between launches (DeviceState::host_kinds, pinned host memory the kernels write straight into): the
+// id of the last launch in which a workgroup's first rays were coherent [0] / incoherent [1].  A hint for the host's choice of kernel, nothing else.
+__device__ __forceinline__ void report_ray_kind(int* host_kinds, int launch_id, bool coherent) {
+    if (host_kinds && threadIdx.x == 0 && blockIdx.x < kStripes) __hip_atomic_store(&host_kinds[coherent ? 0 : 1], launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Persistent form with lane refill (variant "refill"): a wave does not wait for the last ray of a 64-ray chunk.  As soon as REFILL of its lanes
 // are idle it draws that many rays from its stripe's counter (one atomic per refill) and starts them in the idle lanes; the
 // rest keep stepping.  Ticket t of stripe s is ray ((t / 2048) * 64 + s) * 2048 + t % 2048 (the same 32-chunk groups), the first
 // 64 tickets of a wave are static.  Which rays share a wave changes, what a ray visits does not.
 // ADAPT: the threshold is chosen at every draw from the rays just drawn -- rays that share an origin (a camera's) wait for the whole
 // wave like a chunk (their neighbours are in step, a refill would take that away), anything else refills at REFILL idle lanes.
-template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = false>
-__global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = false, bool FENCE = false>
+__device__ __forceinline__ void top_refill_body(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                     const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                                    Ctl* ctl, int* __restrict__ deep_list, const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id) {
+                                                                    Ctl* ctl, int* __restrict__ deep_list, const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id,
+                                                                    int* host_kinds = nullptr, int launch_id = 0) {
     constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroupRays = 32 * kWave;
     static_assert((kStackInts + TOPN * 16) * 4 * (32 / WAVES) <= 160 * 1024, "32 waves per CU must fit their stacks and images in LDS");
     __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
@@ -346,6 +359,7 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(c
     lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
     lds_int* image = (lds_int*)lds_raw + kStackInts;
     const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;
+    if (host_kinds && threadIdx.x == 0) { if (root != 1) atomicAdd(&ctl->stats[6], 1ull); atomicAdd(&ctl->stats[4], 1ull); }   // stats[6] as k_bvh2_top_auto, whose place this kernel takes; stats[4]: workgroups of this kernel launched by the default mapping (read by the tests)
     const int stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
     int* counter = tickets + stripe * kCounterStride;
     const auto ray_of = [&](int t) { return ((t / kGroupRays) * kStripes + stripe) * kGroupRays + t % kGroupRays; };
@@ -357,6 +371,7 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(c
         L = start_lane(rays, hits, r < n ? r : -1, 0, col);
         if (L.top != 0) L.top = root;
     }
+    if (host_kinds && wave == 0) report_ray_kind(host_kinds, launch_id, wave_rays_coherent(L.ray.ox, L.ray.oy, L.ray.oz, L.ray.dx, L.ray.dy, L.ray.dz, L.top != 0));
     // the rays a draw started: one origin for all of them?  (readlane: the leader is wave-uniform)
     const auto one_origin = [&](unsigned long long started) {
         if (!started) return false;
@@ -391,7 +406,121 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(c
             continue;
         }
         if (live == 0) break;
-        if (L.top != 0) bvh2_step<ANY, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+        if (L.top != 0) bvh2_step<ANY, false, true, false, FENCE>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
     }
 }
 
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = false, bool FENCE = false>
+__global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                                    const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                                    Ctl* ctl, int* __restrict__ deep_list, const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id,
+                                                                    int* host_kinds, int launch_id) {
+    top_refill_body<ANY, LDS_N, TOPN, WAVES, REFILL, ADAPT, FENCE>(nodes, tris, rays, hits, n, ctl, deep_list, top_image, tickets, max_id, host_kinds, launch_id);
+}
+#ifdef RODENT_HIP_LAB      // the same with the register budget pinned like the default kernel's
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL>
+__global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_refill_wpe(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                                    const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                                    Ctl* ctl, int* __restrict__ deep_list, const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id) {
+    top_refill_body<ANY, LDS_N, TOPN, WAVES, REFILL, false, false>(nodes, tris, rays, hits, n, ctl, deep_list, top_image, tickets, max_id);
+}
+#endif
+
+// The default from round 4 on: ONE persistent kernel that chooses per wave between the two loop forms above (compaction
+// that switches itself on -- the reference compacts unconditionally, render/mapping_gpu.impala:267-300; Aila's kernel refills unconditionally,
+// tools/bench_aila/kepler_dynamic_fetch.cu:116-127,361-362).  A wave draws 64 consecutive tickets of its stripe (ray-granular tickets, the
+// 2048-ray groups of k_bvh2_top_refill) and looks at the rays it got: if they share an origin (a camera's) or a direction (parallel
+// rays) they are traced as a chunk -- k_bvh2_top_persist's loop: their neighbours stay in step -- and the
+// wave draws the next 64; anything else puts the wave into the refill loop (REFILL idle lanes trigger a draw).
+// The choice is per wave, made once from the wave's first 64 rays (re-deciding at every draw couples the two loops' register
+// allocation: the chunk loop then reloaded the spilled tmax in every iteration), costs ~25 instructions, and needs no probe launch: a list
+// of camera rays runs as it did, a list of incoherent segments as through "refill".
+// The launch finishes itself like k_bvh2_top_persist<FUSED = 2> (last workgroup: deep rays, counters, stale image).
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0 /* lab: 1 = whole chunks whatever the rays, 2 = refill whatever the rays */, bool FUSED = true /* lab: false = a follow-up kernel finishes the launch */>
+__global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_auto(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+                                                                  const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
+                                                                  Ctl* ctl, int* __restrict__ deep_list, int4* __restrict__ top_image, int* __restrict__ tickets, int max_id,
+                                                                  int* host_kinds, int launch_id) {
+    constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroupRays = 32 * kWave;
+    static_assert((kStackInts + TOPN * 16) * 4 * (32 / WAVES) <= 160 * 1024, "32 waves per CU must fit their stacks and images in LDS");
+    __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
+    lds_int* image = (lds_int*)lds_raw + kStackInts;
+    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, (const int4*)top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;
+    if (root != 1 && threadIdx.x == 0) atomicAdd(&ctl->stats[6], 1ull);     // stats[6]: workgroups that ran on the image (read by the tests)
+    const int stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
+    int* counter = tickets + stripe * kCounterStride;
+    const auto ray_of = [&](int t) { return ((t / kGroupRays) * kStripes + stripe) * kGroupRays + t % kGroupRays; };
+    lds_int* const sp_limit = col + LDS_N * kWave;
+    const Bases base = make_bases(nodes, tris);
+    int t = ((blockIdx.x / kStripes) * WAVES + wave) * kWave;               // the wave's first 64 tickets are its rank in the stripe; the counter hands out those behind
+    bool coherent = MODE != 2;
+    if (MODE == 0 && ray_of(t) < n) {                                        // (ray_of grows with the ticket: otherwise this stripe's share is used up already)
+        // one origin or one direction for all of the wave's first 64 rays?
+        const int r = ray_of(t + lane);
+        const float4* p = reinterpret_cast<const float4*>(rays + (r < n ? r : ray_of(t)));
+        const float4 o = p[0], d = p[1];
+        coherent = wave_rays_coherent(o.x, o.y, o.z, d.x, d.y, d.z, r < n);
+        if (wave == 0) report_ray_kind(host_kinds, launch_id, coherent);
+    }
+    if (!coherent && threadIdx.x == 0) atomicAdd(&ctl->stats[5], 1ull);      // stats[5]: workgroups whose first wave chose the refill loop (read by the tests)
+    if (MODE == 1 || (MODE == 0 && coherent)) {
+        for (;;) {                                                           // k_bvh2_top_persist's loop on 64-ticket draws
+            const int first_ray = ray_of(t);
+            if (first_ray >= n) break;
+            const int r = ray_of(t + lane);
+            Lane L = start_lane(rays, hits, r < n ? r : -1, first_ray, col);
+            if (L.top != 0) L.top = root;
+            while (__ballot(L.top != 0)) {
+                if (L.top != 0) bvh2_step<ANY, false, true, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+            }
+            int t_next = 0;
+            if (lane == 0) t_next = atomicAdd(counter, kWave);
+            t = stripe_waves * kWave + __builtin_amdgcn_readfirstlane(t_next);
+        }
+    } else if (MODE != 1) {
+        Lane L;
+        {
+            const int r = ray_of(t + lane);
+            L = start_lane(rays, hits, r < n ? r : -1, 0, col);
+            if (L.top != 0) L.top = root;
+        }
+        // One flat loop, deliberately (see k_bvh2_top_refill).
+        bool more = true;                                                    // wave-uniform: the stripe may have rays left
+        for (;;) {
+            const unsigned long long live = __ballot(L.top != 0);
+            if (more && __popcll(live) <= kWave - REFILL) {
+                const int want = kWave - __popcll(live);
+                int first = 0;
+                if (lane == 0) first = atomicAdd(counter, want);
+                first = stripe_waves * kWave + __builtin_amdgcn_readfirstlane(first);
+                more = ray_of(first) < n;
+                if (L.top == 0) {
+                    const int rr = ray_of(first + __popcll(~live & ((1ull << lane) - 1ull)));
+                    if (rr < n) {
+                        L = start_lane(rays, hits, rr, rr, col);
+                        L.top = root;
+                    }
+                }
+                continue;
+            }
+            if (live == 0) break;
+            if (L.top != 0) bvh2_step<ANY, false, true, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+        }
+    }
+    // the workgroup that finishes last does the follow-up work (k_bvh2_top_persist, FUSED == 2)
+    if (!FUSED) return;
+    __syncthreads();
+    if (threadIdx.x == 0) lds_raw[0] = __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!lds_raw[0] || wave != 0) return;
+    const int deep = __hip_atomic_load(&ctl->deep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (deep > 0) __threadfence();
+    const bool stale = __hip_atomic_load(&ctl->reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)lds_raw, tickets, 0, 1, deep);
+    if (stale) {
+        build_top_image(nodes, top_image, TOPN, (lds_int*)lds_raw);
+        if (lane == 0) ctl->reserved = 0;
+    }
+}

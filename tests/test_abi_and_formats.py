@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(native_build):
 def test_introspection_without_gpu(native_build):
     from rodent_amd import abi
     assert abi.variants(2)[:2] == ["top", "fast"] and abi.variants(4)[:2] == ["top", "single"] and abi.variants(8)[:2] == ["top", "single"] and abi.variants(3) == []
-    assert "k_bvh2_top_persist" in abi.kernel_name(2, 0) and "k_bvh2_single" in abi.kernel_name(2, 1) and "k_wide_top_persist<true,8" in abi.kernel_name(8, 0, any_hit=True) and "k_wide_single<false,4" in abi.kernel_name(4, 1)
+    assert "k_bvh2_top_auto" in abi.kernel_name(2, 0) and "k_bvh2_single" in abi.kernel_name(2, 1) and "k_wide_top_persist<true,8" in abi.kernel_name(8, 0, any_hit=True) and "k_wide_single<false,4" in abi.kernel_name(4, 1)
     assert abi.lib().rodent_hip_device_count() >= 0
     # the product library ships the default mappings only: the measured-and-lost kernels and the instrumented builds
     # are in the lab build (RODENT_HIP_LAB=1)

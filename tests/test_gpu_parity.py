@@ -491,3 +491,45 @@ def test_default_mapping_switches_kernels_at_its_size_threshold(gpu, oracle, cor
             assert gpu.from_device(hd, F.HIT1).tobytes() == ref.tobytes(), n
     finally:
         gpu.lib().rodent_hip_top_min_rays(0)
+
+
+def test_default_mapping_chooses_chunks_or_refill_by_itself(gpu, oracle, cornell, cornell_dev):
+    """BASELINE config 3 ("ray compaction on") without a variant argument: the default kernel (k_bvh2_top_auto) traces rays that share an
+    origin as whole chunks and refills idle lanes otherwise (stats[5]: workgroups that chose the refill loop); a list -- same pointer, same
+    count -- that was incoherent throughout goes to the refill kernel proper from its second launch on (stats[4]), and back when the caller
+    puts coherent rays into the same buffer.  Hits are the oracle's in every case, with the hint switched off too."""
+    import torch
+    top = gpu.variants(2).index("top")
+    nodes, tris = cornell.blocks[2]
+    n = 9216 * 64 + 77
+    base = cornell.ray_sets["primary"]
+    coherent = np.tile(base, (n + len(base) - 1) // len(base))[:n].copy()              # one camera
+    incoherent = coherent.copy()
+    incoherent["org"][:, 1] += (np.arange(n, dtype=np.float32) % 613) * 1e-4
+    expected = {id(coherent): oracle.traverse(2, nodes, tris, coherent)[0], id(incoherent): oracle.traverse(2, nodes, tris, incoherent)[0]}
+    gpu.lib().rodent_hip_top_min_rays(-1)
+    rd = gpu.to_device(incoherent, 0)
+    hd = torch.full((n * 16,), 0xFF, dtype=torch.uint8, device="cuda:0")
+
+    def launch(rays):
+        hd.fill_(0xFF)
+        gpu.read_stats(0)
+        gpu.traverse_async(cornell_dev[2], rd, hd, n, False, top)
+        gpu.check_errors(0)
+        assert gpu.from_device(hd, F.HIT1).tobytes() == expected[id(rays)].tobytes()
+        st = gpu.read_stats(0)
+        return st[4] > 0, st[5] > 0                                                # (the refill kernel ran, the default kernel's waves chose the refill loop)
+    try:
+        for hint in (True, False):
+            gpu.ray_kind_hint(hint)
+            rd.copy_(gpu.to_device(incoherent, 0))
+            first = launch(incoherent)
+            assert first in ((False, True), (True, False)), first                  # (a hint left by an earlier list at this address may already apply)
+            assert launch(incoherent) == ((True, False) if hint else (False, True))
+            rd.copy_(gpu.to_device(coherent, 0))
+            launch(coherent)                                                       # whichever kernel: the hits are right, and it reports what it saw
+            assert launch(coherent) == (False, False)
+            assert launch(coherent) == (False, False)
+    finally:
+        gpu.ray_kind_hint(True)
+        gpu.lib().rodent_hip_top_min_rays(0)
