@@ -301,10 +301,18 @@ def render_section(args, torch, dist, rank, world, dev):
         sc = S.Scene(rscene)
         eye, d, up, fov = scenes.CAMERAS[scene_name]
         cam = S.camera_settings(eye, d, up, fov, w, h)
-        y0, y1 = parallel.row_band(h, rank, world)
+        # N GPUs: rank r renders the interleaved 16-row tiles r, r + N, ... (bands of the atrium frame differ by 27 % in cost, tile shares by 1 %: profiles/r04_band_costs.txt)
+        my_rows = sum(b - a for a, b in parallel.row_tiles(h, rank, world)) if world > 1 else h
+
+        def render_share(r, it):
+            if world > 1:
+                r.render_tiles(cam, it, parallel.TILE_ROWS, rank, world)
+            else:
+                r.render_rows(cam, it, 0, h)
         frames = 3 if spp * w * h < (1 << 28) else 1
         entry = {"scene": f"{scene_name} ({sc.num_tris} triangles, {len(sc.materials)} materials)", "width": w, "height": h, "spp": spp, "max_path_len": max_len,
-                 "samples_per_frame": spp * w * h, "timed_frames": frames, "rows_per_gpu": y1 - y0 if world > 1 else h}
+                 "samples_per_frame": spp * w * h, "timed_frames": frames, "rows_per_gpu": my_rows,
+                 "partition": f"interleaved {parallel.TILE_ROWS}-row tiles" if world > 1 else "whole frame"}
         # auto = what the library chooses for this scene; streaming = the wavefront loop with the library's defaults (shading in stream
         # order); streaming_sorted = the same with the reference's sort by material in front of the shader (rodent_hip_render_sort)
         mappings = ["auto", "streaming", "streaming_sorted", "megakernel"]
@@ -320,7 +328,7 @@ def render_section(args, torch, dist, rank, world, dev):
                 r.close()
                 entry[mapping] = {"same_as": "auto"}
                 continue
-            r.render_rows(cam, 0, y0, y1)                              # warm-up at 4 spp (allocations, code upload)
+            render_share(r, 0)                                         # warm-up at 4 spp (allocations, code upload)
             r.configure(spp, max_len)
             r.clear()
             secs = []
@@ -329,7 +337,7 @@ def render_section(args, torch, dist, rank, world, dev):
                     dist.barrier()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                r.render_rows(cam, it, y0, y1)                         # synchronous: the band is in the device film when it returns
+                render_share(r, it)                                    # synchronous: the share is in the device film when it returns
                 secs.append(time.perf_counter() - t0)
             secs = [max_over_ranks(torch, dist, dev, [s])[0] for s in secs]
             best = float(np.median(secs))
@@ -339,11 +347,11 @@ def render_section(args, torch, dist, rank, world, dev):
                 film = parallel.device_film(dev)
                 torch.cuda.synchronize(); dist.barrier()
                 t0 = time.perf_counter()
-                full = parallel.gather_film_to_root(film, dist)
+                full = parallel.gather_film_to_root(film, dist, tile_rows=parallel.TILE_ROWS)
                 torch.cuda.synchronize()
                 g = max_over_ranks(torch, dist, dev, [time.perf_counter() - t0])[0]
                 res["film_gather_ms"] = round(g * 1e3, 3)
-                res["film_gather_MB"] = round((h - (y1 - y0)) * w * 12 / 1e6, 2) if rank == 0 else None
+                res["film_gather_MB"] = round((h - my_rows) * w * 12 / 1e6, 2) if rank == 0 else None
                 res["Msamples_s_including_gather"] = round(spp * w * h / (best + g) / 1e6, 2)
                 if rank == 0:
                     res["film_complete_on_root"] = bool(torch.isfinite(full).all() and float(full[h - 1].abs().sum()) > 0 and float(full[0].abs().sum()) > 0)

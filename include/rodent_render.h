@@ -179,8 +179,15 @@ int64_t rodent_hip_buffer_size(int32_t dev, const char* file);
 void    rodent_hip_bvh_counts(int32_t dev, const char* file, int32_t bvh_width, int32_t* num_nodes, int32_t* num_tris);
 void    rodent_hip_set_device(int32_t dev);                          /* device used by render() (the reference bakes it in) */
 /* Renders only image rows [y0, y1) (tile sharding across GPUs: seeds depend on absolute (sample, iter, x, y),
- * renderer.impala:28-33, so any tiling reproduces the same samples).  Asynchronous on `stream`. */
+ * renderer.impala:28-33, so any tiling reproduces the same samples).  The work is enqueued on `stream`; the call RETURNS WHEN THE
+ * ROWS ARE IN THE DEVICE FILM: the wavefront loop reads the stream size back every iteration (as the reference does,
+ * mapping_gpu.impala:344-366), so it cannot be asynchronous. */
 void    rodent_hip_render_rows(int32_t dev, const struct Settings* settings, int32_t iter, int32_t y0, int32_t y1, void* stream);
+/* Renders the interleaved row tiles first_tile, first_tile + tile_stride, ... of tile_rows rows each (the last tile of the film may be
+ * shorter): GPU k of K takes first_tile = k, tile_stride = K, which balances the GPUs where contiguous bands do not (SURVEY 8e;
+ * the reference deals ~1024-sample tiles dynamically, render/mapping_gpu.impala:374-420).  Same samples, same film as
+ * rodent_hip_render_rows over the same rows; synchronous like it. */
+void    rodent_hip_render_tiles(int32_t dev, const struct Settings* settings, int32_t iter, int32_t tile_rows, int32_t first_tile, int32_t tile_stride, void* stream);
 /* Counters of the last render call on this device: [0] primary rays traced, [1] shadow rays traced,
  * [2] wavefront iterations, [3] rays generated. */
 void    rodent_hip_render_counters(int32_t dev, uint64_t* out4);

@@ -81,13 +81,15 @@ __device__ __forceinline__ v3 emit_sample(const CameraDev& cam, int iter, int fi
     return normalize(add(add(mulf(LD3(cam.right), cam.w * kx), mulf(LD3(cam.up), cam.h * ky)), LD3(cam.dir)));
 }
 
+// Pixels of a call: [first_pixel, ...) contiguous (tile_pixels == 0: a row band), or interleaved row tiles -- local pixel q is pixel
+// first_pixel + (q / tile_pixels) * stride_pixels + q % tile_pixels (rodent_hip_render_tiles: the film's row tiles dealt round-robin to the GPUs).
 __global__ __launch_bounds__(kBlock) void k_generate(PrimaryStream p, int first_dst, int first_ray_id, int num_rays, CameraDev cam,
-                                                      int iter, int film_w, int film_h, int first_pixel, int spp) {
+                                                      int iter, int film_w, int film_h, int first_pixel, int spp, int tile_pixels, int stride_pixels) {
     const int gid = blockIdx.x * kBlock + threadIdx.x;
     if (gid >= num_rays) return;
     const int ray_id = first_ray_id + gid, dst = first_dst + gid;
-    const int sample = ray_id % spp;
-    const int pixel = first_pixel + ray_id / spp;
+    const int sample = ray_id % spp, q = ray_id / spp;
+    const int pixel = first_pixel + (tile_pixels > 0 ? (q / tile_pixels) * stride_pixels + q % tile_pixels : q);
     const int y = pixel / film_w, x = pixel - y * film_w;          // the reference uses fast_div (common.impala:19-35): same quotient
     uint32_t rnd;
     const v3 d = emit_sample(cam, iter, film_w, film_h, x, y, sample, &rnd);
@@ -1399,8 +1401,9 @@ void ensure_film(RenderDevice& r) {
     HIP_CHECK(hipMemset(r.film, 0, sizeof(float) * 3 * (size_t)r.film_w * r.film_h));
 }
 
-// gpu_streaming_trace (mapping_gpu.impala:308-369) for image rows [y0, y1)
-void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, int y1, hipStream_t stream) {
+// gpu_streaming_trace (mapping_gpu.impala:308-369) for image rows [y0, y1) -- or, with tile_rows > 0, for (y1 - y0) rows that are
+// row tiles of tile_rows rows each, the first at row y0, the next stride_rows further down, ... (y1 - y0 a multiple of tile_rows)
+void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, int y1, hipStream_t stream, int tile_rows = 0, int stride_rows = 0) {
     HIP_CHECK(hipSetDevice(r.dev));
     ensure_film(r);
     require_scene(r);
@@ -1465,7 +1468,7 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
         if (size < kCapacity && id < num_rays) {                                         // regenerate (mapping_gpu.impala:332-336)
             const int n = (int)std::min<long long>(num_rays - id, kCapacity - size);
             hipLaunchKernelGGL(k_generate, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, *primary, size, (int)id, n, cam, iter,
-                               r.film_w, r.film_h, first_pixel, r.spp);
+                               r.film_w, r.film_h, first_pixel, r.spp, tile_rows * r.film_w, stride_rows * r.film_w);
             id += n; size += n; generated += n;
         }
         const int blocks = (size + kBlock - 1) / kBlock;
@@ -1785,6 +1788,25 @@ void rodent_hip_render_rows(int32_t dev, const Settings* settings, int32_t iter,
     render_rows_any(r, settings, iter, y0, y1, (hipStream_t)stream);
 }
 
+// Interleaved row tiles (the reference hands out ~1024-sample tiles dynamically, render/mapping_gpu.impala:374-420, mapping_cpu.impala:200-237):
+// this call renders the row tiles first_tile, first_tile + tile_stride, ... of tile_rows rows each -- GPU k of K takes first_tile = k, tile_stride = K.
+// Seeds depend on absolute (sample, iter, x, y) only: the tiles of all GPUs together are the frame render() produces.
+void rodent_hip_render_tiles(int32_t dev, const Settings* settings, int32_t iter, int32_t tile_rows, int32_t first_tile, int32_t tile_stride, void* stream) {
+    RenderDevice& r = rdev(dev);
+    ensure_film(r);
+    if (tile_rows <= 0 || first_tile < 0 || tile_stride <= 0) { fprintf(stderr, "rodent_hip: invalid tile arguments (%d rows, first %d, stride %d)\n", tile_rows, first_tile, tile_stride); abort(); }
+    const int full_tiles = r.film_h / tile_rows, ragged_rows = r.film_h % tile_rows;
+    const int mine = first_tile < full_tiles ? (full_tiles - first_tile + tile_stride - 1) / tile_stride : 0;          // complete tiles of this call
+    const bool ragged_mine = ragged_rows > 0 && full_tiles >= first_tile && (full_tiles - first_tile) % tile_stride == 0;
+    if (r.mapping == 1) {                                                    // the megakernel tiles the rows it is given itself: one launch per row tile
+        for (int k = 0; k < mine; k++) render_rows_mega(r, settings, iter, (first_tile + k * tile_stride) * tile_rows, (first_tile + k * tile_stride + 1) * tile_rows, (hipStream_t)stream);
+    } else if (mine > 0) {
+        const int y0 = first_tile * tile_rows;
+        render_rows(r, settings, iter, y0, y0 + mine * tile_rows, (hipStream_t)stream, tile_rows, tile_stride * tile_rows);
+    }
+    if (ragged_mine) render_rows_any(r, settings, iter, full_tiles * tile_rows, r.film_h, (hipStream_t)stream);
+}
+
 void render(const Settings* settings, int32_t iter) {                        // generated render(): converter.cpp:628-967
     RenderDevice& r = rdev(g_current_dev);
     ensure_film(r);
@@ -1809,7 +1831,7 @@ void hip_generate_rays(int32_t dev, PrimaryStream* primary, int32_t capacity, in
     if (primary->size + num_rays > capacity) { fprintf(stderr, "rodent_hip: hip_generate_rays exceeds the stream capacity\n"); abort(); }
     if (num_rays > 0)
         hipLaunchKernelGGL(k_generate, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, *primary, primary->size, first_ray_id,
-                           num_rays, to_cam(settings), iter, film_width, film_height, first_pixel, spp);
+                           num_rays, to_cam(settings), iter, film_width, film_height, first_pixel, spp, 0, 0);
     primary->size += num_rays;
     HIP_CHECK(hipGetLastError());
 }

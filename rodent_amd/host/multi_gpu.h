@@ -1,7 +1,8 @@
 // multi_gpu.h -- the GPUs of one node behind the C++ hosts (`rodent --ngpu K`, `bench_traversal -ngpu K`): one host thread per
-// device for the compute, and the ONE collective of the path -- a gather of disjoint parts (row bands of the film,
-// ranges of the Hit1 array) to the root device -- as grouped RCCL point-to-point calls: the root posts one ncclRecv per peer
-// straight into that peer's place in ITS buffer, every peer one ncclSend of its own part.  Each byte crosses one xGMI link
+// device for the compute (kept alive between frames: a frame of a small scene is shorter than creating K threads), and the ONE
+// collective of the path -- a gather of disjoint parts (row tiles of the film, ranges of the Hit1 array) to the root
+// device -- as grouped RCCL point-to-point calls: the root posts one ncclRecv per part straight into its place in ITS buffer,
+// the part's owner one ncclSend.  Each byte crosses one xGMI link
 // once (7 links x ~153 GB/s per GPU, point to point: the peers' sends do not share a link), nothing is padded, nobody but the
 // root receives anything.  With one device nothing is initialised and nothing is sent.
 // (The Python hosts do the same through torch.distributed: rodent_amd/parallel.py gather_parts_to_root.)
@@ -10,7 +11,9 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -22,6 +25,12 @@ namespace rodent {
 class DeviceGroup {
 public:
     ~DeviceGroup() {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            quit_ = true;
+        }
+        wake_.notify_all();
+        for (auto& t : workers_) t.join();
         for (size_t k = 0; k < comms_.size(); k++) ncclCommDestroy(comms_[k]);
         for (size_t k = 0; k < streams_.size(); k++) { (void)hipSetDevice(devs_[k]); (void)hipStreamDestroy(streams_[k]); }
     }
@@ -46,24 +55,32 @@ public:
     int size() const { return (int)devs_.size(); }
     int device(int rank) const { return devs_[rank]; }
 
-    // work(rank) on one host thread per device, all at once; returns when every one has returned
-    void run(const std::function<void(int)>& work) const {
+    // work(rank) on the device's own host thread, all at once; returns when every one has returned.  The threads are created at the
+    // first call and wait for the next one (a generation counter under one mutex: K is 8 at most).
+    void run(const std::function<void(int)>& work) {
         if (size() == 1) { work(0); return; }
-        std::vector<std::thread> threads;
-        for (int k = 0; k < size(); k++) threads.emplace_back(work, k);
-        for (auto& t : threads) t.join();
+        std::unique_lock<std::mutex> lock(m_);
+        if (workers_.empty())
+            for (int k = 0; k < size(); k++) workers_.emplace_back([this, k] { worker(k); });
+        work_ = &work; pending_ = size(); generation_++;
+        wake_.notify_all();
+        done_.wait(lock, [this] { return pending_ == 0; });
+        work_ = nullptr;
     }
 
-    // Rank r's `bytes[r]` bytes at `src[r]` (on device r) go to `dst[r]` on the root device (rank 0); the root's own part is in
-    // place already.  One group of sends / receives, then every stream is waited for.  Returns the seconds it took, < 0 on error.
-    double gather_to_root(const std::vector<const void*>& src, const std::vector<void*>& dst, const std::vector<size_t>& bytes, std::string* err) const {
+    // One part of a gather: `bytes` bytes at `src` on rank `rank`'s device go to `dst` on the root device (rank 0).
+    struct Piece { int rank; const void* src; void* dst; size_t bytes; };
+    // All pieces in ONE group of sends / receives (the root's own parts are in place already: pieces of rank 0 are skipped), then every
+    // stream is waited for.  Returns the seconds it took, < 0 on error.
+    double gather_to_root(const std::vector<Piece>& pieces, std::string* err) const {
         if (size() == 1) return 0.0;
         const auto t0 = std::chrono::steady_clock::now();
         ncclResult_t r = ncclGroupStart();
-        for (int k = 1; k < size() && r == ncclSuccess; k++) {
-            if (!bytes[k]) continue;
-            r = ncclSend(src[k], bytes[k], ncclChar, 0, comms_[k], streams_[k]);
-            if (r == ncclSuccess) r = ncclRecv(dst[k], bytes[k], ncclChar, k, comms_[0], streams_[0]);
+        for (size_t i = 0; i < pieces.size() && r == ncclSuccess; i++) {
+            const Piece& p = pieces[i];
+            if (p.rank == 0 || !p.bytes) continue;
+            r = ncclSend(p.src, p.bytes, ncclChar, 0, comms_[p.rank], streams_[p.rank]);
+            if (r == ncclSuccess) r = ncclRecv(p.dst, p.bytes, ncclChar, p.rank, comms_[0], streams_[0]);
         }
         const ncclResult_t e = ncclGroupEnd();
         if (r == ncclSuccess) r = e;
@@ -74,6 +91,30 @@ public:
     }
 
 private:
+    void worker(int rank) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* work = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                wake_.wait(lock, [&] { return quit_ || generation_ != seen; });
+                if (quit_) return;
+                seen = generation_; work = work_;
+            }
+            (*work)(rank);
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void(int)>* work_ = nullptr;
+    unsigned long long generation_ = 0;
+    int pending_ = 0;
+    bool quit_ = false;
     std::vector<int> devs_;
     std::vector<ncclComm_t> comms_;
     std::vector<hipStream_t> streams_;

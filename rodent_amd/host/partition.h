@@ -19,4 +19,19 @@ inline Part split_range(int n, int rank, int world) {
     return Part{begin, begin + base + (rank < extra ? 1 : 0)};
 }
 
+// Interleaved row tiles (SURVEY 8e "interleaved 16-row tiles for load balance"; the reference deals ~1024-sample tiles dynamically,
+// src/render/mapping_gpu.impala:374-420): rank r owns the tiles r, r + world, ... of tile_rows rows each (the film's last tile may be
+// shorter).  Contiguous bands of the atrium frame differ by 27 % in cost (profiles/r04_band_costs.txt); shares of interleaved tiles by 1 %.
+// The same arithmetic as rodent_amd/parallel.py row_tiles.
+constexpr int kTileRows = 16;
+template <typename F>   // f(Part rows) for every tile of `rank`, top to bottom
+inline void for_each_tile(int height, int rank, int world, int tile_rows, F f) {
+    for (int t = rank; t * tile_rows < height; t += world) f(Part{t * tile_rows, (t + 1) * tile_rows < height ? (t + 1) * tile_rows : height});
+}
+inline int tile_rows_of_rank(int height, int rank, int world, int tile_rows) {
+    int rows = 0;
+    for_each_tile(height, rank, world, tile_rows, [&](Part p) { rows += p.size(); });
+    return rows;
+}
+
 } // namespace rodent

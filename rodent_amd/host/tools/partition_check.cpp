@@ -6,9 +6,13 @@
 #include "../partition.h"
 
 int main(int argc, char** argv) {
-    if (argc != 3) { std::cerr << "Usage: partition_check n world" << std::endl; return 1; }
-    const int n = atoi(argv[1]), world = atoi(argv[2]);
-    if (n < 0 || world < 1) { std::cerr << "Invalid arguments" << std::endl; return 1; }
+    if (argc != 3 && argc != 4) { std::cerr << "Usage: partition_check n world [tile_rows]" << std::endl; return 1; }
+    const int n = atoi(argv[1]), world = atoi(argv[2]), tile_rows = argc == 4 ? atoi(argv[3]) : 0;
+    if (n < 0 || world < 1 || tile_rows < 0) { std::cerr << "Invalid arguments" << std::endl; return 1; }
+    if (tile_rows > 0) {                                   // interleaved row tiles: one "rank begin end" line per tile
+        for (int r = 0; r < world; r++) rodent::for_each_tile(n, r, world, tile_rows, [&](rodent::Part p) { std::cout << r << " " << p.begin << " " << p.end << "\n"; });
+        return 0;
+    }
     for (int r = 0; r < world; r++) { const rodent::Part p = rodent::split_range(n, r, world); std::cout << r << " " << p.begin << " " << p.end << "\n"; }
     return 0;
 }

@@ -37,7 +37,8 @@ static void usage() {
               << "   --spp    n          Samples per pixel per frame\n"
               << "   --max-path-len n    Maximum path length\n"
               << "   -dev     n          GPU device index\n"
-              << "   --ngpu   K          Renders on K GPUs (row bands, one film gather to the first device)\n"
+              << "   --ngpu   K          Renders on K GPUs (interleaved 16-row tiles, one film gather to the first device)\n"
+              << "   --bands             With --ngpu: one contiguous row band per GPU instead of interleaved tiles\n"
               << "   --target t          amdgpu-streaming or amdgpu-megakernel (default: chosen per scene)\n"
               << "   --sort              Sort rays by material before shading (streaming target; default: stream order)\n"
               << "   --no-sort           Do not sort rays by material before shading\n"
@@ -59,6 +60,7 @@ int main(int argc, char** argv) {
     float fov = 60.0f;
     V3 eye(0.0f), dir(0.0f, 0.0f, 1.0f), up(0.0f, 1.0f, 0.0f);
     int spp = 0, max_path_len = -1, dev = 0, mapping = -1, ngpu = 1;
+    bool bands = false;
     int sort = -1;                                                        // -1: the library's default
 
     for (int i = 1; i < argc; ++i) {
@@ -77,6 +79,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--max-path-len")) { need(1); max_path_len = strtol(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "-dev")) { need(1); dev = strtol(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "--ngpu")) { need(1); ngpu = strtol(argv[++i], nullptr, 10); }
+        else if (!strcmp(argv[i], "--bands")) bands = true;
         else if (!strcmp(argv[i], "--no-sort")) sort = 0;
         else if (!strcmp(argv[i], "--sort")) sort = 1;
         else if (!strcmp(argv[i], "--target")) {
@@ -128,8 +131,11 @@ int main(int argc, char** argv) {
         const auto ticks = std::chrono::high_resolution_clock::now();
         if (ngpu == 1) render(&settings, iter++);
         else {
-            // every GPU its band of this frame, all at once; the call returns when the band is in the device's film
-            group.run([&](int r) { const Part band = split_range((int)height, r, ngpu); rodent_hip_render_rows(group.device(r), &settings, (int32_t)iter, band.begin, band.end, nullptr); });
+            // every GPU its share of this frame, all at once; the call returns when the share is in the device's film
+            group.run([&](int r) {
+                if (bands) { const Part band = split_range((int)height, r, ngpu); rodent_hip_render_rows(group.device(r), &settings, (int32_t)iter, band.begin, band.end, nullptr); }
+                else rodent_hip_render_tiles(group.device(r), &settings, (int32_t)iter, kTileRows, r, ngpu, nullptr);
+            });
             iter++;
         }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - ticks).count();
@@ -138,17 +144,18 @@ int main(int argc, char** argv) {
     double gather_s = 0.0;
     if (ngpu > 1) {
         // the one collective: every peer's rows straight into the first device's film, then that film to the host
-        std::vector<const void*> src(ngpu); std::vector<void*> dst(ngpu); std::vector<size_t> bytes(ngpu);
+        std::vector<DeviceGroup::Piece> pieces;
         float* root_film = nullptr; int32_t fw = 0, fh = 0;
         rodent_get_film_data(group.device(0), &root_film, &fw, &fh);
-        for (int r = 0; r < ngpu; r++) {
-            const Part band = split_range((int)height, r, ngpu);
+        for (int r = 1; r < ngpu; r++) {
             float* film = nullptr;
             rodent_get_film_data(group.device(r), &film, &fw, &fh);
-            src[r] = film + (size_t)band.begin * width * 3; dst[r] = root_film + (size_t)band.begin * width * 3; bytes[r] = (size_t)band.size() * width * 3 * sizeof(float);
+            const auto add = [&](Part rows) { pieces.push_back({r, film + (size_t)rows.begin * width * 3, root_film + (size_t)rows.begin * width * 3, (size_t)rows.size() * width * 3 * sizeof(float)}); };
+            if (bands) add(split_range((int)height, r, ngpu));
+            else for_each_tile((int)height, r, ngpu, kTileRows, add);
         }
         std::string err;
-        gather_s = group.gather_to_root(src, dst, bytes, &err);
+        gather_s = group.gather_to_root(pieces, &err);
         if (gather_s < 0) fail(err);
         rodent_present(group.device(0));
     }
@@ -170,8 +177,10 @@ int main(int argc, char** argv) {
     std::sort(samples_sec.begin(), samples_sec.end());
     std::cout << "# " << samples_sec.front() * 1e-6 << "/" << samples_sec[samples_sec.size() / 2] * 1e-6 << "/" << samples_sec.back() * 1e-6
               << " (min/med/max Msamples/s)" << std::endl;
-    if (ngpu > 1)
-        std::cout << "# GPUs: " << ngpu << " (devices " << dev << ".." << dev + ngpu - 1 << "), bands of " << split_range((int)height, 0, ngpu).size() << " row(s); film gather to device " << dev << ": "
-                  << double(height - split_range((int)height, 0, ngpu).size()) * width * 12 / 1e6 << " MB in " << gather_s * 1e3 << " ms (RCCL)" << std::endl;
+    if (ngpu > 1) {
+        const int own_rows = bands ? split_range((int)height, 0, ngpu).size() : tile_rows_of_rank((int)height, 0, ngpu, kTileRows);
+        std::cout << "# GPUs: " << ngpu << " (devices " << dev << ".." << dev + ngpu - 1 << "), " << (bands ? "bands of " + std::to_string(own_rows) + " row(s)" : "interleaved tiles of " + std::to_string(kTileRows) + " rows")
+                  << "; film gather to device " << dev << ": " << double(height - own_rows) * width * 12 / 1e6 << " MB in " << gather_s * 1e3 << " ms (RCCL)" << std::endl;
+    }
     return 0;
 }

@@ -3,8 +3,10 @@ the GPU box, "gloo" in the CPU tests).  The path shards without any data-path co
 the BVH / scene is replicated, rays or image rows are partitioned, and ONE gather to the root collects the results.
 
   traversal : rank r gets its own ray batch (sub-pixel sample r of N, or a contiguous ray range)
-  frames    : rank r renders the row band row_band(height, r, N); seeds depend on absolute
-              (sample, iter, x, y) only (src/render/renderer.impala:28-33), so bands reproduce the frame
+  frames    : rank r renders the interleaved row tiles row_tiles(height, r, N) (rodent_hip_render_tiles; 16-row tiles dealt round
+              robin: contiguous bands of the atrium frame differ by 27 % in cost, tile shares by 1 %, profiles/r04_band_costs.txt)
+              or the row band row_band(height, r, N); seeds depend on absolute (sample, iter, x, y) only
+              (src/render/renderer.impala:28-33), so any partition reproduces the frame
 
 The gather is a grouped send / receive (what ncclGather is made of): the root posts one receive per peer straight into that
 peer's rows of ITS film (or its range of the Hit1 array), every peer posts one send of its own part -- each byte crosses one
@@ -23,6 +25,15 @@ def row_band(height: int, rank: int, world: int):
     return y0, y0 + base + (1 if rank < extra else 0)
 
 
+TILE_ROWS = 16          # host/partition.h kTileRows
+
+
+def row_tiles(height: int, rank: int, world: int, tile_rows: int = TILE_ROWS):
+    """Interleaved row tiles of rank `rank`: [(y0, y1), ...] = tiles rank, rank + world, ... of `tile_rows` rows each, top to bottom
+    (the film's last tile may be shorter).  host/partition.h for_each_tile; what rodent_hip_render_tiles(dev, ..., tile_rows, rank, world) renders."""
+    return [(t * tile_rows, min((t + 1) * tile_rows, height)) for t in range(rank, (height + tile_rows - 1) // tile_rows, world)]
+
+
 def ray_range(num_rays: int, rank: int, world: int):
     """Contiguous ray range [a, b): keeps coherent primary rays coherent."""
     base, extra = divmod(num_rays, world)
@@ -36,8 +47,8 @@ def _active(dist):
 
 def gather_parts_to_root(full, part_of, dist, root: int = 0):
     """ONE gather to `root`, in place: `full` is a tensor of the whole result on every rank (only the rank's own part
-    `full[part_of(rank)]` holds data); afterwards `full` is complete on the root.  `part_of(r)` -> slice of dim 0.
-    Grouped point-to-point: root receives every peer's part into its place, peers send theirs."""
+    `full[part_of(rank)]` holds data); afterwards `full` is complete on the root.  `part_of(r)` -> slice of dim 0, or a list of
+    slices (interleaved tiles).  Grouped point-to-point: root receives every peer's parts into their places, peers send theirs."""
     if not _active(dist):
         return full
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -48,26 +59,32 @@ def gather_parts_to_root(full, part_of, dist, root: int = 0):
             return None
         full.copy_(host)
         return full
+    def parts(r):
+        p = part_of(r)
+        return [q for q in (p if isinstance(p, (list, tuple)) else [p]) if q.stop > q.start]
     ops = []
     if rank == root:
         for r in range(world):
-            if r != root and part_of(r).stop > part_of(r).start:
-                ops.append(dist.P2POp(dist.irecv, full[part_of(r)], r))
-    elif part_of(rank).stop > part_of(rank).start:
-        ops.append(dist.P2POp(dist.isend, full[part_of(rank)], root))
+            if r != root:
+                ops += [dist.P2POp(dist.irecv, full[q], r) for q in parts(r)]
+    else:
+        ops += [dist.P2POp(dist.isend, full[q], root) for q in parts(rank)]
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return full if rank == root else None
 
 
-def gather_film_to_root(film, dist=None, root: int = 0):
-    """Row bands -> the frame on the root.  `film`: [height, width, 3] float32 tensor on the device the collective runs on, the
-    rank's band row_band(height, rank, world) rendered into it (parallel.device_film is such a tensor: a view of the library's
-    film).  Returns the complete film on the root (the same tensor, completed in place), None on the other ranks."""
+def gather_film_to_root(film, dist=None, root: int = 0, tile_rows: int = 0):
+    """The ranks' shares -> the frame on the root.  `film`: [height, width, 3] float32 tensor on the device the collective runs on, the
+    rank's share rendered into it (parallel.device_film is such a tensor: a view of the library's film): its band
+    row_band(height, rank, world), or with tile_rows > 0 its interleaved tiles row_tiles(height, rank, world, tile_rows).
+    Returns the complete film on the root (the same tensor, completed in place), None on the other ranks."""
     if not _active(dist):
         return film
     height, world = film.shape[0], dist.get_world_size()
+    if tile_rows > 0:
+        return gather_parts_to_root(film, lambda r: [slice(a, b) for a, b in row_tiles(height, r, world, tile_rows)], dist, root)
     return gather_parts_to_root(film, lambda r: slice(*row_band(height, r, world)), dist, root)
 
 

@@ -30,7 +30,7 @@ class SceneDesc(C.Structure):
 RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_fused_compact", "rodent_hip_render_mapping_in_effect", "rodent_hip_render_defaults", "rodent_hip_render_lds_image", "rodent_hip_render_mega_joint", "rodent_hip_render_trace_persistent", "rodent_hip_render_trace_refill", "rodent_hip_render_trace_refill_in_effect", "get_spp", "render",
                   "setup_interface", "get_pixels", "clear_pixels", "cleanup_interface", "rodent_get_film_data",
                   "rodent_gpu_get_first_primary_stream", "rodent_gpu_get_second_primary_stream", "rodent_gpu_get_secondary_stream",
-                  "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows",
+                  "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows", "rodent_hip_render_tiles",
                   "rodent_hip_render_counters", "hip_generate_rays", "hip_traverse_primary", "hip_sort_primary", "hip_shade",
                   "hip_traverse_secondary", "hip_compact_primary",
                   "rodent_load_buffer", "rodent_load_bvh2_tri1", "rodent_load_bvh4_tri4", "rodent_load_bvh8_tri4", "rodent_load_png", "rodent_load_jpg",
@@ -68,6 +68,7 @@ def lib():
         l.rodent_present.argtypes = [i32]; l.rodent_present.restype = None
         l.rodent_hip_set_device.argtypes = [i32]; l.rodent_hip_set_device.restype = None
         l.rodent_hip_render_rows.argtypes = [i32, C.POINTER(Settings), i32, i32, i32, vp]; l.rodent_hip_render_rows.restype = None
+        l.rodent_hip_render_tiles.argtypes = [i32, C.POINTER(Settings), i32, i32, i32, i32, vp]; l.rodent_hip_render_tiles.restype = None
         l.rodent_hip_render_counters.argtypes = [i32, C.POINTER(C.c_uint64)]; l.rodent_hip_render_counters.restype = None
         l.rodent_load_buffer.argtypes = [i32, C.c_char_p]; l.rodent_load_buffer.restype = vp
         for name in ("rodent_load_bvh2_tri1", "rodent_load_bvh4_tri4", "rodent_load_bvh8_tri4"):
@@ -147,6 +148,11 @@ class Renderer:
     def render_rows(self, cam, iter_, y0, y1):
         st = make_settings(cam)
         lib().rodent_hip_render_rows(self.dev, C.byref(st), iter_, y0, y1, None)
+
+    def render_tiles(self, cam, iter_, tile_rows, first_tile, tile_stride):
+        """The interleaved row tiles first_tile, first_tile + tile_stride, ... of tile_rows rows each (GPU k of K: first_tile = k, tile_stride = K)."""
+        st = make_settings(cam)
+        lib().rodent_hip_render_tiles(self.dev, C.byref(st), iter_, tile_rows, first_tile, tile_stride, None)
 
     def film(self):
         lib().rodent_present(self.dev)

@@ -43,6 +43,10 @@ for root in (0, world - 1):
     mine = torch.full_like(t, -1.0); mine[y0t:y1t] = t[y0t:y1t]
     got = parallel.gather_film_to_root(mine, dist, root)
     assert (got is None) == (rank != root) and (got is None or torch.equal(got, t))
+    mine = torch.full_like(t, -1.0)                                                  # interleaved tiles of 2 rows: 4 tiles, the last of one row
+    for a_, b_ in parallel.row_tiles(7, rank, world, 2): mine[a_:b_] = t[a_:b_]
+    got = parallel.gather_film_to_root(mine, dist, root, tile_rows=2)
+    assert (got is None) == (rank != root) and (got is None or torch.equal(got, t))
     hb = torch.arange(1001 * 16, dtype=torch.int64).to(torch.uint8)
     at, bt = parallel.ray_range(1001, rank, world)
     mineh = torch.zeros_like(hb); mineh[at * 16: bt * 16] = hb[at * 16: bt * 16]
@@ -68,6 +72,14 @@ def test_partitions_cover_exactly():
         assert max(b - a for a, b in bands) - min(b - a for a, b in bands) <= 1
         assert [parallel.ray_range(n, r, w) for r in range(w)] == bands
     assert parallel.row_band(2160, 3, 8) == (810, 1080)                       # cfg5: 270 rows per GPU
+    for n, w, rows in ((2160, 8, 16), (144, 3, 10), (50, 2, 16), (7, 8, 16)):  # interleaved tiles: every row exactly once
+        owner = np.full(n, -1)
+        for r in range(w):
+            for a, b in parallel.row_tiles(n, r, w, rows):
+                assert (owner[a:b] == -1).all() and 0 <= a < b <= n
+                owner[a:b] = r
+        assert (owner >= 0).all() and all(owner[y] == (y // rows) % w for y in range(n))
+    assert sum(b - a for a, b in parallel.row_tiles(2160, 0, 8)) == 17 * 16 and sum(b - a for a, b in parallel.row_tiles(2160, 7, 8)) == 16 * 16
 
 
 def test_cpp_hosts_partition_like_the_python_hosts(native_build):
@@ -77,6 +89,10 @@ def test_cpp_hosts_partition_like_the_python_hosts(native_build):
         out = subprocess.run([str(tool), str(n), str(w)], check=True, capture_output=True, text=True).stdout.split()
         got = [(int(out[3 * r + 1]), int(out[3 * r + 2])) for r in range(w)]
         assert got == [parallel.row_band(n, r, w) for r in range(w)] == [parallel.ray_range(n, r, w) for r in range(w)], (n, w)
+    for n, w, rows in ((2160, 8, 16), (144, 3, 10), (50, 2, 16), (7, 8, 16), (0, 2, 16)):            # interleaved row tiles
+        out = subprocess.run([str(tool), str(n), str(w), str(rows)], check=True, capture_output=True, text=True).stdout.split()
+        got = [(int(out[k]), int(out[k + 1]), int(out[k + 2])) for k in range(0, len(out), 3)]
+        assert got == [(r, a, b) for r in range(w) for a, b in parallel.row_tiles(n, r, w, rows)], (n, w, rows)
 
 
 @pytest.mark.parametrize("world", [2])

@@ -257,3 +257,24 @@ def test_atrium_row_bands_equal_the_frame(R, atrium_scene, atrium_reference, ban
     film_g = r.film(); r.close()
     assert (primary, shadow) == (counts[0], counts[1])
     assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
+
+
+@pytest.mark.parametrize("gpus,tile_rows", [(2, 16), (3, 10), (8, 16)])
+@pytest.mark.parametrize("mapping", ["streaming", "megakernel"])
+def test_atrium_interleaved_row_tiles_equal_the_frame(R, atrium_scene, atrium_reference, gpus, tile_rows, mapping):
+    """Load-balanced sharding of config 5 (SURVEY 8e "interleaved 16-row tiles"; the reference deals tiles dynamically,
+    render/mapping_gpu.impala:374-420): GPU k of K renders row tiles k, k + K, ... (rodent_hip_render_tiles); all K shares rendered one
+    after the other into one film equal the full frame -- 144 rows in 16-row tiles (9 tiles: shares of unequal size) and in 10-row tiles (a ragged last tile of 4 rows)."""
+    f = ATRIUM_FRAME
+    film_o, counts = atrium_reference
+    cam = atrium_camera(f["W"], f["H"])
+    r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], mapping=mapping)
+    primary = shadow = 0
+    for k in range(gpus):
+        r.render_tiles(cam, f["IT"], tile_rows, k, gpus)
+        if mapping == "streaming":                                  # (the megakernel's share is several launches: the counters are the last one's)
+            c = r.counters(); primary += c["primary_rays"]; shadow += c["shadow_rays"]
+    film_g = r.film(); r.close()
+    if mapping == "streaming" and f["H"] % tile_rows == 0:
+        assert (primary, shadow) == (counts[0], counts[1])
+    assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
