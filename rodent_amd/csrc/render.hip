@@ -337,15 +337,41 @@ __device__ __forceinline__ RayX load_stream_ray(const RayStream& r, int i) {   /
     return make_rayx(r.org_x[i], r.org_y[i], r.org_z[i], r.dir_x[i], r.dir_y[i], r.dir_z[i], r.tmin[i], r.tmax[i]);
 }
 
-// primary: writes geom_id (num_geometries on a miss, driver.impala:106-115), prim_id, t, u, v
+// Hit records of a primary stream.  The ABI's layout (driver.impala:24-61) is five arrays -- geom_id, prim_id, t, u, v -- and a record is five
+// 4-byte stores into five different 32-byte sectors; lanes that were refilled hold non-consecutive rays, so nothing coalesces: the traversal launches of
+// the atrium frame wrote 97 bytes per ray for <= 20 bytes of records (profiles/r03_render_profile_cfg5.json).  Inside the library's own loop
+// (render_rows; PrimaryStream::pad bit 0, never set on a caller's stream) the SAME memory -- the five arrays are consecutive in the slab,
+// carve_primary -- holds one 20-byte record per ray at words [5 i, 5 i + 5): one 16-byte and one 4-byte store into one or two sectors; the
+// shader reads the records in stream order (coalesced).  Record fields: geom_id = num_geometries on a miss (driver.impala:106-115).
+constexpr int kHitRecordsAoS = 1;
+struct HitRecord { int geom, prim; float t, u, v; };
+typedef int i32x4_dword_aligned __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void store_hit_record(const PrimaryStream& p, unsigned i, int geom, int prim, float t, float u, float v) {
+    if (p.pad & kHitRecordsAoS) {
+        int* rec = p.geom_id + 5u * i;
+        *reinterpret_cast<i32x4_dword_aligned*>(rec) = i32x4_dword_aligned{geom, prim, __float_as_int(t), __float_as_int(u)};
+        rec[4] = __float_as_int(v);
+    } else { p.geom_id[i] = geom; p.prim_id[i] = prim; p.t[i] = t; p.u[i] = u; p.v[i] = v; }
+}
+__device__ __forceinline__ HitRecord load_hit_record(const PrimaryStream& p, unsigned i) {
+    if (p.pad & kHitRecordsAoS) {
+        const int* rec = p.geom_id + 5u * i;
+        const i32x4_dword_aligned q = *reinterpret_cast<const i32x4_dword_aligned*>(rec);
+        return HitRecord{q.x, q.y, __int_as_float(q.z), __int_as_float(q.w), __int_as_float(rec[4])};
+    }
+    return HitRecord{p.geom_id[i], p.prim_id[i], p.t[i], p.u[i], p.v[i]};
+}
+__device__ __forceinline__ int load_hit_geom(const PrimaryStream& p, unsigned i) { return (p.pad & kHitRecordsAoS) ? p.geom_id[5u * i] : p.geom_id[i]; }
+
+// primary: writes the hit record (geom_id = num_geometries on a miss, driver.impala:106-115; prim_id, t, u, v)
 template <bool TOP = false>
 __device__ __forceinline__ void trace_primary_ray(const SceneDev& sc, const PrimaryStream& p, int i, CursorStack* cursor, DeepStack* deep, lds_int* image = nullptr) {
     const RayX ray = load_stream_ray(p.rays, i);
-    p.geom_id[i] = sc.num_materials; p.prim_id[i] = -1; p.t[i] = ray.tmax; p.u[i] = 0.0f; p.v[i] = 0.0f;     // the miss record; hits overwrite it
+    store_hit_record(p, (unsigned)i, sc.num_materials, -1, ray.tmax, 0.0f, 0.0f);     // the miss record; hits overwrite it
     auto on_hit = [&](int prim, int geom, float t, float u, float v) {
         unsigned k = (unsigned)i;
         asm volatile("" : "+v"(k));                  // opaque index: SGPR bases + one VGPR offset here, instead of five 64-bit addresses held across the loop
-        p.geom_id[k] = geom; p.prim_id[k] = prim; p.t[k] = t; p.u[k] = u; p.v[k] = v;
+        store_hit_record(p, k, geom, prim, t, u, v);
     };
     if (cursor) trace_one<false, TOP>(sc.nodes, sc.tris, ray, *cursor, on_hit, image);
     else trace_one<false>(sc.nodes, sc.tris, ray, *deep, on_hit);
@@ -531,7 +557,7 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
         if (g < P) {
             if (g >= np) return;
             ray = load_stream_ray(p.rays, g);
-            p.geom_id[g] = sc.num_materials; p.prim_id[g] = -1; p.t[g] = ray.tmax; p.u[g] = 0.0f; p.v[g] = 0.0f;     // the miss record; hits overwrite it
+            store_hit_record(p, (unsigned)g, sc.num_materials, -1, ray.tmax, 0.0f, 0.0f);     // the miss record; hits overwrite it
         } else {
             const int i = g - P;
             if (i >= ns || s.rays.id[i] < 0) return;
@@ -619,7 +645,7 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
                     if (!any) {
                         unsigned k = (unsigned)L.g & (unsigned)kIndexMask;
                         asm volatile("" : "+v"(k));
-                        p.geom_id[k] = __float_as_int(q1.w); p.prim_id[k] = prim_id & 0x7FFFFFFF; p.t[k] = t; p.u[k] = u; p.v[k] = v;
+                        store_hit_record(p, k, __float_as_int(q1.w), prim_id & 0x7FFFFFFF, t, u, v);
                     }
                     L.ray.tmax = t; found = true; L.g |= kFoundBit;
                 }
@@ -793,14 +819,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     // not read lanes that took another path): lanes beyond the stream and rays that missed take part with nothing to add.
     const bool in_range = i < n_valid;
     const int src = (perm && in_range) ? perm[i] : i;
-    const bool live = in_range && !(unsorted && p.geom_id[src] >= sc.num_materials);
+    const bool live = in_range && !(unsorted && load_hit_geom(p, (unsigned)src) >= sc.num_materials);
     if (in_range && !live) { if (!scan) q.rays.id[i] = -1; s.rays.id[i] = -1; }            // unsorted stream: a ray that missed ends here
     PathVertex pv; pv.pixel = -1; pv.depth = 0;
     ShadeOut o; o.emits = false; o.shadow = false; o.bounce = false; o.emitted = V(0, 0, 0);
     if (live) {
         pv.pixel = p.rays.id[src];
         pv.org = V(p.rays.org_x[src], p.rays.org_y[src], p.rays.org_z[src]); pv.dir = V(p.rays.dir_x[src], p.rays.dir_y[src], p.rays.dir_z[src]);
-        pv.prim = p.prim_id[src]; pv.geom = p.geom_id[src]; pv.t = p.t[src]; pv.u = p.u[src]; pv.v = p.v[src];
+        const HitRecord hit = load_hit_record(p, (unsigned)src);
+        pv.prim = hit.prim; pv.geom = hit.geom; pv.t = hit.t; pv.u = hit.u; pv.v = hit.v;
         pv.rnd = p.rnd[src]; pv.mis = p.mis[src];
         pv.contrib = V(p.contrib_r[src], p.contrib_g[src], p.contrib_b[src]);
         pv.depth = p.depth[src];
@@ -1174,6 +1201,7 @@ struct RenderDevice {
     int trace_persistent = 0;                  // in effect: 0 = 2-wave traversal workgroups (31-record image), shadow pass on the second stream; 1 = persistent stream traversal kernels
                                                // (k_trace_persist: 16-wave workgroups, 255-record image, ticket counters); 2 = joint: both passes of a bounce in ONE persistent launch
     int trace_persistent_request = -1;         // -1 = per scene (joint for every scene the per-scene mapping rule sends to the streaming loop), 0 / 1 / 2 = the caller's choice
+    int hit_records_aos = 1;                         // render_rows keeps hit records as 20-byte records (store_hit_record); RODENT_HIP_HIT_AOS=0 / rodent_hip_render_hit_records(dev, 0): the ABI's five arrays
     int trace_refill = 0, trace_refill_shadow = 0;   // in effect, persistent traversal launches: > 0 = lane refill (k_trace_refill) once that many lanes of a wave are idle (bounce rays / shadow rays); 0 = whole chunks (k_trace_persist)
     int trace_refill_request[2] = {-1, -1};    // -1 = per scene (resolve_refill), else the caller's thresholds
     int* tickets[2] = {nullptr, nullptr}; int num_cus = 0;
@@ -1206,6 +1234,8 @@ std::vector<float> g_host_film; size_t g_host_w = 0, g_host_h = 0;
 
 // every option of the renderer at its default, or at what its environment variable says (rodent_hip_render_defaults)
 void render_defaults(RenderDevice& r) {
+    r.hit_records_aos = 1;
+    if (const char* e = getenv("RODENT_HIP_HIT_AOS")) r.hit_records_aos = atoi(e) ? 1 : 0;
     r.sort = 0; r.overlap = 1; r.fused_sort = 0; r.fused_compact = 2; r.mega_joint = 0; r.lds_image = 1; r.trace_persistent_request = -1; r.mapping_request = -1; r.capacity = 0; r.trace_refill_request[0] = r.trace_refill_request[1] = -1;
     if (const char* e = getenv("RODENT_HIP_SORT")) r.sort = atoi(e) ? 1 : 0;
     if (const char* e = getenv("RODENT_HIP_OVERLAP")) r.overlap = atoi(e) ? 1 : 0;
@@ -1414,6 +1444,8 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     const int kCapacity = (int)std::min<long long>(r.capacity > 0 ? r.capacity : env_capacity(), std::max<long long>(64, ((long long)r.spp * r.film_w * std::max(0, y1 - y0) + 63) / 64 * 64));
     carve_primary(a, ensure_slab(r, 0, kCapacity, 20), round_cap(kCapacity));
     carve_primary(b, ensure_slab(r, 1, kCapacity, 20), round_cap(kCapacity));
+    // hit records as 20-byte records instead of five arrays (store_hit_record) -- unless the sort by material runs: its kernels move and read the arrays
+    a.pad = b.pad = (r.hit_records_aos && !r.sort) ? kHitRecordsAoS : 0;
     carve_secondary(sec, ensure_slab(r, 2, kCapacity, 13), round_cap(kCapacity));
     PrimaryStream* primary = &a; PrimaryStream* other = &b;
     int* err = r.ctl + 2;
@@ -1703,6 +1735,7 @@ void rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len) {
 }
 
 void rodent_hip_render_sort(int32_t dev, int32_t enable) { rdev(dev).sort = enable ? 1 : 0; }
+void rodent_hip_render_hit_records(int32_t dev, int32_t aos) { rdev(dev).hit_records_aos = aos ? 1 : 0; }
 void rodent_hip_render_overlap(int32_t dev, int32_t enable) { rdev(dev).overlap = enable ? 1 : 0; }
 void rodent_hip_render_fused_sort(int32_t dev, int32_t enable) { rdev(dev).fused_sort = enable ? 1 : 0; }
 void rodent_hip_render_fused_compact(int32_t dev, int32_t enable) { rdev(dev).fused_compact = std::min(2, std::max(0, (int)enable)); }
@@ -1839,6 +1872,7 @@ void hip_generate_rays(int32_t dev, PrimaryStream* primary, int32_t capacity, in
 void hip_traverse_primary(int32_t dev, PrimaryStream* primary, void* stream) {
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); ensure_film(r); require_scene(r);
     if (primary->size <= 0) return;
+    primary->pad = 0;                                                        // a caller's stream holds its hit records in the ABI's five arrays (store_hit_record)
     launch_trace_primary(r, (hipStream_t)stream, *primary, primary->size);
     HIP_CHECK(hipGetLastError());
 }
@@ -1856,7 +1890,7 @@ void hip_sort_primary(int32_t dev, PrimaryStream* primary, PrimaryStream* other,
 
 void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, int32_t num_rays, void* stream) {
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); ensure_film(r); require_scene(r);
-    primary->size = num_rays; secondary->size = num_rays;
+    primary->size = num_rays; secondary->size = num_rays; primary->pad = 0;
     if (num_rays <= 0) return;
     hipLaunchKernelGGL(k_shade, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, r.scene.dev, *primary, *primary, (const int*)nullptr, *secondary, (const int*)nullptr, num_rays, r.film,
                        1.0f / (float)r.spp, r.max_path_len, /* a ray that missed ends here instead of indexing the material table with the miss id: */ 1, (unsigned*)nullptr, (int*)nullptr);

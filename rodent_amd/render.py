@@ -27,7 +27,7 @@ class SceneDesc(C.Structure):
                [(n, vp) for n in ("texcoords", "textures", "texels")] + [("num_textures", i32), ("num_texels", C.c_uint32)]
 
 
-RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_fused_compact", "rodent_hip_render_mapping_in_effect", "rodent_hip_render_defaults", "rodent_hip_render_lds_image", "rodent_hip_render_mega_joint", "rodent_hip_render_trace_persistent", "rodent_hip_render_trace_refill", "rodent_hip_render_trace_refill_in_effect", "get_spp", "render",
+RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_hit_records", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_fused_compact", "rodent_hip_render_mapping_in_effect", "rodent_hip_render_defaults", "rodent_hip_render_lds_image", "rodent_hip_render_mega_joint", "rodent_hip_render_trace_persistent", "rodent_hip_render_trace_refill", "rodent_hip_render_trace_refill_in_effect", "get_spp", "render",
                   "setup_interface", "get_pixels", "clear_pixels", "cleanup_interface", "rodent_get_film_data",
                   "rodent_gpu_get_first_primary_stream", "rodent_gpu_get_second_primary_stream", "rodent_gpu_get_secondary_stream",
                   "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows", "rodent_hip_render_tiles",
@@ -50,6 +50,7 @@ def lib():
         l.rodent_hip_render_capacity.argtypes = [i32, i32]; l.rodent_hip_render_capacity.restype = None
         l.rodent_hip_render_sort.argtypes = [i32, i32]; l.rodent_hip_render_sort.restype = None
         l.rodent_hip_render_overlap.argtypes = [i32, i32]; l.rodent_hip_render_overlap.restype = None
+        l.rodent_hip_render_hit_records.argtypes = [i32, i32]; l.rodent_hip_render_hit_records.restype = None
         l.rodent_hip_render_fused_sort.argtypes = [i32, i32]; l.rodent_hip_render_fused_sort.restype = None
         l.rodent_hip_render_lds_image.argtypes = [i32, i32]; l.rodent_hip_render_lds_image.restype = None
         l.rodent_hip_render_fused_compact.argtypes = [i32, i32]; l.rodent_hip_render_fused_compact.restype = None
@@ -93,7 +94,7 @@ class Renderer:
     MAPPINGS = {"auto": -1, "streaming": 0, "megakernel": 1}       # per scene / mapping_gpu.impala:308-369 / :371-474
 
     def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming", capacity=0, sort=None, overlap=None, fused_sort=None, lds_image=None,
-                 trace_persistent=None, fused_compact=None, mega_joint=None, trace_refill=None):
+                 trace_persistent=None, fused_compact=None, mega_joint=None, trace_refill=None, hit_records_aos=None):
         """Options left at None take the library's default, or what the option's RODENT_HIP_* environment variable says."""
         import torch
         if not torch.cuda.is_available():
@@ -112,6 +113,7 @@ class Renderer:
         l.rodent_hip_render_capacity(dev, capacity)          # rays per stream, 0 = default (32 Mi)
         for value, setter in ((sort, l.rodent_hip_render_sort),                    # sort hit rays by material before shading (reference behaviour)
                               (overlap, l.rodent_hip_render_overlap),              # shadow rays on a second HIP stream
+                              (hit_records_aos, l.rodent_hip_render_hit_records),  # hit records of the loop's streams as 20-byte records (default) / the ABI's five arrays
                               (fused_sort, l.rodent_hip_render_fused_sort),        # the sort computes a permutation, the shader gathers through it
                               (lds_image, l.rodent_hip_render_lds_image),          # stream traversal kernels stage the top of the BVH in LDS
                               (trace_persistent, l.rodent_hip_render_trace_persistent),   # 0 / 1 / 2: 2-wave kernels + second stream / persistent / joint persistent launch (default: per scene)
