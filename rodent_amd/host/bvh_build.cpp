@@ -249,7 +249,7 @@ WideBvh build_wide_bvh(const std::vector<Triangle>& tris, const BuildParams& p) 
                 Box ov = s.lbox; ov.clip(s.rbox);
                 if (!ov.empty() && ov.half_area() > spatial_threshold) find_spatial_split(c, tris, s);
             }
-            if (!s.valid || s.cost + c.bb.half_area() >= c.cost) { c.tested = true; continue; }
+            if (!s.valid || s.cost + p.traversal_cost * c.bb.half_area() >= c.cost) { c.tested = true; continue; }
 
             Cand l, r;
             bool ok = apply_split(c, s, tris, l, r);

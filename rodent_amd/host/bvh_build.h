@@ -36,6 +36,7 @@ struct WideBvh {
 struct BuildParams {
     int   arity = 2;
     int   leaf_threshold = 2;
+    float traversal_cost = 1.0f; // cost of visiting an inner node, in units of one triangle test, times its half area (the reference: 1, converter.cpp:120-127)
     float alpha = 1e-5f;
     bool  spatial_splits = true;
     int   max_depth = 56;        // keeps the traversal stacks (64 entries, stack.impala:53) safe

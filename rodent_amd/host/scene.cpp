@@ -56,7 +56,7 @@ RodentSceneDesc SceneData::desc() const {
     return d;
 }
 
-bool build_scene_from_obj(const std::string& obj_path, SceneData& scene) {
+bool build_scene_from_obj(const std::string& obj_path, SceneData& scene, const BuildParams* bvh_params) {
     TriMesh mesh;
     if (!load_obj(obj_path, mesh)) return false;
     std::unordered_map<std::string, Material> lib;
@@ -143,7 +143,8 @@ bool build_scene_from_obj(const std::string& obj_path, SceneData& scene) {
     const std::vector<Triangle> tris = mesh.triangles();
     std::vector<uint32_t> geom(nt);
     for (size_t t = 0; t < nt; t++) geom[t] = (uint32_t)scene.indices[4 * t + 3];
-    BuildParams p; p.arity = 2;
+    BuildParams p; if (bvh_params) p = *bvh_params;
+    p.arity = 2;
     const WideBvh bvh = build_wide_bvh(tris, p);
     layout_bvh2_tri1(bvh, tris, geom.data(), scene.nodes, scene.tris);
     return true;

@@ -37,7 +37,8 @@ struct SceneData {
     RodentSceneDesc desc() const;
 };
 
-bool build_scene_from_obj(const std::string& obj_path, SceneData& scene);
+struct BuildParams;
+bool build_scene_from_obj(const std::string& obj_path, SceneData& scene, const BuildParams* bvh = nullptr);   // bvh: builder parameters other than the defaults (arity is always 2)
 bool save_scene(const std::string& path, const SceneData& scene);   // ".rscene" binary
 bool load_scene(const std::string& path, SceneData& scene);           // validates counts against the file size and every index (validate_scene)
 bool validate_scene(const SceneData& scene, std::string* why = nullptr);

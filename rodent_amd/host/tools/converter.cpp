@@ -9,6 +9,7 @@
 #include <cstring>
 #include <iostream>
 
+#include "../bvh_build.h"
 #include "../scene.h"
 
 static void usage() {
@@ -21,6 +22,8 @@ static void usage() {
                  "           --max-path-len         Sets the default maximum path length (default: 64)\n"
                  "    -spp   --samples-per-pixel    Sets the default number of samples per pixel (default: 4)\n"
                  "           --fusion               (accepted for compatibility, ignored)\n"
+                 "           --bvh-leaf n           Stops splitting at n references (default: 2, the reference's threshold)\n"
+                 "           --bvh-traversal-cost x Cost of an inner node in triangle tests (default: 1, the reference's)\n"
                  "           --data-dir dir         Also writes the reference's LZ4 buffer files (vertices.bin, bvh.bin, ...) into dir\n"
                  "           --verify-data-dir dir  Reads such files back and compares them with the converted scene\n";
 }
@@ -29,6 +32,7 @@ int main(int argc, char** argv) {
     if (argc < 2) { std::cerr << "Not enough arguments. Run with --help to get a list of options." << std::endl; return 1; }
     std::string obj, out = "scene.rscene", data_dir, verify_dir;
     int spp = 4, max_path_len = 64;
+    rodent::BuildParams bvh;
     for (int i = 1; i < argc; i++) {
         const char* a = argv[i];
         auto need = [&]() { if (i + 1 >= argc) { std::cerr << "Not enough arguments for " << a << std::endl; exit(1); } return argv[++i]; };
@@ -39,13 +43,15 @@ int main(int argc, char** argv) {
         else if (!strcmp(a, "--max-path-len")) max_path_len = strtol(need(), nullptr, 10);
         else if (!strcmp(a, "-spp") || !strcmp(a, "--samples-per-pixel")) spp = strtol(need(), nullptr, 10);
         else if (!strcmp(a, "--fusion")) {}
+        else if (!strcmp(a, "--bvh-leaf")) bvh.leaf_threshold = strtol(need(), nullptr, 10);
+        else if (!strcmp(a, "--bvh-traversal-cost")) bvh.traversal_cost = strtof(need(), nullptr);
         else if (!strcmp(a, "--data-dir")) data_dir = need();
         else if (!strcmp(a, "--verify-data-dir")) verify_dir = need();
         else { std::cerr << "Unknown option '" << a << "'" << std::endl; return 1; }
     }
     if (obj.empty()) { std::cerr << "Please specify an OBJ file to convert" << std::endl; return 1; }
     rodent::SceneData scene;
-    if (!rodent::build_scene_from_obj(obj, scene)) { std::cerr << "Invalid OBJ file '" << obj << "'" << std::endl; return 1; }
+    if (!rodent::build_scene_from_obj(obj, scene, &bvh)) { std::cerr << "Invalid OBJ file '" << obj << "'" << std::endl; return 1; }
     scene.default_spp = spp; scene.default_max_path_len = max_path_len;
     if (!rodent::save_scene(out, scene)) { std::cerr << "Cannot write '" << out << "'" << std::endl; return 1; }
     if (!data_dir.empty() && !rodent::save_reference_data(data_dir, scene)) { std::cerr << "Cannot write the data files into '" << data_dir << "'" << std::endl; return 1; }
