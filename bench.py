@@ -21,7 +21,7 @@ roofline: the bound that binds this kernel: the larger of the VA
         vector-memory pipeline (TA -> L1 -> L2), both against peaks measured on this chip by the microbenchmarks under
         scripts/ubench (profiles/rNN_calibration.json).  SURVEY 8(d)'s algorithmic-HBM-bytes figure is kept as
         `roofline.hbm_algorithmic` (it exceeds the HBM peak: the 22 MB BVH is served by L1 / L2 / MALL -- a count of cache
-        hits), the measured HBM traffic as `roofline.hbm_measured` / `roofline.traffic`.  Counter-derived figures come from
+        hits), the measured L2-fabric traffic as `roofline.l2_fabric_traffic` / `roofline.traffic`.  Counter-derived figures come from
         profiles committed under profiles/ and are only quoted while the profile's source hash matches the kernels'
         sources (rodent_amd/provenance.py); a stale profile is reported as such, never used.
 render  (`extra.render`): BASELINE configs 4 and 5 through the renderer ABI -- Cornell 1920 x 1080, 64 spp, path length 4 and the
@@ -158,6 +158,11 @@ def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms, lds_steps_pe
         out["valu_issue"] = {"bound": "VALU issue", "unit": "wave-instructions/us/SIMD", "achieved": round(per_simd_us, 1), "peak": cal["valu_issue_peak"],
                              "frac": round(per_simd_us / cal["valu_issue_peak"], 4), "valu_instructions_per_launch": int(c["SQ_INSTS_VALU"]),
                              "lane_utilisation": round(lane_util, 4), "useful_lane_frac": round(per_simd_us / cal["valu_issue_peak"] * lane_util, 4),
+                             # round 4 (scripts/ubench/valu_rate.hip): the same rate against the ceiling of the loop's own instruction classes and against the guide's 2-cycle rate
+                             "frac_of_loop_mix_ceiling": None if "valu_issue_peak_loop_mix_r04" not in cal else round(per_simd_us / cal["valu_issue_peak_loop_mix_r04"], 4),
+                             "frac_of_guide_2_cycle_rate": None if "valu_issue_guide_2_cycle_rate" not in cal else round(per_simd_us / cal["valu_issue_guide_2_cycle_rate"], 4),
+                             "ceilings": "peak = the highest mix measured on this chip (round 2: 771); loop mix of round 4's valu_rate: 645; the guide's 2 cycles per wave64 instruction (1162 at the measured clock) "
+                                         "holds for mul / add / fma with <= 2 VGPR sources only -- min / max / cndmask / compares / 3-source fma issue every ~4 cycles (profiles/r04_ubench_valu_rate.txt)",
                              "peak_source": cal_name, "counter_source": c.get("source")}
     if "TA_TA_BUSY_sum" in c and "GRBM_GUI_ACTIVE" in c:
         out["ta_busy_frac_profiled"] = round(c["TA_TA_BUSY_sum"] / cal["cus"] / (c["GRBM_GUI_ACTIVE"] / 8.0), 4)     # mean over the 256 TAs / cycles of one XCD
@@ -536,6 +541,15 @@ def main():
         refill_rec = {"Mrays_s": round(len(rnd) * steps_r / wall_f / 1e6, 3), "ms_per_step": round(1e3 * wall_f / steps_r, 5), "kernels_ms": round(kf_mean, 5),
                       "variant": "refill: the default's persistent workgroups; a wave whose idle lanes reach 32 draws that many new rays from its stripe's counter",
                       "identical_to_default": bool(torch.equal(hits_refill_dev, hits_rnd_dev))}
+    # the default WITHOUT the ray-kind hint (rodent_hip_ray_kind_hint(0)): what a first launch on a new ray list gets -- the in-kernel choice alone
+    nohint_rec = None
+    if world == 1 and width == 2 and abi.variants(2)[variant] == "top" and args.only != "primary":
+        abi.ray_kind_hint(False)
+        hits_nohint_dev = torch.zeros_like(hits_rnd_dev)
+        wall_n, kn_mean, _, _ = time_passes(abi, torch, bvh, rnd_dev, hits_nohint_dev, len(rnd), variant, steps_r, warm_r, None)
+        abi.ray_kind_hint(True)
+        nohint_rec = {"Mrays_s": round(len(rnd) * steps_r / wall_n / 1e6, 3), "kernels_ms": round(kn_mean, 5), "identical_to_default": bool(torch.equal(hits_nohint_dev, hits_rnd_dev)),
+                      "what": "k_bvh2_top_auto alone: every wave finds its rays incoherent and runs the refill loop; with the hint (the default, random_Mrays_s) the same list goes to k_bvh2_top_refill from its second launch on"}
     abi.check_errors(dev)                                         # the asynchronous entry points report stack overflows through a flag
     # for information only (never `value`): independent batches in flight on two streams -- the fill of one launch
     # overlaps the drain of the other (every (device, stream) has its own launch state)
@@ -627,8 +641,21 @@ def main():
         out["extra"]["random_sorted"] = sorted_rec
     if refill_rec:
         out["extra"]["random_refill"] = refill_rec
+    if nohint_rec:
+        out["extra"]["random_without_kind_hint"] = nohint_rec
     if render is not None:
         out["extra"]["render"] = render
+    # what the driver's record keeps is `config`, `roofline` and `cpu_baseline`: the other headline figures as short scalars
+    out["config"]["random_Mrays_s"] = round(main_part["value_rnd"], 1)
+    if big:
+        out["config"]["primary_16Mi_Mrays_s"] = big.get("Mrays_s")
+    if big_random:
+        out["config"]["random_8Mi_Mrays_s"] = big_random.get("default_Mrays_s")
+    for cfg_name, entry in (render or {}).items():
+        auto = entry.get("auto") or {}
+        if "Msamples_s" in auto:
+            out["config"][cfg_name.split("_")[0] + "_Msamples_s"] = auto["Msamples_s"]
+            out["config"][cfg_name.split("_")[0] + "_mapping"] = entry.get("auto_mapping")
     if not args.no_cpu_baseline:
         from oracle import binding as O      # checker / CPU baseline only: never on the measured path
         # (1) visit counts of the reference algorithm for THIS layout over ALL rays -> algorithmic bytes per ray; full parity check
@@ -662,14 +689,18 @@ def main():
                                 "visits_per_ray": {"inner": round(st["inner_per_ray"], 3), "prim": round(st["prims_per_ray"], 3)},
                                 "note": "SURVEY 8(d): 32 + 16 + 64 N_inner + 48 N_tri bytes per ray x rays / kernel time.  Every node / triangle visit is counted although the BVH "
                                         "is served by L1 / L2 / MALL: a count of cache hits, not a fraction of anything (> 1 is expected)"},
-            "hbm_measured": {"not_quoted": traffic_why} if traffic is None else
-                            {"bytes_per_launch": traffic["bytes"], "GBps": round(traffic["bytes"] / (k_mean * 1e-3) / 1e9, 1), "frac": round(traffic["bytes"] / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            # (rounds 2-3 called this hbm_measured: it is the traffic between the L2s and the fabric -- Infinity-Cache hits included, MI355X_MICROARCH.md -- an upper bound on DRAM bytes;
+            #  FETCH_SIZE x 2 = 128-byte line fills, calibrated on scattered 64-byte node fetches as well: profiles/r04_fetch_size_calibration.txt)
+            "l2_fabric_traffic": {"not_quoted": traffic_why} if traffic is None else
+                            {"what": "FETCH_SIZE x 2 + WRITE_SIZE of separate --pmc passes: bytes between the L2s and the fabric, Infinity-Cache hits included (an upper bound on HBM bytes)",
+                             "bytes_per_launch": traffic["bytes"], "GBps": round(traffic["bytes"] / (k_mean * 1e-3) / 1e9, 1), "frac": round(traffic["bytes"] / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                              "compulsory_bytes_per_launch": int(compulsory), "over_compulsory": round(traffic["bytes"] / compulsory, 3),
                              "write_bytes": traffic["write_bytes"], "write_over_hit1_array": round(traffic["write_bytes"] / (16.0 * n), 3), "source": traffic["source"]},
             "binding": binding,
             "random": {"kernel_ms": round(kr_mean, 5), "visits_per_ray": {"inner": round(st_r["inner_per_ray"], 3), "prim": round(st_r["prims_per_ray"], 3)},
                        "bound": (pick_bound(binding_r) or [None])[0], "frac": (pick_bound(binding_r) or [None, {"frac": None}])[1]["frac"], "binding": binding_r}})
         out["roofline"] = roof
+        out["config"]["hbm_algorithmic_frac"] = roof["hbm_algorithmic"]["frac"]
         # parity on every ray of both sets (bit-exact for the order-preserving kernels)
         out["extra"]["all_rays_bit_exact_vs_oracle"] = {"primary": bool(hits.tobytes() == ref_hits.tobytes()), "random": bool(hits_rnd.tobytes() == ref_rnd.tobytes())}
     if world == 1 and not args.no_cpu_baseline:
