@@ -83,13 +83,24 @@ def build_hip_lib(force: bool = False) -> Path:
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     out = LIB_DIR / "librodent_hip.so"
     srcs = _hip_lib_inputs()
-    digest = f'-DRODENT_HIP_SOURCE_DIGEST="{source_digest()}"'
-    if force or _newer(out, *srcs, *_headers()):
-        _run([HIPCC, *HIP_FLAGS, digest, "-shared", *srcs, "-lz", "-o", out])
+    want = source_digest()
+    digest = f'-DRODENT_HIP_SOURCE_DIGEST="{want}"'
+
+    def stale(lib):
+        # the digest the library was compiled with is also kept in a file beside it: whether a prebuilt .so belongs to these sources can
+        # be decided WITHOUT loading it (a process that has dlopen()ed the old file keeps the old mapping whatever is rebuilt afterwards)
+        side = lib.with_suffix(".so.digest")
+        return force or _newer(lib, *srcs, *_headers()) or not side.exists() or side.read_text().strip() != want
+
+    def compile_to(lib, *extra):
+        _run([HIPCC, *HIP_FLAGS, digest, *extra, "-shared", *srcs, "-lz", "-o", lib])
+        lib.with_suffix(".so.digest").write_text(want + "\n")
+    if stale(out):
+        compile_to(out)
     if os.environ.get("RODENT_HIP_LAB", "0") not in ("", "0"):
         lab = LIB_DIR / "librodent_hip_lab.so"
-        if force or _newer(lab, *srcs, *_headers()):
-            _run([HIPCC, *HIP_FLAGS, digest, "-DRODENT_HIP_LAB", "-shared", *srcs, "-lz", "-o", lab])
+        if stale(lab):
+            compile_to(lab, "-DRODENT_HIP_LAB")
     return out
 
 

@@ -766,8 +766,11 @@ __device__ __forceinline__ ShadeOut shade_vertex(const SceneDev& sc, const PathV
 // Block-wide exclusive prefix over all EARLIER blocks of a launch, single pass ("decoupled look-back"): every block publishes
 // its own total as soon as it knows it (flag A), then adds up its predecessors' words -- 64 at a time, one per lane -- back to
 // the nearest block that already knows its inclusive prefix (flag P), and publishes its own.  A word is (flag << 30) | value;
-// the array is zeroed before the launch (flag 0 = nothing yet: wait).  Blocks are dispatched in index order and a block never
-// waits for a LATER one, so the chain always ends; the values are all that travels (relaxed agent-scope atomics, no fences).
+// the array is zeroed before the launch (flag 0 = nothing yet: wait).  A block never waits for a LATER one, so the chain ends as long as
+// every earlier block is resident or finished -- which holds because the hardware dispatches workgroups in index order, but is not
+// something HIP promises: the wait is therefore BOUNDED (about a second of polling, then the kernel traps and the host reports a HIP
+// error instead of hanging).  This is the opt-in mode rodent_hip_render_fused_compact(dev, 1) (reproducible stream order); the default,
+// mode 2, takes one atomic per block and waits for nobody.  The values are all that travels (relaxed agent-scope atomics, no fences).
 // Called by the first wave of the block; returns the prefix in every lane.
 constexpr unsigned kScanA = 1u << 30, kScanP = 2u << 30, kScanValue = (1u << 30) - 1u;
 unsigned* const kScanAtomic = reinterpret_cast<unsigned*>(8);          // k_shade's `scan` argument for "slots from one atomic counter" (rodent_hip_render_fused_compact(dev, 2))
@@ -780,7 +783,8 @@ __device__ __forceinline__ unsigned lookback_exclusive(unsigned* status, int blo
         unsigned long long upto, is_p;
         unsigned w;
         int first_p;
-        for (;;) {
+        for (unsigned polls = 0;; polls++) {
+            if (polls == (1u << 23)) __builtin_trap();                   // a predecessor that never published: see above
             const int idx = j - lane;
             w = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanP;     // in front of block 0: prefix 0
             is_p = __ballot((w >> 30) == 2u);
@@ -1246,6 +1250,7 @@ void render_defaults(RenderDevice& r) {
     if (const char* e = getenv("RODENT_HIP_TRACE_REFILL")) {                 // "48", "48,32" (bounce rays, shadow rays), "0" = off, "-1" = per scene
         const char* c = strchr(e, ',');
         const int a = std::min(kWave, std::max(-1, atoi(e))), b = c ? std::min(kWave, std::max(-1, atoi(c + 1))) : a;
+        if ((a > 0) != (b > 0) || (a < 0) != (b < 0)) { fprintf(stderr, "rodent_hip: RODENT_HIP_TRACE_REFILL=%s: both thresholds must be positive, both 0 (off) or both -1 (per scene), as for rodent_hip_render_trace_refill\n", e); abort(); }
         if (a > 0 && b > 0) { r.trace_refill_request[0] = a; r.trace_refill_request[1] = b; }
         else r.trace_refill_request[0] = r.trace_refill_request[1] = (a < 0 || b < 0) ? -1 : 0;
     }
@@ -1284,12 +1289,16 @@ RenderDevice& rdev(int dev) {
 
 inline int round_cap(int size) { return (size & ~31) + 32; }                 // interface.cpp:359-366
 
-float* ensure_slab(RenderDevice& r, int which, int size, int multiplier) {
+// may_fail: an allocation the device has no room for returns nullptr (the slab is gone then) instead of aborting
+float* ensure_slab(RenderDevice& r, int which, int size, int multiplier, bool may_fail = false) {
     const int cap = round_cap(size);
     if (r.slab_cap[which] < cap) {
         HIP_CHECK(hipSetDevice(r.dev));
         if (r.slab[which]) HIP_CHECK(hipFree(r.slab[which]));
-        HIP_CHECK(hipMalloc(&r.slab[which], sizeof(float) * (size_t)cap * multiplier));
+        r.slab[which] = nullptr; r.slab_cap[which] = 0;
+        const hipError_t e = hipMalloc(&r.slab[which], sizeof(float) * (size_t)cap * multiplier);
+        if (e != hipSuccess && may_fail) { (void)hipGetLastError(); r.slab[which] = nullptr; return nullptr; }
+        HIP_CHECK(e);
         HIP_CHECK(hipMemset(r.slab[which], 0, sizeof(float) * (size_t)cap * multiplier));
         r.slab_cap[which] = cap;
     }
@@ -1338,13 +1347,15 @@ int persistent_grid(RenderDevice& r) {
 // k_trace_refill keeps a ray's index in 28 bits of a lane register (the renderer's own streams hold at most 64 Mi rays each; a caller's stage-level
 // streams may be larger: those go through k_trace_persist)
 bool refill_indexable(long long n_primary, long long n_secondary) { return n_primary + kWave + n_secondary <= (long long)kIndexMask; }
-// coherent_from: the rays [coherent_from, n) were generated for this launch (camera rays), the ones in front of them are what the last bounce left
-void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n, int coherent_from = 0) {
+// coherent_from: the rays [coherent_from, n) were generated for this launch (camera rays), the ones in front of them are what the last bounce left;
+// < 0 = the caller does not know (the stage-level hip_traverse_primary): whole chunks through k_trace_persist -- with coherent_from = 0 every draw of
+// k_trace_refill would wait for the whole wave anyway, in the heavier loop
+void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n, int coherent_from = -1) {
     ensure_deep(r, 0, n);
     int* tickets = nullptr;
     if (r.trace_persistent && n >= kPersistMinRays) {
         ensure_tickets(r); tickets = r.tickets[0];
-        if (r.trace_refill > 0 && refill_indexable(n, 0))
+        if (r.trace_refill > 0 && coherent_from >= 0 && refill_indexable(n, 0))
             hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
                                r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow);
         else hipLaunchKernelGGL(k_trace_persist<0>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
@@ -1441,7 +1452,16 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     if (G + 1 > kMaxBins) { fprintf(stderr, "rodent_hip: too many geometries (%d)\n", G); abort(); }
     PrimaryStream a, b; SecondaryStream sec;
     // rays per stream: the configured capacity, but no more than this call can ever have in flight (a 256 x 144 frame does not reserve 7 GB)
-    const int kCapacity = (int)std::min<long long>(r.capacity > 0 ? r.capacity : env_capacity(), std::max<long long>(64, ((long long)r.spp * r.film_w * std::max(0, y1 - y0) + 63) / 64 * 64));
+    int kCapacity = (int)std::min<long long>(r.capacity > 0 ? r.capacity : env_capacity(), std::max<long long>(64, ((long long)r.spp * r.film_w * std::max(0, y1 - y0) + 63) / 64 * 64));
+    // The default capacity (32 Mi rays: 7.1 GB of streams) is a choice of speed, not a need: when the device has no room for it (other
+    // tenants, a smaller board) the streams are halved until they fit -- results do not depend on the capacity.  A capacity
+    // the caller asked for (rodent_hip_render_capacity) is taken literally: failing to get it aborts with HIP's message.
+    for (;;) {
+        const bool may_fail = r.capacity <= 0 && kCapacity > (1 << 20);
+        if (ensure_slab(r, 0, kCapacity, 20, may_fail) && ensure_slab(r, 1, kCapacity, 20, may_fail) && ensure_slab(r, 2, kCapacity, 13, may_fail)) break;
+        fprintf(stderr, "rodent_hip: no room for ray streams of %d rays on device %d, trying %d\n", kCapacity, r.dev, kCapacity / 2);
+        kCapacity /= 2;
+    }
     carve_primary(a, ensure_slab(r, 0, kCapacity, 20), round_cap(kCapacity));
     carve_primary(b, ensure_slab(r, 1, kCapacity, 20), round_cap(kCapacity));
     // hit records as 20-byte records instead of five arrays (store_hit_record) -- unless the sort by material runs: its kernels move and read the arrays

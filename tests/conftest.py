@@ -123,6 +123,43 @@ def textured_scene(native_build, tmp_path_factory):
     return S.convert(obj, d / "room.rscene"), d
 
 
+def write_textured_hall(d, floor_cells=56, wall_cells=40):
+    """A MID-SIZE textured scene for the per-scene rules (a few thousand BVH nodes: between the Cornell box's dozen and the atrium's
+    142 444): the textured room's materials on a bumpy floor of floor_cells^2 quads (PNG checker map_Kd), a rippled back wall of
+    wall_cells^2 quads (JPEG map_Kd + TGA map_Ks), a plain side wall and a ceiling light."""
+    import numpy as np
+    write_textured_scene(d)                                           # textures + room.mtl
+    v, vt, f = [], [], {"floor": [], "back": [], "side": [], "lamp": []}
+
+    def grid(name, n, point, uv):
+        base = len(v)
+        for j in range(n + 1):
+            for i in range(n + 1):
+                a, b = i / n, j / n
+                v.append(point(a, b)); vt.append(uv(a, b))
+        for j in range(n):
+            for i in range(n):
+                p = base + j * (n + 1) + i + 1
+                f[name] += [(p, p + 1, p + n + 2), (p, p + n + 2, p + n + 1)]
+    grid("floor", floor_cells, lambda a, b: (-1 + 2 * a, 0.04 * np.sin(9 * a) * np.cos(7 * b), 1 - 2 * b), lambda a, b: (2.5 * a, 2.5 * b))
+    grid("back", wall_cells, lambda a, b: (-1 + 2 * a, 2 * b, -1 + 0.03 * np.sin(11 * a + 5 * b)), lambda a, b: (1 - a, b))
+    grid("side", 1, lambda a, b: (-1, 2 * b, 1 - 2 * a), lambda a, b: (-0.25, -0.25))
+    grid("lamp", 1, lambda a, b: (-0.4 + 0.8 * a, 1.98, -0.4 + 0.8 * b), lambda a, b: (-0.25, -0.25))
+    lines = ["mtllib room.mtl"] + ["v %.6f %.6f %.6f" % p for p in v] + ["vt %.6f %.6f" % t for t in vt]
+    for name, faces in f.items():
+        lines.append(f"usemtl {name}")
+        lines += [f"f {a}/{a} {b}/{b} {c}/{c}" for a, b, c in faces]
+    (d / "hall.obj").write_text("\n".join(lines) + "\n")
+    return d / "hall.obj"
+
+
+@pytest.fixture(scope="session")
+def textured_hall(native_build, tmp_path_factory):
+    from rodent_amd import scene as S
+    d = tmp_path_factory.mktemp("hall")
+    return S.convert(write_textured_hall(d), d / "hall.rscene")
+
+
 def write_materials_scene(d):
     """A closed room whose walls exercise every BSDF of the MTL mapping (converter.cpp:858-920): diffuse, Phong only
     (Kd 0), diffuse + Phong mix, mirror (illum 5), glass (illum 7, Ni 1.5, Tf), black (Kd = Ks = 0), and an emitter."""

@@ -396,7 +396,7 @@ def test_bench_py_contract(native_build):
 
 def test_bench_py_with_two_ranks(native_build):
     """The N > 1 code path of bench.py -- strong partition as `value` (one ray set in contiguous ranges, Hit1 gather to rank 0,
-    assembled array equal to a single-GPU trace), weak partition beside it, config 5 as row bands with a film gather -- with two
+    assembled array equal to a single-GPU trace), weak partition beside it, config 5 as interleaved 16-row tiles with a film gather -- with two
     ranks.  On a box with one GPU the ranks share it and the collectives go through gloo (RODENT_BENCH_SHARE_GPUS / _BACKEND);
     with two or more GPUs this is the driver's RCCL launch."""
     import json, os, sys
@@ -416,7 +416,7 @@ def test_bench_py_with_two_ranks(native_build):
     assert e["weak_scaling"]["rays_per_gpu_per_step"] == (1 << 20) and e["weak_scaling"]["Mrays_s"] > 1000 and len(e["weak_scaling"]["kernel_ms_per_rank[primary,random]"]) == 2
     assert e["all_rays_bit_exact_vs_oracle"] == {"primary": True, "random": True}          # rank 0's range against the oracle
     c5 = e["render"]["cfg5_atrium_3840x2160_256spp_len8"]
-    assert c5["rows_per_gpu"] == 1080 and c5["auto"]["film_complete_on_root"] is True and c5["auto"]["film_gather_ms"] > 0 and "cfg4_cornell_1920x1080_64spp_len4" not in e["render"]
+    assert c5["rows_per_gpu"] == 68 * 16 and "interleaved" in c5["partition"] and c5["auto"]["film_complete_on_root"] is True      # rank 0: tiles 0, 2, ..., 134 of 135 and c5["auto"]["film_gather_ms"] > 0 and "cfg4_cornell_1920x1080_64spp_len4" not in e["render"]
     assert "cpu_baseline" not in d                                                          # rank 0, N = 1 only
 
 

@@ -464,3 +464,35 @@ def test_device_film_view_aliases_the_library_film(R, cornell_scene):
     assert np.array_equal(view.cpu().numpy(), r.film())
     assert parallel.gather_film_to_root(view, None) is view                                   # single process: no collective
     r.close()
+
+
+def test_mid_size_textured_scene_gets_the_rules_it_should(R, oracle, textured_hall):
+    """The per-scene rules on a third kind of scene: a textured hall of ~9 500 triangles, a few thousand BVH nodes -- far above the
+    128 nodes up to which the megakernel is chosen (render.hip resolve_mapping), below the 16 384 from which the traversal launches refill
+    idle lanes (resolve_refill).  The library must choose the streaming loop without lane refill, both mappings must trace the oracle's
+    paths through the textures, and the choice must not lose to the alternative by more than the run-to-run spread."""
+    import time, torch
+    sc = textured_hall
+    assert 128 < len(sc.nodes) < 16384, len(sc.nodes)
+    W, H = 192, 120
+    cam = S.camera_settings((0.3, 1.0, 3.2), (-0.1, -0.25, -1), (0, 1, 0), 55, W, H)
+    film_o, counts = oracle.render(sc, cam, 1, 3, 7, W, H)
+    for mapping in ("auto", "streaming", "megakernel"):
+        r = R.Renderer(sc, W, H, 3, 7, mapping=mapping)
+        if mapping == "auto":
+            assert r.mapping_name() == "streaming" and r.trace_refill() == (0, 0)
+        r.render(cam, 1)
+        c = r.counters(); film_g = r.film(); r.close()
+        assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1]), mapping
+        assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL), mapping
+    ms = {}
+    for mapping in ("streaming", "megakernel"):                      # the rule against the measurement, at a frame size where the mappings differ
+        r = R.Renderer(sc, 1280, 720, 16, 8, mapping=mapping)
+        cam2 = S.camera_settings((0.3, 1.0, 3.2), (-0.1, -0.25, -1), (0, 1, 0), 55, 1280, 720)
+        r.render_rows(cam2, 0, 0, 720)
+        t = []
+        for it in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); r.render_rows(cam2, it, 0, 720); torch.cuda.synchronize(); t.append(time.perf_counter() - t0)
+        ms[mapping] = min(t) * 1e3
+        r.close()
+    assert ms["streaming"] <= 1.15 * ms["megakernel"], ms
