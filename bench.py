@@ -675,7 +675,9 @@ def main():
         achieved = bytes_per_ray * n / (k_mean * 1e-3) / 1e9
         traffic, traffic_why = measured_traffic(kname)
         binding = binding_bounds(kname, "primary", n, st["inner_per_ray"] + st["prims_per_ray"], k_mean, lds_p)
-        binding_r = binding_bounds(kname, "random", len(rnd), st_r["inner_per_ray"] + st_r["prims_per_ray"], kr_mean, lds_r)
+        # the random set through the default mapping is traced by k_bvh2_top_refill from its second launch on (ray-kind hint): that kernel's counters
+        kname_r = abi.kernel_name(width, abi.variants(width).index("refill")) if width == 2 and abi.variants(2)[variant] == "top" and n >= 9216 * 64 else kname
+        binding_r = binding_bounds(kname_r, "random", len(rnd), st_r["inner_per_ray"] + st_r["prims_per_ray"], kr_mean, lds_r)
         top = pick_bound(binding)
         roof = {"bound": top[0], "achieved": top[1]["achieved"], "peak": top[1]["peak"], "unit": top[1]["unit"], "frac": top[1]["frac"]} if top else \
                {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "note": "no calibration under profiles/"}
@@ -697,7 +699,7 @@ def main():
                              "compulsory_bytes_per_launch": int(compulsory), "over_compulsory": round(traffic["bytes"] / compulsory, 3),
                              "write_bytes": traffic["write_bytes"], "write_over_hit1_array": round(traffic["write_bytes"] / (16.0 * n), 3), "source": traffic["source"]},
             "binding": binding,
-            "random": {"kernel_ms": round(kr_mean, 5), "visits_per_ray": {"inner": round(st_r["inner_per_ray"], 3), "prim": round(st_r["prims_per_ray"], 3)},
+            "random": {"kernel": kname_r, "kernel_ms": round(kr_mean, 5), "visits_per_ray": {"inner": round(st_r["inner_per_ray"], 3), "prim": round(st_r["prims_per_ray"], 3)},
                        "bound": (pick_bound(binding_r) or [None])[0], "frac": (pick_bound(binding_r) or [None, {"frac": None}])[1]["frac"], "binding": binding_r}})
         out["roofline"] = roof
         out["config"]["hbm_algorithmic_frac"] = roof["hbm_algorithmic"]["frac"]

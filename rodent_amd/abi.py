@@ -20,6 +20,8 @@ from . import formats as F
 # and the instrumented builds; made by `RODENT_HIP_LAB=1 python -m rodent_amd.build`).  Default: the product library.
 LAB = os.environ.get("RODENT_HIP_LAB", "0") not in ("", "0")
 LIB_PATH = Path(__file__).resolve().parent / "lib" / ("librodent_hip_lab.so" if LAB else "librodent_hip.so")
+if os.environ.get("RODENT_HIP_LIB"):               # lab: another build of the library (A/B runs of compiler options, scripts/flags_experiment.sh)
+    LIB_PATH = Path(os.environ["RODENT_HIP_LIB"]).resolve()
 
 SYNC_ENTRY_POINTS = [
     "amdgpu_intersect_single_ray1_bvh2_tri1", "amdgpu_occluded_single_ray1_bvh2_tri1",

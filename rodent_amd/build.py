@@ -41,6 +41,11 @@ HOST_FLAGS = ["-O2", "-std=c++17", "-Wall", "-fPIC", f"-I{ROOT / 'include'}"]
 ORACLE_FLAGS = ["-O2", "-std=c11", "-Wall", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma"]
 
 HIP_SOURCES = ["traversal.hip", "render.hip", "services.hip"]
+# Per-source options.  render.hip: the AMDGPU backend's "max-ilp" instruction scheduling strategy -- the renderer's traversal kernels are
+# compiled under an 8-waves-per-SIMD register budget, under which the default strategy serialises their loads; measured on one MI355X
+# (profiles/r04_flags_experiment.txt): config 5's frame +3.0 %, config 4 (megakernel) +1.1 %.  Scheduling only: the arithmetic is untouched
+# (parity tests).  traversal.hip keeps the default: the benchmark kernel's chunk loop loses 2 % under max-ilp.
+HIP_SOURCE_FLAGS = {"render.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 HIP_LIB_HOST_SOURCES = ["image.cpp"]             # host code the library links: texture decoders of rodent_load_png / _jpg
 HOST_LIB_SOURCES = ["mesh.cpp", "bvh_build.cpp", "atrium.cpp", "scene.cpp", "image.cpp"]
 HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png", "converter", "tex_dump", "buffer_tool", "partition_check"]
@@ -76,6 +81,7 @@ def source_digest() -> str:
     for f in sorted(_hip_lib_inputs() + _headers(), key=lambda p: str(p.relative_to(ROOT))):
         h.update(str(f.relative_to(ROOT)).encode())
         h.update(f.read_bytes())
+    h.update(repr((HIP_FLAGS[:5], sorted(HIP_SOURCE_FLAGS.items()))).encode())          # ... and the options that change the code
     return h.hexdigest()[:16]
 
 
@@ -93,7 +99,18 @@ def build_hip_lib(force: bool = False) -> Path:
         return force or _newer(lib, *srcs, *_headers()) or not side.exists() or side.read_text().strip() != want
 
     def compile_to(lib, *extra):
-        _run([HIPCC, *HIP_FLAGS, digest, *extra, "-shared", *srcs, "-lz", "-o", lib])
+        # one object per source (their options differ), compiled side by side, then one link
+        OBJ_DIR.mkdir(parents=True, exist_ok=True)
+        objs, procs = [], []
+        for src in srcs:
+            obj = OBJ_DIR / f"{lib.stem}.{src.stem}.o"
+            cmd = [HIPCC, *HIP_FLAGS, digest, *extra, *HIP_SOURCE_FLAGS.get(src.name, []), "-c", src, "-o", obj]
+            print("+", " ".join(str(c) for c in cmd), flush=True)
+            procs.append((subprocess.Popen([str(c) for c in cmd]), cmd)); objs.append(obj)
+        for proc, cmd in procs:
+            if proc.wait() != 0:
+                raise subprocess.CalledProcessError(proc.returncode, [str(c) for c in cmd])
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-o", lib])
         lib.with_suffix(".so.digest").write_text(want + "\n")
     if stale(out):
         compile_to(out)

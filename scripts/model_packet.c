@@ -37,7 +37,7 @@ struct ChunkCounts {          /* per chunk, all uint32 */
     uint32_t f_lane_steps;                        /* lanes stepping, summed over those iterations */
     uint32_t f_phases;                            /* fallbacks taken (mode 0: per-lane phases; mode 1: deferred entries) */
     uint32_t max_deferred;                        /* mode 1: most entries one lane had to keep */
-    uint32_t pad;
+    uint32_t window_overflows;                    /* mode 2: rays whose kept entries + own depth exceed the LDS window (WINDOW entries): they would go to the deep list */
 };
 
 static inline void box2(const struct RayX* ray, const struct Node2* nd, int* h0, int* h1, float* te0, float* te1) {
@@ -92,12 +92,15 @@ static inline int lane_step(struct LaneState* L, const struct Node2* nodes, cons
 static uint64_t* g_iter_profile = 0;
 void model_set_iteration_profile(uint64_t* buf) { g_iter_profile = buf; }
 
+static int g_window = 1 << 30;      /* entries of the per-lane LDS window (mode 2) */
 static void lane_loop(struct LaneState* lanes, const struct Node2* nodes, const struct Tri1* tris, int any_hit, struct ChunkCounts* c) {
+    uint64_t over = 0;
     for (int it = 0;; it++) {
         int nn = 0, nt = 0;
         for (int l = 0; l < W; l++) {
             if (lanes[l].top == 0) continue;
             if (lane_step(&lanes[l], nodes, tris, any_hit) == 1) nn++; else nt++;
+            if (lanes[l].ptr >= g_window && !((over >> l) & 1)) { over |= 1ull << l; c->window_overflows++; }
         }
         if (nn + nt == 0) break;
         if (nt == 0) c->f_it_node++; else if (nn == 0) c->f_it_tri++; else c->f_it_mixed++;
@@ -116,6 +119,7 @@ int model_packet(const struct Node2* nodes, const struct Tri1* tris, const struc
                  int32_t any_hit, int32_t mode, int32_t T, const uint8_t* in_image, struct ChunkCounts* counts, uint64_t* hist /* [65] active lanes per packet visit */) {
     static struct LaneState lanes[W];
     int overflow = 0;
+    g_window = mode == 2 ? 15 : (1 << 30);
     for (int32_t first = 0, chunk = 0; first < n; first += W, chunk++) {
         struct ChunkCounts c; memset(&c, 0, sizeof c);
         uint64_t valid = 0;
@@ -128,6 +132,61 @@ int model_packet(const struct Node2* nodes, const struct Tri1* tris, const struc
         }
         int32_t snode[PSTACK]; uint64_t smask[PSTACK]; int sp = 0;
         int32_t cur = 1; uint64_t curmask = valid;
+        if (mode == 2) {
+            /* the buildable form: no masks on the shared stack (every live lane tests every node the packet pops: child boxes lie inside their
+             * parent's, so a lane that missed the parent misses the children); the fallback is decided at the PARENT -- a child that fewer than T
+             * lanes hit goes onto those lanes' own stacks (each lane its nearer child first) unless one of them already keeps dlim entries */
+            const int dlim = T >> 8; const int TT = T & 255;
+            uint64_t alive = valid;
+            if (popc(valid) < TT) { for (int l = 0; l < W; l++) if ((valid >> l) & 1) lanes[l].deferred[lanes[l].ndeferred++] = 1; cur = 0; }
+            for (;;) {
+                if (cur == 0) { if (sp == 0) break; sp--; cur = snode[sp]; }
+                if (any_hit) { for (int l = 0; l < W; l++) if (lanes[l].done) alive &= ~(1ull << l); }
+                if (alive == 0) break;
+                if (cur > 0) {
+                    const struct Node2* nd = &nodes[cur - 1];
+                    if (in_image[cur - 1]) c.p_node_img++; else c.p_node_mem++;
+                    uint64_t m0 = 0, m1 = 0, near0 = 0; int pref0 = 0, pref1 = 0;
+                    for (int l = 0; l < W; l++) {
+                        if (!((alive >> l) & 1)) continue;
+                        int h0, h1; float te0, te1;
+                        box2(&lanes[l].ray, nd, &h0, &h1, &te0, &te1);
+                        if (h0) m0 |= 1ull << l;
+                        if (h1) m1 |= 1ull << l;
+                        if (h0 && (!h1 || te0 < te1)) { pref0++; near0 |= 1ull << l; } else if (h1) pref1++;
+                    }
+                    c.p_lanes_node += (uint32_t)popc(m0 | m1);
+                    hist[popc(m0 | m1)]++;
+                    uint64_t full = 0;
+                    for (int l = 0; l < W; l++) if (lanes[l].ndeferred >= dlim) full |= 1ull << l;
+                    const int pk0 = m0 && (popc(m0) >= TT || (m0 & full)), pk1 = m1 && (popc(m1) >= TT || (m1 & full));
+                    /* deferred children: each lane its own nearer child first */
+                    for (int l = 0; l < W; l++) {
+                        const int d0 = !pk0 && ((m0 >> l) & 1), d1 = !pk1 && ((m1 >> l) & 1);
+                        if (!d0 && !d1) continue;
+                        const int first = (d0 && d1) ? (((near0 >> l) & 1) ? 0 : 1) : (d0 ? 0 : 1);
+                        lanes[l].deferred[lanes[l].ndeferred++] = nd->child[first]; c.f_phases++;
+                        if (d0 && d1) { lanes[l].deferred[lanes[l].ndeferred++] = nd->child[1 - first]; c.f_phases++; }
+                        if (lanes[l].ndeferred >= STACK_CAP - 2) overflow = 1;
+                    }
+                    if (pk0 && pk1) {
+                        const int c0first = pref0 >= pref1;
+                        if (sp >= PSTACK) { overflow = 1; cur = 0; continue; }
+                        snode[sp++] = c0first ? nd->child[1] : nd->child[0];
+                        cur = c0first ? nd->child[0] : nd->child[1];
+                    } else cur = pk0 ? nd->child[0] : (pk1 ? nd->child[1] : 0);
+                } else {
+                    int32_t j = ~cur;
+                    for (;;) {
+                        const struct Tri1* tr = &tris[j++];
+                        c.p_tri++; c.p_lanes_tri += (uint32_t)popc(alive);
+                        for (int l = 0; l < W; l++) if (((alive >> l) & 1) && !lanes[l].done) tri_test(&lanes[l], tr, any_hit);
+                        if (tr->prim_id < 0) break;
+                    }
+                    cur = 0;
+                }
+            }
+        } else
         for (;;) {
             if (cur == 0) {
                 if (sp == 0) break;
@@ -181,7 +240,7 @@ int model_packet(const struct Node2* nodes, const struct Tri1* tris, const struc
                 cur = 0;
             }
         }
-        if (mode == 1) {
+        if (mode >= 1) {
             /* the lanes drain what they kept: entries in the order the packet met them (near first), i.e. reversed onto the stack */
             for (int l = 0; l < W; l++) {
                 struct LaneState* L = &lanes[l];

@@ -40,6 +40,8 @@ ap.add_argument("--tile", default="", help="THxTW: re-chunk the dump (a WIDTH-wi
 ap.add_argument("--width", type=int, default=1024)
 ap.add_argument("--thresholds", default="8,16,24,32,48")
 ap.add_argument("--limit", type=int, default=0, help="only the first N rays")
+ap.add_argument("--buildable", action="store_true", help="also mode 2: no masks on the shared stack, fallback decided at the parent, at most --keep-limit kept entries per lane, 15-entry windows")
+ap.add_argument("--keep-limit", type=int, default=8)
 a = ap.parse_args()
 
 so = Path("/tmp/model_packet.so")
@@ -48,7 +50,7 @@ if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, (ROOT / "ora
     subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-shared", str(src), "-lm", "-o", str(so)], check=True)
 lib = C.CDLL(str(so))
 COUNTS = np.dtype([(k, "<u4") for k in ("p_node_img", "p_node_mem", "p_tri", "p_lanes_node", "p_lanes_tri", "f_it_node", "f_it_mixed", "f_it_tri",
-                                        "f_lane_steps", "f_phases", "max_deferred", "pad")])
+                                        "f_lane_steps", "f_phases", "max_deferred", "window_overflows")])
 lib.model_packet.restype = C.c_int
 lib.model_packet.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p] * 3
 
@@ -181,9 +183,10 @@ for lo, hi in ((0, 10), (10, 20), (20, 30), (30, 40), (40, 60), (60, 100), (100,
 print()
 hdr = f"{'mode':10s} {'T':>3s} | {'pkt node img/mem':>17s} {'pkt tri':>8s} {'lanes/visit':>11s} | {'lane iters':>10s} {'(longest)':>9s} {'lane util':>9s} {'max kept':>8s} | {'VALU M':>8s} {'vs now':>6s} | {'longest alone us':>16s} {'launch us':>9s} {'vs now':>6s} | {'t differs':>9s} {'id differs':>10s}"
 print(hdr)
-for mode_name, mode in (("immediate", 0), ("deferred", 1)):
+ap_modes = (("immediate", 0), ("deferred", 1)) + ((("buildable", 2),) if a.buildable else ())
+for mode_name, mode in ap_modes:
     for T in [int(x) for x in a.thresholds.split(",")]:
-        hits, c, hist = run(mode, T)
+        hits, c, hist = run(mode, T + (a.keep_limit << 8 if mode == 2 else 0))
         v, al = price(c)
         tl = schedule(v, al)
         it = c["f_it_node"].astype(np.int64) + c["f_it_mixed"] + c["f_it_tri"]
@@ -195,4 +198,4 @@ for mode_name, mode in (("immediate", 0), ("deferred", 1)):
             tdiff = int((hits["t"].view(np.uint32) != ref["t"].view(np.uint32)).sum())
             iddiff = int((hits["tri_id"] != ref["tri_id"]).sum())
         print(f"{mode_name:10s} {T:3d} | {c['p_node_img'].mean():8.1f}/{c['p_node_mem'].mean():8.1f} {c['p_tri'].mean():8.1f} {lanes_per_visit:11.1f} | {it.mean():10.1f} {it.max():9d} "
-              f"{c['f_lane_steps'].sum() / max(1.0, 64.0 * it.sum()):9.3f} {c['max_deferred'].max():8d} | {v.sum() / 1e6:8.1f} {bv.sum() / v.sum():6.2f} | {al.max() / GHZ / 1e3:16.1f} {tl:9.1f} {bt / tl:6.2f} | {tdiff:9d} {iddiff:10d}")
+              f"{c['f_lane_steps'].sum() / max(1.0, 64.0 * it.sum()):9.3f} {str(c['max_deferred'].max()) + ('/' + str(int(c['window_overflows'].sum())) if mode == 2 else ''):>8s} | {v.sum() / 1e6:8.1f} {bv.sum() / v.sum():6.2f} | {al.max() / GHZ / 1e3:16.1f} {tl:9.1f} {bt / tl:6.2f} | {tdiff:9d} {iddiff:10d}")
