@@ -194,3 +194,18 @@ def test_top_image_node_set_is_a_breadth_first_prefix(cornell):
         for i in ids:
             assert int(i) in seen                                  # reached from a node earlier in the list
             seen.update(int(c) - 1 for c in child[i] if c > 0)
+
+
+def test_packet_model_reproduces_the_oracle_at_threshold_65():
+    """scripts/model_packet.py (the wave-packet traversal that was modelled and not built): with every subtree falling back at the
+    root (T = 65) the model IS the per-lane kernel and must reproduce oracle B1 bit for bit (the script asserts it), and no packet mode may change
+    a hit record on the Cornell fixtures."""
+    import subprocess, sys
+    from conftest import ROOT
+    for rays, tmax in (("cornell-primary-64x64.rays", "5000"), ("cornell-random-4096.rays", "1")):
+        r = subprocess.run([sys.executable, str(ROOT / "scripts/model_packet.py"), "--bvh", str(ROOT / "tests/golden/cornell.bvh"), "--rays", str(ROOT / "tests/golden" / rays),
+                            "--tmax", tmax, "--thresholds", "8,32", "--buildable"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "hits == B1: yes" in r.stdout
+        rows = [l.split("|") for l in r.stdout.splitlines() if l.startswith(("immediate", "deferred", "buildable"))]
+        assert len(rows) == 6 and all(row[-1].split() == ["0", "0"] for row in rows), r.stdout
