@@ -84,6 +84,16 @@ def variants(width):
     return [l.rodent_hip_variant_name(width, i).decode() for i in range(l.rodent_hip_num_variants(width))]
 
 
+# Mappings that do NOT keep the reference's per-ray visit order (lab build only: work stealing inside the wave, measured and lost): last-bit ties in t
+# resolve to another triangle.  Every shipped mapping is bit-identical to the oracle.
+ORDER_CHANGING = ("steal",)
+
+
+def order_preserving_variants(width):
+    """Indices of the mappings whose hit records equal the reference kernel's bit for bit."""
+    return [i for i, n in enumerate(variants(width)) if not n.startswith(ORDER_CHANGING)]
+
+
 def kernel_name(width, variant, any_hit=False):
     return lib().rodent_hip_kernel_name(width, variant, int(any_hit)).decode()
 

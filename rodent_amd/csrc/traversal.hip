@@ -220,9 +220,13 @@ __device__ __forceinline__ Bases make_bases(const Node2* nodes, const Tri1* tris
 // and the kernel stores the miss record of the rays that never got one when their chunk ends (finish_lane).
 // FENCE (kernels that finish the launch themselves, k_bvh2_top_persist<.., FUSED = 2>): a lane that hands its ray to the deep list
 // publishes the list entry and everything it stored for that ray before its workgroup counts itself done.
-template <bool ANY, bool PF = false, bool TOP = false, bool LAZY = false, bool FENCE = false>
+// SHARED (k_bvh2_top_steal): the ray's tmax lives in LDS (`shared_tmax`: one word per ray of the chunk) because several lanes may be working on
+// subtrees of the SAME ray: it is read with the step's other loads, an accepted triangle shortens it with ds_min_f32, and of the lanes that
+// accept in one instruction the one that holds the minimum stores the hit record.  ANY: the first acceptance stores -inf, which ends the others.
+typedef __attribute__((address_space(3))) float lds_float;
+template <bool ANY, bool PF = false, bool TOP = false, bool LAZY = false, bool FENCE = false, bool SHARED = false>
 __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __restrict__ hits, lds_int* sp_limit, Ctl* ctl, int* __restrict__ deep_list,
-                                          bool prefetch = false, lds_int* pf_row = nullptr, lds_int* image = nullptr) {
+                                          bool prefetch = false, lds_int* pf_row = nullptr, lds_int* image = nullptr, lds_float* shared_tmax = nullptr) {
     const bool is_node = L.top > 0;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -245,10 +249,16 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
         ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
     }
     const int popped = *L.sp;
+    float shared_now = 0.0f;
+    if (SHARED) shared_now = *shared_tmax;
     // All four loads must be in flight together: without this barrier the compiler narrows the shared loads to
     // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
     // (Whole-vector operands: the loaded register quads stay where the loads put them.)
     asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
+    if (SHARED) {
+        L.ray.tmax = shared_now;
+        if (ANY && shared_now == -__builtin_inff()) { L.top = 0; return; }        // another lane found this ray's hit
+    }
     if (PF && prefetch && is_node) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -280,7 +290,10 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
         float t, u, v;
         bool found = false;
         if (intersect_tri(L.ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v)) {
-            store_hit(hits, L.ray_id, prim_id & 0x7FFFFFFF, t, u, v);
+            if (SHARED) {
+                __builtin_amdgcn_ds_fminf(shared_tmax, ANY ? -__builtin_inff() : t, 0, 0, false);
+                if (ANY || *shared_tmax == t) store_hit(hits, L.ray_id, prim_id & 0x7FFFFFFF, t, u, v);     // (read after every lane's ds_min of this instruction)
+            } else store_hit(hits, L.ray_id, prim_id & 0x7FFFFFFF, t, u, v);
             L.ray.tmax = t; found = true;
             if (LAZY) L.found = true;
         }
@@ -904,6 +917,20 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL> void L_top_refil
 }
 #endif
 
+#ifdef RODENT_HIP_LAB
+// "steal" (lab): whole chunks with work stealing inside the wave (k_bvh2_top_steal); small launches take the one-chunk kernel like the default
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int I0, int EVERY> void L_top_steal(LAUNCH_ARGS) {
+    const int max_id = n < g_top_min_rays ? 0 : mapped_node_ids(nodes);
+    if (max_id == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }
+    ensure_deep_list(s, n);
+    ensure_top_buffers(s);
+    s.top_image_nodes = nullptr; s.order_rays = 0;
+    const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;
+    hipLaunchKernelGGL((k_bvh2_top_steal<ANY, LDS_N, TOPN, WAVES, I0, EVERY>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+                       s.top_image, s.tickets, max_id);
+}
+#endif
+
 // Phased traversal: caps of the capped phases (the last, uncapped phase follows).  Launches too small to fill the chip
 // once take the single kernel.
 // "sorted": permutation by origin cell, then the single kernel through it
@@ -1012,6 +1039,17 @@ const Variant2 kVariants2[] = {
     K2("top-prio64",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 64),    // s_setprio 3 once a chunk has run 64 / 96 / 128 iterations
     K2("top-prio96",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 96),
     K2("top-prio128",        "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 128),
+    // work stealing inside the wave (k_bvh2_top_steal; modelled at 1.2 - 1.5 x, measured -5 ... -12 %: profiles/r04_sweep_steal.log).  NOT the reference's visit order.
+    //                                                                   LDS_N TOPN WAVES I0 EVERY
+    K2("steal",              "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 24, 4),
+    K2("steal-16-2",         "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 16, 2),
+    K2("steal-8-2",          "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 8, 2),
+    K2("steal-32-8",         "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 32, 8),
+    K2("steal-24-2",         "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 24, 2),
+    K2("steal-0-1",          "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 0, 1),
+    K2("steal-never",        "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 1048576, 1),   // what the shared tmax and the loop form cost without any stealing
+    K2("steal-48-16",        "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 48, 16),
+    K2("steal-64-8",         "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 64, 8),
     K2("top255r16-48",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 48),
     K2("top-adaptive-32",    "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 32, true),     // refill unless the rays a draw started share an origin (then: whole chunks)
     K2("top-adaptive-48",    "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 48, true),

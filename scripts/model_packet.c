@@ -112,6 +112,59 @@ static void lane_loop(struct LaneState* lanes, const struct Node2* nodes, const 
 static inline int popc(uint64_t m) { return __builtin_popcountll(m); }
 
 /*
+ * mode 3, "steal": the per-lane kernel with WORK STEALING INSIDE THE WAVE.  The launch at 1 Mi rays ends with waves in which a few lanes walk long
+ * paths while the others idle; a lane's stack entries are independent subtrees, so from iteration i0 on, every `every` iterations, each idle lane takes
+ * the top stack entry of a lane that has one (its ray and its tmax are SHARED: the thief tests against the owner's current tmax and shortens it, a hit
+ * record belongs to the ray).  The per-ray visit order is not the reference's any more: t stays the minimum over all accepted triangles, exact ties may
+ * resolve to another triangle.  Returns through `c` the iterations by kind (as lane_loop), the stealing events in f_phases, entries moved in max_deferred.
+ */
+struct Worker { int owner; int32_t top; int32_t mem[4 * STACK_CAP]; int ptr; };
+static void steal_loop(struct LaneState* lanes, uint64_t valid, const struct Node2* nodes, const struct Tri1* tris, int any_hit, int i0, int every, struct ChunkCounts* c) {
+    static struct Worker w[W];
+    for (int l = 0; l < W; l++) { w[l].owner = l; w[l].top = ((valid >> l) & 1) ? 1 : 0; w[l].ptr = 0; w[l].mem[0] = 0; }
+    for (int it = 0;; it++) {
+        int nn = 0, nt = 0;
+        for (int l = 0; l < W; l++) {
+            struct Worker* k = &w[l];
+            if (k->top == 0) continue;
+            struct LaneState* L = &lanes[k->owner];
+            if (any_hit && L->done) { k->top = 0; continue; }
+            if (k->top > 0) {
+                const struct Node2* nd = &nodes[k->top - 1];
+                int h0, h1; float te0, te1;
+                box2(&L->ray, nd, &h0, &h1, &te0, &te1);
+                if (!h0 && !h1) { k->top = k->mem[k->ptr]; k->ptr--; }
+                else if (h0 && h1) { const int c0first = te0 < te1; k->mem[++k->ptr] = c0first ? nd->child[1] : nd->child[0]; k->top = c0first ? nd->child[0] : nd->child[1]; }
+                else k->top = h0 ? nd->child[0] : nd->child[1];
+                nn++;
+            } else {
+                const struct Tri1* tr = &tris[~k->top];
+                tri_test(L, tr, any_hit);
+                if (any_hit && L->done) k->top = 0;
+                else if (tr->prim_id < 0) { k->top = k->mem[k->ptr]; k->ptr--; }
+                else k->top = k->top - 1;
+                nt++;
+            }
+        }
+        if (nn + nt == 0) break;
+        if (nt == 0) c->f_it_node++; else if (nn == 0) c->f_it_tri++; else c->f_it_mixed++;
+        c->f_lane_steps += (uint32_t)(nn + nt);
+        if (g_iter_profile) { const int q = it < 511 ? it : 511; g_iter_profile[q] += (uint64_t)(nn + nt); g_iter_profile[512 + q]++; }
+        if (it >= i0 && (it - i0) % every == 0) {
+            int thief = 0, moved = 0;
+            for (int d = 0; d < W; d++) {
+                if (w[d].top == 0 || w[d].ptr < 1) continue;
+                while (thief < W && w[thief].top != 0) thief++;
+                if (thief >= W) break;
+                w[thief].owner = w[d].owner; w[thief].top = w[d].mem[w[d].ptr--]; w[thief].ptr = 0; w[thief].mem[0] = 0;
+                moved++; thief++;
+            }
+            if (moved) { c->f_phases++; c->max_deferred += (uint32_t)moved; }
+        }
+    }
+}
+
+/*
  * in_image[i] != 0: node i (0-based) is in the LDS image.  mode: 0 immediate fallback, 1 deferred.  threshold T: a subtree
  * entered by fewer than T lanes falls back.  hits: Hit1 per ray.  counts: one record per chunk.
  */
@@ -132,6 +185,9 @@ int model_packet(const struct Node2* nodes, const struct Tri1* tris, const struc
         }
         int32_t snode[PSTACK]; uint64_t smask[PSTACK]; int sp = 0;
         int32_t cur = 1; uint64_t curmask = valid;
+        if (mode == 3) {
+            steal_loop(lanes, valid, nodes, tris, any_hit, T & 255, T >> 8, &c);
+        } else
         if (mode == 2) {
             /* the buildable form: no masks on the shared stack (every live lane tests every node the packet pops: child boxes lie inside their
              * parent's, so a lane that missed the parent misses the children); the fallback is decided at the PARENT -- a child that fewer than T
@@ -240,7 +296,7 @@ int model_packet(const struct Node2* nodes, const struct Tri1* tris, const struc
                 cur = 0;
             }
         }
-        if (mode >= 1) {
+        if (mode == 1 || mode == 2) {
             /* the lanes drain what they kept: entries in the order the packet met them (near first), i.e. reversed onto the stack */
             for (int l = 0; l < W; l++) {
                 struct LaneState* L = &lanes[l];

@@ -42,6 +42,7 @@ ap.add_argument("--thresholds", default="8,16,24,32,48")
 ap.add_argument("--limit", type=int, default=0, help="only the first N rays")
 ap.add_argument("--buildable", action="store_true", help="also mode 2: no masks on the shared stack, fallback decided at the parent, at most --keep-limit kept entries per lane, 15-entry windows")
 ap.add_argument("--keep-limit", type=int, default=8)
+ap.add_argument("--steal", default="", help="i0:every[,i0:every...]: also mode 3, the per-lane kernel with work stealing inside the wave from iteration i0 on, every `every` iterations")
 a = ap.parse_args()
 
 so = Path("/tmp/model_packet.so")
@@ -183,11 +184,23 @@ for lo, hi in ((0, 10), (10, 20), (20, 30), (30, 40), (40, 60), (60, 100), (100,
 print()
 hdr = f"{'mode':10s} {'T':>3s} | {'pkt node img/mem':>17s} {'pkt tri':>8s} {'lanes/visit':>11s} | {'lane iters':>10s} {'(longest)':>9s} {'lane util':>9s} {'max kept':>8s} | {'VALU M':>8s} {'vs now':>6s} | {'longest alone us':>16s} {'launch us':>9s} {'vs now':>6s} | {'t differs':>9s} {'id differs':>10s}"
 print(hdr)
-ap_modes = (("immediate", 0), ("deferred", 1)) + ((("buildable", 2),) if a.buildable else ())
-for mode_name, mode in ap_modes:
-    for T in [int(x) for x in a.thresholds.split(",")]:
+V_STEAL_PER_ITERATION, V_STEAL_EVENT = 3, 45        # the shared tmax is read from LDS every iteration; a stealing event moves 13 ray registers through ds_bpermute
+ap_modes = [(("immediate", 0, int(x)), ("deferred", 1, int(x))) for x in a.thresholds.split(",") if x]
+ap_modes = [m for pair in zip(*ap_modes) for m in pair] if ap_modes else []
+ap_modes = sorted(ap_modes, key=lambda m: m[1])
+if a.buildable:
+    ap_modes += [("buildable", 2, int(x)) for x in a.thresholds.split(",") if x]
+for spec in a.steal.split(","):
+    if spec:
+        i0, every = (int(x) for x in spec.split(":"))
+        ap_modes.append((f"steal {i0}/{every}", 3, i0 + (every << 8)))
+for mode_name, mode, T in ap_modes:
+    if True:
         hits, c, hist = run(mode, T + (a.keep_limit << 8 if mode == 2 else 0))
         v, al = price(c)
+        if mode == 3:
+            extra = V_STEAL_PER_ITERATION * (c["f_it_node"].astype(np.float64) + c["f_it_mixed"] + c["f_it_tri"]) + V_STEAL_EVENT * c["f_phases"]
+            v, al = v + extra, al + extra * CYC_VALU_ALONE
         tl = schedule(v, al)
         it = c["f_it_node"].astype(np.int64) + c["f_it_mixed"] + c["f_it_tri"]
         visits = c["p_node_img"].astype(np.int64) + c["p_node_mem"] + c["p_tri"]
@@ -197,5 +210,5 @@ for mode_name, mode in ap_modes:
         else:
             tdiff = int((hits["t"].view(np.uint32) != ref["t"].view(np.uint32)).sum())
             iddiff = int((hits["tri_id"] != ref["tri_id"]).sum())
-        print(f"{mode_name:10s} {T:3d} | {c['p_node_img'].mean():8.1f}/{c['p_node_mem'].mean():8.1f} {c['p_tri'].mean():8.1f} {lanes_per_visit:11.1f} | {it.mean():10.1f} {it.max():9d} "
+        print(f"{mode_name:10s} {T & 255:3d} | {c['p_node_img'].mean():8.1f}/{c['p_node_mem'].mean():8.1f} {c['p_tri'].mean():8.1f} {lanes_per_visit:11.1f} | {it.mean():10.1f} {it.max():9d} "
               f"{c['f_lane_steps'].sum() / max(1.0, 64.0 * it.sum()):9.3f} {str(c['max_deferred'].max()) + ('/' + str(int(c['window_overflows'].sum())) if mode == 2 else ''):>8s} | {v.sum() / 1e6:8.1f} {bv.sum() / v.sum():6.2f} | {al.max() / GHZ / 1e3:16.1f} {tl:9.1f} {bt / tl:6.2f} | {tdiff:9d} {iddiff:10d}")

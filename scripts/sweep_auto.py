@@ -49,6 +49,9 @@ for any_hit in (False, True):
             row.append(float(np.median([s.elapsed_time(e) for s, e in ev])))
             h = abi.from_device(hd, F.HIT1)
             base.setdefault(k, h)
-            same.append(h.tobytes() == base[k].tobytes() if not any_hit else bool(((h["tri_id"] >= 0) == (base[k]["tri_id"] >= 0)).all()))
+            if label.startswith("steal") and not any_hit:      # order-changing: how many rays differ from the first row (t bits / ids)
+                same.append((int((h["t"].view("<u4") != base[k]["t"].view("<u4")).sum()), int((h["tri_id"] != base[k]["tri_id"]).sum())))
+            else:
+                same.append(h.tobytes() == base[k].tobytes() if not any_hit else bool(((h["tri_id"] >= 0) == (base[k]["tri_id"] >= 0)).all()))
             del rd, hd
         print(f"{v}:{label:26s} " + " ".join(f"{x:16.4f}" for x in row) + f"  {same}", flush=True)
