@@ -85,7 +85,7 @@ def variants(width):
 
 
 # Mappings that do NOT keep the reference's per-ray visit order (lab build only: work stealing inside the wave, measured and lost): last-bit ties in t
-# resolve to another triangle.  Every shipped mapping is bit-identical to the oracle.
+# resolve to another triangle.  Every shipped mapping reproduces the reference kernel bit for bit (tests/).
 ORDER_CHANGING = ("steal",)
 
 
