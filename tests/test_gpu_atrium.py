@@ -279,3 +279,19 @@ def test_atrium_interleaved_row_tiles_equal_the_frame(R, atrium_scene, atrium_re
         assert (primary, shadow) == (counts[0], counts[1])
     assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
 
+
+
+@pytest.mark.parametrize("aos", [False, True])
+@pytest.mark.parametrize("sort", [False, True])
+def test_atrium_hit_record_layouts_render_the_same_frame(R, atrium_scene, atrium_reference, aos, sort):
+    """rodent_hip_render_hit_records: the loop's streams keep a hit as one 20-byte record in the memory of the geom_id / prim_id / t / u / v arrays
+    (default) or in those five arrays (the ABI's layout, which the stage-level entry points always use and which the loop falls back to while the
+    sort by material is on): same ray counts, same film, small streams (every traversal kernel of the loop) and large ones."""
+    f = ATRIUM_FRAME
+    film_o, counts = atrium_reference
+    for capacity in (20000, 0):
+        r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], mapping="streaming", sort=sort, hit_records_aos=aos, capacity=capacity)
+        r.render(atrium_camera(f["W"], f["H"]), f["IT"])
+        c = r.counters(); film_g = r.film(); r.close()
+        assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1]), (aos, sort, capacity)
+        assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL), (aos, sort, capacity)
