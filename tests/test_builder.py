@@ -156,3 +156,29 @@ def test_obj_without_faces_is_an_error_not_a_crash(tmp_path, native_build):
     for tool, args in (("bvh_extractor", ["-obj", tmp_path / "empty.obj", "-o", tmp_path / "e.bvh"]), ("converter", [tmp_path / "empty.obj", "-o", tmp_path / "e.rscene"])):
         r = subprocess.run([native_build.BIN_DIR / tool, *args], capture_output=True, text=True)
         assert r.returncode == 1 and "no faces" in r.stderr, (tool, r.returncode, r.stderr)
+
+
+def test_converter_builder_parameters(tmp_path, native_build, oracle):
+    """converter --bvh-leaf / --bvh-traversal-cost (the sweep of DESIGN 3.4.2): larger leaves and a dearer inner node give smaller hierarchies that are
+    still valid BVH2 blocks and still trace to the exhaustive checker's hits; the defaults are the reference's parameters (2 references, cost 1)."""
+    from conftest import ROOT, write_textured_hall
+    from rodent_amd import build, raygen, scene as S
+    obj = write_textured_hall(tmp_path)
+    scenes = {}
+    for name, args in (("default", []), ("explicit", ["--bvh-leaf", "2", "--bvh-traversal-cost", "1"]), ("leaf8", ["--bvh-leaf", "8"]), ("cost3", ["--bvh-traversal-cost", "3"])):
+        out = tmp_path / f"{name}.rscene"
+        subprocess.run([str(build.BIN_DIR / "converter"), str(obj), "-o", str(out), *args], check=True, stdout=subprocess.DEVNULL)
+        scenes[name] = S.Scene(out)
+    assert scenes["default"].nodes.tobytes() == scenes["explicit"].nodes.tobytes() and scenes["default"].tris.tobytes() == scenes["explicit"].tris.tobytes()
+    assert len(scenes["leaf8"].nodes) < 0.5 * len(scenes["default"].nodes) and len(scenes["cost3"].nodes) < len(scenes["default"].nodes)
+    b = np.asarray(scenes["default"].nodes["bounds"][0]).reshape(2, 6)
+    lo, hi = np.minimum(b[0, 0::2], b[1, 0::2]), np.maximum(b[0, 1::2], b[1, 1::2])
+    rays = raygen.random_rays(lo, hi, 4096, 7, 0.0, 1.0)
+    ref, _ = oracle.traverse(2, scenes["default"].nodes, scenes["default"].tris, rays)
+    for name in ("leaf8", "cost3"):
+        sc = scenes[name]
+        check_bvh2(sc.nodes, sc.tris, sc.num_tris)
+        got, _ = oracle.traverse(2, sc.nodes, sc.tris, rays)
+        assert np.array_equal(got["tri_id"] >= 0, ref["tri_id"] >= 0)
+        hit = ref["tri_id"] >= 0
+        assert np.allclose(got["t"][hit], ref["t"][hit], rtol=1e-5, atol=0)                 # another hierarchy: the same surfaces (ties may name another triangle)
