@@ -132,6 +132,10 @@ void hip_traverse_bvh8_tri4_async(int32_t dev,
 int32_t rodent_hip_check_errors(int32_t dev, void* stream);
 
 /* Introspection / plumbing. */
+/* anydsl_get_kernel_time() of the AnyDSL runtime, which the reference's bench_traversal brackets its GPU calls with
+ * (tools/bench_traversal/bench_traversal.cpp:125-133): microseconds of KERNEL time accumulated over the synchronous entry points above
+ * (HIP events around what a call enqueues; launch gaps, the call's synchronisation and its flag read-back are not in it). */
+uint64_t    rodent_hip_get_kernel_time(void);
 int32_t     rodent_hip_device_count(void);              /* 0 when no GPU is visible */
 int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2, 4 or 8 */
 /* The phased BVH2 mappings ("phased-*": capped phases with ray compaction in between) take the single kernel for launches

@@ -30,7 +30,7 @@ SYNC_ENTRY_POINTS = [
 ]
 ASYNC_ENTRY_POINTS = ["hip_traverse_bvh2_tri1_async", "hip_traverse_bvh4_tri4_async", "hip_traverse_bvh8_tri4_async"]
 EXPORTS = SYNC_ENTRY_POINTS + ASYNC_ENTRY_POINTS + [
-    "rodent_hip_check_errors", "rodent_hip_device_count", "rodent_hip_num_variants", "rodent_hip_variant_name",
+    "rodent_hip_check_errors", "rodent_hip_get_kernel_time", "rodent_hip_device_count", "rodent_hip_num_variants", "rodent_hip_variant_name",
     "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_source_digest", "rodent_hip_is_lab_build", "rodent_hip_phased_min_rays", "rodent_hip_top_min_rays", "rodent_hip_ray_kind_hint", "rodent_hip_schedule_history", "rodent_hip_read_stats", "rodent_hip_read_trace", "rodent_hip_debug_set_perm",
 ]
 BLOCK_OF_WIDTH = {2: F.BVH2_TRI1, 4: F.BVH4_TRI4, 8: F.BVH8_TRI4}
@@ -58,6 +58,7 @@ def lib():
         l.rodent_hip_is_lab_build.restype = i32; l.rodent_hip_is_lab_build.argtypes = []
         l.rodent_hip_phased_min_rays.restype = None; l.rodent_hip_phased_min_rays.argtypes = [i32]
         l.rodent_hip_top_min_rays.restype = None; l.rodent_hip_top_min_rays.argtypes = [i32]
+        l.rodent_hip_get_kernel_time.restype = C.c_uint64; l.rodent_hip_get_kernel_time.argtypes = []
         l.rodent_hip_ray_kind_hint.restype = None; l.rodent_hip_ray_kind_hint.argtypes = [i32]
         l.rodent_hip_schedule_history.restype = None; l.rodent_hip_schedule_history.argtypes = [i32]
         l.rodent_hip_device_count.restype = i32; l.rodent_hip_device_count.argtypes = []

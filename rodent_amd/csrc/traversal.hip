@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -606,6 +607,7 @@ struct DeviceState {
     int*  order_agree = nullptr;               // per stripe: {chunks the last two launches both found in their expensive half, half the stripe's chunks}
     const int* debug_perm = nullptr;           // lab: caller-supplied ray permutation of the "top-userperm" mapping (rodent_hip_debug_set_perm)
     int*  host_flags = nullptr;                // pinned: where the error flags are copied back to
+    hipEvent_t timer[2] = {nullptr, nullptr};  // the synchronous entry points' kernel time (rodent_hip_get_kernel_time)
     // Ray-kind hint of the default mapping (L_default): host_kinds[0] / [1] = id of the last launch whose rays some workgroup found coherent / incoherent
     // (pinned host memory the kernels store into); hint_* = the ray list the hint is about and the first launch that traced it.
     int*  host_kinds = nullptr; int launch_id = 0; const void* hint_rays = nullptr; int hint_n = 0, hint_first_id = 0;
@@ -1202,29 +1204,45 @@ int32_t rodent_hip_check_errors(int32_t dev, void* stream) {
     return read_and_clear_error_flags(s, (hipStream_t)stream) ? 1 : 0;
 }
 
+// The reference's host times its GPU kernels with anydsl_get_kernel_time() (tools/bench_traversal/bench_traversal.cpp:125-133): the AnyDSL runtime's
+// accumulated KERNEL time in microseconds -- no launch gap, no synchronisation, no copy.  The synchronous entry points keep the same account: HIP events
+// around what they enqueue, added up in g_kernel_ns after the call's own synchronisation.
+}  // extern "C"
+namespace {
+std::atomic<uint64_t> g_kernel_ns{0};
+template <typename Launch> void timed_sync_call(int32_t dev, Launch launch) {
+    DeviceState& s = device_state(dev, nullptr);
+    HIP_CHECK(hipSetDevice(dev));
+    if (!s.timer[0]) { HIP_CHECK(hipEventCreate(&s.timer[0])); HIP_CHECK(hipEventCreate(&s.timer[1])); }
+    HIP_CHECK(hipEventRecord(s.timer[0], nullptr));
+    launch();
+    HIP_CHECK(hipEventRecord(s.timer[1], nullptr));
+    check_error_flag(s, nullptr);                                          // synchronises; aborts on a stack overflow like the reference's error()
+    float ms = 0.0f;
+    HIP_CHECK(hipEventElapsedTime(&ms, s.timer[0], s.timer[1]));
+    g_kernel_ns.fetch_add((uint64_t)((double)ms * 1e6 + 0.5), std::memory_order_relaxed);
+}
+}  // namespace
+extern "C" {
+uint64_t rodent_hip_get_kernel_time(void) { return g_kernel_ns.load(std::memory_order_relaxed) / 1000u; }
+
 void amdgpu_intersect_single_ray1_bvh2_tri1(int32_t dev, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    hip_traverse_bvh2_tri1_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(2), nullptr);
-    check_error_flag(device_state(dev, nullptr), nullptr);
+    timed_sync_call(dev, [&] { hip_traverse_bvh2_tri1_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(2), nullptr); });
 }
 void amdgpu_occluded_single_ray1_bvh2_tri1(int32_t dev, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    hip_traverse_bvh2_tri1_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(2), nullptr);
-    check_error_flag(device_state(dev, nullptr), nullptr);
+    timed_sync_call(dev, [&] { hip_traverse_bvh2_tri1_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(2), nullptr); });
 }
 void hip_intersect_single_ray1_bvh4_tri4(int32_t dev, const Node4* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    hip_traverse_bvh4_tri4_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(4), nullptr);
-    check_error_flag(device_state(dev, nullptr), nullptr);
+    timed_sync_call(dev, [&] { hip_traverse_bvh4_tri4_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(4), nullptr); });
 }
 void hip_occluded_single_ray1_bvh4_tri4(int32_t dev, const Node4* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    hip_traverse_bvh4_tri4_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(4), nullptr);
-    check_error_flag(device_state(dev, nullptr), nullptr);
+    timed_sync_call(dev, [&] { hip_traverse_bvh4_tri4_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(4), nullptr); });
 }
 void hip_intersect_single_ray1_bvh8_tri4(int32_t dev, const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    hip_traverse_bvh8_tri4_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(8), nullptr);
-    check_error_flag(device_state(dev, nullptr), nullptr);
+    timed_sync_call(dev, [&] { hip_traverse_bvh8_tri4_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(8), nullptr); });
 }
 void hip_occluded_single_ray1_bvh8_tri4(int32_t dev, const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    hip_traverse_bvh8_tri4_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(8), nullptr);
-    check_error_flag(device_state(dev, nullptr), nullptr);
+    timed_sync_call(dev, [&] { hip_traverse_bvh8_tri4_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(8), nullptr); });
 }
 
 int32_t rodent_hip_device_count(void) {
