@@ -128,9 +128,14 @@ using StreamStack = StreamStackT<false>;
 // stack outgrows the 16-entry window is abandoned (overflow = true) and traced again by k_trace_deep with the
 // 64-entry stack in global memory -- the arrangement of traversal.hip (k_bvh2_single / k_bvh2_finish): no overflow
 // handling inside the hot loop.
+// The persistent kernels (k_trace_persist, k_trace_refill) do not abandon it: the oldest entries move to the wave's block of global memory and the
+// ray goes on in its lane (SPILLW = the window's rows; stack_spill / stack_reload, traversal_device.h).
 struct CursorStack {
     lds_int* sp; lds_int* limit; bool overflow;
-    __device__ __forceinline__ void init(lds_int* col, int window = kLdsStack) { sp = col; limit = col + window * kWave; overflow = false; col[0] = 0; }
+    int* spill_wave; int* err;
+    __device__ __forceinline__ void init(lds_int* col, int window = kLdsStack, int* spill_wave_ = nullptr, int* err_ = nullptr) {
+        sp = col; limit = col + window * kWave; overflow = false; col[0] = 0; spill_wave = spill_wave_; err = err_;
+    }
 };
 // 64 entries ([entry][lane]), the reference's capacity (stack.impala:53), in 16 KB of LDS; used by k_trace_deep only.  (In global
 // memory, rounds 1-2, every push and pop was a round trip: ~100 us for the first deep ray of a launch.)
@@ -187,7 +192,7 @@ __device__ __forceinline__ void film_add_wave(float* film, int pixel, bool valid
 // anything was hit.  The stream kernels store from on_hit instead of carrying a hit record in registers.
 // TOP: `image` is the scene's top-of-tree image staged in LDS by the workgroup (traversal_device.h); a node id >= kLdsTag is a
 // link into it and is fetched with ds_read_b128 instead of through the vector-memory pipeline.
-template <bool ANY, bool TOP = false, typename Stack, typename OnHit>
+template <bool ANY, bool TOP = false, int SPILLW = 0, typename Stack, typename OnHit>
 __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, RayX ray, Stack& st, OnHit on_hit, lds_int* image = nullptr) {
     constexpr bool kCursor = is_cursor<Stack>::value;
     bool any_found = false;
@@ -232,7 +237,10 @@ __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const
                 if constexpr (kCursor) {
                     st.sp[kWave] = c0first ? ch.y : ch.x;
                     st.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
-                    if (both && st.sp >= st.limit) { st.overflow = true; top = 0; }      // (`both`: popping the sentinel moves sp below its column)
+                    if (both && st.sp >= st.limit) {                                  // (`both`: popping the sentinel moves sp below its column)
+                        if constexpr (SPILLW > 0) stack_spill<SPILLW>(st.sp, top, st.limit - SPILLW * kWave, st.spill_wave, st.err);
+                        else { st.overflow = true; top = 0; }
+                    }
                 } else {
                     st.put(ptr + 1, c0first ? ch.y : ch.x);
                     ptr += (both ? 1 : 0) - ((h0 || h1) ? 0 : 1);
@@ -251,6 +259,7 @@ __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const
                 if constexpr (kCursor) st.sp -= (leave && !(ANY && found)) ? kWave : 0;
                 else ptr -= (leave && !(ANY && found)) ? 1 : 0;
             }
+            if constexpr (kCursor && SPILLW > 0) if (top >= kSpillMark) stack_reload(st.sp, top, st.limit - SPILLW * kWave, st.spill_wave);      // popped row 0 while entries are out
         }
     }
     return any_found;
@@ -364,7 +373,7 @@ __device__ __forceinline__ HitRecord load_hit_record(const PrimaryStream& p, uns
 __device__ __forceinline__ int load_hit_geom(const PrimaryStream& p, unsigned i) { return (p.pad & kHitRecordsAoS) ? p.geom_id[5u * i] : p.geom_id[i]; }
 
 // primary: writes the hit record (geom_id = num_geometries on a miss, driver.impala:106-115; prim_id, t, u, v)
-template <bool TOP = false>
+template <bool TOP = false, int SPILLW = 0>
 __device__ __forceinline__ void trace_primary_ray(const SceneDev& sc, const PrimaryStream& p, int i, CursorStack* cursor, DeepStack* deep, lds_int* image = nullptr) {
     const RayX ray = load_stream_ray(p.rays, i);
     store_hit_record(p, (unsigned)i, sc.num_materials, -1, ray.tmax, 0.0f, 0.0f);     // the miss record; hits overwrite it
@@ -373,7 +382,7 @@ __device__ __forceinline__ void trace_primary_ray(const SceneDev& sc, const Prim
         asm volatile("" : "+v"(k));                  // opaque index: SGPR bases + one VGPR offset here, instead of five 64-bit addresses held across the loop
         store_hit_record(p, k, geom, prim, t, u, v);
     };
-    if (cursor) trace_one<false, TOP>(sc.nodes, sc.tris, ray, *cursor, on_hit, image);
+    if (cursor) trace_one<false, TOP, SPILLW>(sc.nodes, sc.tris, ray, *cursor, on_hit, image);
     else trace_one<false>(sc.nodes, sc.tris, ray, *deep, on_hit);
 }
 
@@ -456,7 +465,8 @@ constexpr int kPersistWaves = 16, kPersistTopNodes = 255, kTraceStripes = 64, kT
 template <int MODE>
 __global__ __launch_bounds__(kWave * kPersistWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
-                     int* deep_count_primary, int* deep_count_secondary, unsigned long long* counters, int* deep_list_primary, int* deep_list_secondary, int* tickets) {
+                     int* deep_count_primary, int* deep_count_secondary, unsigned long long* counters, int* deep_list_primary, int* deep_list_secondary, int* tickets,
+                     int* spill, int* err) {
     constexpr int kStackInts = kPersistWaves * (kTopStack + 1) * kWave;
     __shared__ __attribute__((aligned(16))) int lds[kStackInts + kPersistTopNodes * 16];
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
@@ -470,6 +480,7 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStrea
     int* counter = tickets + stripe * kTraceCounterStride;
     int t = (blockIdx.x / kTraceStripes) * kPersistWaves + wave;
     lds_int* col = (lds_int*)lds + wave * (kTopStack + 1) * kWave + lane;
+    int* const spill_wave = spill + (size_t)(blockIdx.x * kPersistWaves + wave) * kSpillWaveInts;     // this wave's block of the out-of-window stack
     __syncthreads();
     if (MODE != 1 && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)np);
     for (;;) {
@@ -478,9 +489,8 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStrea
         if (chunk < chunks_p) {
             const int i = chunk * kWave + lane;
             if (i < np) {
-                CursorStack st; st.init(col, kTopStack);
-                trace_primary_ray<true>(sc, p, i, &st, nullptr, image);
-                if (st.overflow) deep_list_primary[atomicAdd(deep_count_primary, 1)] = i;
+                CursorStack st; st.init(col, kTopStack, spill_wave, err);
+                trace_primary_ray<true, kTopStack>(sc, p, i, &st, nullptr, image);
             }
         } else if (chunk < total_chunks) {
             const int c = chunk - chunks_p, i = c * kWave + lane;
@@ -489,9 +499,8 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStrea
             if (lane == 0 && live) atomicAdd(&counters[4 + (c & 63)], (unsigned long long)__popcll(live));
             bool lit = false;
             if (pixel >= 0) {
-                CursorStack st; st.init(col, kTopStack);
-                lit = !trace_one<true, true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {}, image);
-                if (st.overflow) { deep_list_secondary[atomicAdd(deep_count_secondary, 1)] = i; lit = false; }      // k_trace_deep decides
+                CursorStack st; st.init(col, kTopStack, spill_wave, err);
+                lit = !trace_one<true, true, kTopStack>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {}, image);
             }
             film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
         }
@@ -520,7 +529,7 @@ constexpr int kFoundBit = 1 << 29, kIndexMask = (1 << 28) - 1;
 __global__ __launch_bounds__(kWave * kPersistWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_from, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
                     int* deep_count_primary, int* deep_count_secondary, unsigned long long* counters, int* deep_list_primary, int* deep_list_secondary, int* tickets,
-                    int idle_bounce, int idle_shadow) {
+                    int idle_bounce, int idle_shadow, int* spill, int* err) {
     constexpr int kStackInts = kPersistWaves * (kTopStack + 1) * kWave, kGroupRays = 32 * kWave;
     __shared__ __attribute__((aligned(16))) int lds[kStackInts + kPersistTopNodes * 16];
     const int lane = threadIdx.x % kWave, wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -535,6 +544,7 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
     const auto index_of = [&](int t) { return ((t / kGroupRays) * kTraceStripes + stripe) * kGroupRays + t % kGroupRays; };
     lds_int* const wave_stack = (lds_int*)lds + wave * (kTopStack + 1) * kWave;        // wave-uniform; lane l's column starts at wave_stack + l
     lds_int* const wave_limit = wave_stack + kTopStack * kWave;                        // sp >= wave_limit  <=>  the lane's cursor is at entry kTopStack (l < kWave)
+    int* const spill_wave = spill + (size_t)(blockIdx.x * kPersistWaves + wave) * kSpillWaveInts;     // this wave's block of the out-of-window stack
     __syncthreads();
     if (np && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)np);
     typedef const __attribute__((address_space(1))) char* gptr;
@@ -629,12 +639,7 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
                 L.top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
                 L.sp[kWave] = c0first ? ch.y : ch.x;
                 L.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
-                if (both && L.sp >= wave_limit) {                                // abandoned: k_trace_deep traces it again with the 64-entry stack and decides
-                    const int g = L.g & kIndexMask;
-                    if (g >= P) deep_list_secondary[atomicAdd(deep_count_secondary, 1)] = g - P;
-                    else deep_list_primary[atomicAdd(deep_count_primary, 1)] = g;
-                    L.g |= kFoundBit; L.top = 0;
-                }
+                if (both && L.sp >= wave_limit) stack_spill<kTopStack>(L.sp, L.top, wave_stack + lane, spill_wave, err);      // deeper than the window: the oldest entries move out
             } else {
                 const int prim_id = __float_as_int(q2.w);
                 const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
@@ -653,21 +658,28 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
                 L.top = ends ? 0 : (leave ? popped : top - 1);
                 L.sp -= (leave && !ends) ? kWave : 0;
             }
+            if (L.top >= kSpillMark) stack_reload(L.sp, L.top, wave_stack + lane, spill_wave);       // popped row 0 while entries are out: they come back
         }
     }
 }
 
-// The rays the two kernels above abandoned (stack deeper than the LDS window), traced again from the root with the
-// 64-entry stack in global memory; one wave, enqueued behind every stream traversal launch; resets the list.
+// The rays the one-chunk stream kernels (k_trace_primary / k_trace_secondary: launches below one resident generation of rays) abandoned
+// because their stack outgrew the LDS window, traced again from the root with the reference's 64-entry stack ([entry][lane] in LDS).
+// kDeepGroups one-wave workgroups behind every stream traversal launch, each taking every kDeepGroups-th batch of 64 rays (one
+// wave until round 4: a launch with many deep rays waited for a serial drain); workgroup 0 also resets the persistent kernels' ticket
+// counters and the shader's slot counter, and the last workgroup to finish resets the list (`done`: zero between launches).
+constexpr int kDeepGroups = 64;
 template <bool SECONDARY>
 __global__ __launch_bounds__(kWave) void k_trace_deep(SceneDev sc, PrimaryStream p, SecondaryStream s, float* film, float inv_spp, int* err, int* deep_count,
-                                                      const int* deep_list, int* deep_stack, int* tickets, int* zero_word) {
+                                                      const int* deep_list, int* done, int* tickets, int* zero_word) {
     __shared__ int stack_lds[kStackCap * kWave];
-    if (tickets) tickets[threadIdx.x * kTraceCounterStride] = 0;            // the persistent kernel's 64 ticket counters, ready for its next launch
-    if (zero_word && threadIdx.x == 0) *zero_word = 0;                      // primary pass: the slot counter of the shader that follows (fused compaction)
-    const int count = *deep_count;
+    if (blockIdx.x == 0) {
+        if (tickets) tickets[threadIdx.x * kTraceCounterStride] = 0;        // the persistent kernel's 64 ticket counters, ready for its next launch
+        if (zero_word && threadIdx.x == 0) *zero_word = 0;                  // primary pass: the slot counter of the shader that follows (fused compaction)
+    }
+    const int count = __hip_atomic_load(deep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     DeepStack st{(lds_int*)stack_lds + threadIdx.x, err};
-    for (int k = threadIdx.x; k < count; k += kWave) {
+    for (int k = blockIdx.x * kWave + threadIdx.x; k < count; k += gridDim.x * kWave) {
         const int i = deep_list[k];
         if (SECONDARY) {
             const bool lit = !trace_one<true>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {});
@@ -680,7 +692,11 @@ __global__ __launch_bounds__(kWave) void k_trace_deep(SceneDev sc, PrimaryStream
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) *deep_count = 0;
+    // every workgroup has read the count before it counts itself done, so the last one may zero it (no deep rays -- the usual case -- : nobody waits for anybody)
+    if (threadIdx.x == 0 && count > 0 && atomicAdd(done, 1) == (int)gridDim.x - 1) {
+        __hip_atomic_store(deep_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __global__ void k_copy_int(const int* src, int* dst) { *dst = *src; }
@@ -1222,7 +1238,8 @@ struct RenderDevice {
     float* slab[3] = {nullptr, nullptr, nullptr}; int slab_cap[3] = {0, 0, 0};       // first primary, second primary, secondary
     int* tmp = nullptr; int tmp_cap = 0;
     int* deep_list[2] = {nullptr, nullptr}; int deep_cap[2] = {0, 0};   // rays handed to k_trace_deep: [0] primary, [1] secondary (may run at the same time)
-    int* deep_stack[2] = {nullptr, nullptr};       // their 64 x 64-entry stacks
+    int* deep_done[2] = {nullptr, nullptr};        // k_trace_deep's workgroup counters (zero between launches)
+    int* spill[2] = {nullptr, nullptr};            // out-of-window stack entries of the persistent traversal launches: one block per resident wave (stack_spill); [1]: the shadow pass on the second stream
     hipStream_t aux = nullptr;                     // shadow-ray traversal runs here, beside the compaction / next primary pass
     hipEvent_t ev_shade = nullptr, ev_sec = nullptr, ev_copy = nullptr;
     int overlap = 1;                               // 0: everything on the caller's stream
@@ -1328,7 +1345,16 @@ void ensure_deep(RenderDevice& r, int which, int rays) {
         HIP_CHECK(hipMalloc(&r.deep_list[which], sizeof(int) * (size_t)rays));
         r.deep_cap[which] = rays;
     }
-    if (!r.deep_stack[which]) HIP_CHECK(hipMalloc(&r.deep_stack[which], sizeof(int) * kStackCap * kWave));
+    if (!r.deep_done[which]) { HIP_CHECK(hipMalloc(&r.deep_done[which], sizeof(int) * 16)); HIP_CHECK(hipMemset(r.deep_done[which], 0, sizeof(int) * 16)); }
+}
+int persistent_grid(RenderDevice& r);
+// the spill blocks of a persistent launch on stream `which` (103 MB for the 8192 resident waves of this chip, allocated with the first such launch)
+int* ensure_spill(RenderDevice& r, int which) {
+    if (!r.spill[which]) {
+        HIP_CHECK(hipSetDevice(r.dev));
+        HIP_CHECK(hipMalloc(&r.spill[which], sizeof(int) * (size_t)persistent_grid(r) * kPersistWaves * kSpillWaveInts));
+    }
+    return r.spill[which];
 }
 
 // Stream traversal launches: the main kernel, then the one-wave kernel for the rays it abandoned.
@@ -1357,12 +1383,12 @@ void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStre
         ensure_tickets(r); tickets = r.tickets[0];
         if (r.trace_refill > 0 && coherent_from >= 0 && refill_indexable(n, 0))
             hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
-                               r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow);
+                               r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow, ensure_spill(r, 0), r.ctl + 2);
         else hipLaunchKernelGGL(k_trace_persist<0>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
-                           r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets);
+                           r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, ensure_spill(r, 0), r.ctl + 2);
     } else if (r.lds_image) hipLaunchKernelGGL((k_trace_primary<kTraceWaves, kSceneTopNodes>), dim3((n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
     else hipLaunchKernelGGL((k_trace_primary<1, 0>), dim3((n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, p, (const int*)nullptr, n, r.ctl + 3, r.counters, r.deep_list[0]);
-    hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_stack[0], tickets, r.ctl + 6);
+    hipLaunchKernelGGL(k_trace_deep<false>, dim3(kDeepGroups), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_done[0], tickets, r.ctl + 6);
 }
 void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const SecondaryStream& s, const int* size_ptr, int max_n, float inv_spp) {
     ensure_deep(r, 1, max_n);
@@ -1371,12 +1397,12 @@ void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const Secondary
         ensure_tickets(r); tickets = r.tickets[1];
         if (r.trace_refill > 0 && refill_indexable(0, max_n))
             hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, 0, s, size_ptr, max_n, r.film, inv_spp,
-                               r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow);
+                               r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow, ensure_spill(r, 1), r.ctl + 2);
         else hipLaunchKernelGGL(k_trace_persist<1>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, s, size_ptr, max_n, r.film, inv_spp,
-                           r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets);
+                           r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, ensure_spill(r, 1), r.ctl + 2);
     } else if (r.lds_image) hipLaunchKernelGGL((k_trace_secondary<kTraceWaves, kSceneTopNodes>), dim3((max_n + kTraceWaves * kWave - 1) / (kTraceWaves * kWave)), dim3(kTraceWaves * kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
     else hipLaunchKernelGGL((k_trace_secondary<1, 0>), dim3((max_n + kWave - 1) / kWave), dim3(kWave), 0, stream, r.scene.dev, s, size_ptr, max_n, r.film, inv_spp, r.ctl + 4, r.counters, r.deep_list[1]);
-    hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_stack[1], tickets, (int*)nullptr);
+    hipLaunchKernelGGL(k_trace_deep<true>, dim3(kDeepGroups), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_done[1], tickets, (int*)nullptr);
 }
 
 // Joint form: the closest-hit pass over `p` (n rays) and the shadow pass over `s` (size *size_ptr, or max_n) in ONE persistent launch,
@@ -1386,11 +1412,11 @@ void launch_trace_joint(RenderDevice& r, hipStream_t stream, const PrimaryStream
     ensure_tickets(r);
     if (r.trace_refill > 0 && refill_indexable(n, max_n))
         hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, s, size_ptr, max_n, r.film, inv_spp,
-                           r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0], r.trace_refill, r.trace_refill_shadow);
+                           r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0], r.trace_refill, r.trace_refill_shadow, ensure_spill(r, 0), r.ctl + 2);
     else hipLaunchKernelGGL(k_trace_persist<2>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, s, size_ptr, max_n, r.film, inv_spp,
-                       r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0]);
-    hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_stack[0], r.tickets[0], r.ctl + 6);
-    hipLaunchKernelGGL(k_trace_deep<true>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, PrimaryStream{}, s, r.film, inv_spp, r.ctl + 2, r.ctl + 4, r.deep_list[1], r.deep_stack[1], (int*)nullptr, (int*)nullptr);
+                       r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0], ensure_spill(r, 0), r.ctl + 2);
+    // (nothing is abandoned by the persistent kernels any more: the follow-up kernel is the launch's housekeeping -- ticket counters, the shader's slot counter)
+    hipLaunchKernelGGL(k_trace_deep<false>, dim3(1), dim3(kWave), 0, stream, r.scene.dev, p, SecondaryStream{}, (float*)nullptr, 0.0f, r.ctl + 2, r.ctl + 3, r.deep_list[0], r.deep_done[0], r.tickets[0], r.ctl + 6);
 }
 
 void ensure_hist(RenderDevice& r, size_t ints) {

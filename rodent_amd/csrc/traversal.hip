@@ -225,9 +225,13 @@ __device__ __forceinline__ Bases make_bases(const Node2* nodes, const Tri1* tris
 // subtrees of the SAME ray: it is read with the step's other loads, an accepted triangle shortens it with ds_min_f32, and of the lanes that
 // accept in one instruction the one that holds the minimum stores the hit record.  ANY: the first acceptance stores -inf, which ends the others.
 typedef __attribute__((address_space(3))) float lds_float;
-template <bool ANY, bool PF = false, bool TOP = false, bool LAZY = false, bool FENCE = false, bool SHARED = false>
+// SPILL (> 0: the rows of the lane's LDS window, sp_limit = col + SPILL * kWave): a stack that outgrows the window moves its oldest entries to
+// `spill_wave`, the wave's block of global memory, and the ray goes on in its lane (stack_spill / stack_reload, traversal_device.h); 0: the
+// ray is handed to the launch's deep list and traced again from the root by the follow-up pass (finish_launch).
+template <bool ANY, bool PF = false, bool TOP = false, bool LAZY = false, bool FENCE = false, bool SHARED = false, int SPILL = 0>
 __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __restrict__ hits, lds_int* sp_limit, Ctl* ctl, int* __restrict__ deep_list,
-                                          bool prefetch = false, lds_int* pf_row = nullptr, lds_int* image = nullptr, lds_float* shared_tmax = nullptr) {
+                                          bool prefetch = false, lds_int* pf_row = nullptr, lds_int* image = nullptr, lds_float* shared_tmax = nullptr,
+                                          int* __restrict__ spill_wave = nullptr) {
     const bool is_node = L.top > 0;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -277,11 +281,14 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
         L.sp[kWave] = c0first ? ch.y : ch.x;
         L.top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
         L.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
-        if (both && L.sp >= sp_limit) {                                 // (`both`: popping the sentinel moves sp below col, which wraps)                                           // deeper than the LDS window: k_bvh2_finish redoes this ray
-            deep_list[atomicAdd(&ctl->deep_count, 1)] = L.ray_id;
-            L.top = 0;
-            if (LAZY) L.found = true;                                   // its record is the follow-up pass's business
-            if (FENCE) __threadfence();
+        if (both && L.sp >= sp_limit) {                                 // (`both`: popping the sentinel moves sp below col, which wraps)
+            if constexpr (SPILL > 0) stack_spill<SPILL>(L.sp, L.top, sp_limit - SPILL * kWave, spill_wave, &ctl->err, &ctl->stats[7]);      // deeper than the LDS window: the oldest entries move out
+            else {                                                      // ... or k_bvh2_finish redoes this ray
+                deep_list[atomicAdd(&ctl->deep_count, 1)] = L.ray_id;
+                L.top = 0;
+                if (LAZY) L.found = true;                               // its record is the follow-up pass's business
+                if (FENCE) __threadfence();
+            }
         }
     } else {
         const int prim_id = __float_as_int(q2.w);
@@ -302,6 +309,7 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
         L.top = (ANY && found) ? 0 : (leave ? popped : L.top - 1);    // top - 1 == ~(j + 1)
         L.sp -= (leave && !(ANY && found)) ? kWave : 0;
     }
+    if constexpr (SPILL > 0) if (L.top >= kSpillMark) stack_reload(L.sp, L.top, sp_limit - SPILL * kWave, spill_wave);       // popped row 0 while entries are out: they come back
 }
 
 // A fresh ray: loads it, stores the miss record, empty stack (col[0] = the 0 that ends the traversal when popped).
@@ -330,10 +338,10 @@ __device__ __forceinline__ void finish_lane(const Lane& L, const Ray1* __restric
 
 // PRIO (lab): 0 = none; 1 = a wave raises its issue priority as it ages (48 / 96 / 144 iterations -> s_setprio 1 / 2 / 3);
 // 2 = the waves of the second dispatch round (workgroup index >= 8192) run at priority 2 from the start; 3 = both.
-template <bool ANY, int LDS_N, int PRIO = 0>
+template <bool ANY, int LDS_N, int PRIO = 0, bool SPILL = false>
 __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, const Ray1* __restrict__ rays,
                                               Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray,
-                                              const int* __restrict__ perm = nullptr) {
+                                              const int* __restrict__ perm = nullptr, int* __restrict__ spill_wave = nullptr) {
     const int lane_ray = first_ray + (int)threadIdx.x;
     // perm (k_bvh2_single's "sorted" mapping): lane j traces ray perm[j]; its hit still goes to hits[ray id]
     Lane L = start_lane(rays, hits, lane_ray < n ? (perm ? perm[lane_ray] : lane_ray) : -1, perm ? perm[first_ray] : first_ray, col);
@@ -341,7 +349,7 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
     const Bases base = make_bases(nodes, tris);
     if (PRIO == 0) {
         while (__ballot(L.top != 0)) {
-            if (L.top != 0) bvh2_step<ANY>(L, base, hits, sp_limit, ctl, deep_list);
+            if (L.top != 0) bvh2_step<ANY, false, false, false, false, false, SPILL ? LDS_N : 0>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, nullptr, nullptr, spill_wave);
         }
     } else if (PRIO >= 256) {                         // lab: triangle turns.  Lanes at a triangle step only every K-th iteration while the wave is
         // young (iteration < SWITCH), so that most iterations run the node path alone (62 instead of 127 VALU instructions); old
@@ -480,10 +488,12 @@ static_assert(kMaxPhases == 4 && kStripes == 64 && kCounterStride == 16, "k_bvh2
 // waiting workgroups hold slots.  An age-based s_setprio for long-running waves was slower as well, and so was giving
 // every wave two chunks (b and b + grid/2) with idle lanes refilled from the second one (one dispatch round, all waves
 // start at t = 0: 0.247 vs 0.214 ms -- the second chunk's expensive rays still start late, inside the wave).
-template <bool ANY, int LDS_N, int XCD, bool TRACE = false, int PRIO = 0>
+// SPILL: the launch has no more chunks than the context has spill blocks (every launch the default mapping sends here): a stack that outgrows the
+// LDS window goes on in its lane (stack_spill); otherwise such rays go to the deep list and k_bvh2_finish.
+template <bool ANY, int LDS_N, int XCD, bool TRACE = false, int PRIO = 0, bool SPILL = false>
 __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                        Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm) {
+                                                        Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm, int* __restrict__ spill) {
     __shared__ int lds_raw[(LDS_N + (PRIO >= 16 && PRIO < 256 ? 2 : 1)) * kWave];
     lds_int* col = (lds_int*)lds_raw + threadIdx.x;
     const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__
             chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
         }
     }
-    unified_chunk<ANY, LDS_N, PRIO>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, perm);
+    unified_chunk<ANY, LDS_N, PRIO, SPILL>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, perm, SPILL ? spill + (size_t)blockIdx.x * kSpillWaveInts : nullptr);
     if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
         unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
         tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
@@ -612,6 +622,7 @@ struct DeviceState {
     // (pinned host memory the kernels store into); hint_* = the ray list the hint is about and the first launch that traced it.
     int*  host_kinds = nullptr; int launch_id = 0; const void* hint_rays = nullptr; int hint_n = 0, hint_first_id = 0;
     int*  tickets = nullptr;                   // persistent "top*p" mappings: chunk tickets per XCD (zero between launches)
+    int*  spill = nullptr;                     // out-of-window stack entries: kSpillSlots wave blocks of kSpillWaveInts ints (stack_spill, traversal_device.h)
     Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
 };
 // One DeviceState per (device, stream): launches enqueued on different streams of a device may overlap, so each
@@ -704,6 +715,22 @@ void ensure_deep_list(DeviceState& s, int n) {
     s.deep_cap = n;
 }
 
+// The blocks the traversal stacks spill into beyond their LDS windows: one per wave slot of a resident generation of the persistent
+// kernels (num_cus x 32 waves = 8192), which the one-chunk kernels' launches below rodent_hip_top_min_rays (9216 chunks) fit as well.
+// 113 MB per (device, stream) context, allocated with the context's first launch, touched only by rays deeper than their window.
+constexpr int kSpillSlots = 9216;
+void ensure_spill(DeviceState& s) {
+    if (s.spill) return;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (!s.spill) HIP_CHECK(hipMalloc(&s.spill, sizeof(int) * (size_t)kSpillSlots * kSpillWaveInts));
+}
+
+// a persistent grid's wave slots must fit the context's spill blocks (they do on every gfx950 part: 256 CUs x 32 waves)
+int spill_checked(int groups, int waves) {
+    if ((long)groups * waves > kSpillSlots) { fprintf(stderr, "rodent_hip: %d x %d resident waves exceed the %d stack spill blocks\n", groups, waves, kSpillSlots); abort(); }
+    return groups;
+}
+
 // Copies back and clears both stack-overflow flags (scratch[1]: the lab kernels' LaneStack; ctl->err: the follow-up
 // kernels' 64-entry global stack) after everything enqueued on `stream` has finished.
 bool read_and_clear_error_flags(DeviceState& s, hipStream_t stream) {
@@ -742,7 +769,11 @@ constexpr int kFinishGroups = 256;
 
 template <bool ANY, int LDS_N, int XCD, bool TR = false, int PRIO = 0> void L_single(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
-    hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR, PRIO>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr);
+    if (PRIO == 0 && !TR && blocks_for(n) <= kSpillSlots) {        // every chunk has a spill block: deep stacks stay in their lanes
+        ensure_spill(s);
+        hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, false, 0, true>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr, s.spill);
+    } else
+        hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR, PRIO>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr, (int*)nullptr);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 
@@ -779,6 +810,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool SORTED = false, bool KE
 
 template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, int OCC, bool TRACE = false, int PRIO = 0, int FUSED = 0, bool LAZY = false> void launch_top_persist(LAUNCH_ARGS, int max_id) {
     ensure_deep_list(s, n);
+    ensure_spill(s);
     if (!s.top_image || !s.tickets) {
         std::lock_guard<std::mutex> lock(g_mutex);
         if (!s.top_image) { HIP_CHECK(hipMalloc(&s.top_image, kMaxTopNodes * sizeof(Node2))); HIP_CHECK(hipMemset(s.top_image, 0, kMaxTopNodes * sizeof(Node2))); }
@@ -798,7 +830,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, 
         perm = s.sort_perm;
     }
     if (!SORTED && PRIO == -1) perm = s.debug_perm;                          // lab "top-userperm"
-    const int groups = ((s.num_cus * (OCC / WAVES) + kStripes - 1) / kStripes) * kStripes;   // one resident generation, the same number in every stripe
+    const int groups = spill_checked(((s.num_cus * (OCC / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);   // one resident generation, the same number in every stripe
     const int total_chunks = blocks_for(n), stride = ((total_chunks + 31) / 32 + kStripes - 1) / kStripes * 32;       // chunks of the fullest stripe
     if (g_schedule_history && !SORTED && !TRACE && PRIO == 0 && FUSED != 1 && !PREFETCH && stride <= kMaxStripeChunks) {      // (with the history on, the launch is followed by k_bvh2_top_finish_history whatever FUSED says)
         // schedule history: this launch records its chunks' costs; it draws them in the order the previous launch of the same
@@ -813,7 +845,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, 
         const bool have_previous = s.order_rays == n;
         const History hist{have_previous ? s.chunk_order : nullptr, s.chunk_cost, stride, s.order_agree};
         hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, false, OCC, false, 0, false, true>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(),
-                           s.deep_list, perm, s.top_image, s.tickets, max_id, s.deep_stack, hist);
+                           s.deep_list, perm, s.top_image, s.tickets, max_id, s.spill, hist);
         hipLaunchKernelGGL((k_bvh2_top_finish_history<ANY>), dim3(kStripes), dim3(kHistoryThreads), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets,
                            s.top_image, TOPN, total_chunks, (const int*)s.chunk_cost, s.chunk_order, stride, have_previous ? 1 : 0, s.order_agree);
         s.order_rays = n;
@@ -821,7 +853,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, 
     }
     s.order_rays = 0;
     hipLaunchKernelGGL((k_bvh2_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, OCC, TRACE, PRIO, FUSED, false, LAZY>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                       perm, s.top_image, s.tickets, max_id, s.deep_stack, History{nullptr, nullptr, 0, nullptr});
+                       perm, s.top_image, s.tickets, max_id, s.spill, History{nullptr, nullptr, 0, nullptr});
     if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool SORTED = false, int OCC = 32, bool TRACE = false, int PRIO = 0, int FUSED = 0, bool LAZY = false> void L_top_persist(LAUNCH_ARGS) {
@@ -860,8 +892,9 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0, bo
     if (g_schedule_history) { launch_top_persist<ANY, LDS_N, TOPN, WAVES, false, false, 32, false, 0, 2>(s, nodes, tris, rays, hits, n, stream, max_id); return; }
     ensure_deep_list(s, n);
     ensure_top_buffers(s);
+    ensure_spill(s);
     s.top_image_nodes = nullptr; s.order_rays = 0;
-    const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;   // one resident generation, the same number in every stripe
+    const int groups = spill_checked(((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);   // one resident generation, the same number in every stripe
     // Which kernel?  k_bvh2_top_auto decides per wave and is right for any list; but its refill loop, compiled under the chunk loop's
     // register budget, runs 7 % behind k_bvh2_top_refill's (profiles/r04_sweep_auto.log).  So the kernels report what they saw
     // (report_ray_kind) and a list that earlier launches found incoherent throughout goes to k_bvh2_top_refill -- from the second launch
@@ -877,12 +910,12 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0, bo
     const bool incoherent = MODE == 0 && g_kind_hint && kinds[1] >= s.hint_first_id && kinds[0] < kinds[1];
     if (incoherent) {
         hipLaunchKernelGGL((k_bvh2_top_refill<ANY, LDS_N, TOPN, WAVES, REFILL, false, false>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                           (const int4*)s.top_image, s.tickets, max_id, s.host_kinds, id);
+                           (const int4*)s.top_image, s.tickets, max_id, s.spill, s.host_kinds, id);
         hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
         return;
     }
     hipLaunchKernelGGL((k_bvh2_top_auto<ANY, LDS_N, TOPN, WAVES, REFILL, MODE, FUSED>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                       s.top_image, s.tickets, max_id, s.host_kinds, id);
+                       s.top_image, s.tickets, max_id, s.spill, s.host_kinds, id);
     if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 
@@ -901,9 +934,10 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = fal
         }
     }
     s.top_image_nodes = nullptr;
-    const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;
+    ensure_spill(s);
+    const int groups = spill_checked(((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);
     hipLaunchKernelGGL((k_bvh2_top_refill<ANY, LDS_N, TOPN, WAVES, REFILL, ADAPT, FENCE>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                       (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes), (int*)nullptr, 0);
+                       (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes), s.spill, (int*)nullptr, 0);
     hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 
@@ -912,9 +946,10 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL> void L_top_refil
     ensure_deep_list(s, n);
     ensure_top_buffers(s);
     s.top_image_nodes = nullptr;
-    const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;
+    ensure_spill(s);
+    const int groups = spill_checked(((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);
     hipLaunchKernelGGL((k_bvh2_top_refill_wpe<ANY, LDS_N, TOPN, WAVES, REFILL>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                       (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes));
+                       (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes), s.spill);
     hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 #endif
@@ -943,7 +978,7 @@ template <bool ANY, int LDS_N> void L_sorted(LAUNCH_ARGS) {
     hipLaunchKernelGGL(k_raysort_count, dim3(blocks), dim3(kSortThreads), 0, stream, nodes, rays, n, s.sort_keys, s.sort_totals);
     hipLaunchKernelGGL(k_raysort_scan, dim3(1), dim3(kSortCells), 0, stream, s.sort_totals, s.sort_totals + kSortCells);
     hipLaunchKernelGGL(k_raysort_scatter, dim3(blocks), dim3(kSortThreads), 0, stream, s.sort_keys, n, s.sort_totals + kSortCells, s.sort_perm);
-    hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, 32, false, 0>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)s.sort_perm);
+    hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, 32, false, 0>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)s.sort_perm, (int*)nullptr);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 

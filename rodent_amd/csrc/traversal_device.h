@@ -115,6 +115,49 @@ typedef __attribute__((address_space(3))) int lds_int;
 // ---------------------------------------------------------------------------------------------
 constexpr int kLdsTag = 0x40000000;
 
+// ---------------------------------------------------------------------------------------------
+// The part of a lane's traversal stack that does not fit its LDS window (the reference's stack costs the same at depth 5 and
+// at depth 50, stack.impala:52-123; until round 4 a ray that outgrew the window was abandoned and traced again from the root
+// by a follow-up pass).  The window is WINDOW + 1 rows of [entry][lane] words behind a cursor: row 0 is the word that ends the
+// traversal when it is popped, rows 1..WINDOW - 1 hold entries, and the step that fills row WINDOW moves the OLDEST kSpillRows
+// entries (rows 1..kSpillRows) to the wave's block of global memory, shifts the rest down and goes on -- the ray stays in its
+// lane, nothing is traced twice.  Row 0 then holds kSpillMark + (blocks spilled) instead of 0; popping THAT is the signal to
+// bring the newest block back (one compare per step in the loop; everything else is off the hot path).  Capacity: WINDOW - 1
+// entries in LDS + kSpillBlocks x kSpillRows behind them = 14 + 49 = 63 with the 15-row windows of the persistent kernels:
+// the reference's 64 slots minus its sentinel (stack.impala:53-54,62-66).  One wave's block: [kSpillBlocks x kSpillRows][lane]
+// ints, indexed by the wave's slot in the resident grid -- nobody else touches it during the launch, nothing carries over.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSpillMark = 0x7F000000;          // above every node id (<= 0x3FFFFFFF) and every image link (kLdsTag + offset)
+constexpr int kSpillRows = 7, kSpillBlocks = 7;
+constexpr int kSpillWaveInts = kSpillRows * kSpillBlocks * kWave;       // 12 544 bytes per resident wave
+
+// Called (exec-masked: the rare path) by a lane whose push filled row WINDOW: sp == col + WINDOW * kWave.
+// `events` (may be null): a counter of blocks moved out, for the tests and the per-scene reports (one atomic per block, on the rare path only).
+template <int WINDOW>
+__device__ __forceinline__ void stack_spill(lds_int*& sp, int& top, lds_int* col, int* __restrict__ spill_wave, int* err, unsigned long long* events = nullptr) {
+    static_assert(WINDOW > kSpillRows + 1, "something must stay in the window");
+    const int mark = col[0], blocks = mark ? mark - kSpillMark : 0;
+    if (blocks >= kSpillBlocks) { *err = 1; top = 0; return; }        // more than the reference's 64 slots: the host reports it
+    if (events) atomicAdd(events, 1ull);
+    int* g = spill_wave + blocks * kSpillRows * kWave + (int)(threadIdx.x % kWave);
+#pragma unroll 1
+    for (int j = 0; j < kSpillRows; j++) g[j * kWave] = col[(1 + j) * kWave];
+#pragma unroll 1
+    for (int j = 1; j <= WINDOW - kSpillRows; j++) col[j * kWave] = col[(j + kSpillRows) * kWave];
+    col[0] = kSpillMark + blocks + 1;
+    sp -= kSpillRows * kWave;
+}
+// Called by a lane that popped row 0 while blocks are out (top >= kSpillMark): the newest block comes back, its newest entry is the new top.
+__device__ __forceinline__ void stack_reload(lds_int*& sp, int& top, lds_int* col, const int* __restrict__ spill_wave) {
+    const int blocks = top - kSpillMark;                                // >= 1
+    const int* g = spill_wave + (blocks - 1) * kSpillRows * kWave + (int)(threadIdx.x % kWave);
+#pragma unroll 1
+    for (int j = 0; j < kSpillRows - 1; j++) col[(1 + j) * kWave] = g[j * kWave];
+    top = g[(kSpillRows - 1) * kWave];
+    col[0] = blocks > 1 ? kSpillMark + blocks - 1 : 0;
+    sp = col + (kSpillRows - 1) * kWave;
+}
+
 __device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // One wave (the LDS operations of a wave complete in program order: between one lane's write and another lane's read the
 // compiler only has to keep that order).  Record layout: ints 0..11 bounds, 12..13 child ids / links, 14 = the node's own 1-based id (0: slot unused), 15 = 0.

@@ -241,7 +241,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int OCC = 32,
 __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_persist(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                      const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                                      Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm,
-                                                                     int4* __restrict__ top_image, int* __restrict__ tickets, int max_id, int* deep_stack, History hist) {
+                                                                     int4* __restrict__ top_image, int* __restrict__ tickets, int max_id, int* spill, History hist) {
     constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroup = 32;
     static_assert((kStackInts + TOPN * 16) * 4 * (OCC / WAVES) <= 160 * 1024, "OCC waves per CU must fit their stacks and images in LDS");
     __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     int* counter = tickets + stripe * kCounterStride;
     int t = (blockIdx.x / kStripes) * WAVES + wave;
     lds_int* const sp_limit = col + LDS_N * kWave;
+    int* const spill_wave = spill + (size_t)(blockIdx.x * WAVES + wave) * kSpillWaveInts;       // this wave's block of the out-of-window stack (stack_spill)
     const Bases base = make_bases(nodes, tris);
     const int my_chunks = HISTORY ? stripe_chunks(total_chunks, stripe) : 0;
     static_assert(kStripes == kWave, "one stripe's agreement record per lane");
@@ -285,10 +286,10 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
             int iterations = 0;
             if (PRIO > 0) __builtin_amdgcn_s_setprio(0);
             while (__ballot(L.top != 0)) {
-                if (L.top != 0) bvh2_step<ANY, false, true, LAZY, FUSED == 2>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+                if (L.top != 0) bvh2_step<ANY, false, true, LAZY, false, false, LDS_N>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill_wave);
                 // lab (PRIO == -2, "top-double"): a lane whose next node is in the LDS image visits it in the same iteration -- two levels of the top
                 // of the tree per dependent step where the fetch is a ds_read (VERDICT r2 item 2's "BVH4-collapsed image", without a second layout)
-                if (PRIO == -2 && L.top >= kLdsTag) bvh2_step<ANY, false, true, LAZY, FUSED == 2>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+                if (PRIO == -2 && L.top >= kLdsTag) bvh2_step<ANY, false, true, LAZY, false, false, LDS_N>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill_wave);
                 if (TRACE || PRIO > 0 || HISTORY) iterations++;
                 if (PRIO > 0 && iterations == PRIO) __builtin_amdgcn_s_setprio(3);          // lab: a chunk that is still running after PRIO iterations is on the critical path
             }
@@ -351,7 +352,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = fal
 __device__ __forceinline__ void top_refill_body(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                     const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                                     Ctl* ctl, int* __restrict__ deep_list, const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id,
-                                                                    int* host_kinds = nullptr, int launch_id = 0) {
+                                                                    int* spill, int* host_kinds = nullptr, int launch_id = 0) {
     constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroupRays = 32 * kWave;
     static_assert((kStackInts + TOPN * 16) * 4 * (32 / WAVES) <= 160 * 1024, "32 waves per CU must fit their stacks and images in LDS");
     __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
@@ -364,6 +365,7 @@ __device__ __forceinline__ void top_refill_body(const Node2* __restrict__ nodes,
     int* counter = tickets + stripe * kCounterStride;
     const auto ray_of = [&](int t) { return ((t / kGroupRays) * kStripes + stripe) * kGroupRays + t % kGroupRays; };
     lds_int* const sp_limit = col + LDS_N * kWave;
+    int* const spill_wave = spill + (size_t)(blockIdx.x * WAVES + wave) * kSpillWaveInts;
     const Bases base = make_bases(nodes, tris);
     Lane L;
     {
@@ -406,7 +408,7 @@ __device__ __forceinline__ void top_refill_body(const Node2* __restrict__ nodes,
             continue;
         }
         if (live == 0) break;
-        if (L.top != 0) bvh2_step<ANY, false, true, false, FENCE>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+        if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill_wave);
     }
 }
 
@@ -414,15 +416,15 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = fal
 __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                     const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                                     Ctl* ctl, int* __restrict__ deep_list, const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id,
-                                                                    int* host_kinds, int launch_id) {
-    top_refill_body<ANY, LDS_N, TOPN, WAVES, REFILL, ADAPT, FENCE>(nodes, tris, rays, hits, n, ctl, deep_list, top_image, tickets, max_id, host_kinds, launch_id);
+                                                                    int* spill, int* host_kinds, int launch_id) {
+    top_refill_body<ANY, LDS_N, TOPN, WAVES, REFILL, ADAPT, FENCE>(nodes, tris, rays, hits, n, ctl, deep_list, top_image, tickets, max_id, spill, host_kinds, launch_id);
 }
 #ifdef RODENT_HIP_LAB      // the same with the register budget pinned like the default kernel's
 template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL>
 __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_refill_wpe(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                     const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                                    Ctl* ctl, int* __restrict__ deep_list, const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id) {
-    top_refill_body<ANY, LDS_N, TOPN, WAVES, REFILL, false, false>(nodes, tris, rays, hits, n, ctl, deep_list, top_image, tickets, max_id);
+                                                                    Ctl* ctl, int* __restrict__ deep_list, const int4* __restrict__ top_image, int* __restrict__ tickets, int max_id, int* spill) {
+    top_refill_body<ANY, LDS_N, TOPN, WAVES, REFILL, false, false>(nodes, tris, rays, hits, n, ctl, deep_list, top_image, tickets, max_id, spill);
 }
 #endif
 
@@ -440,7 +442,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0 /* 
 __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_auto(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                   const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                                   Ctl* ctl, int* __restrict__ deep_list, int4* __restrict__ top_image, int* __restrict__ tickets, int max_id,
-                                                                  int* host_kinds, int launch_id) {
+                                                                  int* spill, int* host_kinds, int launch_id) {
     constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroupRays = 32 * kWave;
     static_assert((kStackInts + TOPN * 16) * 4 * (32 / WAVES) <= 160 * 1024, "32 waves per CU must fit their stacks and images in LDS");
     __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
@@ -453,6 +455,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     int* counter = tickets + stripe * kCounterStride;
     const auto ray_of = [&](int t) { return ((t / kGroupRays) * kStripes + stripe) * kGroupRays + t % kGroupRays; };
     lds_int* const sp_limit = col + LDS_N * kWave;
+    int* const spill_wave = spill + (size_t)(blockIdx.x * WAVES + wave) * kSpillWaveInts;       // this wave's block of the out-of-window stack (stack_spill)
     const Bases base = make_bases(nodes, tris);
     int t = ((blockIdx.x / kStripes) * WAVES + wave) * kWave;               // the wave's first 64 tickets are its rank in the stripe; the counter hands out those behind
     bool coherent = MODE != 2;
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
             Lane L = start_lane(rays, hits, r < n ? r : -1, first_ray, col);
             if (L.top != 0) L.top = root;
             while (__ballot(L.top != 0)) {
-                if (L.top != 0) bvh2_step<ANY, false, true, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+                if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill_wave);
             }
             int t_next = 0;
             if (lane == 0) t_next = atomicAdd(counter, kWave);
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
                 continue;
             }
             if (live == 0) break;
-            if (L.top != 0) bvh2_step<ANY, false, true, false, true>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image);
+            if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill_wave);
         }
     }
     // the workgroup that finishes last does the follow-up work (k_bvh2_top_persist, FUSED == 2)

@@ -79,6 +79,29 @@ def chain_bvh2(depth, z0=200.0):
     return nodes, tris
 
 
+def pad_bvh2_depth(nodes, levels):
+    """The same hierarchy under `levels` extra nodes above its root, each of which leaves ONE entry on the stack of every ray
+    that enters the scene box: wrapper i = {child0: a dummy inner node with two empty slots, child1: the next wrapper (the last
+    one: the old root)}, both with the scene box, so the two entry distances are equal, the strict `<` of mapping_gpu.impala:128
+    sends the ray into child1 and child0 is pushed.  A ray's deepest stack grows by `levels` entries, its hit does not change;
+    it pays 2 x levels extra node steps (the wrappers, and the dummies popped at the very end)."""
+    from rodent_amd import formats as F
+    b = nodes[0]["bounds"]
+    box = [min(b[0], b[6]), max(b[1], b[7]), min(b[2], b[8]), max(b[3], b[9]), min(b[4], b[10]), max(b[5], b[11])]
+    shift = levels + 1
+    out = np.zeros(len(nodes) + shift, F.NODE2)
+    out[shift:] = nodes
+    child = out["child"][shift:]
+    child[child > 0] += shift                                           # inner ids are 1-based indices; leaves (~first triangle) stay
+    inf = np.float32(np.inf)
+    for i in range(levels):
+        out[i]["bounds"] = box + box
+        out[i]["child"] = [levels + 1, i + 2 if i + 1 < levels else levels + 2]      # dummy (index `levels`), next wrapper / old root (index levels + 1)
+    out[levels]["bounds"] = [inf, -inf] * 6
+    out[levels]["child"] = [0, 0]
+    return out
+
+
 def write_textured_scene(d):
     """A small textured room for the texture tests: floor with a PNG checker map_Kd, back wall with a JPEG map_Kd AND a
     TGA map_Ks (diffuse/Phong mix whose weight varies per texel), a plain red side wall and a ceiling light.  Texture

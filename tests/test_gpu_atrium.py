@@ -105,6 +105,53 @@ def test_default_mapping_is_not_slower_than_the_one_chunk_kernel_where_it_is_sel
         gpu.lib().rodent_hip_top_min_rays(-1)
 
 
+def test_deep_stacks_cost_no_cliff(gpu, oracle, dumps):
+    """VERDICT r4 item 1(d).  The reference's stack costs the same at depth 5 and at depth 50 (stack.impala:52-123).  Here a lane's
+    stack is a 15-row LDS window; what does not fit moves to the wave's block of global memory and the ray stays in its lane
+    (stack_spill, traversal_device.h) -- until round 4 such a ray was abandoned and traced again by ONE wave after the launch
+    (14 000 rays = 219 serial batches of ~100 us against a 0.19 ms launch).  The atrium under 7 extra levels (conftest.pad_bvh2_depth:
+    every ray's deepest stack + 7, so the 1.3 % of the camera rays that need 8 entries now need 15) must trace bit for bit like
+    the oracle and within 1.5 x the time of the unpadded hierarchy -- which includes the 14 extra node steps per ray the padding
+    itself costs; the random segments likewise."""
+    import torch
+    from conftest import pad_bvh2_depth
+    path, rays = dumps
+    nodes, tris = F.read_bvh(path, F.BVH2_TRI1)
+    deep_nodes = pad_bvh2_depth(nodes, 7)
+    plain, deep = gpu.DeviceBvh(2, nodes, tris, 0), gpu.DeviceBvh(2, deep_nodes, tris, 0)
+    st = torch.cuda.current_stream()
+
+    def timed(bvh, rd, hd, n):
+        for _ in range(4):
+            gpu.traverse_async(bvh, rd, hd, n, False, 0, st)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(25)]
+        for s, e in ev:
+            s.record(st); gpu.traverse_async(bvh, rd, hd, n, False, 0, st); e.record(st)
+        torch.cuda.synchronize()
+        return float(np.median([s.elapsed_time(e) for s, e in ev]))
+
+    for kind, r in rays.items():
+        n = len(r)
+        depth = oracle.ray_depths(deep_nodes, tris, r)
+        share = float((depth >= 15).mean())
+        assert share >= (0.01 if kind == "primary" else 0.005), (kind, share)          # profiles/r02_stack_depth.txt: 1.34 % / 0.72 % need 8 entries unpadded
+        ref, _ = oracle.traverse(2, deep_nodes, tris, r)
+        ref_plain, _ = oracle.traverse(2, nodes, tris, r)
+        assert ref.tobytes() == ref_plain.tobytes()                                    # the padding changes no hit
+        for v in gpu.order_preserving_variants(2):
+            assert gpu.traverse(deep, r, variant=v).tobytes() == ref.tobytes(), (kind, gpu.variants(2)[v])
+        gpu.read_stats()
+        rd = gpu.to_device(r, 0); hd = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
+        gpu.traverse_async(deep, rd, hd, n, False, 0, st); torch.cuda.synchronize()
+        spilled = gpu.read_stats()[7]
+        assert spilled >= int(share * n), (kind, spilled, share)                      # blocks moved out: at least one per ray deeper than the window
+        t_plain, t_deep = timed(plain, rd, hd, n), timed(deep, rd, hd, n)
+        print(f"deep stacks, {kind}: {share:.2%} of the rays beyond the window, {spilled} blocks spilled, {t_deep:.4f} ms against {t_plain:.4f} ms unpadded")
+        assert t_deep <= 1.5 * t_plain, (kind, t_deep, t_plain)
+    gpu.check_errors(0)
+
+
 @pytest.fixture(scope="module")
 def atrium_scene(native_build, tmp_path_factory):
     from rodent_amd import scenes

@@ -179,7 +179,8 @@ def test_special_tmin_tmax_values(gpu, oracle, cornell, cornell_dev):
 
 
 def test_deep_stack_falls_back_to_global_stack(gpu, oracle):
-    """Stacks deeper than the LDS window (16 entries) take the deep-ray epilogue / scratch spill;
+    """Stacks deeper than the LDS window (15 / 16 entries) move their oldest entries to the wave's block of global memory
+    (stack_spill; the wide kernels and the launches without a spill block: deep-ray list + follow-up kernel);
     results must not change.  Mix deep and shallow rays in one wave and across waves."""
     from conftest import chain_bvh2
     nodes, tris = chain_bvh2(40)
@@ -197,15 +198,45 @@ def test_deep_stack_falls_back_to_global_stack(gpu, oracle):
             assert got.tobytes() == ref.tobytes(), f"variant {v} any={any_hit}"
         # and again: the launch counters must have been reset by the epilogue
         assert gpu.traverse(bvh, rays, any_hit=any_hit, variant=0).tobytes() == ref.tobytes()
-    # the follow-up kernel is for the deep rays only: it traces one wave at a time, so a kernel that hands over rays it
-    # could finish itself stays correct and gets 1000x slower (stats word 7 = rays handed over, summed by k_bvh2_finish)
+    # stats word 7 = blocks of stack entries moved out (+ rays handed to a follow-up kernel): only rays that enter the 40-deep chain
+    # spill, four times each (at 15, 22, 29 and 36 entries); a launch on a shallow tree touches nothing
     gpu.read_stats()
     gpu.traverse(bvh, rays, variant=0)
     deep = gpu.read_stats()[7]
-    assert 0 < deep <= int((ref["tri_id"] >= 0).sum())           # only rays that enter the 40-deep chain
+    assert 0 < deep <= 4 * int((ref["tri_id"] >= 0).sum())
     cb = gpu.DeviceBvh.load(cornell_bvh_path(), 2, 0)
     gpu.traverse(cb, F.read_rays(GOLDEN_DIR / "cornell-primary-64x64.rays", 0.0, 100.0), variant=0)
     assert gpu.read_stats()[7] == 0
+
+
+@pytest.mark.parametrize("depth", [16, 23, 40, 63])
+def test_deep_stacks_in_the_persistent_kernels(gpu, oracle, depth):
+    """The same through the persistent kernels (rodent_hip_top_min_rays(0): the default mapping's k_bvh2_top_auto / k_bvh2_top_refill, "refill", and the
+    wide kernels' persistent form), at depths around every block boundary of the spill (15 + 7 k entries) up to the reference's capacity of 63
+    entries (stack.impala:53: 64 slots, one of them the sentinel), 30 000 rays of which a third miss, coherent and shuffled (the refill loop), twice
+    (the second launch runs on the image the first one built), closest and any hit."""
+    from conftest import chain_bvh2
+    nodes, tris = chain_bvh2(depth)
+    rng = np.random.default_rng(depth)
+    n = 30000
+    org = np.zeros((n, 3), "<f4"); org[:, :2] = rng.uniform(-4, 4, (n, 2)); org[::3, 0] += 50.0
+    d = np.tile(np.float32([0.001, 0.002, 1.0]), (n, 1)); d[:, :2] += rng.uniform(-1e-4, 1e-4, (n, 2)).astype("<f4")      # no common direction: the refill loop
+    rays = F.make_rays(org, d, 0.0, 1000.0)
+    bvh = gpu.DeviceBvh(2, nodes, tris, 0)
+    gpu.lib().rodent_hip_top_min_rays(0)
+    try:
+        for any_hit in (False, True):
+            ref, st = oracle.traverse(2, nodes, tris, rays, any_hit=any_hit)
+            if not any_hit:
+                assert st["max_stack"] == depth
+            for v in variants(gpu, 2):
+                for rep in range(2):
+                    assert gpu.traverse(bvh, rays, any_hit=any_hit, variant=v).tobytes() == ref.tobytes(), (gpu.variants(2)[v], any_hit, rep)
+        gpu.read_stats()
+        gpu.traverse(bvh, rays, variant=0)
+        assert gpu.read_stats()[7] > 0
+    finally:
+        gpu.lib().rodent_hip_top_min_rays(-1)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])

@@ -202,3 +202,18 @@ def test_config0_cpu_bench_traversal_plumbing(oracle, cornell, tmp_path):
     hy = subprocess.run([c for c in cmd if c != "-s"], capture_output=True, text=True, check=True)
     assert "4096 intersection(s)" in hy.stdout
     assert np.allclose(F.read_fbuf(out), cornell.expected["bvh8_cpu.primary_tmin.closest"]["t"], rtol=1e-4)
+
+
+def test_depth_padding_changes_the_stack_not_the_hits(oracle, cornell):
+    """conftest.pad_bvh2_depth (the deep-stack fixtures of the GPU tests): `levels` extra nodes above the root leave one entry each on
+    the stack of every ray that enters the scene box -- the deepest stack grows by exactly `levels`, no hit record changes."""
+    from conftest import pad_bvh2_depth
+    nodes, tris = cornell.blocks[2]
+    for rayset in ("primary", "random"):
+        rays = cornell.ray_sets[rayset]
+        ref, st = oracle.traverse(2, nodes, tris, rays)
+        for levels in (1, 7, 30):
+            hits, st_p = oracle.traverse(2, pad_bvh2_depth(nodes, levels), tris, rays)
+            assert hits.tobytes() == ref.tobytes()
+            assert st_p["max_stack"] == st["max_stack"] + levels
+            assert st_p["prims_per_ray"] == st["prims_per_ray"]
