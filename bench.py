@@ -192,8 +192,11 @@ def pick_bound(binding):
 # timing
 # ------------------------------------------------------------------------------------------------
 def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, dist, any_hit=False):
-    """W untimed + K timed launches.  Returns (wall seconds for K steps [max over ranks is taken by
-    the caller], mean / median / min kernel ms from HIP events recorded on the launch stream)."""
+    """W untimed + K timed launches, back to back on one stream.  Returns (wall seconds for the K steps [max over ranks is taken by the caller],
+    average launch duration in ms from ONE pair of HIP events around the timed region on the launch stream, ... and, from a second, untimed pass with an
+    event pair around every single launch, the median and minimum of those).  Until round 4 the timed region itself carried an event pair per step:
+    two marker packets between every two kernels cost 17 us per 0.18 ms step (profiles/r05_host_call_costs.txt: 174.9 us per launch back to back
+    against 192.3 with them) -- time the benchmark spent measuring itself."""
     stream = torch.cuda.current_stream()
     for _ in range(warmup):
         abi.traverse_async(bvh, rays_dev, hits_dev, n, any_hit, variant, stream)
@@ -201,20 +204,28 @@ def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, 
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    first, last = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    first.record(stream)
     for i in range(steps):
-        starts[i].record(stream)
         abi.traverse_async(bvh, rays_dev, hits_dev, n, any_hit, variant, stream)
-        ends[i].record(stream)
+    last.record(stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
-    return wall, float(np.mean(kernel_ms)), float(np.median(kernel_ms)), float(np.min(kernel_ms))
+    region_ms = first.elapsed_time(last) / max(1, steps)
+    # per-launch spread (not part of the timed region): every launch between its own two events, which adds the dispatch latency the back-to-back region hides
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    for i in range(steps):
+        starts[i].record(stream)
+        abi.traverse_async(bvh, rays_dev, hits_dev, n, any_hit, variant, stream)
+        ends[i].record(stream)
+    torch.cuda.synchronize()
+    single = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    return wall, float(region_ms), float(np.median(single)), float(np.min(single))
 
 
 def _collective_device(dist, dev):
@@ -541,15 +552,16 @@ def main():
         refill_rec = {"Mrays_s": round(len(rnd) * steps_r / wall_f / 1e6, 3), "ms_per_step": round(1e3 * wall_f / steps_r, 5), "kernels_ms": round(kf_mean, 5),
                       "variant": "refill: the default's persistent workgroups; a wave whose idle lanes reach 32 draws that many new rays from its stripe's counter",
                       "identical_to_default": bool(torch.equal(hits_refill_dev, hits_rnd_dev))}
-    # the default WITHOUT the ray-kind hint (rodent_hip_ray_kind_hint(0)): what a first launch on a new ray list gets -- the in-kernel choice alone
-    nohint_rec = None
+    # the default WITH the ray-kind hint (rodent_hip_ray_kind_hint(1); off by default from round 5 on): state carried from launch to launch, therefore not the headline
+    hint_rec = None
     if world == 1 and width == 2 and abi.variants(2)[variant] == "top" and args.only != "primary":
-        abi.ray_kind_hint(False)
-        hits_nohint_dev = torch.zeros_like(hits_rnd_dev)
-        wall_n, kn_mean, _, _ = time_passes(abi, torch, bvh, rnd_dev, hits_nohint_dev, len(rnd), variant, steps_r, warm_r, None)
         abi.ray_kind_hint(True)
-        nohint_rec = {"Mrays_s": round(len(rnd) * steps_r / wall_n / 1e6, 3), "kernels_ms": round(kn_mean, 5), "identical_to_default": bool(torch.equal(hits_nohint_dev, hits_rnd_dev)),
-                      "what": "k_bvh2_top_auto alone: every wave finds its rays incoherent and runs the refill loop; with the hint (the default, random_Mrays_s) the same list goes to k_bvh2_top_refill from its second launch on"}
+        hits_hint_dev = torch.zeros_like(hits_rnd_dev)
+        wall_n, kn_mean, _, _ = time_passes(abi, torch, bvh, rnd_dev, hits_hint_dev, len(rnd), variant, steps_r, warm_r, None)
+        abi.ray_kind_hint(False)
+        hint_rec = {"Mrays_s": round(len(rnd) * steps_r / wall_n / 1e6, 3), "kernels_ms": round(kn_mean, 5), "identical_to_default": bool(torch.equal(hits_hint_dev, hits_rnd_dev)),
+                    "what": "rodent_hip_ray_kind_hint(1): the list goes to k_bvh2_top_refill from its second launch on; the default (random_Mrays_s) is k_bvh2_top_auto alone, whose waves "
+                            "find their rays incoherent and run the refill loop -- no state between launches"}
     abi.check_errors(dev)                                         # the asynchronous entry points report stack overflows through a flag
     # for information only (never `value`): independent batches in flight on two streams -- the fill of one launch
     # overlaps the drain of the other (every (device, stream) has its own launch state)
@@ -622,8 +634,9 @@ def main():
                    "variant": abi.variants(width)[variant], "parallelism": f"replicated BVH x {world}" + (f", {sharding}" if world > 1 else ""),
                    "world_size": world, "collective_backend": (None if dist is None else ("nccl (RCCL)" if dist.get_backend() == "nccl" else dist.get_backend() + " (test mode)"))},
         "extra": {"random_Mrays_s": round(main_part["value_rnd"], 3), "random_ms_per_step": round(1e3 * main_part["wall_r"] / steps_r, 5),
-                  "primary_kernel_ms": {"mean": round(k_mean, 5), "median": round(k_med, 5), "min": round(k_min, 5)},
-                  "random_kernel_ms": {"mean": round(kr_mean, 5), "median": round(kr_med, 5), "min": round(kr_min, 5)},
+                  # mean: HIP events around the whole timed region / steps; single_*: each launch between its own event pair in a second pass (adds the dispatch latency)
+                  "primary_kernel_ms": {"mean": round(k_mean, 5), "single_launch_median": round(k_med, 5), "single_launch_min": round(k_min, 5)},
+                  "random_kernel_ms": {"mean": round(kr_mean, 5), "single_launch_median": round(kr_med, 5), "single_launch_min": round(kr_min, 5)},
                   "kernel_ms_per_rank[primary,random]": main_part["kernel_ms_per_rank"],
                   "hit_counts[primary,random]": [int((hits["tri_id"] >= 0).sum()), int((hits_rnd["tri_id"] >= 0).sum())],
                   "library": {"version": abi.lib().rodent_hip_version().decode(), "source_digest": abi.lib().rodent_hip_source_digest().decode(),
@@ -641,8 +654,8 @@ def main():
         out["extra"]["random_sorted"] = sorted_rec
     if refill_rec:
         out["extra"]["random_refill"] = refill_rec
-    if nohint_rec:
-        out["extra"]["random_without_kind_hint"] = nohint_rec
+    if hint_rec:
+        out["extra"]["random_with_kind_hint"] = hint_rec
     if render is not None:
         out["extra"]["render"] = render
     # what the driver's record keeps is `config`, `roofline` and `cpu_baseline`: the other headline figures as short scalars
@@ -675,8 +688,7 @@ def main():
         achieved = bytes_per_ray * n / (k_mean * 1e-3) / 1e9
         traffic, traffic_why = measured_traffic(kname)
         binding = binding_bounds(kname, "primary", n, st["inner_per_ray"] + st["prims_per_ray"], k_mean, lds_p)
-        # the random set through the default mapping is traced by k_bvh2_top_refill from its second launch on (ray-kind hint): that kernel's counters
-        kname_r = abi.kernel_name(width, abi.variants(width).index("refill")) if width == 2 and abi.variants(2)[variant] == "top" and n >= 9216 * 64 else kname
+        kname_r = kname                               # (the ray-kind hint is off by default: both sets run through the same kernel)
         binding_r = binding_bounds(kname_r, "random", len(rnd), st_r["inner_per_ray"] + st_r["prims_per_ray"], kr_mean, lds_r)
         top = pick_bound(binding)
         roof = {"bound": top[0], "achieved": top[1]["achieved"], "peak": top[1]["peak"], "unit": top[1]["unit"], "frac": top[1]["frac"]} if top else \

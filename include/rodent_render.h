@@ -193,8 +193,8 @@ void    rodent_hip_render_rows(int32_t dev, const struct Settings* settings, int
  * the reference deals ~1024-sample tiles dynamically, render/mapping_gpu.impala:374-420).  Same samples, same film as
  * rodent_hip_render_rows over the same rows; synchronous like it. */
 void    rodent_hip_render_tiles(int32_t dev, const struct Settings* settings, int32_t iter, int32_t tile_rows, int32_t first_tile, int32_t tile_stride, void* stream);
-/* Counters of the last render call on this device: [0] primary rays traced, [1] shadow rays traced,
- * [2] wavefront iterations, [3] rays generated. */
+/* Counters of the last render call on this device (render, rodent_hip_render_rows, rodent_hip_render_tiles -- the whole call, however
+ * many launches it took): [0] primary rays traced, [1] shadow rays traced, [2] wavefront iterations, [3] rays generated. */
 void    rodent_hip_render_counters(int32_t dev, uint64_t* out4);
 
 /* The wavefront stages as separate entry points (the reference's device kernels,

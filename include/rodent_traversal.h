@@ -154,11 +154,12 @@ void        rodent_hip_top_min_rays(int32_t rays);
  * atrium: 0.187 -> 0.150 ms).  It changes only the order in which chunks are traced, never a hit record; a launch without a
  * usable history takes the default order.  State is per (device, stream); launches of more than 4 Mi rays do not use it (they are throughput-bound: measured -8 % at 16 Mi). */
 void        rodent_hip_schedule_history(int32_t enable);
-/* Ray-kind hint of the default BVH2 mapping (on by default; RODENT_HIP_KIND_HINT=0).  The default kernel decides per wavefront whether
- * the rays it drew share an origin or a direction (traced as whole 64-ray chunks) or not (idle lanes are refilled: the compaction of
- * BASELINE config 3; reference: render/mapping_gpu.impala:267-300 compacts unconditionally).  With the hint on, the kernels also note
- * what they saw in a host-visible word, and a list -- same pointer, same count -- that every workgroup of the earlier launches found
- * incoherent is traced by the kernel specialised for that ("refill") from its second launch on.  Hit records never depend on it. */
+/* Ray-kind hint of the default BVH2 mapping (OFF by default from round 5 on; RODENT_HIP_KIND_HINT=1).  The default kernel decides per wavefront,
+ * once, from the first 64 rays the wave draws, whether they share an origin or a direction (traced as whole 64-ray chunks) or not (idle lanes are
+ * refilled: the compaction of BASELINE config 3; reference: render/mapping_gpu.impala:267-300 compacts unconditionally) -- no state between launches.
+ * With the hint on, every workgroup also notes what it saw in a host-visible word, and a list -- same pointer, same count -- that all workgroups
+ * of the earlier launches found incoherent is traced by the kernel specialised for that ("refill") from its second launch on (+2 ... 4 % on random
+ * segments): kernel selection then depends on earlier launches and, for asynchronous callers, on when they finished.  Hit records never depend on it. */
 void        rodent_hip_ray_kind_hint(int32_t enable);
 int32_t     rodent_hip_is_lab_build(void);              /* 1 = librodent_hip_lab.so (-DRODENT_HIP_LAB: also the measured-and-lost kernels) */
 const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant);

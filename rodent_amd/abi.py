@@ -177,7 +177,7 @@ def top_min_rays(rays: int):
 
 def ray_kind_hint(enable: bool):
     """rodent_hip_ray_kind_hint: may the default BVH2 mapping remember that a ray list (pointer, count) was incoherent and trace it with
-    the refill kernel from its second launch on (default: yes; hit records do not depend on it)."""
+    the refill kernel from its second launch on (default: no -- kernel selection is stateless; hit records do not depend on it)."""
     lib().rodent_hip_ray_kind_hint(int(bool(enable)))
 
 

@@ -81,7 +81,8 @@ def source_digest() -> str:
     for f in sorted(_hip_lib_inputs() + _headers(), key=lambda p: str(p.relative_to(ROOT))):
         h.update(str(f.relative_to(ROOT)).encode())
         h.update(f.read_bytes())
-    h.update(repr((HIP_FLAGS[:5], sorted(HIP_SOURCE_FLAGS.items()))).encode())          # ... and the options that change the code
+    # ... and every option that can change the code (everything but the include path, which differs between checkouts of the same sources)
+    h.update(repr(([f for f in HIP_FLAGS if not f.startswith("-I")], sorted(HIP_SOURCE_FLAGS.items()))).encode())
     return h.hexdigest()[:16]
 
 
@@ -110,7 +111,7 @@ def build_hip_lib(force: bool = False) -> Path:
         for proc, cmd in procs:
             if proc.wait() != 0:
                 raise subprocess.CalledProcessError(proc.returncode, [str(c) for c in cmd])
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-o", lib])
+        _run([HIPCC, HIP_FLAGS[0], "-shared", "-fPIC", *objs, "-lz", "-o", lib])
         lib.with_suffix(".so.digest").write_text(want + "\n")
     if stale(out):
         compile_to(out)

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(PrimaryStream p, int first_
 // (branch-free node step).  Stack: 16-entry window in LDS; deeper rays go to k_trace_deep (stream kernels) / scratch (megakernel).
 // ---------------------------------------------------------------------------------------------
 constexpr int kLdsStack = 16;
+constexpr int kPersistWaves = 16;               // waves per workgroup of the persistent traversal kernels (k_trace_persist, k_trace_refill)
 constexpr int kSpillEntries = kStackCap - kLdsStack;
 // Stack of the megakernel (one workgroup per film tile): 16-entry window in LDS, deeper entries in scratch.
 template <bool UNUSED>
@@ -132,9 +133,9 @@ using StreamStack = StreamStackT<false>;
 // ray goes on in its lane (SPILLW = the window's rows; stack_spill / stack_reload, traversal_device.h).
 struct CursorStack {
     lds_int* sp; lds_int* limit; bool overflow;
-    int* spill_wave; int* err;
-    __device__ __forceinline__ void init(lds_int* col, int window = kLdsStack, int* spill_wave_ = nullptr, int* err_ = nullptr) {
-        sp = col; limit = col + window * kWave; overflow = false; col[0] = 0; spill_wave = spill_wave_; err = err_;
+    int* spill; int* err;                          // the launch's spill buffer (wave-uniform) and error flag
+    __device__ __forceinline__ void init(lds_int* col, int window = kLdsStack, int* spill_ = nullptr, int* err_ = nullptr) {
+        sp = col; limit = col + window * kWave; overflow = false; col[0] = 0; spill = spill_; err = err_;
     }
 };
 // 64 entries ([entry][lane]), the reference's capacity (stack.impala:53), in 16 KB of LDS; used by k_trace_deep only.  (In global
@@ -237,8 +238,8 @@ __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const
                 if constexpr (kCursor) {
                     st.sp[kWave] = c0first ? ch.y : ch.x;
                     st.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
-                    if (both && st.sp >= st.limit) {                                  // (`both`: popping the sentinel moves sp below its column)
-                        if constexpr (SPILLW > 0) stack_spill<SPILLW>(st.sp, top, st.limit - SPILLW * kWave, st.spill_wave, st.err);
+                    if (__builtin_expect(both && st.sp >= st.limit, 0)) {            // (`both`: popping the sentinel moves sp below its column)
+                        if constexpr (SPILLW > 0) stack_spill<SPILLW>(st.sp, top, st.limit, st.spill, kPersistWaves, st.err);
                         else { st.overflow = true; top = 0; }
                     }
                 } else {
@@ -259,7 +260,7 @@ __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const
                 if constexpr (kCursor) st.sp -= (leave && !(ANY && found)) ? kWave : 0;
                 else ptr -= (leave && !(ANY && found)) ? 1 : 0;
             }
-            if constexpr (kCursor && SPILLW > 0) if (top >= kSpillMark) stack_reload(st.sp, top, st.limit - SPILLW * kWave, st.spill_wave);      // popped row 0 while entries are out
+            if constexpr (kCursor && SPILLW > 0) if (__builtin_expect(top >= kSpillMark, 0)) stack_reload<SPILLW>(st.sp, top, st.limit, st.spill, kPersistWaves);      // popped row 0 while entries are out
         }
     }
     return any_found;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(kWave * WAVES) void k_trace_secondary(SceneDev sc, 
 // generation of 16-wave workgroups, each stages the scene's 255-record image once and its waves draw 64-ray chunks from 64
 // striped ticket counters (ticket t of stripe s = chunk ((t / 32) * 64 + s) * 32 + t % 32; a wave's first ticket is its rank in
 // the stripe).  The stream size may live on the device: the grid does not depend on it.  k_trace_deep zeroes the counters.
-constexpr int kPersistWaves = 16, kPersistTopNodes = 255, kTraceStripes = 64, kTraceCounterStride = 16;
+constexpr int kPersistTopNodes = 255, kTraceStripes = 64, kTraceCounterStride = 16;
 // MODE 0: the closest-hit pass over `p`; 1: the shadow pass over `s`; 2 ("joint", rodent_hip_render_trace_persistent(dev, 2)): BOTH in
 // one launch -- the closest-hit pass of an iteration and the shadow pass of the iteration before it depend on the same shader
 // run and on nothing else, so their chunks go through one ticket sequence (the closest-hit chunks first): one resident
@@ -480,7 +481,6 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStrea
     int* counter = tickets + stripe * kTraceCounterStride;
     int t = (blockIdx.x / kTraceStripes) * kPersistWaves + wave;
     lds_int* col = (lds_int*)lds + wave * (kTopStack + 1) * kWave + lane;
-    int* const spill_wave = spill + (size_t)(blockIdx.x * kPersistWaves + wave) * kSpillWaveInts;     // this wave's block of the out-of-window stack
     __syncthreads();
     if (MODE != 1 && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)np);
     for (;;) {
@@ -489,7 +489,7 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStrea
         if (chunk < chunks_p) {
             const int i = chunk * kWave + lane;
             if (i < np) {
-                CursorStack st; st.init(col, kTopStack, spill_wave, err);
+                CursorStack st; st.init(col, kTopStack, spill, err);
                 trace_primary_ray<true, kTopStack>(sc, p, i, &st, nullptr, image);
             }
         } else if (chunk < total_chunks) {
@@ -499,7 +499,7 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStrea
             if (lane == 0 && live) atomicAdd(&counters[4 + (c & 63)], (unsigned long long)__popcll(live));
             bool lit = false;
             if (pixel >= 0) {
-                CursorStack st; st.init(col, kTopStack, spill_wave, err);
+                CursorStack st; st.init(col, kTopStack, spill, err);
                 lit = !trace_one<true, true, kTopStack>(sc.nodes, sc.tris, load_stream_ray(s.rays, i), st, [](int, int, float, float, float) {}, image);
             }
             film_add_wave(film, pixel, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
@@ -544,7 +544,6 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
     const auto index_of = [&](int t) { return ((t / kGroupRays) * kTraceStripes + stripe) * kGroupRays + t % kGroupRays; };
     lds_int* const wave_stack = (lds_int*)lds + wave * (kTopStack + 1) * kWave;        // wave-uniform; lane l's column starts at wave_stack + l
     lds_int* const wave_limit = wave_stack + kTopStack * kWave;                        // sp >= wave_limit  <=>  the lane's cursor is at entry kTopStack (l < kWave)
-    int* const spill_wave = spill + (size_t)(blockIdx.x * kPersistWaves + wave) * kSpillWaveInts;     // this wave's block of the out-of-window stack
     __syncthreads();
     if (np && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)np);
     typedef const __attribute__((address_space(1))) char* gptr;
@@ -639,7 +638,7 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
                 L.top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
                 L.sp[kWave] = c0first ? ch.y : ch.x;
                 L.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
-                if (both && L.sp >= wave_limit) stack_spill<kTopStack>(L.sp, L.top, wave_stack + lane, spill_wave, err);      // deeper than the window: the oldest entries move out
+                if (__builtin_expect(both && L.sp >= wave_limit, 0)) stack_spill<kTopStack>(L.sp, L.top, wave_limit + lane, spill, kPersistWaves, err);      // deeper than the window: the oldest entries move out
             } else {
                 const int prim_id = __float_as_int(q2.w);
                 const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
@@ -658,7 +657,7 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
                 L.top = ends ? 0 : (leave ? popped : top - 1);
                 L.sp -= (leave && !ends) ? kWave : 0;
             }
-            if (L.top >= kSpillMark) stack_reload(L.sp, L.top, wave_stack + lane, spill_wave);       // popped row 0 while entries are out: they come back
+            if (__builtin_expect(L.top >= kSpillMark, 0)) stack_reload<kTopStack>(L.sp, L.top, wave_limit + lane, spill, kPersistWaves);       // popped row 0 while entries are out: they come back
         }
     }
 }
@@ -1246,6 +1245,8 @@ struct RenderDevice {
     int* hist = nullptr; size_t hist_cap = 0;
     int* ctl = nullptr;       // [0] primary size, [1] secondary size, [2] error flag, [8..] bin_total, bin_begin, bin_end (kMaxBins each)
     unsigned long long* counters = nullptr;    // [0] primary rays, [1] unused, [2] iterations, [3] generated, [4..67] shadow rays (striped)
+    bool counters_continue = false;            // rodent_hip_render_tiles: its sub-calls after the first ADD to the counters instead of starting them again
+    unsigned long long call_iterations = 0, call_generated = 0;
     int* host_pinned = nullptr;
 };
 RenderDevice g_rdev[16];
@@ -1503,7 +1504,7 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     const int first_pixel = y0 * r.film_w;
     long long id = 0; int size = 0;
     HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 8, stream));
-    HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * kNumCounters, stream));
+    if (!r.counters_continue) { HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * kNumCounters, stream)); r.call_iterations = r.call_generated = 0; }
     unsigned long long iterations = 0, generated = 0;
     const int* d_valid = bin_end(r, 0) + (G - 1);      // rays that hit something = exclusive end of the last geometry bin (:347-357)
     // Shadow rays are independent of what follows the shader on the primary stream (compaction, regeneration, the next
@@ -1606,7 +1607,8 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     }
     if (shadow_pending) launch_trace_secondary(r, stream, sec, shadow_size_ptr, shadow_n, inv_spp);       // joint: the last iteration's shadow rays
     if (overlap && iterations) HIP_CHECK(hipStreamWaitEvent(stream, r.ev_sec, 0));           // the last shadow rays belong to this call
-    const unsigned long long host_counts[2] = {iterations, generated};
+    r.call_iterations += iterations; r.call_generated += generated;
+    const unsigned long long host_counts[2] = {r.call_iterations, r.call_generated};
     HIP_CHECK(hipMemcpyAsync(r.counters + 2, host_counts, sizeof(host_counts), hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(r.host_pinned + 2, err, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -1624,7 +1626,7 @@ void render_rows_mega(RenderDevice& r, const Settings* settings, int iter, int y
     const dim3 grid((r.film_w + tile - 1) >> log2_tile, (y1 - y0 + tile - 1) >> log2_tile);
     int* err = r.ctl + 2;
     HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 3, stream));
-    HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * kNumCounters, stream));
+    if (!r.counters_continue) { HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * kNumCounters, stream)); r.call_iterations = r.call_generated = 0; }
     if (y1 > y0) {
         if (r.mega_joint) hipLaunchKernelGGL(k_mega_joint, grid, dim3(kWave), 0, stream, r.scene.dev, to_cam(settings), r.film, r.film_w, r.film_h, y0, y1, iter, r.spp,
                                              r.max_path_len, log2_tile, 1.0f / (float)r.spp, err, r.counters);
@@ -1632,7 +1634,8 @@ void render_rows_mega(RenderDevice& r, const Settings* settings, int iter, int y
                                 r.max_path_len, log2_tile, 1.0f / (float)r.spp, err, r.counters);
     }
     HIP_CHECK(hipGetLastError());
-    const unsigned long long host_counts[2] = {1ull, (unsigned long long)r.spp * r.film_w * (unsigned long long)(y1 - y0)};
+    r.call_iterations += 1ull; r.call_generated += (unsigned long long)r.spp * r.film_w * (unsigned long long)(y1 - y0);
+    const unsigned long long host_counts[2] = {r.call_iterations, r.call_generated};
     HIP_CHECK(hipMemcpyAsync(r.counters + 2, host_counts, sizeof(host_counts), hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(r.host_pinned + 2, err, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -1877,13 +1880,17 @@ void rodent_hip_render_tiles(int32_t dev, const Settings* settings, int32_t iter
     const int full_tiles = r.film_h / tile_rows, ragged_rows = r.film_h % tile_rows;
     const int mine = first_tile < full_tiles ? (full_tiles - first_tile + tile_stride - 1) / tile_stride : 0;          // complete tiles of this call
     const bool ragged_mine = ragged_rows > 0 && full_tiles >= first_tile && (full_tiles - first_tile) % tile_stride == 0;
+    // the counters (rodent_hip_render_counters) are those of the whole call: its sub-calls after the first add to them
+    r.counters_continue = false;
     if (r.mapping == 1) {                                                    // the megakernel tiles the rows it is given itself: one launch per row tile
-        for (int k = 0; k < mine; k++) render_rows_mega(r, settings, iter, (first_tile + k * tile_stride) * tile_rows, (first_tile + k * tile_stride + 1) * tile_rows, (hipStream_t)stream);
+        for (int k = 0; k < mine; k++) { render_rows_mega(r, settings, iter, (first_tile + k * tile_stride) * tile_rows, (first_tile + k * tile_stride + 1) * tile_rows, (hipStream_t)stream); r.counters_continue = true; }
     } else if (mine > 0) {
         const int y0 = first_tile * tile_rows;
         render_rows(r, settings, iter, y0, y0 + mine * tile_rows, (hipStream_t)stream, tile_rows, tile_stride * tile_rows);
+        r.counters_continue = true;
     }
     if (ragged_mine) render_rows_any(r, settings, iter, full_tiles * tile_rows, r.film_h, (hipStream_t)stream);
+    r.counters_continue = false;
 }
 
 void render(const Settings* settings, int32_t iter) {                        // generated render(): converter.cpp:628-967

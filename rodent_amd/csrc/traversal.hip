@@ -108,7 +108,9 @@ __device__ __forceinline__ int node2_step(const Node2* __restrict__ nodes, int t
 constexpr int kMaxTopNodes = 1024;       // capacity of a launch context's top-of-tree image buffer
 
 // Launch control block in device memory (zero between launches).
-struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; int finish_done; };
+// host_err: a word of pinned host memory (DeviceState::host_page) the rare error paths store into -- the host reads it after its synchronisation
+// without a device-to-host copy (12 us of every synchronous call until round 4, profiles/r05_host_call_costs.txt).
+struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; int finish_done; int* host_err; };
 
 
 // Per-lane stack of the fast / sched kernels: an LDS-only window of LDS_N entries behind an
@@ -140,7 +142,7 @@ __device__ __forceinline__ void finish_launch(const Node2* __restrict__ nodes, c
     if (phase_counters && group == 0) for (int k = threadIdx.x; k < 4 * 64; k += kWave) phase_counters[k * 16] = 0;
     const int count = known_count >= 0 ? known_count : ctl->deep_count;
     if (count > 0) {
-        DeepStack st{stack_lds + threadIdx.x, &ctl->err};
+        DeepStack st{stack_lds + threadIdx.x, ctl->host_err};
         for (int k = group * kWave + threadIdx.x; k < count; k += groups * kWave) {
             const int i = deep_list[k];
             RayX ray = load_ray(rays, i);
@@ -226,12 +228,12 @@ __device__ __forceinline__ Bases make_bases(const Node2* nodes, const Tri1* tris
 // accept in one instruction the one that holds the minimum stores the hit record.  ANY: the first acceptance stores -inf, which ends the others.
 typedef __attribute__((address_space(3))) float lds_float;
 // SPILL (> 0: the rows of the lane's LDS window, sp_limit = col + SPILL * kWave): a stack that outgrows the window moves its oldest entries to
-// `spill_wave`, the wave's block of global memory, and the ray goes on in its lane (stack_spill / stack_reload, traversal_device.h); 0: the
-// ray is handed to the launch's deep list and traced again from the root by the follow-up pass (finish_launch).
-template <bool ANY, bool PF = false, bool TOP = false, bool LAZY = false, bool FENCE = false, bool SHARED = false, int SPILL = 0>
+// its wave's block of `spill` (the context's buffer; WPG = waves per workgroup) and the ray goes on in its lane (stack_spill / stack_reload,
+// traversal_device.h); 0: the ray is handed to the launch's deep list and traced again from the root by the follow-up pass (finish_launch).
+template <bool ANY, bool PF = false, bool TOP = false, bool LAZY = false, bool FENCE = false, bool SHARED = false, int SPILL = 0, int WPG = 1>
 __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __restrict__ hits, lds_int* sp_limit, Ctl* ctl, int* __restrict__ deep_list,
                                           bool prefetch = false, lds_int* pf_row = nullptr, lds_int* image = nullptr, lds_float* shared_tmax = nullptr,
-                                          int* __restrict__ spill_wave = nullptr) {
+                                          int* __restrict__ spill = nullptr) {
     const bool is_node = L.top > 0;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -281,8 +283,8 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
         L.sp[kWave] = c0first ? ch.y : ch.x;
         L.top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
         L.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
-        if (both && L.sp >= sp_limit) {                                 // (`both`: popping the sentinel moves sp below col, which wraps)
-            if constexpr (SPILL > 0) stack_spill<SPILL>(L.sp, L.top, sp_limit - SPILL * kWave, spill_wave, &ctl->err, &ctl->stats[7]);      // deeper than the LDS window: the oldest entries move out
+        if (__builtin_expect(both && L.sp >= sp_limit, 0)) {           // (`both`: popping the sentinel moves sp below col, which wraps)
+            if constexpr (SPILL > 0) stack_spill<SPILL>(L.sp, L.top, sp_limit, spill, WPG, ctl->host_err, &ctl->stats[7]);      // deeper than the LDS window: the oldest entries move out
             else {                                                      // ... or k_bvh2_finish redoes this ray
                 deep_list[atomicAdd(&ctl->deep_count, 1)] = L.ray_id;
                 L.top = 0;
@@ -309,7 +311,7 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
         L.top = (ANY && found) ? 0 : (leave ? popped : L.top - 1);    // top - 1 == ~(j + 1)
         L.sp -= (leave && !(ANY && found)) ? kWave : 0;
     }
-    if constexpr (SPILL > 0) if (L.top >= kSpillMark) stack_reload(L.sp, L.top, sp_limit - SPILL * kWave, spill_wave);       // popped row 0 while entries are out: they come back
+    if constexpr (SPILL > 0) if (__builtin_expect(L.top >= kSpillMark, 0)) stack_reload<SPILL>(L.sp, L.top, sp_limit, spill, WPG);       // popped row 0 while entries are out: they come back
 }
 
 // A fresh ray: loads it, stores the miss record, empty stack (col[0] = the 0 that ends the traversal when popped).
@@ -341,7 +343,7 @@ __device__ __forceinline__ void finish_lane(const Lane& L, const Ray1* __restric
 template <bool ANY, int LDS_N, int PRIO = 0, bool SPILL = false>
 __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, const Ray1* __restrict__ rays,
                                               Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray,
-                                              const int* __restrict__ perm = nullptr, int* __restrict__ spill_wave = nullptr) {
+                                              const int* __restrict__ perm = nullptr, int* __restrict__ spill = nullptr) {
     const int lane_ray = first_ray + (int)threadIdx.x;
     // perm (k_bvh2_single's "sorted" mapping): lane j traces ray perm[j]; its hit still goes to hits[ray id]
     Lane L = start_lane(rays, hits, lane_ray < n ? (perm ? perm[lane_ray] : lane_ray) : -1, perm ? perm[first_ray] : first_ray, col);
@@ -349,7 +351,7 @@ __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, c
     const Bases base = make_bases(nodes, tris);
     if (PRIO == 0) {
         while (__ballot(L.top != 0)) {
-            if (L.top != 0) bvh2_step<ANY, false, false, false, false, false, SPILL ? LDS_N : 0>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, nullptr, nullptr, spill_wave);
+            if (L.top != 0) bvh2_step<ANY, false, false, false, false, false, SPILL ? LDS_N : 0, 1>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, nullptr, nullptr, spill);
         }
     } else if (PRIO >= 256) {                         // lab: triangle turns.  Lanes at a triangle step only every K-th iteration while the wave is
         // young (iteration < SWITCH), so that most iterations run the node path alone (62 instead of 127 VALU instructions); old
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__
             chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
         }
     }
-    unified_chunk<ANY, LDS_N, PRIO, SPILL>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, perm, SPILL ? spill + (size_t)blockIdx.x * kSpillWaveInts : nullptr);
+    unified_chunk<ANY, LDS_N, PRIO, SPILL>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, perm, spill);
     if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
         unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
         tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
@@ -597,9 +599,10 @@ __global__ __launch_bounds__(kSortThreads) void k_raysort_scatter(const unsigned
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
+constexpr int kHostPageInts = 64, kHostErr = 16;        // (the error word in a cache line of its own, away from the ray-kind words)
 struct DeviceState {
     bool  init = false;
-    int*  scratch = nullptr;    // [0] ray counter of the first persistent kernels, [1] error flag, [16..19] Ctl
+    int*  scratch = nullptr;    // [0] ray counter of the first persistent kernels, [16..] Ctl
     int   num_cus = 0;
     int*  deep_list = nullptr;  // ray indices whose stack overflowed the LDS window
     int   deep_cap = 0;
@@ -616,8 +619,9 @@ struct DeviceState {
     int   order_rays = 0;                      // ray count of the launch chunk_order was sorted for (0: none)
     int*  order_agree = nullptr;               // per stripe: {chunks the last two launches both found in their expensive half, half the stripe's chunks}
     const int* debug_perm = nullptr;           // lab: caller-supplied ray permutation of the "top-userperm" mapping (rodent_hip_debug_set_perm)
-    int*  host_flags = nullptr;                // pinned: where the error flags are copied back to
+    int*  host_page = nullptr;                 // pinned host memory the kernels store into: [0] / [1] ray-kind reports (host_kinds), [kHostErr] stack-overflow flag (Ctl::host_err)
     hipEvent_t timer[2] = {nullptr, nullptr};  // the synchronous entry points' kernel time (rodent_hip_get_kernel_time)
+    std::mutex sync_mutex;                     // ... one synchronous call at a time per context (the events are the context's)
     // Ray-kind hint of the default mapping (L_default): host_kinds[0] / [1] = id of the last launch whose rays some workgroup found coherent / incoherent
     // (pinned host memory the kernels store into); hint_* = the ray list the hint is about and the first launch that traced it.
     int*  host_kinds = nullptr; int launch_id = 0; const void* hint_rays = nullptr; int hint_n = 0, hint_first_id = 0;
@@ -631,6 +635,17 @@ struct DeviceStreams { std::vector<std::pair<hipStream_t, std::unique_ptr<Device
 DeviceStreams g_dev[16];
 std::mutex  g_mutex;
 constexpr size_t kMaxStreamContexts = 64;
+
+// The entry points work on the device they are given and leave the caller's current device as they found it.
+struct DeviceGuard {
+    int prev = -1; bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != dev) { HIP_CHECK(hipSetDevice(dev)); changed = true; }
+    }
+    ~DeviceGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete; DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 DeviceState& device_state(int dev, hipStream_t stream) {
     if (dev < 0 || dev >= 16) { fprintf(stderr, "rodent_hip: invalid device index %d\n", dev); abort(); }
@@ -649,6 +664,11 @@ DeviceState& device_state(int dev, hipStream_t stream) {
     s->num_cus = prop.multiProcessorCount;
     HIP_CHECK(hipMalloc(&s->scratch, 64 * sizeof(int)));
     HIP_CHECK(hipMemset(s->scratch, 0, 64 * sizeof(int)));
+    static_assert(16 * sizeof(int) + sizeof(Ctl) <= 64 * sizeof(int), "the control block lives in the scratch words");
+    HIP_CHECK(hipHostMalloc(&s->host_page, sizeof(int) * kHostPageInts, hipHostMallocCoherent));
+    for (int k = 0; k < kHostPageInts; k++) s->host_page[k] = 0;
+    s->host_kinds = s->host_page;
+    { int* err = s->host_page + kHostErr; HIP_CHECK(hipMemcpy(&s->ctl()->host_err, &err, sizeof(err), hipMemcpyHostToDevice)); }
     HIP_CHECK(hipMalloc(&s->deep_stack, kStackCap * kWave * sizeof(int)));
     s->init = true;
     d.ctx.emplace_back(stream, std::move(s));
@@ -731,21 +751,13 @@ int spill_checked(int groups, int waves) {
     return groups;
 }
 
-// Copies back and clears both stack-overflow flags (scratch[1]: the lab kernels' LaneStack; ctl->err: the follow-up
-// kernels' 64-entry global stack) after everything enqueued on `stream` has finished.
+// Waits for everything enqueued on `stream`, then reads and clears the stack-overflow flag: a word of pinned host memory the kernels' error paths
+// store into (Ctl::host_err) -- no device-to-host copy on the synchronous entry points' path.
 bool read_and_clear_error_flags(DeviceState& s, hipStream_t stream) {
-    // one copy of the words that hold both flags (scratch[1] .. ctl->err) into pinned memory: the synchronous, reference-named
-    // entry points pay this on every call (two copies into pageable memory cost ~20 us of a 0.19 ms launch)
-    const size_t first = 1, last = (size_t)(&s.ctl()->err - s.scratch);
-    if (!s.host_flags) HIP_CHECK(hipHostMalloc(&s.host_flags, sizeof(int) * 32, hipHostMallocDefault));
-    HIP_CHECK(hipMemcpyAsync(s.host_flags, s.scratch + first, sizeof(int) * (last - first + 1), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    const bool raised = s.host_flags[0] != 0 || s.host_flags[last - first] != 0;
-    if (raised) {
-        HIP_CHECK(hipMemsetAsync(s.scratch + 1, 0, sizeof(int), stream));
-        HIP_CHECK(hipMemsetAsync(&s.ctl()->err, 0, sizeof(int), stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-    }
+    volatile int* page = s.host_page;
+    const bool raised = page[kHostErr] != 0;
+    page[kHostErr] = 0;
     return raised;
 }
 // the reference's entry points have no return code (bench_traversal.impala:17-21: message + abort)
@@ -866,7 +878,10 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool S
 // launches whose node array the runtime cannot give a mapped range for (nothing bounds the ids of an older image then).
 constexpr int kTopMinRays = 9216 * kWave;      // the measured cross-over lies between 512 Ki and 768 Ki rays (profiles/r02_threshold_sweep.txt)
 int g_top_min_rays = kTopMinRays;               // rodent_hip_top_min_rays()
-int g_kind_hint = [] { const char* e = getenv("RODENT_HIP_KIND_HINT"); return e && !atoi(e) ? 0 : 1; }();      // rodent_hip_ray_kind_hint(): 0 = the default mapping never remembers what a ray list was
+// rodent_hip_ray_kind_hint() / RODENT_HIP_KIND_HINT: 1 = the default mapping remembers what its kernels saw of a ray list and sends one that was incoherent throughout to
+// k_bvh2_top_refill from its second launch on (+2 ... 4 % on random segments).  OFF by default from round 5 on: which kernel a launch gets must not depend on earlier launches
+// or on when an asynchronous caller's previous launch happened to finish; k_bvh2_top_auto's choice per wave needs no memory.
+int g_kind_hint = [] { const char* e = getenv("RODENT_HIP_KIND_HINT"); return e && atoi(e) ? 1 : 0; }();
 // FUSED = 2: the launch finishes itself (its last workgroup does the follow-up kernel's work; fences on the rare paths only): one
 // kernel per call instead of two, +1.1 % / +1.8 % on the benchmark's primary / random set in wall-clock terms (bench.py, 100 steps).
 template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int FUSED = 2> void L_chunks(LAUNCH_ARGS) {
@@ -874,9 +889,9 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int FUSED = 2
     if (max_id == 0) L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream);
     else launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, false, 32, false, 0, FUSED>(s, nodes, tris, rays, hits, n, stream, max_id);
 }
-// Round 4: the persistent kernel chooses per wave and per draw between whole chunks (rays that share an origin or a direction) and lane
-// refill (anything else): k_bvh2_top_auto, traversal_top.h.  With the schedule history on, launches keep the chunk kernel (the history
-// orders CHUNKS).
+// Round 4: the persistent kernel chooses per wave -- once, from the first 64 rays the wave draws -- between whole chunks (rays that share an origin
+// or a direction) and lane refill (anything else): k_bvh2_top_auto, traversal_top.h.  With the schedule history on, launches keep the chunk kernel
+// (the history orders CHUNKS).
 void ensure_top_buffers(DeviceState& s) {
     if (s.top_image && s.tickets) return;
     std::lock_guard<std::mutex> lock(g_mutex);
@@ -896,26 +911,24 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0, bo
     s.top_image_nodes = nullptr; s.order_rays = 0;
     const int groups = spill_checked(((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);   // one resident generation, the same number in every stripe
     // Which kernel?  k_bvh2_top_auto decides per wave and is right for any list; but its refill loop, compiled under the chunk loop's
-    // register budget, runs 7 % behind k_bvh2_top_refill's (profiles/r04_sweep_auto.log).  So the kernels report what they saw
-    // (report_ray_kind) and a list that earlier launches found incoherent throughout goes to k_bvh2_top_refill -- from the second launch
-    // on the same (pointer, count); a stale or missing hint costs speed, never correctness, and either kernel corrects it.
-    if (!s.host_kinds) {
-        std::lock_guard<std::mutex> lock(g_mutex);
-        if (!s.host_kinds) { HIP_CHECK(hipHostMalloc(&s.host_kinds, sizeof(int) * 16, hipHostMallocDefault)); s.host_kinds[0] = s.host_kinds[1] = 0; }
-    }
+    // register budget, runs a few per cent behind k_bvh2_top_refill's (profiles/r04_sweep_auto.log).  With the ray-kind hint ON (off by default, see
+    // g_kind_hint) every workgroup reports what its first wave saw (report_ray_kind) and a list that earlier launches found incoherent throughout goes
+    // to k_bvh2_top_refill -- from the second launch on the same (pointer, count); a stale or missing hint costs speed, never correctness.
     if (s.hint_rays != rays || s.hint_n != n) { s.hint_rays = rays; s.hint_n = n; s.hint_first_id = s.launch_id + 1; }
     const int id = ++s.launch_id;
     const volatile int* kinds = s.host_kinds;
+    const bool hinting = MODE == 0 && g_kind_hint;
+    int* const report_to = hinting ? s.host_kinds : nullptr;
     // incoherent: the newest report of "incoherent" is about this list and newer than the newest report of "coherent" (a list of both kinds reports both in one launch)
-    const bool incoherent = MODE == 0 && g_kind_hint && kinds[1] >= s.hint_first_id && kinds[0] < kinds[1];
+    const bool incoherent = hinting && kinds[1] >= s.hint_first_id && kinds[0] < kinds[1];
     if (incoherent) {
         hipLaunchKernelGGL((k_bvh2_top_refill<ANY, LDS_N, TOPN, WAVES, REFILL, false, false>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                           (const int4*)s.top_image, s.tickets, max_id, s.spill, s.host_kinds, id);
+                           (const int4*)s.top_image, s.tickets, max_id, s.spill, report_to, id);
         hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
         return;
     }
     hipLaunchKernelGGL((k_bvh2_top_auto<ANY, LDS_N, TOPN, WAVES, REFILL, MODE, FUSED>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                       s.top_image, s.tickets, max_id, s.spill, s.host_kinds, id);
+                       s.top_image, s.tickets, max_id, s.spill, report_to, id);
     if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 
@@ -1213,44 +1226,48 @@ extern "C" {
 
 void hip_traverse_bvh2_tri1_async(int32_t dev, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits,
                                   int32_t num_rays, int32_t any_hit, int32_t variant, void* stream) {
+    DeviceGuard on(dev);
     DeviceState& s = device_state(dev, (hipStream_t)stream);
-    HIP_CHECK(hipSetDevice(dev));
     if (any_hit) launch_bvh2<true>(s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
     else         launch_bvh2<false>(s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
 }
 
 void hip_traverse_bvh4_tri4_async(int32_t dev, const Node4* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits,
                                   int32_t num_rays, int32_t any_hit, int32_t variant, void* stream) {
+    DeviceGuard on(dev);
     DeviceState& s = device_state(dev, (hipStream_t)stream);
-    HIP_CHECK(hipSetDevice(dev));
     launch_wide(4, any_hit != 0, s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
 }
 
 void hip_traverse_bvh8_tri4_async(int32_t dev, const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits,
                                   int32_t num_rays, int32_t any_hit, int32_t variant, void* stream) {
+    DeviceGuard on(dev);
     DeviceState& s = device_state(dev, (hipStream_t)stream);
-    HIP_CHECK(hipSetDevice(dev));
     launch_wide(8, any_hit != 0, s, nodes, tris, rays, hits, num_rays, variant, (hipStream_t)stream);
 }
 
 int32_t rodent_hip_check_errors(int32_t dev, void* stream) {
+    DeviceGuard on(dev);
     DeviceState& s = device_state(dev, (hipStream_t)stream);
-    HIP_CHECK(hipSetDevice(dev));
     return read_and_clear_error_flags(s, (hipStream_t)stream) ? 1 : 0;
 }
 
 // The reference's host times its GPU kernels with anydsl_get_kernel_time() (tools/bench_traversal/bench_traversal.cpp:125-133): the AnyDSL runtime's
-// accumulated KERNEL time in microseconds -- no launch gap, no synchronisation, no copy.  The synchronous entry points keep the same account: HIP events
-// around what they enqueue, added up in g_kernel_ns after the call's own synchronisation.
+// accumulated KERNEL time in microseconds -- no synchronisation, no copy.  The synchronous entry points keep the same account: HIP events around what
+// they enqueue -- the context's buffers are allocated BEFORE the first event, so a first call does not book its hipMalloc as kernel time; where a
+// mapping is two kernels (the one-chunk kernel + its follow-up) the microsecond between them is included -- added up after the call's own
+// synchronisation in one process-wide sum over all devices, like the reference's.  One synchronous call at a time per (device, null stream) context.
 }  // extern "C"
 namespace {
 std::atomic<uint64_t> g_kernel_ns{0};
-template <typename Launch> void timed_sync_call(int32_t dev, Launch launch) {
+template <typename Launch> void timed_sync_call(int32_t dev, int32_t num_rays, Launch launch) {
+    DeviceGuard on(dev);
     DeviceState& s = device_state(dev, nullptr);
-    HIP_CHECK(hipSetDevice(dev));
+    std::lock_guard<std::mutex> one_call(s.sync_mutex);
     if (!s.timer[0]) { HIP_CHECK(hipEventCreate(&s.timer[0])); HIP_CHECK(hipEventCreate(&s.timer[1])); }
+    if (num_rays > 0) { ensure_deep_list(s, num_rays); ensure_spill(s); ensure_top_buffers(s); }       // every lazy allocation of the default mappings
     HIP_CHECK(hipEventRecord(s.timer[0], nullptr));
-    launch();
+    launch(s);
     HIP_CHECK(hipEventRecord(s.timer[1], nullptr));
     check_error_flag(s, nullptr);                                          // synchronises; aborts on a stack overflow like the reference's error()
     float ms = 0.0f;
@@ -1262,22 +1279,22 @@ extern "C" {
 uint64_t rodent_hip_get_kernel_time(void) { return g_kernel_ns.load(std::memory_order_relaxed) / 1000u; }
 
 void amdgpu_intersect_single_ray1_bvh2_tri1(int32_t dev, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    timed_sync_call(dev, [&] { hip_traverse_bvh2_tri1_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(2), nullptr); });
+    timed_sync_call(dev, num_rays, [&](DeviceState& s) { launch_bvh2<false>(s, nodes, tris, rays, hits, num_rays, default_variant(2), nullptr); });
 }
 void amdgpu_occluded_single_ray1_bvh2_tri1(int32_t dev, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    timed_sync_call(dev, [&] { hip_traverse_bvh2_tri1_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(2), nullptr); });
+    timed_sync_call(dev, num_rays, [&](DeviceState& s) { launch_bvh2<true>(s, nodes, tris, rays, hits, num_rays, default_variant(2), nullptr); });
 }
 void hip_intersect_single_ray1_bvh4_tri4(int32_t dev, const Node4* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    timed_sync_call(dev, [&] { hip_traverse_bvh4_tri4_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(4), nullptr); });
+    timed_sync_call(dev, num_rays, [&](DeviceState& s) { launch_wide(4, false, s, nodes, tris, rays, hits, num_rays, default_variant(4), nullptr); });
 }
 void hip_occluded_single_ray1_bvh4_tri4(int32_t dev, const Node4* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    timed_sync_call(dev, [&] { hip_traverse_bvh4_tri4_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(4), nullptr); });
+    timed_sync_call(dev, num_rays, [&](DeviceState& s) { launch_wide(4, true, s, nodes, tris, rays, hits, num_rays, default_variant(4), nullptr); });
 }
 void hip_intersect_single_ray1_bvh8_tri4(int32_t dev, const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    timed_sync_call(dev, [&] { hip_traverse_bvh8_tri4_async(dev, nodes, tris, rays, hits, num_rays, 0, default_variant(8), nullptr); });
+    timed_sync_call(dev, num_rays, [&](DeviceState& s) { launch_wide(8, false, s, nodes, tris, rays, hits, num_rays, default_variant(8), nullptr); });
 }
 void hip_occluded_single_ray1_bvh8_tri4(int32_t dev, const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t num_rays) {
-    timed_sync_call(dev, [&] { hip_traverse_bvh8_tri4_async(dev, nodes, tris, rays, hits, num_rays, 1, default_variant(8), nullptr); });
+    timed_sync_call(dev, num_rays, [&](DeviceState& s) { launch_wide(8, true, s, nodes, tris, rays, hits, num_rays, default_variant(8), nullptr); });
 }
 
 int32_t rodent_hip_device_count(void) {

@@ -131,15 +131,32 @@ constexpr int kSpillMark = 0x7F000000;          // above every node id (<= 0x3FF
 constexpr int kSpillRows = 7, kSpillBlocks = 7;
 constexpr int kSpillWaveInts = kSpillRows * kSpillBlocks * kWave;       // 12 544 bytes per resident wave
 
-// Called (exec-masked: the rare path) by a lane whose push filled row WINDOW: sp == col + WINDOW * kWave.
-// `events` (may be null): a counter of blocks moved out, for the tests and the per-scene reports (one atomic per block, on the rare path only).
+// Both helpers run exec-masked on the rare path and take what they need in its cheapest loop-invariant form -- the lane's window LIMIT
+// (col + WINDOW rows, which the step compares against anyway), the launch's spill buffer and the workgroup's wave count -- and derive the rest
+// behind an opaque barrier: computed outside, the column base and the 64-bit address of the lane's spill words would be three more VGPRs
+// carried around a loop that is compiled under a 64-VGPR budget (measured: +2 ... 3 % on the benchmark launches).
+__device__ __forceinline__ int* spill_words(int* __restrict__ spill, int waves_per_group) {
+    unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    int slot = (int)blockIdx.x * waves_per_group + __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);     // the wave's slot in the resident grid
+    asm volatile("" : "+v"(lane), "+s"(slot));
+    return spill + (size_t)slot * kSpillWaveInts + lane;
+}
 template <int WINDOW>
-__device__ __forceinline__ void stack_spill(lds_int*& sp, int& top, lds_int* col, int* __restrict__ spill_wave, int* err, unsigned long long* events = nullptr) {
+__device__ __forceinline__ lds_int* window_base(lds_int* limit) {
+    unsigned a = (unsigned)(size_t)limit;
+    asm volatile("" : "+v"(a));
+    return (lds_int*)(size_t)(a - (unsigned)(WINDOW * kWave * sizeof(int)));
+}
+// Called by a lane whose push filled row WINDOW (sp == limit).  `events` (may be null): a counter of blocks moved out, for the tests and
+// the per-scene reports (one atomic per block).
+template <int WINDOW>
+__device__ __forceinline__ void stack_spill(lds_int*& sp, int& top, lds_int* limit, int* __restrict__ spill, int waves_per_group, int* err, unsigned long long* events = nullptr) {
     static_assert(WINDOW > kSpillRows + 1, "something must stay in the window");
+    lds_int* const col = window_base<WINDOW>(limit);
     const int mark = col[0], blocks = mark ? mark - kSpillMark : 0;
     if (blocks >= kSpillBlocks) { *err = 1; top = 0; return; }        // more than the reference's 64 slots: the host reports it
     if (events) atomicAdd(events, 1ull);
-    int* g = spill_wave + blocks * kSpillRows * kWave + (int)(threadIdx.x % kWave);
+    int* g = spill_words(spill, waves_per_group) + blocks * kSpillRows * kWave;
 #pragma unroll 1
     for (int j = 0; j < kSpillRows; j++) g[j * kWave] = col[(1 + j) * kWave];
 #pragma unroll 1
@@ -148,9 +165,11 @@ __device__ __forceinline__ void stack_spill(lds_int*& sp, int& top, lds_int* col
     sp -= kSpillRows * kWave;
 }
 // Called by a lane that popped row 0 while blocks are out (top >= kSpillMark): the newest block comes back, its newest entry is the new top.
-__device__ __forceinline__ void stack_reload(lds_int*& sp, int& top, lds_int* col, const int* __restrict__ spill_wave) {
+template <int WINDOW>
+__device__ __forceinline__ void stack_reload(lds_int*& sp, int& top, lds_int* limit, int* __restrict__ spill, int waves_per_group) {
+    lds_int* const col = window_base<WINDOW>(limit);
     const int blocks = top - kSpillMark;                                // >= 1
-    const int* g = spill_wave + (blocks - 1) * kSpillRows * kWave + (int)(threadIdx.x % kWave);
+    const int* g = spill_words(spill, waves_per_group) + (blocks - 1) * kSpillRows * kWave;
 #pragma unroll 1
     for (int j = 0; j < kSpillRows - 1; j++) col[(1 + j) * kWave] = g[j * kWave];
     top = g[(kSpillRows - 1) * kWave];

@@ -256,7 +256,6 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     int* counter = tickets + stripe * kCounterStride;
     int t = (blockIdx.x / kStripes) * WAVES + wave;
     lds_int* const sp_limit = col + LDS_N * kWave;
-    int* const spill_wave = spill + (size_t)(blockIdx.x * WAVES + wave) * kSpillWaveInts;       // this wave's block of the out-of-window stack (stack_spill)
     const Bases base = make_bases(nodes, tris);
     const int my_chunks = HISTORY ? stripe_chunks(total_chunks, stripe) : 0;
     static_assert(kStripes == kWave, "one stripe's agreement record per lane");
@@ -286,10 +285,10 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
             int iterations = 0;
             if (PRIO > 0) __builtin_amdgcn_s_setprio(0);
             while (__ballot(L.top != 0)) {
-                if (L.top != 0) bvh2_step<ANY, false, true, LAZY, false, false, LDS_N>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill_wave);
+                if (L.top != 0) bvh2_step<ANY, false, true, LAZY, false, false, LDS_N, WAVES>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill);
                 // lab (PRIO == -2, "top-double"): a lane whose next node is in the LDS image visits it in the same iteration -- two levels of the top
                 // of the tree per dependent step where the fetch is a ds_read (VERDICT r2 item 2's "BVH4-collapsed image", without a second layout)
-                if (PRIO == -2 && L.top >= kLdsTag) bvh2_step<ANY, false, true, LAZY, false, false, LDS_N>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill_wave);
+                if (PRIO == -2 && L.top >= kLdsTag) bvh2_step<ANY, false, true, LAZY, false, false, LDS_N, WAVES>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill);
                 if (TRACE || PRIO > 0 || HISTORY) iterations++;
                 if (PRIO > 0 && iterations == PRIO) __builtin_amdgcn_s_setprio(3);          // lab: a chunk that is still running after PRIO iterations is on the critical path
             }
@@ -336,10 +335,11 @@ __device__ __forceinline__ bool wave_rays_coherent(float ox, float oy, float oz,
     const bool o = differs(ox) | differs(oy) | differs(oz), d = differs(dx) | differs(dy) | differs(dz);
     return __ballot(valid && o) == 0ull || __ballot(valid && d) == 0ull;      // (lane 0 is valid whenever any lane is: rays are handed out in lane order)
 }
-// What the default mapping remembers between launches (DeviceState::host_kinds, pinned host memory the kernels write straight into): the
-// id of the last launch in which a workgroup's first rays were coherent [0] / incoherent [1].  A hint for the host's choice of kernel, nothing else.
+// What the default mapping remembers between launches while the ray-kind hint is on (DeviceState::host_kinds, pinned host memory the kernels write
+// straight into; null while it is off): the id of the last launch in which a workgroup's first rays -- EVERY workgroup reports, so a list that is
+// coherent anywhere says so -- were coherent [0] / incoherent [1].  A hint for the host's choice of kernel, nothing else.
 __device__ __forceinline__ void report_ray_kind(int* host_kinds, int launch_id, bool coherent) {
-    if (host_kinds && threadIdx.x == 0 && blockIdx.x < kStripes) __hip_atomic_store(&host_kinds[coherent ? 0 : 1], launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (host_kinds && threadIdx.x == 0) __hip_atomic_store(&host_kinds[coherent ? 0 : 1], launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Persistent form with lane refill (variant "refill"): a wave does not wait for the last ray of a 64-ray chunk.  As soon as REFILL of its lanes
@@ -365,7 +365,6 @@ __device__ __forceinline__ void top_refill_body(const Node2* __restrict__ nodes,
     int* counter = tickets + stripe * kCounterStride;
     const auto ray_of = [&](int t) { return ((t / kGroupRays) * kStripes + stripe) * kGroupRays + t % kGroupRays; };
     lds_int* const sp_limit = col + LDS_N * kWave;
-    int* const spill_wave = spill + (size_t)(blockIdx.x * WAVES + wave) * kSpillWaveInts;
     const Bases base = make_bases(nodes, tris);
     Lane L;
     {
@@ -408,7 +407,7 @@ __device__ __forceinline__ void top_refill_body(const Node2* __restrict__ nodes,
             continue;
         }
         if (live == 0) break;
-        if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill_wave);
+        if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N, WAVES>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill);
     }
 }
 
@@ -455,7 +454,6 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     int* counter = tickets + stripe * kCounterStride;
     const auto ray_of = [&](int t) { return ((t / kGroupRays) * kStripes + stripe) * kGroupRays + t % kGroupRays; };
     lds_int* const sp_limit = col + LDS_N * kWave;
-    int* const spill_wave = spill + (size_t)(blockIdx.x * WAVES + wave) * kSpillWaveInts;       // this wave's block of the out-of-window stack (stack_spill)
     const Bases base = make_bases(nodes, tris);
     int t = ((blockIdx.x / kStripes) * WAVES + wave) * kWave;               // the wave's first 64 tickets are its rank in the stripe; the counter hands out those behind
     bool coherent = MODE != 2;
@@ -476,7 +474,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
             Lane L = start_lane(rays, hits, r < n ? r : -1, first_ray, col);
             if (L.top != 0) L.top = root;
             while (__ballot(L.top != 0)) {
-                if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill_wave);
+                if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N, WAVES>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill);
             }
             int t_next = 0;
             if (lane == 0) t_next = atomicAdd(counter, kWave);
@@ -509,7 +507,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
                 continue;
             }
             if (live == 0) break;
-            if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill_wave);
+            if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N, WAVES>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill);
         }
     }
     // the workgroup that finishes last does the follow-up work (k_bvh2_top_persist, FUSED == 2)

@@ -386,10 +386,10 @@ bool needs_wide_offsets(const void* nodes, const void* tris) {
 }
 
 template <bool ANY, int LDS_N> void L_lane(LAUNCH_ARGS) {
-    hipLaunchKernelGGL((k_bvh2_lane<ANY, LDS_N>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.scratch + 1);
+    hipLaunchKernelGGL((k_bvh2_lane<ANY, LDS_N>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.host_page + kHostErr);
 }
 template <bool ANY, int LDS_N, int NE> void L_ww(LAUNCH_ARGS) {
-    hipLaunchKernelGGL((k_bvh2_ww<ANY, LDS_N, NE>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.scratch + 1);
+    hipLaunchKernelGGL((k_bvh2_ww<ANY, LDS_N, NE>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.host_page + kHostErr);
 }
 template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false, int XCD = 0, bool TR = false, bool SC = false> void L_fast(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kWave) void k_wide_lane(const char* __restrict__ no
     store_hit(hits, i, hit.id, hit.t, hit.u, hit.v);
 }
 template <bool ANY, int N, int LDS_N> void L_wide_lane(WIDE_LAUNCH_ARGS) {
-    hipLaunchKernelGGL((k_wide_lane<ANY, N, LDS_N>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, n, s.scratch + 1);
+    hipLaunchKernelGGL((k_wide_lane<ANY, N, LDS_N>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, n, s.host_page + kHostErr);
 }
 
 

@@ -115,7 +115,7 @@ __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const
                     }
                 }
                 top = cur;
-                if (wp - kWave >= sp_limit && wp > sp + kWave) {              // grew beyond the LDS window: k_wide_finish redoes this ray
+                if (__builtin_expect(wp - kWave >= sp_limit && wp > sp + kWave, 0)) {      // grew beyond the LDS window: k_wide_finish redoes this ray
                     deep_list[atomicAdd(&ctl->deep_count, 1)] = ray_id;
                     top = 0;
                 }
@@ -293,29 +293,35 @@ __device__ __forceinline__ HitAcc wide_ray_literal(const char* __restrict__ node
     return hit;
 }
 
+// kFinishGroups one-wave workgroups, each taking every kFinishGroups-th batch of 64 deep rays (one wave until round 4: a launch with many deep rays
+// waited for a serial drain); the last workgroup to finish resets the launch's control words (finish_launch's protocol).
 template <bool ANY, int N>
 __global__ __launch_bounds__(kWave) void k_wide_finish(const char* __restrict__ nodes, const Tri4* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
                                                         Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* tickets) {
     __shared__ int stack_lds[kStackCap * kWave];                    // the reference's 64 entries per lane, in LDS (see DeepStack)
-    if (tickets) for (int k = threadIdx.x; k < 4 * 64; k += kWave) tickets[k * 16] = 0;     // the persistent form's ticket counters, ready for the next launch
+    if (tickets && blockIdx.x == 0) for (int k = threadIdx.x; k < 4 * 64; k += kWave) tickets[k * 16] = 0;     // the persistent form's ticket counters, ready for the next launch
     const int count = ctl->deep_count;
     if (count > 0) {
-        DeepStack st{(lds_int*)stack_lds + threadIdx.x, &ctl->err};
-        for (int k = threadIdx.x; k < count; k += kWave) {
+        DeepStack st{(lds_int*)stack_lds + threadIdx.x, ctl->host_err};
+        for (int k = blockIdx.x * kWave + threadIdx.x; k < count; k += gridDim.x * kWave) {
             const int i = deep_list[k];
             const HitAcc hit = wide_ray_literal<ANY, N>(nodes, tris, load_ray(rays, i), st);
             store_hit(hits, i, hit.id, hit.t, hit.u, hit.v);
         }
     }
-    if (threadIdx.x == 0) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; }
+    if (threadIdx.x == 0) {
+        // (every workgroup has read deep_count before it counts itself done, so the last one may zero it; no deep rays -- the usual case --: workgroup 0 rewrites the zeros)
+        const bool last = gridDim.x == 1 || (count == 0 ? blockIdx.x == 0 : atomicAdd(&ctl->finish_done, 1) == (int)gridDim.x - 1);
+        if (last) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; ctl->finish_done = 0; }
+    }
 }
 
 #define WIDE_LAUNCH_ARGS DeviceState& s, const void* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
 template <bool ANY, int N, int LDS_N, int XCD> void L_wide_single(WIDE_LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     hipLaunchKernelGGL((k_wide_single<ANY, N, LDS_N, XCD>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
-    hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(1), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
+    hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(kFinishGroups), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 // "top": the persistent form with the staged top levels for launches that fill the chip (as the BVH2 default: rodent_hip_top_min_rays),
 // the one-chunk kernel below that
@@ -333,5 +339,5 @@ template <bool ANY, int N, int LDS_N> void L_wide_top(WIDE_LAUNCH_ARGS) {
     constexpr int kWaves = 16;
     const int groups = ((s.num_cus + kStripes - 1) / kStripes) * kStripes;   // one workgroup per CU, the same number in every stripe
     hipLaunchKernelGGL((k_wide_top_persist<ANY, N, LDS_N, kWaves>), dim3(groups), dim3(kWave * kWaves), 0, stream, (const char*)nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.tickets);
-    hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(1), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets);
+    hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(kFinishGroups), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets);
 }

@@ -1,9 +1,11 @@
 #include "bvh_build.h"
 
+#include <atomic>
 #include <cassert>
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <thread>
 
 namespace rodent {
 namespace {
@@ -196,80 +198,83 @@ bool apply_split(Cand& c, const SplitChoice& s, const std::vector<Triangle>& tri
     return true;
 }
 
-} // namespace
 
-WideBvh build_wide_bvh(const std::vector<Triangle>& tris, const BuildParams& p) {
-    WideBvh out; out.arity = p.arity;
+
+// A subtree as the serial builder numbers it: nodes in the order their tasks are taken (pre-order), leaves in the order they are made.
+struct Piece {
+    std::vector<WideNode> nodes;
+    std::vector<std::vector<uint32_t>> leaves;
+    size_t num_refs = 0, object_splits = 0, spatial_splits = 0;
+    int depth = 0;
+    bool root_is_leaf = false;                 // the piece's root did not split: leaves[0] is the piece
+};
+
+// One task of the build (bvh.h:61-82): candidate `c` is split greedily -- always the untested child of largest cost -- into up to
+// p.arity children, returned in order of decreasing reference count; kids[i].tested = "this child becomes a leaf".
+std::vector<Cand> expand(Cand&& c, int level, const std::vector<Triangle>& tris, const BuildParams& p, float spatial_threshold,
+                         std::vector<Box>& scratch, Piece& stats) {
     const int N = p.arity;
-    assert(N >= 2 && N <= 8);
+    std::vector<Cand> kids; kids.reserve(N);
+    kids.push_back(std::move(c));
+    if (level >= p.max_depth) kids[0].tested = true;
+    while ((int)kids.size() < N) {
+        int pick = -1;
+        for (int i = 0; i < (int)kids.size(); i++)
+            if (!kids[i].tested && (pick < 0 || kids[i].cost > kids[pick].cost)) pick = i;
+        if (pick < 0) break;
+        Cand& k = kids[pick];
+        if (k.refs.size() <= (size_t)p.leaf_threshold) { k.tested = true; continue; }
 
-    Cand root;
-    root.refs.resize(tris.size());
-    for (size_t i = 0; i < tris.size(); i++) {
-        Box b; b.grow(tris[i].v0); b.grow(tris[i].v1); b.grow(tris[i].v2);
-        root.refs[i] = {(uint32_t)i, b}; root.bb.grow(b);
+        SplitChoice s;
+        if (k.refs.size() <= kSweepLimit) find_object_split_sweep(k, s, scratch);
+        else find_object_split_binned(k, s);
+        if (!s.valid && k.refs.size() > kSweepLimit) find_object_split_sweep(k, s, scratch);  // all centroids equal
+        const SplitChoice object_choice = s;
+        if (p.spatial_splits && s.valid) {
+            Box ov = s.lbox; ov.clip(s.rbox);
+            if (!ov.empty() && ov.half_area() > spatial_threshold) find_spatial_split(k, tris, s);
+        }
+        if (!s.valid || s.cost + p.traversal_cost * k.bb.half_area() >= k.cost) { k.tested = true; continue; }
+
+        Cand l, r;
+        bool ok = apply_split(k, s, tris, l, r);
+        if (!ok && s.spatial) { l = Cand(); r = Cand(); ok = apply_split(k, object_choice, tris, l, r); if (ok) stats.object_splits++; }
+        else if (ok) (s.spatial ? stats.spatial_splits : stats.object_splits)++;
+        if (!ok) { k.tested = true; continue; }
+        kids[pick] = std::move(l);
+        kids.push_back(std::move(r));
     }
-    root.finish();
-    const float spatial_threshold = root.bb.half_area() * p.alpha;
+    if (kids.size() > 1) std::stable_sort(kids.begin(), kids.end(), [](const Cand& a, const Cand& b) { return a.refs.size() > b.refs.size(); });
+    return kids;
+}
 
+std::vector<uint32_t> leaf_ids(const Cand& c) {
+    std::vector<uint32_t> ids(c.refs.size());
+    for (size_t i = 0; i < ids.size(); i++) ids[i] = c.refs[i].id;
+    return ids;
+}
+
+// The serial build of one subtree: a stack of tasks, depth first, child 0 first.
+void build_piece(Cand&& root, int root_level, const std::vector<Triangle>& tris, const BuildParams& p, float spatial_threshold, Piece& out) {
     struct Task { Cand c; int parent, slot, level; };
     std::vector<Task> stack;
-    stack.push_back({std::move(root), -1, 0, 0});
+    stack.push_back({std::move(root), -1, 0, root_level});
     std::vector<Box> scratch;
-
     auto make_leaf = [&](const Cand& c) {
-        std::vector<uint32_t> ids(c.refs.size());
-        for (size_t i = 0; i < ids.size(); i++) ids[i] = c.refs[i].id;
-        out.num_refs += ids.size();
-        out.leaves.push_back(std::move(ids));
+        out.num_refs += c.refs.size();
+        out.leaves.push_back(leaf_ids(c));
         return ~(int)(out.leaves.size() - 1);
     };
-
     while (!stack.empty()) {
         Task t = std::move(stack.back()); stack.pop_back();
         out.depth = std::max(out.depth, t.level);
-        std::vector<Cand> kids; kids.reserve(N);
-        kids.push_back(std::move(t.c));
-        if (t.level >= p.max_depth) kids[0].tested = true;
-
-        while ((int)kids.size() < N) {
-            int pick = -1;
-            for (int i = 0; i < (int)kids.size(); i++)
-                if (!kids[i].tested && (pick < 0 || kids[i].cost > kids[pick].cost)) pick = i;
-            if (pick < 0) break;
-            Cand& c = kids[pick];
-            if (c.refs.size() <= (size_t)p.leaf_threshold) { c.tested = true; continue; }
-
-            SplitChoice s;
-            if (c.refs.size() <= kSweepLimit) find_object_split_sweep(c, s, scratch);
-            else find_object_split_binned(c, s);
-            if (!s.valid && c.refs.size() > kSweepLimit) find_object_split_sweep(c, s, scratch);  // all centroids equal
-            const SplitChoice object_choice = s;
-            if (p.spatial_splits && s.valid) {
-                Box ov = s.lbox; ov.clip(s.rbox);
-                if (!ov.empty() && ov.half_area() > spatial_threshold) find_spatial_split(c, tris, s);
-            }
-            if (!s.valid || s.cost + p.traversal_cost * c.bb.half_area() >= c.cost) { c.tested = true; continue; }
-
-            Cand l, r;
-            bool ok = apply_split(c, s, tris, l, r);
-            if (!ok && s.spatial) { l = Cand(); r = Cand(); ok = apply_split(c, object_choice, tris, l, r); if (ok) out.object_splits++; }
-            else if (ok) (s.spatial ? out.spatial_splits : out.object_splits)++;
-            if (!ok) { c.tested = true; continue; }
-            kids[pick] = std::move(l);
-            kids.push_back(std::move(r));
-        }
-
+        std::vector<Cand> kids = expand(std::move(t.c), t.level, tris, p, spatial_threshold, scratch, out);
         if (kids.size() == 1) {
             const int leaf = make_leaf(kids[0]);
-            if (t.parent < 0) {                       // a single-leaf scene still gets a root node (bvh.h:218-224)
-                WideNode n; n.count = 1; n.box[0] = kids[0].bb; n.child[0] = leaf;
-                out.nodes.push_back(n);
-            } else out.nodes[t.parent].child[t.slot] = leaf;
+            if (t.parent < 0) out.root_is_leaf = true;
+            else out.nodes[t.parent].child[t.slot] = leaf;
             continue;
         }
-
-        std::stable_sort(kids.begin(), kids.end(), [](const Cand& a, const Cand& b) { return a.refs.size() > b.refs.size(); });
         const int me = (int)out.nodes.size();
         out.nodes.emplace_back();
         if (t.parent >= 0) out.nodes[t.parent].child[t.slot] = me;
@@ -280,6 +285,122 @@ WideBvh build_wide_bvh(const std::vector<Triangle>& tris, const BuildParams& p) 
             else stack.push_back({std::move(kids[i]), me, i, t.level + 1});
         }
     }
+}
+
+} // namespace
+
+// Large inputs are built on several host threads WITHOUT changing the result: the serial builder works through a subtree completely before
+// it touches the next one, so a subtree's nodes and leaves are contiguous runs of its output.  The top of the tree (tasks above
+// `piece_limit` references) is expanded first, in the serial order, into a list of events -- node, leaf, or "a subtree goes here" --; the
+// subtrees are built independently, each numbering its nodes and leaves from zero; then the events are replayed and every subtree is spliced
+// in with its offsets.  Same nodes, same order, same leaves as one thread would produce (tests/test_builder.py).
+WideBvh build_wide_bvh(const std::vector<Triangle>& tris, const BuildParams& p) {
+    WideBvh out; out.arity = p.arity;
+    assert(p.arity >= 2 && p.arity <= 8);
+
+    Cand root;
+    root.refs.resize(tris.size());
+    for (size_t i = 0; i < tris.size(); i++) {
+        Box b; b.grow(tris[i].v0); b.grow(tris[i].v1); b.grow(tris[i].v2);
+        root.refs[i] = {(uint32_t)i, b}; root.bb.grow(b);
+    }
+    root.finish();
+    const float spatial_threshold = root.bb.half_area() * p.alpha;
+    const Box root_box = root.bb;
+
+    int threads = p.threads > 0 ? p.threads : (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    constexpr size_t kParallelMinRefs = 65536, kMinPieceRefs = 8192;
+    Piece whole;
+    if (threads == 1 || tris.size() < kParallelMinRefs) {
+        build_piece(std::move(root), 0, tris, p, spatial_threshold, whole);
+        if (whole.root_is_leaf) {                  // a single-leaf scene still gets a root node (bvh.h:218-224)
+            WideNode n; n.count = 1; n.box[0] = root_box; n.child[0] = ~0;
+            whole.nodes.push_back(n);
+        }
+    } else {
+        const size_t piece_limit = std::max(kMinPieceRefs, tris.size() / (size_t)(8 * threads));
+        struct Event { int kind; int parent, slot; WideNode node; std::vector<uint32_t> ids; int piece; };    // kind 0: node, 1: leaf, 2: piece; parent = index of the parent's node EVENT
+        std::vector<Event> events;
+        struct PieceIn { Cand c; int level; };
+        std::vector<PieceIn> todo;
+        {
+            struct Task { Cand c; int parent, slot, level; };
+            std::vector<Task> stack;
+            stack.push_back({std::move(root), -1, 0, 0});
+            std::vector<Box> scratch;
+            while (!stack.empty()) {
+                Task t = std::move(stack.back()); stack.pop_back();
+                if (t.parent >= 0 && t.c.refs.size() <= piece_limit) {
+                    events.push_back({2, t.parent, t.slot, WideNode(), {}, (int)todo.size()});
+                    todo.push_back({std::move(t.c), t.level});
+                    continue;
+                }
+                whole.depth = std::max(whole.depth, t.level);
+                std::vector<Cand> kids = expand(std::move(t.c), t.level, tris, p, spatial_threshold, scratch, whole);
+                if (kids.size() == 1) {                // (cannot be the root: it holds >= kParallelMinRefs references and would have split)
+                    events.push_back({1, t.parent, t.slot, WideNode(), leaf_ids(kids[0]), -1});
+                    continue;
+                }
+                const int me = (int)events.size();
+                Event ev{0, t.parent, t.slot, WideNode(), {}, -1};
+                ev.node.count = (int)kids.size();
+                for (int i = 0; i < (int)kids.size(); i++) ev.node.box[i] = kids[i].bb;
+                events.push_back(std::move(ev));
+                for (int i = (int)kids.size() - 1; i >= 0; i--) {
+                    if (kids[i].tested) events.push_back({1, me, i, WideNode(), leaf_ids(kids[i]), -1});
+                    else stack.push_back({std::move(kids[i]), me, i, t.level + 1});
+                }
+            }
+        }
+        std::vector<Piece> pieces(todo.size());
+        {
+            // largest first: the pieces differ in size by what the top's splits left
+            std::vector<int> order(todo.size());
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return todo[a].c.refs.size() > todo[b].c.refs.size(); });
+            std::atomic<size_t> next{0};
+            auto worker = [&] {
+                for (size_t k; (k = next.fetch_add(1)) < order.size();) {
+                    const int i = order[k];
+                    build_piece(std::move(todo[i].c), todo[i].level, tris, p, spatial_threshold, pieces[i]);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int k = 1; k < std::min<int>(threads, (int)order.size()); k++) pool.emplace_back(worker);
+            worker();
+            for (auto& th : pool) th.join();
+        }
+        // replay: the serial numbering
+        std::vector<int> node_of_event(events.size(), -1);
+        for (size_t e = 0; e < events.size(); e++) {
+            Event& ev = events[e];
+            int child;
+            if (ev.kind == 0) {
+                child = (int)whole.nodes.size();
+                node_of_event[e] = child;
+                whole.nodes.push_back(ev.node);
+            } else if (ev.kind == 1) {
+                whole.num_refs += ev.ids.size();
+                whole.leaves.push_back(std::move(ev.ids));
+                child = ~(int)(whole.leaves.size() - 1);
+            } else {
+                Piece& pc = pieces[ev.piece];
+                const int node_off = (int)whole.nodes.size(), leaf_off = (int)whole.leaves.size();
+                child = pc.root_is_leaf ? ~leaf_off : node_off;
+                for (WideNode n : pc.nodes) {
+                    for (int i = 0; i < n.count; i++) n.child[i] = n.child[i] >= 0 ? n.child[i] + node_off : ~(~n.child[i] + leaf_off);
+                    whole.nodes.push_back(n);
+                }
+                for (auto& l : pc.leaves) whole.leaves.push_back(std::move(l));
+                whole.num_refs += pc.num_refs; whole.object_splits += pc.object_splits; whole.spatial_splits += pc.spatial_splits;
+                whole.depth = std::max(whole.depth, pc.depth);
+            }
+            if (ev.parent >= 0) whole.nodes[node_of_event[ev.parent]].child[ev.slot] = child;
+        }
+    }
+    out.nodes = std::move(whole.nodes); out.leaves = std::move(whole.leaves);
+    out.num_refs = whole.num_refs; out.object_splits = whole.object_splits; out.spatial_splits = whole.spatial_splits; out.depth = whole.depth;
 
     // SAH cost relative to the root area (traversal 1 per inner node, 1 per referenced triangle)
     Box rb; for (int i = 0; i < out.nodes[0].count; i++) rb.grow(out.nodes[0].box[i]);

@@ -40,6 +40,7 @@ struct BuildParams {
     float alpha = 1e-5f;
     bool  spatial_splits = true;
     int   max_depth = 56;        // keeps the traversal stacks (64 entries, stack.impala:53) safe
+    int   threads = 0;           // host threads for inputs of 65 536 triangles and more (0 = all hardware threads); the result does not depend on it
 };
 
 WideBvh build_wide_bvh(const std::vector<Triangle>& tris, const BuildParams& p);

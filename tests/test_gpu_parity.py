@@ -447,7 +447,9 @@ def test_bench_py_with_two_ranks(native_build):
     assert e["weak_scaling"]["rays_per_gpu_per_step"] == (1 << 20) and e["weak_scaling"]["Mrays_s"] > 1000 and len(e["weak_scaling"]["kernel_ms_per_rank[primary,random]"]) == 2
     assert e["all_rays_bit_exact_vs_oracle"] == {"primary": True, "random": True}          # rank 0's range against the oracle
     c5 = e["render"]["cfg5_atrium_3840x2160_256spp_len8"]
-    assert c5["rows_per_gpu"] == 68 * 16 and "interleaved" in c5["partition"] and c5["auto"]["film_complete_on_root"] is True      # rank 0: tiles 0, 2, ..., 134 of 135 and c5["auto"]["film_gather_ms"] > 0 and "cfg4_cornell_1920x1080_64spp_len4" not in e["render"]
+    # rank 0: tiles 0, 2, ..., 134 of 135
+    assert c5["rows_per_gpu"] == 68 * 16 and "interleaved" in c5["partition"] and c5["auto"]["film_complete_on_root"] is True
+    assert c5["auto"]["film_gather_ms"] > 0 and "cfg4_cornell_1920x1080_64spp_len4" not in e["render"]
     assert "cpu_baseline" not in d                                                          # rank 0, N = 1 only
 
 
@@ -526,9 +528,9 @@ def test_default_mapping_switches_kernels_at_its_size_threshold(gpu, oracle, cor
 
 def test_default_mapping_chooses_chunks_or_refill_by_itself(gpu, oracle, cornell, cornell_dev):
     """BASELINE config 3 ("ray compaction on") without a variant argument: the default kernel (k_bvh2_top_auto) traces rays that share an
-    origin as whole chunks and refills idle lanes otherwise (stats[5]: workgroups that chose the refill loop); a list -- same pointer, same
-    count -- that was incoherent throughout goes to the refill kernel proper from its second launch on (stats[4]), and back when the caller
-    puts coherent rays into the same buffer.  Hits are the oracle's in every case, with the hint switched off too."""
+    origin as whole chunks and refills idle lanes otherwise (stats[5]: workgroups that chose the refill loop).  With the ray-kind hint ON
+    (rodent_hip_ray_kind_hint; off by default) a list -- same pointer, same count -- that was incoherent throughout goes to the refill kernel proper
+    from its second launch on (stats[4]), and back when the caller puts coherent rays into the same buffer.  Hits are the oracle's in every case."""
     import torch
     top = gpu.variants(2).index("top")
     nodes, tris = cornell.blocks[2]
@@ -562,5 +564,5 @@ def test_default_mapping_chooses_chunks_or_refill_by_itself(gpu, oracle, cornell
             assert launch(coherent) == (False, False)
             assert launch(coherent) == (False, False)
     finally:
-        gpu.ray_kind_hint(True)
+        gpu.ray_kind_hint(False)                                                       # the shipped default (round 5): kernel selection does not depend on earlier launches
         gpu.lib().rodent_hip_top_min_rays(0)
