@@ -47,7 +47,7 @@ HIP_SOURCES = ["traversal.hip", "render.hip", "services.hip"]
 # (parity tests).  traversal.hip keeps the default: the benchmark kernel's chunk loop loses 2 % under max-ilp.
 HIP_SOURCE_FLAGS = {"render.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 HIP_LIB_HOST_SOURCES = ["image.cpp"]             # host code the library links: texture decoders of rodent_load_png / _jpg
-HOST_LIB_SOURCES = ["mesh.cpp", "bvh_build.cpp", "atrium.cpp", "scene.cpp", "image.cpp"]
+HOST_LIB_SOURCES = ["mesh.cpp", "bvh_build.cpp", "atrium.cpp", "stress_scenes.cpp", "scene.cpp", "image.cpp"]
 HOST_TOOLS = ["bvh_extractor", "ray_gen", "scene_gen", "fbuf2png", "converter", "tex_dump", "buffer_tool", "partition_check"]
 HIP_TOOLS = {"bench_traversal": [], "rodent": ["mesh.o", "bvh_build.o", "scene.o", "image.o"]}   # tool -> host objects it links
 

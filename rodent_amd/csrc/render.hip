@@ -238,7 +238,7 @@ __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const
                 if constexpr (kCursor) {
                     st.sp[kWave] = c0first ? ch.y : ch.x;
                     st.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
-                    if (__builtin_expect(both && st.sp >= st.limit, 0)) {            // (`both`: popping the sentinel moves sp below its column)
+                    if (both && st.sp >= st.limit) {                                  // (`both`: popping the sentinel moves sp below its column)
                         if constexpr (SPILLW > 0) stack_spill<SPILLW>(st.sp, top, st.limit, st.spill, kPersistWaves, st.err);
                         else { st.overflow = true; top = 0; }
                     }
@@ -260,7 +260,7 @@ __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const
                 if constexpr (kCursor) st.sp -= (leave && !(ANY && found)) ? kWave : 0;
                 else ptr -= (leave && !(ANY && found)) ? 1 : 0;
             }
-            if constexpr (kCursor && SPILLW > 0) if (__builtin_expect(top >= kSpillMark, 0)) stack_reload<SPILLW>(st.sp, top, st.limit, st.spill, kPersistWaves);      // popped row 0 while entries are out
+            if constexpr (kCursor && SPILLW > 0) if (top >= kSpillMark) stack_reload<SPILLW>(st.sp, top, st.limit, st.spill, kPersistWaves);      // popped row 0 while entries are out
         }
     }
     return any_found;
@@ -638,7 +638,7 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
                 L.top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
                 L.sp[kWave] = c0first ? ch.y : ch.x;
                 L.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
-                if (__builtin_expect(both && L.sp >= wave_limit, 0)) stack_spill<kTopStack>(L.sp, L.top, wave_limit + lane, spill, kPersistWaves, err);      // deeper than the window: the oldest entries move out
+                if (both && L.sp >= wave_limit) stack_spill<kTopStack>(L.sp, L.top, wave_limit + lane, spill, kPersistWaves, err);      // deeper than the window: the oldest entries move out
             } else {
                 const int prim_id = __float_as_int(q2.w);
                 const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
@@ -657,7 +657,7 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
                 L.top = ends ? 0 : (leave ? popped : top - 1);
                 L.sp -= (leave && !ends) ? kWave : 0;
             }
-            if (__builtin_expect(L.top >= kSpillMark, 0)) stack_reload<kTopStack>(L.sp, L.top, wave_limit + lane, spill, kPersistWaves);       // popped row 0 while entries are out: they come back
+            if (L.top >= kSpillMark) stack_reload<kTopStack>(L.sp, L.top, wave_limit + lane, spill, kPersistWaves);       // popped row 0 while entries are out: they come back
         }
     }
 }

@@ -108,8 +108,10 @@ __device__ __forceinline__ int node2_step(const Node2* __restrict__ nodes, int t
 constexpr int kMaxTopNodes = 1024;       // capacity of a launch context's top-of-tree image buffer
 
 // Launch control block in device memory (zero between launches).
-// host_err: a word of pinned host memory (DeviceState::host_page) the rare error paths store into -- the host reads it after its synchronisation
-// without a device-to-host copy (12 us of every synchronous call until round 4, profiles/r05_host_call_costs.txt).
+// err: raised (agent-scope atomic store) by a stack that outgrows the reference's 64 slots.  host_err: a word of pinned host memory
+// (DeviceState::host_page) into which whoever finishes the launch (finish_launch, k_wide_finish) copies a raised flag -- the host reads it after its
+// synchronisation without a device-to-host copy (12 us of every synchronous call until round 4, profiles/r05_host_call_costs.txt).  (The error paths
+// do not store into the host word themselves: with the pointer loaded inside the traversal loop the benchmark launch was 3 % slower.)
 struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long long stats[8]; unsigned long long* trace; int finish_done; int* host_err; };
 
 
@@ -125,9 +127,17 @@ struct Ctl { int counter; int reserved; int err; int deep_count; unsigned long l
 // it in global memory: every push and pop a round trip, ~100 us for the first deep ray of a launch.)
 struct DeepStack {
     lds_int* base; int* err;
-    __device__ __forceinline__ void put(int e, int v) { if (e < kStackCap) base[e * kWave] = v; else *err = 1; }
+    __device__ __forceinline__ void put(int e, int v) { if (e < kStackCap) base[e * kWave] = v; else __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ __forceinline__ int  get(int e) const { return base[(e < kStackCap ? e : kStackCap - 1) * kWave]; }
 };
+
+// Run by the one thread that finishes a launch: a raised overflow flag goes to the host's pinned word (Ctl::host_err) and is cleared.
+__device__ __forceinline__ void report_error(Ctl* ctl) {
+    if (__hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(ctl->host_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&ctl->err, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // The deep rays of a launch, restarted from the root with the 64-entry stack; `stack_lds`: kStackCap x kWave ints of LDS.  Run by
 // ONE wave per workgroup (threads 0..63); with a grid of several workgroups each takes every gridDim.x-th batch of 64 rays and
@@ -142,7 +152,7 @@ __device__ __forceinline__ void finish_launch(const Node2* __restrict__ nodes, c
     if (phase_counters && group == 0) for (int k = threadIdx.x; k < 4 * 64; k += kWave) phase_counters[k * 16] = 0;
     const int count = known_count >= 0 ? known_count : ctl->deep_count;
     if (count > 0) {
-        DeepStack st{stack_lds + threadIdx.x, ctl->host_err};
+        DeepStack st{stack_lds + threadIdx.x, &ctl->err};
         for (int k = group * kWave + threadIdx.x; k < count; k += groups * kWave) {
             const int i = deep_list[k];
             RayX ray = load_ray(rays, i);
@@ -164,7 +174,10 @@ __device__ __forceinline__ void finish_launch(const Node2* __restrict__ nodes, c
         // (every workgroup has read deep_count before it counts itself done, so the last one may zero it)
         // (with no deep rays -- the usual case -- nobody needs to wait for anybody: workgroup 0 rewrites the zeros)
         const bool last = groups == 1 || (count == 0 ? group == 0 : atomicAdd(&ctl->finish_done, 1) == groups - 1);
-        if (last) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; ctl->finish_done = 0; }   // stats[7]: rays handed over (read by the tests); ready for the next launch
+        if (last) {
+            ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; ctl->finish_done = 0;   // stats[7]: rays handed over (read by the tests); ready for the next launch
+            report_error(ctl);
+        }
     }
 }
 
@@ -283,8 +296,8 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
         L.sp[kWave] = c0first ? ch.y : ch.x;
         L.top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
         L.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
-        if (__builtin_expect(both && L.sp >= sp_limit, 0)) {           // (`both`: popping the sentinel moves sp below col, which wraps)
-            if constexpr (SPILL > 0) stack_spill<SPILL>(L.sp, L.top, sp_limit, spill, WPG, ctl->host_err, &ctl->stats[7]);      // deeper than the LDS window: the oldest entries move out
+        if (both && L.sp >= sp_limit) {                                 // (`both`: popping the sentinel moves sp below col, which wraps)
+            if constexpr (SPILL > 0) stack_spill<SPILL>(L.sp, L.top, sp_limit, spill, WPG, &ctl->err, &ctl->stats[7]);      // deeper than the LDS window: the oldest entries move out
             else {                                                      // ... or k_bvh2_finish redoes this ray
                 deep_list[atomicAdd(&ctl->deep_count, 1)] = L.ray_id;
                 L.top = 0;
@@ -311,7 +324,7 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
         L.top = (ANY && found) ? 0 : (leave ? popped : L.top - 1);    // top - 1 == ~(j + 1)
         L.sp -= (leave && !(ANY && found)) ? kWave : 0;
     }
-    if constexpr (SPILL > 0) if (__builtin_expect(L.top >= kSpillMark, 0)) stack_reload<SPILL>(L.sp, L.top, sp_limit, spill, WPG);       // popped row 0 while entries are out: they come back
+    if constexpr (SPILL > 0) if (L.top >= kSpillMark) stack_reload<SPILL>(L.sp, L.top, sp_limit, spill, WPG);       // popped row 0 while entries are out: they come back
 }
 
 // A fresh ray: loads it, stores the miss record, empty stack (col[0] = the 0 that ends the traversal when popped).

@@ -154,7 +154,7 @@ __device__ __forceinline__ void stack_spill(lds_int*& sp, int& top, lds_int* lim
     static_assert(WINDOW > kSpillRows + 1, "something must stay in the window");
     lds_int* const col = window_base<WINDOW>(limit);
     const int mark = col[0], blocks = mark ? mark - kSpillMark : 0;
-    if (blocks >= kSpillBlocks) { *err = 1; top = 0; return; }        // more than the reference's 64 slots: the host reports it
+    if (blocks >= kSpillBlocks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); top = 0; return; }        // more than the reference's 64 slots: the host reports it
     if (events) atomicAdd(events, 1ull);
     int* g = spill_words(spill, waves_per_group) + blocks * kSpillRows * kWave;
 #pragma unroll 1
@@ -164,7 +164,9 @@ __device__ __forceinline__ void stack_spill(lds_int*& sp, int& top, lds_int* lim
     col[0] = kSpillMark + blocks + 1;
     sp -= kSpillRows * kWave;
 }
-// Called by a lane that popped row 0 while blocks are out (top >= kSpillMark): the newest block comes back, its newest entry is the new top.
+// Called at the end of a step by a lane that popped row 0 while blocks are out (its new top is the mark, >= kSpillMark): the newest block comes
+// back into rows 1..kSpillRows - 1, its newest entry is the new top.  (Measured beside the alternative -- testing the word UNDER the cursor at the
+// start of the step, off the dependency chain: 0.1857 against 0.1872 ms on the benchmark launch, profiles/r05_spill_experiment.txt.)
 template <int WINDOW>
 __device__ __forceinline__ void stack_reload(lds_int*& sp, int& top, lds_int* limit, int* __restrict__ spill, int waves_per_group) {
     lds_int* const col = window_base<WINDOW>(limit);

@@ -115,7 +115,7 @@ __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const
                     }
                 }
                 top = cur;
-                if (__builtin_expect(wp - kWave >= sp_limit && wp > sp + kWave, 0)) {      // grew beyond the LDS window: k_wide_finish redoes this ray
+                if (wp - kWave >= sp_limit && wp > sp + kWave) {              // grew beyond the LDS window: k_wide_finish redoes this ray
                     deep_list[atomicAdd(&ctl->deep_count, 1)] = ray_id;
                     top = 0;
                 }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kWave) void k_wide_finish(const char* __restrict__ 
     if (tickets && blockIdx.x == 0) for (int k = threadIdx.x; k < 4 * 64; k += kWave) tickets[k * 16] = 0;     // the persistent form's ticket counters, ready for the next launch
     const int count = ctl->deep_count;
     if (count > 0) {
-        DeepStack st{(lds_int*)stack_lds + threadIdx.x, ctl->host_err};
+        DeepStack st{(lds_int*)stack_lds + threadIdx.x, &ctl->err};
         for (int k = blockIdx.x * kWave + threadIdx.x; k < count; k += gridDim.x * kWave) {
             const int i = deep_list[k];
             const HitAcc hit = wide_ray_literal<ANY, N>(nodes, tris, load_ray(rays, i), st);
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kWave) void k_wide_finish(const char* __restrict__ 
     if (threadIdx.x == 0) {
         // (every workgroup has read deep_count before it counts itself done, so the last one may zero it; no deep rays -- the usual case --: workgroup 0 rewrites the zeros)
         const bool last = gridDim.x == 1 || (count == 0 ? blockIdx.x == 0 : atomicAdd(&ctl->finish_done, 1) == (int)gridDim.x - 1);
-        if (last) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; ctl->finish_done = 0; }
+        if (last) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; ctl->finish_done = 0; report_error(ctl); }
     }
 }
 

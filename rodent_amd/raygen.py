@@ -62,6 +62,22 @@ def scene_bounds(nodes4):
     return b[[0, 2, 4]].min(axis=1).astype(f32), b[[1, 3, 5]].max(axis=1).astype(f32)
 
 
+def scene_bounds2(nodes2):
+    """The same box from a BVH2 block (a .bvh without a BVH4 block: the generated scenes): union of the root's two child boxes."""
+    b = nodes2["bounds"][0].reshape(2, 6)
+    b = b[np.isfinite(b).all(axis=1)]
+    return b[:, [0, 2, 4]].min(axis=0).astype(f32), b[:, [1, 3, 5]].max(axis=0).astype(f32)
+
+
+def shadow_rays(light, rays, t, tmin=0.0, tmax=1.0):
+    """ray_gen's third mode (tools/ray_gen/ray_gen.cpp:60-85): from a point light towards the hit points of a previous pass -- org = light,
+    dir = (org + t * dir) - light, t = the .fbuf of that pass (the miss value where a ray hit nothing).  Traced any-hit with tmax just under 1
+    this is the suite's occlusion class (benchmarks/benchmark.py:36-41 "ao": -any, short tmax)."""
+    light = np.asarray(light, f32)
+    hit = rays["org"] + np.asarray(t, f32)[:, None] * rays["dir"]
+    return F.make_rays(np.broadcast_to(light, hit.shape), (hit - light).astype(f32), tmin, tmax)
+
+
 def random_rays(lo, hi, count, seed, tmin=0.0, tmax=1.0):
     """Segments between two uniform points of the box: org = p1, dir = p2 - p1 (ray_gen.cpp:97-103)."""
     lo = np.asarray(lo, f32); hi = np.asarray(hi, f32)

@@ -4,7 +4,10 @@ BASELINE.json's inputs (testing/sponza.bvh, sponza-primary.rays, sponza-random.r
 are absent from the reference checkout, so the workloads are:
   * "sponza"  -- used as-is if data/sponza.bvh + data/sponza-{primary,random}.rays exist;
   * "atrium"  -- seeded procedural Sponza-class scene (host/atrium.cpp), ~265 K triangles;
-  * "cornell" -- the reference's testing/cornell_box.obj (36 triangles).
+  * "cornell" -- the reference's testing/cornell_box.obj (36 triangles);
+  * "gallery", "crown", "plant" -- the other scene classes of the reference's benchmark suite (benchmarks/benchmark.py:16-21) as seeded
+    stand-ins (host/atrium.cpp at detail 4, host/stress_scenes.cpp): 4.2 M-triangle architecture, a 4.2 M-triangle organic surface,
+    2.1 M long thin triangles; traversal only (a .bvh with a BVH2 block, built where it is needed; "<scene>/<detail>" = a smaller build).
 Ray dumps follow SURVEY.md 8(d): 1024x1024 primary rays (fov 60, unnormalised
 directions; README.md:34-37 uses --tmax 5000) and 1 Mi random segments (--tmax 1), seed 42.
 """
@@ -24,7 +27,13 @@ GOLDEN = ROOT / "tests" / "golden"
 CAMERAS = {
     "atrium": ((-1150.0, 350.0, 30.0), (1.0, 0.12, -0.05), (0.0, 1.0, 0.0), 60.0),
     "cornell": ((0.0, 1.0, 2.7), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 60.0),
+    "gallery": ((-1150.0, 350.0, 30.0), (1.0, 0.12, -0.05), (0.0, 1.0, 0.0), 60.0),
+    "crown": ((150.0, 420.0, 1500.0), (-0.08, -0.22, -1.0), (0.0, 1.0, 0.0), 50.0),
+    "plant": ((-1900.0, 760.0, -1150.0), (1.0, -0.18, 0.62), (0.0, 1.0, 0.0), 65.0),
 }
+# point lights of the "ao" ray class (ray_gen shadow, tools/ray_gen/ray_gen.cpp:60-85): rays from the light to the camera rays' hit points
+LIGHTS = {"atrium": (0.0, 1450.0, 0.0), "gallery": (0.0, 1450.0, 0.0), "crown": (600.0, 1500.0, 900.0), "plant": (0.0, 1350.0, 0.0), "cornell": (0.0, 1.9, 0.0)}
+GENERATED = {"gallery": 4, "crown": 4, "plant": 4}          # scene_gen kinds built straight to a .bvh, with their default detail
 PRIMARY_TMAX, RANDOM_TMAX = 5000.0, 1.0
 
 
@@ -41,6 +50,13 @@ def _run(cmd):
 
 def scene_bvh(scene: str) -> Path:
     DATA.mkdir(parents=True, exist_ok=True)
+    kind, _, detail = scene.partition("/")
+    if kind in GENERATED:                                   # "plant", "plant/1": BVH2 block only, no OBJ round trip
+        detail = int(detail) if detail else GENERATED[kind]
+        out = DATA / f"{kind}-d{detail}.bvh"
+        if not out.exists():
+            _run([_tool("scene_gen"), kind, "--bvh", out, 1, detail])
+        return out
     out = DATA / f"{scene}.bvh"
     if out.exists():
         return out

