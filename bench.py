@@ -17,13 +17,14 @@ N > 1 = no data-path collective: the BVH is replicated.  BOTH partitions are tim
         trace of the whole set;
         weak (`extra.weak_scaling`): rank r traces sub-pixel sample r of N through the same 1024 x 1024 pixel grid (primary) /
         seed 42 + r (random): 1 Mi rays per GPU per step.  `--weak` makes this one `value` instead.
-roofline: the bound that binds this kernel: the larger of the VALU issue rate and the node-fetch rate of the
-        vector-memory pipeline (TA -> L1 -> L2), both against peaks measured on this chip by the microbenchmarks under
-        scripts/ubench (profiles/rNN_calibration.json).  SURVEY 8(d)'s algorithmic-HBM-bytes figure is kept as
-        `roofline.hbm_algorithmic` (it exceeds the HBM peak: the 22 MB BVH is served by L1 / L2 / MALL -- a count of cache
-        hits), the measured L2-fabric traffic as `roofline.l2_fabric_traffic` / `roofline.traffic`.  Counter-derived figures come from
-        profiles committed under profiles/ and are only quoted while the profile's source hash matches the kernels'
-        sources (rodent_amd/provenance.py); a stale profile is reported as such, never used.
+roofline: ONE bound, stated once: VALU issue.  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU of the committed counter
+        pass of THIS kernel on THESE sources) / live kernel time / SIMDs; peak = the guide's 2 cycles per wave64 VALU instruction at the clock measured
+        in the calibration loop (MI355X_MICROARCH.md: 1 162 wave-instructions per us per SIMD at 2 323 MHz); frac = achieved / peak.  Beside it, each
+        one division away from a file under profiles/: `frac_of_measured_loop_mix_ceiling` (the same rate against the microbenchmarked ceiling of the
+        loop's own instruction classes), `lane_utilisation`, `hbm_measured_frac` (= `traffic`, the FETCH_SIZE x 2 + WRITE_SIZE bytes of separate --pmc
+        passes, / kernel time / 8 TB/s) and `hbm_algorithmic_frac` (SURVEY 8(d)'s bytes per ray x rays / kernel time / 8 TB/s: > 1, because the 22 MB BVH
+        is served by LDS / L1 / L2 / MALL -- a count of cache hits, labelled so).  Counter-derived figures are only quoted while the profile's source
+        hash matches the kernels' sources (rodent_amd/provenance.py); a stale profile is reported as such and the live node-fetch bound stands in.
 render  (`extra.render`): BASELINE configs 4 and 5 through the renderer ABI -- Cornell 1920 x 1080, 64 spp, path length 4 and the
         config-5 scene at 3840 x 2160, 256 spp, path length 8 (one GPU: the whole frame; N GPUs: row bands + one film gather
         to rank 0), streaming and megakernel mappings, Msamples/s = spp * w * h / frame seconds / 1e6 (driver.cpp:300).
@@ -155,14 +156,14 @@ def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms, lds_steps_pe
     if "SQ_INSTS_VALU" in c:
         per_simd_us = c["SQ_INSTS_VALU"] / (kernel_ms * 1e3) / cal["simds"]
         lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
-        out["valu_issue"] = {"bound": "VALU issue", "unit": "wave-instructions/us/SIMD", "achieved": round(per_simd_us, 1), "peak": cal["valu_issue_peak"],
-                             "frac": round(per_simd_us / cal["valu_issue_peak"], 4), "valu_instructions_per_launch": int(c["SQ_INSTS_VALU"]),
-                             "lane_utilisation": round(lane_util, 4), "useful_lane_frac": round(per_simd_us / cal["valu_issue_peak"] * lane_util, 4),
-                             # round 4 (scripts/ubench/valu_rate.hip): the same rate against the ceiling of the loop's own instruction classes and against the guide's 2-cycle rate
-                             "frac_of_loop_mix_ceiling": None if "valu_issue_peak_loop_mix_r04" not in cal else round(per_simd_us / cal["valu_issue_peak_loop_mix_r04"], 4),
-                             "frac_of_guide_2_cycle_rate": None if "valu_issue_guide_2_cycle_rate" not in cal else round(per_simd_us / cal["valu_issue_guide_2_cycle_rate"], 4),
-                             "ceilings": "peak = the highest mix measured on this chip (round 2: 771); loop mix of round 4's valu_rate: 645; the guide's 2 cycles per wave64 instruction (1162 at the measured clock) "
-                                         "holds for mul / add / fma with <= 2 VGPR sources only -- min / max / cndmask / compares / 3-source fma issue every ~4 cycles (profiles/r04_ubench_valu_rate.txt)",
+        peak = cal["valu_issue_guide_2_cycle_rate"]           # MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD, at the clock measured in the calibration loop
+        out["valu_issue"] = {"bound": "VALU issue", "unit": "wave-instructions/us/SIMD", "achieved": round(per_simd_us, 1), "peak": peak,
+                             "frac": round(per_simd_us / peak, 4), "valu_instructions_per_launch": int(c["SQ_INSTS_VALU"]),
+                             "lane_utilisation": round(lane_util, 4), "useful_lane_frac": round(per_simd_us / peak * lane_util, 4),
+                             # scripts/ubench/valu_rate.hip: the same rate against the measured ceiling of the loop's own instruction classes
+                             "frac_of_measured_loop_mix_ceiling": round(per_simd_us / cal["valu_issue_peak_loop_mix_r04"], 4), "measured_loop_mix_ceiling": cal["valu_issue_peak_loop_mix_r04"],
+                             "ceilings": "peak = the guide's 2 cycles per wave64 instruction at the clock measured in the calibration loop (2 323 MHz -> 1 162); it holds for mul / add / fma with <= 2 VGPR "
+                                         "sources only -- min / max / cndmask / compares / 3-source fma issue every ~4 cycles, so the loop's own mix tops out at 645 (profiles/r04_ubench_valu_rate.txt)",
                              "peak_source": cal_name, "counter_source": c.get("source")}
     if "TA_TA_BUSY_sum" in c and "GRBM_GUI_ACTIVE" in c:
         out["ta_busy_frac_profiled"] = round(c["TA_TA_BUSY_sum"] / cal["cus"] / (c["GRBM_GUI_ACTIVE"] / 8.0), 4)     # mean over the 256 TAs / cycles of one XCD
@@ -179,13 +180,13 @@ def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms, lds_steps_pe
 
 
 def pick_bound(binding):
-    """The top-level roofline: whichever of the two throughput bounds of the kernel is closer to its peak."""
-    best = None
+    """The top-level roofline: VALU issue -- whenever the committed counter pass belongs to the running sources; the live
+    node-fetch bound stands in (and says so) while it does not."""
     for key in ("valu_issue", "vmem_node_fetch"):
         b = (binding or {}).get(key)
-        if b and (best is None or b["frac"] > best[1]["frac"]):
-            best = (key, b)
-    return best
+        if b:
+            return key, b
+    return None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -659,7 +660,15 @@ def main():
     if render is not None:
         out["extra"]["render"] = render
     # what the driver's record keeps is `config`, `roofline` and `cpu_baseline`: the other headline figures as short scalars
-    out["config"]["random_Mrays_s"] = round(main_part["value_rnd"], 1)
+    out["config"]["random_Mrays_s"] = round(main_part["value_rnd"], 1)          # stateless: the in-kernel choice alone (the ray-kind hint is off by default)
+    if hint_rec:
+        out["config"]["random_with_kind_hint_Mrays_s"] = hint_rec["Mrays_s"]
+    if world > 1:
+        # what one GPU predicts for N (profiles/r04_range_costs.txt, r04_band_costs.txt: every rank's share timed alone): ONE 1 Mi-ray set does not shard its tail
+        out["config"]["predicted_scaling_x"] = {"strong_1Mi_primary_contiguous_ranges": {"2": 1.31, "4": 1.78, "8": 2.21}, "strong_1Mi_random": {"2": 1.27, "4": 1.92, "8": 2.19},
+                                                "cfg5_frame_interleaved_16_row_tiles": {"2": 1.99, "4": 3.99, "8": 7.94}, "weak": "1 Mi rays per GPU: ~N",
+                                                "source": "profiles/r04_range_costs.txt, profiles/r04_band_costs.txt"}
+        out["config"]["world_size_seen_by_the_collective_backend"] = dist.get_world_size()
     if big:
         out["config"]["primary_16Mi_Mrays_s"] = big.get("Mrays_s")
     if big_random:
@@ -694,17 +703,23 @@ def main():
         roof = {"bound": top[0], "achieved": top[1]["achieved"], "peak": top[1]["peak"], "unit": top[1]["unit"], "frac": top[1]["frac"]} if top else \
                {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "note": "no calibration under profiles/"}
         compulsory = 48 * n + nodes.nbytes + tris.nbytes
+        vi = (binding or {}).get("valu_issue") or {}
+        hbm_alg = achieved / HBM_PEAK_GBPS
         roof.update({
             "traffic": None if traffic is None else traffic["bytes"],
             "kernel": kname, "kernel_ms": round(k_mean, 5),
-            "what": "the larger of the kernel's two throughput bounds (VALU issue, node fetches through the vector-memory pipeline), peaks measured on this chip; "
-                    "at 1 Mi rays per launch neither is near 1: the launch is a tail (DESIGN.md 3.1.1), the same kernel at 16 Mi rays is in extra.primary_16Mi_rays_per_launch",
-            "hbm_algorithmic": {"bound": "hbm", "GBps": round(achieved, 2), "peak_GBps": HBM_PEAK_GBPS, "frac": round(achieved / HBM_PEAK_GBPS, 5), "bytes_per_ray": round(bytes_per_ray, 2),
+            "frac_of_measured_loop_mix_ceiling": vi.get("frac_of_measured_loop_mix_ceiling"), "lane_utilisation": vi.get("lane_utilisation"),
+            "hbm_measured_frac": None if traffic is None else round(traffic["bytes"] / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "hbm_algorithmic_frac": round(hbm_alg, 4),
+            "hbm_algorithmic_frac_is": "cache-served, not a fraction: SURVEY 8(d)'s bytes per ray count every node / triangle visit although the BVH is served by LDS / L1 / L2 / MALL (> 1 is expected)",
+            "what": "VALU issue: wave-instructions per us per SIMD of this kernel (SQ_INSTS_VALU of the committed counter pass / live kernel time / SIMDs) against the guide's 2-cycle rate at the "
+                    "measured clock.  At 1 Mi rays per launch the launch is a tail (DESIGN.md 3.1.1); the same kernel at 16 Mi rays is in extra.primary_16Mi_rays_per_launch"
+                    + ("" if top and top[0] == "valu_issue" else "  [the committed counter pass does not belong to the running sources: the live node-fetch bound stands in]"),
+            "hbm_algorithmic": {"bound": "hbm", "GBps": round(achieved, 2), "peak_GBps": HBM_PEAK_GBPS, "frac": round(hbm_alg, 5), "bytes_per_ray": round(bytes_per_ray, 2),
                                 "visits_per_ray": {"inner": round(st["inner_per_ray"], 3), "prim": round(st["prims_per_ray"], 3)},
-                                "note": "SURVEY 8(d): 32 + 16 + 64 N_inner + 48 N_tri bytes per ray x rays / kernel time.  Every node / triangle visit is counted although the BVH "
-                                        "is served by L1 / L2 / MALL: a count of cache hits, not a fraction of anything (> 1 is expected)"},
-            # (rounds 2-3 called this hbm_measured: it is the traffic between the L2s and the fabric -- Infinity-Cache hits included, MI355X_MICROARCH.md -- an upper bound on DRAM bytes;
-            #  FETCH_SIZE x 2 = 128-byte line fills, calibrated on scattered 64-byte node fetches as well: profiles/r04_fetch_size_calibration.txt)
+                                "note": "SURVEY 8(d): 32 + 16 + 64 N_inner + 48 N_tri bytes per ray x rays / kernel time: a count of cache hits, not a fraction of anything"},
+            # FETCH_SIZE x 2 = 128-byte line fills, calibrated on scattered 64-byte node fetches as well (profiles/r04_fetch_size_calibration.txt): bytes between the L2s and the fabric,
+            # Infinity-Cache hits included -- an upper bound on DRAM bytes
             "l2_fabric_traffic": {"not_quoted": traffic_why} if traffic is None else
                             {"what": "FETCH_SIZE x 2 + WRITE_SIZE of separate --pmc passes: bytes between the L2s and the fabric, Infinity-Cache hits included (an upper bound on HBM bytes)",
                              "bytes_per_launch": traffic["bytes"], "GBps": round(traffic["bytes"] / (k_mean * 1e-3) / 1e9, 1), "frac": round(traffic["bytes"] / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -714,7 +729,8 @@ def main():
             "random": {"kernel": kname_r, "kernel_ms": round(kr_mean, 5), "visits_per_ray": {"inner": round(st_r["inner_per_ray"], 3), "prim": round(st_r["prims_per_ray"], 3)},
                        "bound": (pick_bound(binding_r) or [None])[0], "frac": (pick_bound(binding_r) or [None, {"frac": None}])[1]["frac"], "binding": binding_r}})
         out["roofline"] = roof
-        out["config"]["hbm_algorithmic_frac"] = roof["hbm_algorithmic"]["frac"]
+        out["config"]["hbm_measured_frac"] = roof["hbm_measured_frac"]
+        out["config"]["hbm_algorithmic_frac_cache_served"] = roof["hbm_algorithmic_frac"]
         # parity on every ray of both sets (bit-exact for the order-preserving kernels)
         out["extra"]["all_rays_bit_exact_vs_oracle"] = {"primary": bool(hits.tobytes() == ref_hits.tobytes()), "random": bool(hits_rnd.tobytes() == ref_rnd.tobytes())}
     if world == 1 and not args.no_cpu_baseline:

@@ -65,7 +65,8 @@ def _run(cmd, **kw):
 
 
 def _headers():
-    return list((ROOT / "include").glob("*.h")) + list(HOST.glob("*.h")) + list(CSRC.glob("*.h")) + list(CSRC.glob("*.hpp"))
+    return (list((ROOT / "include").glob("*.h")) + list(HOST.glob("*.h")) + list(CSRC.glob("*.h")) + list(CSRC.glob("*.hpp"))
+            + list((CSRC / "lab").glob("*.h")) + list((CSRC / "lab").glob("*.inc")))          # csrc/lab: compiled into the lab build only
 
 
 def _hip_lib_inputs():

@@ -25,9 +25,9 @@
 //    -ffp-contract=off so results are bit-identical to the CPU parity oracle.
 //
 // This file: shared device helpers, the BVH2 kernels (k_bvh2_top_persist, k_bvh2_single, k_bvh2_phase, the ray sort) and
-// their follow-up kernels, the host side and the C ABI.  traversal_wide.h holds the BVH4 / BVH8 + Tri4 kernels (same schedule).  The kernels that
-// were measured along the way and lost (traversal_variants.h) are compiled only into the lab build
-// (-DRODENT_HIP_LAB, librodent_hip_lab.so): the product library ships the default mappings only.
+// their follow-up kernels, the host side and the C ABI.  traversal_top.h holds the default mapping's kernels, traversal_wide.h the BVH4 / BVH8 + Tri4
+// kernels (same schedule).  Everything that was measured along the way and lost lives under lab/ (kernels, launchers, ~120 rows of the variant
+// table) and is compiled only into the lab build (-DRODENT_HIP_LAB, librodent_hip_lab.so): the product library ships the default mappings only.
 // Kernel variants ("mappings") are selected at run time; see kVariants below.
 #include <hip/hip_runtime.h>
 
@@ -802,36 +802,6 @@ template <bool ANY, int LDS_N, int XCD, bool TR = false, int PRIO = 0> void L_si
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 
-#ifdef RODENT_HIP_LAB
-// "top*": top-of-tree image per launch, then k_bvh2_top (SORTED: through the "sorted" mapping's permutation)
-template <bool ANY, int LDS_N, int TOPN, int WAVES, bool SORTED = false, bool KEEP = false> void L_top(LAUNCH_ARGS) {
-    ensure_deep_list(s, n);
-    if (!s.top_image) {
-        std::lock_guard<std::mutex> lock(g_mutex);
-        if (!s.top_image) HIP_CHECK(hipMalloc(&s.top_image, kMaxTopNodes * sizeof(Node2)));
-    }
-    static_assert(TOPN <= kMaxTopNodes, "image buffer");
-    // KEEP (measurement only): the image is reused while the array pointer and the image size stay the same -- shows what the
-    // per-launch rebuild costs
-    if (!KEEP || s.top_image_nodes != nodes || s.top_image_n != TOPN) {
-        hipLaunchKernelGGL((k_bvh2_top_image<TOPN>), dim3(1), dim3(kWave), 0, stream, nodes, s.top_image);
-        s.top_image_nodes = nodes; s.top_image_n = TOPN;
-    }
-    const int* perm = nullptr;
-    if (SORTED) {
-        ensure_sort_buffers(s, n);
-        const int blocks = (n + kSortBlockRays - 1) / kSortBlockRays;
-        hipLaunchKernelGGL(k_raysort_count, dim3(blocks), dim3(kSortThreads), 0, stream, nodes, rays, n, s.sort_keys, s.sort_totals);
-        hipLaunchKernelGGL(k_raysort_scan, dim3(1), dim3(kSortCells), 0, stream, s.sort_totals, s.sort_totals + kSortCells);
-        hipLaunchKernelGGL(k_raysort_scatter, dim3(blocks), dim3(kSortThreads), 0, stream, s.sort_keys, n, s.sort_totals + kSortCells, s.sort_perm);
-        perm = s.sort_perm;
-    }
-    const int groups = (blocks_for(n) + WAVES - 1) / WAVES;
-    hipLaunchKernelGGL((k_bvh2_top<ANY, LDS_N, 32, TOPN, WAVES>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, perm,
-                       (const int4*)s.top_image);
-    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
-}
-#endif
 
 template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, int OCC, bool TRACE = false, int PRIO = 0, int FUSED = 0, bool LAZY = false> void launch_top_persist(LAUNCH_ARGS, int max_id) {
     ensure_deep_list(s, n);
@@ -967,32 +937,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = fal
     hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 
-#ifdef RODENT_HIP_LAB
-template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL> void L_top_refill_wpe(LAUNCH_ARGS) {
-    ensure_deep_list(s, n);
-    ensure_top_buffers(s);
-    s.top_image_nodes = nullptr;
-    ensure_spill(s);
-    const int groups = spill_checked(((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);
-    hipLaunchKernelGGL((k_bvh2_top_refill_wpe<ANY, LDS_N, TOPN, WAVES, REFILL>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                       (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes), s.spill);
-    hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
-}
-#endif
 
-#ifdef RODENT_HIP_LAB
-// "steal" (lab): whole chunks with work stealing inside the wave (k_bvh2_top_steal); small launches take the one-chunk kernel like the default
-template <bool ANY, int LDS_N, int TOPN, int WAVES, int I0, int EVERY> void L_top_steal(LAUNCH_ARGS) {
-    const int max_id = n < g_top_min_rays ? 0 : mapped_node_ids(nodes);
-    if (max_id == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }
-    ensure_deep_list(s, n);
-    ensure_top_buffers(s);
-    s.top_image_nodes = nullptr; s.order_rays = 0;
-    const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;
-    hipLaunchKernelGGL((k_bvh2_top_steal<ANY, LDS_N, TOPN, WAVES, I0, EVERY>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                       s.top_image, s.tickets, max_id);
-}
-#endif
 
 // Phased traversal: caps of the capped phases (the last, uncapped phase follows).  Launches too small to fill the chip
 // once take the single kernel.
@@ -1031,7 +976,9 @@ template <bool ANY, int LDS_N, int CAPS, int LAST_RAYS = kWave> void L_phased(LA
 #include "traversal_wide.h"          // BVH4 / BVH8 + Tri4: k_wide_single, k_wide_top_persist, k_wide_finish, L_wide_single, L_wide_top
 int wide_top_min_rays() { return g_top_min_rays; }
 #ifdef RODENT_HIP_LAB
-#include "traversal_variants.h"      // lab build only: the kernels that were measured and lost, instrumented builds
+#include "lab/top_kernels.h"         // lab build only: superseded forms of the LDS-image kernels
+#include "lab/top_launchers.h"
+#include "lab/traversal_variants.h"  // lab build only: the kernels that were measured and lost, instrumented builds
 #endif
 
 using Launch2 = void (*)(LAUNCH_ARGS);
@@ -1054,128 +1001,7 @@ const Variant2 kVariants2[] = {
     //                                                                    LDS_N TOPN WAVES REFILL (idle lanes that trigger a refill)
     K2("refill",             "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 32),   // the default's persistent workgroups, but a wave replaces finished rays instead of waiting for the last ray of a chunk (for incoherent ray sets)
 #ifdef RODENT_HIP_LAB
-    // LDS-staged top of the tree, what was swept (profiles/r02_sweep_top_*.log): image size x workgroup shape, one chunk per
-    // workgroup wave (L_top) or persistent (L_top_persist), ticket prefetch, waves per CU, lane refill
-    //                                                      LDS_N TOPN WAVES [SORTED KEEP]
-    K2("top15",              "k_bvh2_top",           L_top, 15, 15, 1),
-    K2("top31w2",            "k_bvh2_top",           L_top, 15, 31, 2),
-    K2("top63w4",            "k_bvh2_top",           L_top, 15, 63, 4),
-    K2("top127w8",           "k_bvh2_top",           L_top, 15, 127, 8),
-    K2("top255w16",          "k_bvh2_top",           L_top, 15, 255, 16),
-    K2("top23",              "k_bvh2_top",           L_top, 13, 23, 1),
-    K2("top15-keep",         "k_bvh2_top",           L_top, 15, 15, 1, false, true),
-    K2("top127w8-keep",      "k_bvh2_top",           L_top, 15, 127, 8, false, true),
-    K2("sorted-top63w4",     "k_bvh2_top",           L_top, 15, 63, 4, true),
-    //                                                                     LDS_N TOPN WAVES PREFETCH [SORTED waves per CU]
-    K2("top255p16-pf",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, true),
-    K2("top127p8",           "k_bvh2_top_persist",   L_top_persist, 15, 127, 8, false),
-    K2("top63p4",            "k_bvh2_top_persist",   L_top_persist, 15, 63, 4, false),
-    K2("top15p1",            "k_bvh2_top_persist",   L_top_persist, 15, 15, 1, false),
-    K2("sorted-top255p16",   "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, true),
-    K2("top383p16-l13",      "k_bvh2_top_persist",   L_top_persist, 13, 383, 16, false),                // 13-entry stack windows: 128 more records
-    K2("top511p16-l11",      "k_bvh2_top_persist",   L_top_persist, 11, 511, 16, false),                // 11-entry windows: 256 more
-    K2("top639p16-l9",       "k_bvh2_top_persist",   L_top_persist, 9, 639, 16, false),
-    K2("top255p16-o16",      "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 16),
-    K2("top1023p16-o16",     "k_bvh2_top_persist",   L_top_persist, 15, 1023, 16, false, false, 16),
-    K2("top255p8-o24",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 8, false, false, 24),
-    K2("top63p4-o28",        "k_bvh2_top_persist",   L_top_persist, 15, 63, 4, false, false, 28),
-    //                                                                    LDS_N TOPN WAVES REFILL (idle lanes that trigger a refill)
-    K2("top-fused",          "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 1),   // the last workgroup does the follow-up kernel's work (every workgroup fences)
-    K2("top-one",            "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 2),   // the same, fences on the rare paths only (= the default from 576 Ki rays on)
-    K2("top-two",            "k_bvh2_top_persist",   L_chunks, 15, 255, 16, false, 0),                           // whole chunks only, with a follow-up kernel (round 2's default)
-    K2("auto-chunks-only",   "k_bvh2_top_auto",      L_default, 15, 255, 16, 32, 1),
-    K2("auto-refill-only",   "k_bvh2_top_auto",      L_default, 15, 255, 16, 32, 2),
-    K2("refill-fence",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 32, false, true),
-    K2("auto-refill-only-two", "k_bvh2_top_auto",    L_default, 15, 255, 16, 32, 2, false),
-    K2("refill-wpe",         "k_bvh2_top_refill_wpe", L_top_refill_wpe, 15, 255, 16, 32),
-    K2("top-chunks",         "k_bvh2_top_persist",   L_chunks, 15, 255, 16, false, 2),                           // whole chunks only, the launch finishes itself (round 3's default)
-    //                                                                     LDS_N TOPN WAVES HOT_ITER HOT_LANES
-    K2("top-partner-48-24",  "k_bvh2_top_partner",   L_top_partner, 15, 255, 16, 48, 24),   // stateless order attempt: second-generation chunks = vertical partners of the first generation, partners of chunks that look expensive first
-    K2("top-partner-32-40",  "k_bvh2_top_partner",   L_top_partner, 15, 255, 16, 32, 40),
-    K2("top-partner-64-16",  "k_bvh2_top_partner",   L_top_partner, 15, 255, 16, 64, 16),
-    K2("top-partner-999-64", "k_bvh2_top_partner",   L_top_partner, 15, 255, 16, 999, 64),  // the paired ticket map alone (nothing ever hot): what the even / odd row order is worth
-    K2("top-lazy",           "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 0, true),   // miss records stored at chunk end
-    K2("top-lazy-one",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 0, 2, true),
-    K2("top-userperm-lazy-one", "k_bvh2_top_persist", L_top_persist, 15, 255, 16, false, false, 32, false, -1, 2, true),
-    K2("top-userperm",       "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, -1),    // lane j traces ray perm[j] of a caller-supplied permutation (scheduling experiments)
-    K2("top-double",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, -2, 2),   // two image levels per iteration (a lane whose next node is in LDS visits it at once)
-    K2("top-prio64",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 64),    // s_setprio 3 once a chunk has run 64 / 96 / 128 iterations
-    K2("top-prio96",         "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 96),
-    K2("top-prio128",        "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, false, 128),
-    // work stealing inside the wave (k_bvh2_top_steal; modelled at 1.2 - 1.5 x, measured -5 ... -12 %: profiles/r04_sweep_steal.log).  NOT the reference's visit order.
-    //                                                                   LDS_N TOPN WAVES I0 EVERY
-    K2("steal",              "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 24, 4),
-    K2("steal-16-2",         "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 16, 2),
-    K2("steal-8-2",          "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 8, 2),
-    K2("steal-32-8",         "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 32, 8),
-    K2("steal-24-2",         "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 24, 2),
-    K2("steal-0-1",          "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 0, 1),
-    K2("steal-never",        "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 1048576, 1),   // what the shared tmax and the loop form cost without any stealing
-    K2("steal-48-16",        "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 48, 16),
-    K2("steal-64-8",         "k_bvh2_top_steal",     L_top_steal, 14, 255, 16, 64, 8),
-    K2("top255r16-48",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 48),
-    K2("top-adaptive-32",    "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 32, true),     // refill unless the rays a draw started share an origin (then: whole chunks)
-    K2("top-adaptive-48",    "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 48, true),
-    K2("top255r16-64",       "k_bvh2_top_refill",    L_top_refill, 15, 255, 16, 64),           // whole chunks through the refill kernel: what its loop costs
-    // what was swept on the way (profiles/r02_sweep_phased*.log, r02_sweep_prio.log): other phase caps, fewer rays per wave in
-    // the last phase, issue priorities by wave age / dispatch round
-    K2("phased-40-24",       "k_bvh2_phase",         L_phased, 16, 0),
-    K2("phased-32-24",       "k_bvh2_phase",         L_phased, 16, 1),
-    K2("phased-32",          "k_bvh2_phase",         L_phased, 16, 3),
-    K2("phased-48",          "k_bvh2_phase",         L_phased, 16, 4),
-    K2("phased-48-32",       "k_bvh2_phase",         L_phased, 16, 5),
-    K2("phased-32-32-32",    "k_bvh2_phase",         L_phased, 16, 6),
-    K2("phased-24-24-24",    "k_bvh2_phase",         L_phased, 16, 7),
-    K2("phased-24-24",       "k_bvh2_phase",         L_phased, 16, 8),
-    K2("phased-64-32",       "k_bvh2_phase",         L_phased, 16, 9),
-    K2("phased-40-24-r32",   "k_bvh2_phase",         L_phased, 16, 0, 32),
-    K2("phased-40-24-r16",   "k_bvh2_phase",         L_phased, 16, 0, 16),
-    K2("phased-40-r32",      "k_bvh2_phase",         L_phased, 16, 2, 32),
-    K2("phased-40-r16",      "k_bvh2_phase",         L_phased, 16, 2, 16),
-    K2("phased-48-r16",      "k_bvh2_phase",         L_phased, 16, 4, 16),
-    K2("fast-prio-age",      "k_bvh2_single",        L_single, 16, 32, false, 1),
-    K2("fast-prio-young",    "k_bvh2_single",        L_single, 16, 32, false, 2),
-    K2("fast-prio-both",     "k_bvh2_single",        L_single, 16, 32, false, 3),
-    K2("fast-tri2-48",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 2 * 1024 + 48),    // triangle turns every K-th iteration until iteration SWITCH
-    K2("fast-tri4-48",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 4 * 1024 + 48),
-    K2("fast-tri4-32",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 4 * 1024 + 32),
-    K2("fast-tri4-64",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 4 * 1024 + 64),
-    K2("fast-tri4-999",      "k_bvh2_single",        L_single, 16, 32, false, 256 + 4 * 1024 + 999),
-    K2("fast-tri2-999",      "k_bvh2_single",        L_single, 16, 32, false, 256 + 2 * 1024 + 999),
-    K2("fast-tri8-48",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 8 * 1024 + 48),
-    K2("fast-tri3-40",       "k_bvh2_single",        L_single, 16, 32, false, 256 + 3 * 1024 + 40),
-    K2("fast-pf0",           "k_bvh2_single",        L_single, 16, 32, false, 16),     // child prefetch from iteration 0 / 48 / 80 / 112 on
-    K2("fast-pf48",          "k_bvh2_single",        L_single, 16, 32, false, 64),
-    K2("fast-pf80",          "k_bvh2_single",        L_single, 16, 32, false, 96),
-    K2("fast-pf112",         "k_bvh2_single",        L_single, 16, 32, false, 128),
-    K2("lane",               "k_bvh2_lane",          L_lane, 24),                      // literal reference mapping
-    K2("ww",                 "k_bvh2_ww",            L_ww, 24, 8),                     // while-while, LDS+scratch stack
-    //                                                      LDS_N NODE_EXIT PERSIST REFILL_IDLE CHUNK STATS XCD_GROUP
-    K2("fast-ww",            "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32),   // while-while schedule (the default before the single-step loop)
-    K2("fast-exit0",         "k_bvh2_fast",          L_fast, 16, 0,  false, 64, 64, false, 32),
-    K2("fast-exit16",        "k_bvh2_fast",          L_fast, 16, 16, false, 64, 64, false, 32),
-    K2("fast-lds24",         "k_bvh2_fast",          L_fast, 24, 8,  false, 64, 64, false, 32),
-    K2("fast-persistent",    "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 128),
-    K2("fast-ww-noxcd",      "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64),
-    //                                                       LDS_N PERSIST REFILL_IDLE CHUNK TRI_BIAS(x/4) PERMUTE
-    K2("sched",              "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false),
-    K2("sched-persistent",   "k_bvh2_sched",         L_sched, 16, true,  16, 64,  8, false),
-    K2("sched-perm",         "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, true),
-    // instrumented builds (phase / lane-utilisation counters, per-wave timeline); not for timing
-    K2("stats-fast",         "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64,  true),
-    K2("stats-sched",        "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false, true),
-    K2("stats-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, true),
-    K2("trace-sched",        "k_bvh2_sched",         L_sched, 16, false, 64, 64,  4, false, false, true),
-    K2("trace-sched-persistent", "k_bvh2_sched",     L_sched, 16, true,  16, 64,  8, false, false, true),
-    K2("trace-fast",         "k_bvh2_single",        L_single, 16, 32, true),
-    K2("trace-top",          "k_bvh2_top_persist",   L_top_persist, 15, 255, 16, false, false, 32, true),
-    K2("trace-fast-ww",      "k_bvh2_fast",          L_fast, 16, 8,  false, 64, 64, false, 32, true),
-    //   static-stride persistent waves: one wave per resident slot, tickets b, b + grid, ... (no atomics)
-    K2("fast-static-r64",    "k_bvh2_fast",          L_fast, 16, 8,  true,  64, 64, false, 32, false, true),
-    K2("fast-static-r32",    "k_bvh2_fast",          L_fast, 16, 8,  true,  32, 64, false, 32, false, true),
-    K2("fast-static-r16",    "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 64, false, 32, false, true),
-    K2("fast-static-r8",     "k_bvh2_fast",          L_fast, 16, 8,  true,  8,  64, false, 32, false, true),
-    K2("trace-fast-static",  "k_bvh2_fast",          L_fast, 16, 8,  true,  16, 64, false, 32, true,  true),
+#include "lab/variant_rows_bvh2.inc"      // ~120 rows: everything that was swept on the way
 #endif
 };
 constexpr int kNumVariants2 = sizeof(kVariants2) / sizeof(kVariants2[0]);
@@ -1192,7 +1018,7 @@ const VariantW kVariants4[] = {
     KW("single",             "k_wide_single",        L_wide_single, 4, 16, 32),        // one 64-ray chunk per workgroup, every node from memory (default of round 2)
     KW("single-noxcd",       "k_wide_single",        L_wide_single, 4, 16, 0),
 #ifdef RODENT_HIP_LAB
-    KW("lane",               "k_wide_lane",          L_wide_lane, 4, 16),              // literal reference mapping
+#include "lab/variant_rows_wide4.inc"
 #endif
 };
 const VariantW kVariants8[] = {
@@ -1200,7 +1026,7 @@ const VariantW kVariants8[] = {
     KW("single",             "k_wide_single",        L_wide_single, 8, 24, 32),
     KW("single-noxcd",       "k_wide_single",        L_wide_single, 8, 24, 0),
 #ifdef RODENT_HIP_LAB
-    KW("lane",               "k_wide_lane",          L_wide_lane, 8, 24),
+#include "lab/variant_rows_wide8.inc"
 #endif
 };
 constexpr int kNumVariants4 = sizeof(kVariants4) / sizeof(kVariants4[0]);

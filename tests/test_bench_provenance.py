@@ -57,11 +57,24 @@ def test_counters_are_quoted_only_from_a_profile_of_these_sources_and_this_kerne
     assert bench.measured_traffic(kernel)[0] is None
 
 
-def test_the_top_level_roofline_is_the_larger_throughput_bound(bench):
-    b = {"vmem_node_fetch": {"frac": 0.30, "achieved": 1, "peak": 2, "unit": "fetches/ns"}, "valu_issue": {"frac": 0.54, "achieved": 3, "peak": 4, "unit": "i"}, "lds_fetch": {"frac": 0.9}}
+def test_the_top_level_roofline_is_valu_issue_against_the_guides_rate(bench, tmp_path):
+    """ONE roofline: VALU issue against the guide's 2-cycle rate at the measured clock; the measured loop-mix ceiling and the lane
+    utilisation ride along; the round-2 figure 771 is gone from the calibration bench.py reads.  The live node-fetch bound stands in only while the
+    committed counter pass does not belong to the running sources."""
+    from rodent_amd import provenance
+    b = {"vmem_node_fetch": {"frac": 0.80, "achieved": 1, "peak": 2, "unit": "fetches/ns"}, "valu_issue": {"frac": 0.35, "achieved": 3, "peak": 4, "unit": "i"}, "lds_fetch": {"frac": 0.9}}
     assert bench.pick_bound(b)[0] == "valu_issue"
     del b["valu_issue"]                                            # counters not quoted: the live bound is all there is
     assert bench.pick_bound(b)[0] == "vmem_node_fetch" and bench.pick_bound({}) is None and bench.pick_bound(None) is None
+    cal = json.loads(sorted((ROOT / "profiles").glob("r*_calibration.json"))[-1].read_text())
+    assert "valu_issue_peak" not in cal and cal["valu_issue_guide_2_cycle_rate"] == 1162.0 and cal["valu_issue_peak_loop_mix_r04"] == 644.7
+    (tmp_path / "profiles" / "r09_calibration.json").write_text(json.dumps(cal))
+    kernel = "k_bvh2_top_auto<false,15, 255, 16, 32>"
+    groups = {"r09_pmc_primary_sq1": {"k_bvh2_top_auto<false, 15, 255, 16, 32, 0, true>": {"SQ_INSTS_VALU": 7.7e7, "SQ_ACTIVE_INST_VALU": 7.8e7, "SQ_THREAD_CYCLES_VALU": 2.4e9}}, "_meta": provenance.stamp("traversal")}
+    (tmp_path / "profiles" / "r09_pmc_counters.json").write_text(json.dumps(groups))
+    vi = bench.binding_bounds(kernel, "primary", 1 << 20, 39.3, 0.19, 18.8)["valu_issue"]
+    assert vi["peak"] == 1162.0 and abs(vi["achieved"] - 7.7e7 / 190.0 / 1024) < 0.1 and abs(vi["frac"] - vi["achieved"] / 1162.0) < 1e-3
+    assert abs(vi["frac_of_measured_loop_mix_ceiling"] - vi["achieved"] / 644.7) < 1e-3 and abs(vi["lane_utilisation"] - 2.4e9 / 64 / 7.8e7) < 1e-3
 
 
 def test_renderer_profiles_are_checked_the_same_way(bench, tmp_path):
