@@ -212,23 +212,22 @@ __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const
             typedef int i32x2 __attribute__((ext_vector_type(2)));
             f32x4 q0, q1, q2;
             i32x2 ch;
-            if (TOP && top >= kLdsTag) {
-                typedef __attribute__((address_space(3))) const char* lds_bytes;
-                const lds_bytes rec = (lds_bytes)image + (unsigned)(top - kLdsTag);
-                const __attribute__((address_space(3))) f32x4* p = (const __attribute__((address_space(3))) f32x4*)rec;
-                q0 = p[0]; q1 = p[1]; q2 = p[2];
-                ch = *(const __attribute__((address_space(3))) i32x2*)(rec + 48);
+            int popped;
+            if constexpr (TOP && kCursor) {
+                // both kinds of fetch -- LDS image, memory -- and the word under the cursor in flight together (joint_fetch, traversal_device.h)
+                const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
+                const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
+                joint_fetch(q0, q1, q2, ch, popped, top >= kLdsTag, (unsigned)(size_t)image + (unsigned)(top - kLdsTag), addr, addr + (is_node ? 48u : 40u), st.sp);
             } else {
                 const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
                 const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
                 const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
                 q0 = p[0]; q1 = p[1]; q2 = p[2];
                 ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));   // child ids / (triangle lanes) own last 8 bytes
+                if constexpr (kCursor) popped = *st.sp; else popped = st.get(ptr);
+                // keep all four loads in flight together (see unified_chunk)
+                asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
             }
-            int popped;
-            if constexpr (kCursor) popped = *st.sp; else popped = st.get(ptr);
-            // keep all four loads in flight together (see unified_chunk)
-            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
             if (is_node) {
                 float te0, te1;
                 const bool h0 = slab_canonical(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
@@ -526,6 +525,10 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStrea
 // Kept small on purpose: 64 VGPRs is the budget of 8 waves per SIMD, and a spill lands inside the step.
 struct RefillLane { RayX ray; int top; lds_int* sp; int g; };
 constexpr int kFoundBit = 1 << 29, kIndexMask = (1 << 28) - 1;
+// SHADOW_ORDER (lab, RODENT_HIP_SHADOW_ORDER): what a node step does with an any-hit (shadow) ray when both children are hit -- 0 = the nearer child
+// first, like a closest-hit ray (the reference: src/render/mapping_gpu.impala:47-80 shares the kernel); 1 = child 0 first, no ordering; 2 = the FARTHER child first
+// (the light's side: a shadow ray runs from the surface to the light).  Occlusion does not depend on the order, so films and counts must not.
+template <int SHADOW_ORDER = 0>
 __global__ __launch_bounds__(kWave * kPersistWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_from, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
                     int* deep_count_primary, int* deep_count_secondary, unsigned long long* counters, int* deep_list_primary, int* deep_list_secondary, int* tickets,
@@ -612,21 +615,13 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
             typedef int i32x2 __attribute__((ext_vector_type(2)));
             f32x4 q0, q1, q2;
             i32x2 ch;
-            if (top >= kLdsTag) {
-                typedef __attribute__((address_space(3))) const char* lds_bytes;
-                const lds_bytes rec = (lds_bytes)image + (unsigned)(top - kLdsTag);
-                const __attribute__((address_space(3))) f32x4* q = (const __attribute__((address_space(3))) f32x4*)rec;
-                q0 = q[0]; q1 = q[1]; q2 = q[2];
-                ch = *(const __attribute__((address_space(3))) i32x2*)(rec + 48);
-            } else {
+            int popped;
+            {
+                // both kinds of fetch -- LDS image, memory -- and the word under the cursor in flight together (joint_fetch, traversal_device.h)
                 const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
                 const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
-                const __attribute__((address_space(1))) f32x4* q = (const __attribute__((address_space(1))) f32x4*)addr;
-                q0 = q[0]; q1 = q[1]; q2 = q[2];
-                ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
+                joint_fetch(q0, q1, q2, ch, popped, top >= kLdsTag, (unsigned)(size_t)image + (unsigned)(top - kLdsTag), addr, addr + (is_node ? 48u : 40u), L.sp);
             }
-            const int popped = *L.sp;
-            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
             if (is_node) {
                 float te0, te1;
                 // -(o * 1/d) is computed here, not carried (make_rayx's product, the same value): three multiplications per node step for three
@@ -634,7 +629,9 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
                 RayX rr = L.ray; rr.iox = -(rr.ox * rr.idx); rr.ioy = -(rr.oy * rr.idy); rr.ioz = -(rr.oz * rr.idz);
                 const bool h0 = slab_canonical(rr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
                 const bool h1 = slab_canonical(rr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
-                const bool c0first = te0 < te1, both = h0 && h1;
+                bool c0first = te0 < te1;
+                if (SHADOW_ORDER != 0) { const bool shadow = (L.g & kIndexMask) >= P; c0first = shadow ? (SHADOW_ORDER == 1 ? true : te0 > te1) : c0first; }
+                const bool both = h0 && h1;
                 L.top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
                 L.sp[kWave] = c0first ? ch.y : ch.x;
                 L.sp += (both ? kWave : 0) - ((h0 || h1) ? 0 : kWave);
@@ -1349,6 +1346,9 @@ void ensure_deep(RenderDevice& r, int which, int rays) {
     if (!r.deep_done[which]) { HIP_CHECK(hipMalloc(&r.deep_done[which], sizeof(int) * 16)); HIP_CHECK(hipMemset(r.deep_done[which], 0, sizeof(int) * 16)); }
 }
 int persistent_grid(RenderDevice& r);
+int shadow_order() { static const int v = [] { const char* e = getenv("RODENT_HIP_SHADOW_ORDER"); return e ? std::min(2, std::max(0, atoi(e))) : 0; }(); return v; }
+#define LAUNCH_TRACE_REFILL(...) do { const int so_ = shadow_order(); \
+        if (so_ == 1) hipLaunchKernelGGL(k_trace_refill<1>, __VA_ARGS__); else if (so_ == 2) hipLaunchKernelGGL(k_trace_refill<2>, __VA_ARGS__); else hipLaunchKernelGGL(k_trace_refill<0>, __VA_ARGS__); } while (0)
 // the spill blocks of a persistent launch on stream `which` (103 MB for the 8192 resident waves of this chip, allocated with the first such launch)
 int* ensure_spill(RenderDevice& r, int which) {
     if (!r.spill[which]) {
@@ -1383,7 +1383,7 @@ void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStre
     if (r.trace_persistent && n >= kPersistMinRays) {
         ensure_tickets(r); tickets = r.tickets[0];
         if (r.trace_refill > 0 && coherent_from >= 0 && refill_indexable(n, 0))
-            hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
+            LAUNCH_TRACE_REFILL(dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
                                r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow, ensure_spill(r, 0), r.ctl + 2);
         else hipLaunchKernelGGL(k_trace_persist<0>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
                            r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, ensure_spill(r, 0), r.ctl + 2);
@@ -1397,7 +1397,7 @@ void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const Secondary
     if (r.trace_persistent && max_n >= kPersistMinRays) {
         ensure_tickets(r); tickets = r.tickets[1];
         if (r.trace_refill > 0 && refill_indexable(0, max_n))
-            hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, 0, s, size_ptr, max_n, r.film, inv_spp,
+            LAUNCH_TRACE_REFILL(dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, 0, s, size_ptr, max_n, r.film, inv_spp,
                                r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow, ensure_spill(r, 1), r.ctl + 2);
         else hipLaunchKernelGGL(k_trace_persist<1>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, s, size_ptr, max_n, r.film, inv_spp,
                            r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, ensure_spill(r, 1), r.ctl + 2);
@@ -1412,7 +1412,7 @@ void launch_trace_joint(RenderDevice& r, hipStream_t stream, const PrimaryStream
     ensure_deep(r, 0, n); ensure_deep(r, 1, max_n);
     ensure_tickets(r);
     if (r.trace_refill > 0 && refill_indexable(n, max_n))
-        hipLaunchKernelGGL(k_trace_refill, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, s, size_ptr, max_n, r.film, inv_spp,
+        LAUNCH_TRACE_REFILL(dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, s, size_ptr, max_n, r.film, inv_spp,
                            r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0], r.trace_refill, r.trace_refill_shadow, ensure_spill(r, 0), r.ctl + 2);
     else hipLaunchKernelGGL(k_trace_persist<2>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, s, size_ptr, max_n, r.film, inv_spp,
                        r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0], ensure_spill(r, 0), r.ctl + 2);

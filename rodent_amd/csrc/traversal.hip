@@ -252,29 +252,36 @@ __device__ __forceinline__ void bvh2_step(Lane& L, const Bases& base, Hit1* __re
     typedef int i32x2 __attribute__((ext_vector_type(2)));
     f32x4 q0, q1, q2;
     i32x2 ch;
-    if (TOP && L.top >= kLdsTag) {
-        typedef __attribute__((address_space(3))) const char* lds_bytes;
-        const lds_bytes rec = (lds_bytes)image + (unsigned)(L.top - kLdsTag);
-        const __attribute__((address_space(3))) f32x4* p = (const __attribute__((address_space(3))) f32x4*)rec;
-        q0 = p[0]; q1 = p[1]; q2 = p[2];
-        ch = *(const __attribute__((address_space(3))) i32x2*)(rec + 48);
-    } else {
-        // one address for both kinds: base + index * stride with per-lane selected operands (straight-line code)
+    int popped;
+    float shared_now = 0.0f;
+    if constexpr (TOP && !SHARED) {
+        // both kinds of fetch -- LDS image, memory -- and the word under the cursor in flight together (joint_fetch, traversal_device.h)
         const unsigned idx = (unsigned)(is_node ? L.top : ~L.top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
         const gptr addr = (is_node ? base.node : base.tri) + (size_t)idx * stride;
-        const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
-        q0 = p[0]; q1 = p[1]; q2 = p[2];
-        // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays
-        // inside the array
-        ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
+        // child ids of a node = its bytes 48..55; a triangle lane re-reads its own last 8 bytes so that the load stays inside the array
+        joint_fetch(q0, q1, q2, ch, popped, L.top >= kLdsTag, (unsigned)(size_t)image + (unsigned)(L.top - kLdsTag), addr, addr + (is_node ? 48u : 40u), L.sp);
+    } else {
+        if (TOP && L.top >= kLdsTag) {                                  // (lab: the work-stealing kernel keeps the compiler's two branches)
+            typedef __attribute__((address_space(3))) const char* lds_bytes;
+            const lds_bytes rec = (lds_bytes)image + (unsigned)(L.top - kLdsTag);
+            const __attribute__((address_space(3))) f32x4* p = (const __attribute__((address_space(3))) f32x4*)rec;
+            q0 = p[0]; q1 = p[1]; q2 = p[2];
+            ch = *(const __attribute__((address_space(3))) i32x2*)(rec + 48);
+        } else {
+            // one address for both kinds: base + index * stride with per-lane selected operands (straight-line code)
+            const unsigned idx = (unsigned)(is_node ? L.top : ~L.top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
+            const gptr addr = (is_node ? base.node : base.tri) + (size_t)idx * stride;
+            const __attribute__((address_space(1))) f32x4* p = (const __attribute__((address_space(1))) f32x4*)addr;
+            q0 = p[0]; q1 = p[1]; q2 = p[2];
+            ch = *(const __attribute__((address_space(1))) i32x2*)(addr + (is_node ? 48u : 40u));
+        }
+        popped = *L.sp;
+        if (SHARED) shared_now = *shared_tmax;
+        // All four loads must be in flight together: without this barrier the compiler narrows the shared loads to
+        // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
+        // (Whole-vector operands: the loaded register quads stay where the loads put them.)
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
     }
-    const int popped = *L.sp;
-    float shared_now = 0.0f;
-    if (SHARED) shared_now = *shared_tmax;
-    // All four loads must be in flight together: without this barrier the compiler narrows the shared loads to
-    // what the triangle branch reads and issues the rest inside the node branch, a second full memory latency.
-    // (Whole-vector operands: the loaded register quads stay where the loads put them.)
-    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(ch));
     if (SHARED) {
         L.ray.tmax = shared_now;
         if (ANY && shared_now == -__builtin_inff()) { L.top = 0; return; }        // another lane found this ray's hit

@@ -179,6 +179,46 @@ __device__ __forceinline__ void stack_reload(lds_int*& sp, int& top, lds_int* li
     sp = col + (kSpillRows - 1) * kWave;
 }
 
+// ---------------------------------------------------------------------------------------------
+// One step's fetches, both kinds in flight TOGETHER.  A lane whose node is in the LDS image (in_lds: ds_read_b128 x 3 + ds_read_b64 at `lds_addr`)
+// and a lane whose node / triangle comes from memory (global_load_dwordx4 x 3 at `addr` + dwordx2 at `addr_ids`) write the same registers.
+// Compiled from the two branches of an if, the second kind's loads wait for the first kind's to LAND -- the compiler cannot know that the
+// two exec masks are disjoint and sees a write-after-write on q0 .. ids -- so every iteration in which a wave holds both kinds pays an LDS
+// round trip behind a memory round trip.  Here they are issued back to back under their own exec masks and waited for once, together with
+// the word under the stack cursor (`popped`).  A kind nobody in the wave needs is skipped (a memory instruction with an empty exec mask
+// still makes the round trip).  Measured on one MI355X (profiles/r05_joint_loads.txt): random segments -6 % (atrium) ... -13 % (crown,
+// plant), camera rays +1 % (atrium) ... -4 % (crown).  Results cannot change: the same loads, the same lanes.
+// ---------------------------------------------------------------------------------------------
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef int vi2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) char* gbytes;
+__device__ __forceinline__ void joint_fetch(vf4& q0, vf4& q1, vf4& q2, vi2& ids, int& popped, bool in_lds, unsigned lds_addr, gbytes addr, gbytes addr_ids, lds_int* sp) {
+    const unsigned long long lds_mask = __ballot(in_lds);
+    const unsigned sp_addr = (unsigned)(size_t)sp;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %[save], exec\n\t"
+                 "s_andn2_b64 exec, exec, %[lm]\n\t"
+                 "s_cbranch_execz .Ljoint_a_%=\n\t"
+                 "global_load_dwordx4 %[q1], %[a], off offset:16\n\t"
+                 "global_load_dwordx4 %[q0], %[a], off\n\t"
+                 "global_load_dwordx4 %[q2], %[a], off offset:32\n\t"
+                 "global_load_dwordx2 %[ch], %[ac], off\n"
+                 ".Ljoint_a_%=:\n\t"
+                 "s_and_b64 exec, %[save], %[lm]\n\t"
+                 "s_cbranch_execz .Ljoint_b_%=\n\t"
+                 "ds_read_b128 %[q0], %[l]\n\t"
+                 "ds_read_b128 %[q1], %[l] offset:16\n\t"
+                 "ds_read_b128 %[q2], %[l] offset:32\n\t"
+                 "ds_read_b64 %[ch], %[l] offset:48\n"
+                 ".Ljoint_b_%=:\n\t"
+                 "s_mov_b64 exec, %[save]\n\t"
+                 "ds_read_b32 %[pop], %[sp]\n\t"
+                 "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [ch] "=&v"(ids), [pop] "=&v"(popped), [save] "=&s"(save)
+                 : [a] "v"(addr), [ac] "v"(addr_ids), [l] "v"(lds_addr), [sp] "v"(sp_addr), [lm] "s"(lds_mask)
+                 : "memory");
+}
+
 __device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // One wave (the LDS operations of a wave complete in program order: between one lane's write and another lane's read the
 // compiler only has to keep that order).  Record layout: ints 0..11 bounds, 12..13 child ids / links, 14 = the node's own 1-based id (0: slot unused), 15 = 0.

@@ -39,6 +39,7 @@ static void usage() {
               << "   -dev     n          GPU device index\n"
               << "   --ngpu   K          Renders on K GPUs (interleaved 16-row tiles, one film gather to the first device)\n"
               << "   --bands             With --ngpu: one contiguous row band per GPU instead of interleaved tiles\n"
+              << "   --check             With --ngpu: renders the same frames again on the first GPU alone and compares the two films\n"
               << "   --target t          amdgpu-streaming or amdgpu-megakernel (default: chosen per scene)\n"
               << "   --sort              Sort rays by material before shading (streaming target; default: stream order)\n"
               << "   --no-sort           Do not sort rays by material before shading\n"
@@ -60,7 +61,7 @@ int main(int argc, char** argv) {
     float fov = 60.0f;
     V3 eye(0.0f), dir(0.0f, 0.0f, 1.0f), up(0.0f, 1.0f, 0.0f);
     int spp = 0, max_path_len = -1, dev = 0, mapping = -1, ngpu = 1;
-    bool bands = false;
+    bool bands = false, check = false;
     int sort = -1;                                                        // -1: the library's default
 
     for (int i = 1; i < argc; ++i) {
@@ -80,6 +81,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "-dev")) { need(1); dev = strtol(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "--ngpu")) { need(1); ngpu = strtol(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "--bands")) bands = true;
+        else if (!strcmp(argv[i], "--check")) check = true;
         else if (!strcmp(argv[i], "--no-sort")) sort = 0;
         else if (!strcmp(argv[i], "--sort")) sort = 1;
         else if (!strcmp(argv[i], "--target")) {
@@ -125,7 +127,7 @@ int main(int argc, char** argv) {
     }
     clear_pixels();
 
-    std::vector<double> samples_sec;
+    std::vector<double> samples_sec, rank_ms(ngpu, 0.0);
     uint32_t iter = 0;
     while (samples_sec.size() < bench_iter) {
         const auto ticks = std::chrono::high_resolution_clock::now();
@@ -133,8 +135,10 @@ int main(int argc, char** argv) {
         else {
             // every GPU its share of this frame, all at once; the call returns when the share is in the device's film
             group.run([&](int r) {
+                const auto t0 = std::chrono::high_resolution_clock::now();
                 if (bands) { const Part band = split_range((int)height, r, ngpu); rodent_hip_render_rows(group.device(r), &settings, (int32_t)iter, band.begin, band.end, nullptr); }
                 else rodent_hip_render_tiles(group.device(r), &settings, (int32_t)iter, kTileRows, r, ngpu, nullptr);
+                rank_ms[r] = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
             });
             iter++;
         }
@@ -159,6 +163,25 @@ int main(int argc, char** argv) {
         if (gather_s < 0) fail(err);
         rodent_present(group.device(0));
     }
+    // --check: the same frames once more on the first device alone; the two films may differ by the order of their fp32 atomic adds only
+    std::string verdict;
+    if (ngpu > 1 && check) {
+        const size_t words = width * height * 3;
+        const std::vector<float> gathered(get_pixels(), get_pixels() + words);
+        clear_pixels();
+        for (uint32_t it = 0; it < iter; it++) rodent_hip_render_rows(group.device(0), &settings, (int32_t)it, 0, (int32_t)height, nullptr);
+        rodent_present(group.device(0));
+        const float* alone = get_pixels();
+        size_t off = 0; double worst = 0;
+        for (size_t k = 0; k < words; k++) {
+            const double d = std::fabs((double)alone[k] - gathered[k]), tol = 1e-5 * std::fabs((double)alone[k]) + 1e-6 * iter;
+            if (d > tol) off++;
+            worst = std::max(worst, d / (std::fabs((double)alone[k]) + 1e-6 * iter));
+        }
+        verdict = std::string("the gathered film ") + (off == 0 ? "EQUALS" : "DIFFERS FROM") + " the first device's own render of the whole frame(s) (1e-5 relative; largest relative difference "
+                  + std::to_string(worst) + (off ? ", " + std::to_string(off) + " values off" : "") + ")";
+        std::copy(gathered.begin(), gathered.end(), get_pixels());       // the image that is saved is the multi-GPU one
+    }
 
     if (!out_file.empty()) {                                             // driver.cpp:138-162
         const float* film = get_pixels();
@@ -180,7 +203,13 @@ int main(int argc, char** argv) {
     if (ngpu > 1) {
         const int own_rows = bands ? split_range((int)height, 0, ngpu).size() : tile_rows_of_rank((int)height, 0, ngpu, kTileRows);
         std::cout << "# GPUs: " << ngpu << " (devices " << dev << ".." << dev + ngpu - 1 << "), " << (bands ? "bands of " + std::to_string(own_rows) + " row(s)" : "interleaved tiles of " + std::to_string(kTileRows) + " rows")
-                  << "; film gather to device " << dev << ": " << double(height - own_rows) * width * 12 / 1e6 << " MB in " << gather_s * 1e3 << " ms (RCCL)" << std::endl;
+                  << "; film gather to device " << dev << ": " << double(height - own_rows) * width * 12 / 1e6 << " MB in " << gather_s * 1e3 << " ms" << std::endl;
+        std::cout << "# Collective: " << group.describe() << std::endl;
+        std::cout << "# Render ms per rank (last frame):";
+        for (double ms : rank_ms) std::cout << " " << ms;
+        std::cout << std::endl;
+        if (check) std::cout << "# Check: " << verdict << std::endl;
+        if (check && verdict.find("DIFFERS") != std::string::npos) return 2;
     }
     return 0;
 }

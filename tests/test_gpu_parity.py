@@ -383,6 +383,19 @@ def test_bench_traversal_cli(gpu, native_build, oracle, cornell, tmp_path):
         assert np.array_equal(hits["t"], cornell.expected["bvh2_gpu.primary_tmin.closest"]["t"]) and (hits["tri_id"] >= 0).all()
     r = subprocess.run(cmd + ["-gpu", "hip", "-ngpu", str(have + 1)], capture_output=True, text=True)
     assert r.returncode != 0 and "No such GPU device(s)" in r.stderr
+    # The K > 1 path on however few GPUs the box has: RODENT_SHARE_GPUS=1 puts the K ranks' threads, ray ranges and Hit1 pieces on the
+    # devices there are; RCCL cannot place two ranks on one device, so the gather takes its fallback (one hipMemcpyPeerAsync per piece) and says so; the tool
+    # then checks the assembled array against one device's trace of all rays by itself.  An injected RCCL failure takes the same branch.
+    import os
+    for k, env in ((3, {"RODENT_SHARE_GPUS": "1"}), (min(have, 2), {"RODENT_FORCE_RCCL_INIT_FAILURE": "1"})):
+        if k < 2:
+            continue
+        r = subprocess.run(cmd + ["-gpu", "hip", "-ngpu", str(k), "--hits", tmp_path / "h.bin"], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        assert f"# GPUs: {k}" in r.stdout and "# Collective: hipMemcpyPeerAsync per piece" in r.stdout and "WARNING: RCCL is not used" in r.stderr
+        assert "# Check: the gathered Hit1 array EQUALS" in r.stdout and "# Kernel ms per rank" in r.stdout
+        hits = np.fromfile(tmp_path / "h.bin", F.HIT1)
+        assert np.array_equal(hits["t"], cornell.expected["bvh2_gpu.primary_tmin.closest"]["t"])
 
 
 def test_bench_py_contract(native_build):
