@@ -17,7 +17,7 @@ N > 1 = no data-path collective: the BVH is replicated.  BOTH partitions are tim
         trace of the whole set;
         weak (`extra.weak_scaling`): rank r traces sub-pixel sample r of N through the same 1024 x 1024 pixel grid (primary) /
         seed 42 + r (random): 1 Mi rays per GPU per step.  `--weak` makes this one `value` instead.
-roofline: ONE bound, stated once (DESIGN.md 3.1): VALU issue.  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU of the committed counter
+roofline: ONE bound, stated once (DESIGN.md 5): VALU issue.  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU of the committed counter
         pass of THIS kernel on THESE sources) / live kernel time / SIMDs; peak = the guide's 2 cycles per wave64 VALU instruction at the clock measured
         in the calibration loop (MI355X_MICROARCH.md: 1 162 wave-instructions per us per SIMD at 2 323 MHz); frac = achieved / peak.  Beside it, each
         one division away from a file under profiles/: `frac_of_measured_loop_mix_ceiling` (the same rate against the microbenchmarked ceiling of the
@@ -180,7 +180,7 @@ def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms, lds_steps_pe
 
 
 def pick_bound(binding):
-    """The top-level roofline: VALU issue (DESIGN.md 3.1) -- whenever the committed counter pass belongs to the running sources; the live
+    """The top-level roofline: VALU issue (DESIGN.md 5) -- whenever the committed counter pass belongs to the running sources; the live
     node-fetch bound stands in (and says so) while it does not."""
     for key in ("valu_issue", "vmem_node_fetch"):
         b = (binding or {}).get(key)
@@ -265,12 +265,8 @@ def scene_file(scene_name):
     """.rscene of a benchmark scene (converted once by rank 0; rodent_amd/bin/converter = the reference's converter as a
     table emitter)."""
     from rodent_amd import scene as S, scenes
-    if scene_name == "cornell":
-        obj = ROOT / "tests" / "golden" / "cornell_box.obj"
-    else:
-        scenes.scene_bvh(scene_name)                                  # generates data/<scene>.obj on the way
-        obj = scenes.DATA / f"{scene_name}.obj"
-    out = scenes.DATA / f"{scene_name}.bench.rscene"
+    obj = scenes.scene_obj(scene_name)                                # (generates data/<scene>.obj where it has to)
+    out = scenes.DATA / f"{scene_name.replace('/', '-d')}.bench.rscene"
     if not out.exists():
         scenes.DATA.mkdir(parents=True, exist_ok=True)
         S.convert(obj, out)
@@ -583,7 +579,7 @@ def main():
         except Exception as e:                                    # informational only: never lose the bench line over it
             print(f"bench.py: two-stream measurement skipped ({e})", file=sys.stderr)
         # the same camera at 4096 x 4096 = 16 Mi primary rays per launch -- the kernel's throughput regime (at 1 Mi rays
-        # the launch is bound by its schedule)
+        # the launch is bound by its schedule, LAB_NOTES.md 3.1.1)
         if scene != "sponza":
             try:
                 eye, d, up, fov = scenes.CAMERAS[scene]
@@ -713,7 +709,7 @@ def main():
             "hbm_algorithmic_frac": round(hbm_alg, 4),
             "hbm_algorithmic_frac_is": "cache-served, not a fraction: SURVEY 8(d)'s bytes per ray count every node / triangle visit although the BVH is served by LDS / L1 / L2 / MALL (> 1 is expected)",
             "what": "VALU issue: wave-instructions per us per SIMD of this kernel (SQ_INSTS_VALU of the committed counter pass / live kernel time / SIMDs) against the guide's 2-cycle rate at the "
-                    "measured clock.  At 1 Mi rays per launch the launch is a tail (DESIGN.md 3.1.1); the same kernel at 16 Mi rays is in extra.primary_16Mi_rays_per_launch"
+                    "measured clock.  At 1 Mi rays per launch the launch is a tail (LAB_NOTES.md 3.1.1); the same kernel at 16 Mi rays is in extra.primary_16Mi_rays_per_launch"
                     + ("" if top and top[0] == "valu_issue" else "  [the committed counter pass does not belong to the running sources: the live node-fetch bound stands in]"),
             "hbm_algorithmic": {"bound": "hbm", "GBps": round(achieved, 2), "peak_GBps": HBM_PEAK_GBPS, "frac": round(hbm_alg, 5), "bytes_per_ray": round(bytes_per_ray, 2),
                                 "visits_per_ray": {"inner": round(st["inner_per_ray"], 3), "prim": round(st["prims_per_ray"], 3)},

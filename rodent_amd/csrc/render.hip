@@ -232,7 +232,8 @@ __device__ __forceinline__ bool trace_one(const Node2* __restrict__ nodes, const
                 float te0, te1;
                 const bool h0 = slab_canonical(ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
                 const bool h1 = slab_canonical(ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
-                const bool c0first = te0 < te1, both = h0 && h1;
+                // (any-hit rays -- the renderer's shadow rays -- take child 0 first: occlusion does not depend on the order, see k_trace_refill's SHADOW_ORDER)
+                const bool c0first = ANY ? true : te0 < te1, both = h0 && h1;
                 top = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : (h1 ? ch.y : popped));
                 if constexpr (kCursor) {
                     st.sp[kWave] = c0first ? ch.y : ch.x;
@@ -525,9 +526,11 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStrea
 // Kept small on purpose: 64 VGPRs is the budget of 8 waves per SIMD, and a spill lands inside the step.
 struct RefillLane { RayX ray; int top; lds_int* sp; int g; };
 constexpr int kFoundBit = 1 << 29, kIndexMask = (1 << 28) - 1;
-// SHADOW_ORDER (lab, RODENT_HIP_SHADOW_ORDER): what a node step does with an any-hit (shadow) ray when both children are hit -- 0 = the nearer child
-// first, like a closest-hit ray (the reference: src/render/mapping_gpu.impala:47-80 shares the kernel); 1 = child 0 first, no ordering; 2 = the FARTHER child first
-// (the light's side: a shadow ray runs from the surface to the light).  Occlusion does not depend on the order, so films and counts must not.
+// SHADOW_ORDER (RODENT_HIP_SHADOW_ORDER): what a node step does with an any-hit (shadow) ray when both children are hit -- 0 = the nearer child
+// first, like a closest-hit ray (the reference: src/render/mapping_gpu.impala:47-80 shares the kernel); 1 (the default from round 5 on) = child 0 first, no ordering;
+// 2 = the FARTHER child first (the light's side: a shadow ray runs from the surface to the light).  Occlusion does not depend on the order, so films and counts
+// do not (checked: scripts/render_rules_check.py).  Measured on config 5's frame (profiles/r05_render_rules_check.txt): 1 = +3.0 ... 4.1 %, 2 = +2.7 ... 3.7 % -- an
+// any-hit ray wants an occluder, not the nearest one, and the builder orders a node's children by decreasing reference count (bvh.h:215): child 0 is the bigger subtree.
 template <int SHADOW_ORDER = 0>
 __global__ __launch_bounds__(kWave * kPersistWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_from, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
@@ -1346,7 +1349,7 @@ void ensure_deep(RenderDevice& r, int which, int rays) {
     if (!r.deep_done[which]) { HIP_CHECK(hipMalloc(&r.deep_done[which], sizeof(int) * 16)); HIP_CHECK(hipMemset(r.deep_done[which], 0, sizeof(int) * 16)); }
 }
 int persistent_grid(RenderDevice& r);
-int shadow_order() { static const int v = [] { const char* e = getenv("RODENT_HIP_SHADOW_ORDER"); return e ? std::min(2, std::max(0, atoi(e))) : 0; }(); return v; }
+int shadow_order() { static const int v = [] { const char* e = getenv("RODENT_HIP_SHADOW_ORDER"); return e ? std::min(2, std::max(0, atoi(e))) : 1; }(); return v; }
 #define LAUNCH_TRACE_REFILL(...) do { const int so_ = shadow_order(); \
         if (so_ == 1) hipLaunchKernelGGL(k_trace_refill<1>, __VA_ARGS__); else if (so_ == 2) hipLaunchKernelGGL(k_trace_refill<2>, __VA_ARGS__); else hipLaunchKernelGGL(k_trace_refill<0>, __VA_ARGS__); } while (0)
 // the spill blocks of a persistent launch on stream `which` (103 MB for the 8192 resident waves of this chip, allocated with the first such launch)

@@ -72,6 +72,22 @@ def scene_bvh(scene: str) -> Path:
     return out
 
 
+def scene_obj(scene: str) -> Path:
+    """OBJ (+ atrium.mtl beside it) of a scene, for the renderer's converter: the atrium, or a generated kind ("gallery", "crown/2", ...)."""
+    DATA.mkdir(parents=True, exist_ok=True)
+    kind, _, detail = scene.partition("/")
+    if kind == "cornell":
+        return GOLDEN / "cornell_box.obj"
+    if kind == "atrium":
+        scene_bvh("atrium")
+        return DATA / "atrium.obj"
+    detail = int(detail) if detail else GENERATED[kind]
+    out = DATA / f"{kind}-d{detail}.obj"
+    if not out.exists():
+        _run([_tool("scene_gen"), kind, out, 1, detail])
+    return out
+
+
 def primary_rays(scene: str, width=1024, height=1024) -> Path:
     sfx = "" if (width, height) == (1024, 1024) else f"-{width}x{height}"
     out = DATA / f"{scene}-primary{sfx}.rays"

@@ -21,7 +21,7 @@ a = ap.parse_args()
 w, h = (int(x) for x in a.size.split("x"))
 rscene = a.rscene or bench.scene_file(a.scene)[1]
 sc = S.Scene(rscene)
-eye, d, up, fov = scenes.CAMERAS[a.scene]
+eye, d, up, fov = scenes.CAMERAS[a.scene.split("/")[0]]
 cam = S.camera_settings(eye, d, up, fov, w, h)
 r = R.Renderer(sc, w, h, spp=4, max_path_len=a.len, dev=0, mapping=a.mapping)
 r.render_rows(cam, 0, 0, h)

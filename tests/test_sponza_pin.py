@@ -8,7 +8,7 @@ The three Sponza blobs are missing from the reference checkout (.MISSING_LARGE_B
 sponza-random.rays), so these tests SKIP until someone drops them into data/ -- bench.py and rodent_amd.scenes.default_scene() switch
 to them by themselves the same day.  tests/golden/ref-primary.png is the reference's committed expected image (a data fixture).  This is
 the one route by which the traversal's parity becomes pinned by an artefact the REFERENCE holds rather than by this repository's
-restatement of its kernel (DESIGN.md section 4, VERDICT r4 "What's missing" 1).  The reference tests primary rays only ("the random rays
+restatement of its kernel (DESIGN.md section 8, VERDICT r4 "What's missing" 1).  The reference tests primary rays only ("the random rays
 are often too close to surfaces and often give slightly different results for each algorithm", tools/CMakeLists.txt:24-25).
 """
 import subprocess
