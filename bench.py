@@ -59,6 +59,7 @@ def parse_args():
     ap.add_argument("--strong", action="store_true", help="accepted for compatibility: strong scaling is the default for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="profiling aid: no oracle leg, no CPU baselines, no informational extras")
     ap.add_argument("--no-render", action="store_true", help="skip the renderer section (extra.render)")
+    ap.add_argument("--no-scenes", action="store_true", help="skip the scene x ray-class matrix (extra.scenes: the gallery / crown / plant classes are generated and built first, ~80 s)")
     ap.add_argument("--render-spp5", type=int, default=256, help="samples per pixel of the config-5 frame (BASELINE: 256)")
     ap.add_argument("--only", choices=("primary", "random"), default=None, help="profiling aid: time only one ray set")
     return ap.parse_args()
@@ -609,6 +610,22 @@ def main():
     hits = abi.from_device(hits_dev, F.HIT1)[:n]
     hits_rnd = abi.from_device(hits_rnd_dev, F.HIT1)[:len(rnd)]
 
+    # ---- the other scene classes and the any-hit ray class (scripts/scene_matrix.py; the oracle checks a 32 Ki-ray sample of every cell) ----
+    scene_rows = None
+    if info and world == 1 and width == 2 and not args.no_scenes and scene != "sponza":
+        try:
+            sys.path.insert(0, str(ROOT / "scripts"))
+            import scene_matrix                                          # lab tooling; imports the oracle as its checker
+            scene_rows, t_scenes = {}, time.time()
+            for sc_name in (scene, "gallery", "crown", "plant"):
+                if time.time() - t_scenes > 300:                         # a slow host must not cost the bench line
+                    scene_rows[sc_name] = {"skipped": "the scenes before this one took more than 300 s to build and trace"}
+                    continue
+                scene_rows[sc_name] = scene_matrix.measure(sc_name, steps=args.steps, quiet=True)
+        except Exception as e:                                          # informational: never lose the bench line over it
+            print(f"bench.py: scene matrix skipped ({e})", file=sys.stderr)
+            scene_rows = scene_rows or None
+
     # ---- renderer (BASELINE configs 4 / 5): after the traversal's timed regions, own timed frames ----
     render = None
     if info and not args.no_render and width == 2:
@@ -655,6 +672,13 @@ def main():
         out["extra"]["random_with_kind_hint"] = hint_rec
     if render is not None:
         out["extra"]["render"] = render
+    if scene_rows:
+        out["extra"]["scenes"] = scene_rows
+        out["extra"]["scenes_what"] = ("1 Mi camera rays / random segments (closest hit) / ao rays (ray_gen shadow, any hit, tmax 0.999) per scene class through the default mapping (top) and "
+                                       "'fast' / 'refill' beside it: kernel ms, Mrays/s of the default, oracle parity of a 32 Ki-ray sample, oracle visits per ray and stack depths, blocks spilled")
+        out["config"]["ao_Mrays_s"] = (scene_rows.get(scene, {}).get("ao") or {}).get("Mrays_s")
+        out["config"]["scene_classes_Mrays_s[primary,random,ao]"] = {k: [(v.get(c) or {}).get("Mrays_s") for c in ("primary", "random", "ao")] for k, v in scene_rows.items() if "primary" in v}
+        out["config"]["scene_classes_parity"] = all(v[c]["sample_parity"] for v in scene_rows.values() if "primary" in v for c in ("primary", "random", "ao"))
     # what the driver's record keeps is `config`, `roofline` and `cpu_baseline`: the other headline figures as short scalars
     out["config"]["random_Mrays_s"] = round(main_part["value_rnd"], 1)          # stateless: the in-kernel choice alone (the ray-kind hint is off by default)
     if hint_rec:

@@ -17,14 +17,6 @@ import torch
 from rodent_amd import abi, formats as F, raygen, scenes
 from oracle import binding as O          # checker only
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--scenes", default="atrium,gallery,crown,plant")
-ap.add_argument("--steps", type=int, default=20)
-ap.add_argument("--variants", default="top,fast,refill")
-ap.add_argument("--json", default=None)
-ap.add_argument("--pmc", action="store_true")
-a = ap.parse_args()
-names = abi.variants(2)
 st = torch.cuda.current_stream()
 
 
@@ -40,8 +32,10 @@ def timed(bvh, rd, hd, n, any_hit, v, steps):
     return e0.elapsed_time(e1) / steps
 
 
-out = {}
-for scene in a.scenes.split(","):
+def measure(scene, steps=20, variants=("top", "fast", "refill"), pmc=False, quiet=False):
+    """One scene, three ray classes: the record described in the module docstring (the oracle is the CHECKER of a 32 Ki-ray sample)."""
+    say = (lambda *x, **k: None) if quiet else print
+    names = abi.variants(2)
     t0 = time.time()
     path = scenes.scene_bvh(scene)
     build_s = time.time() - t0
@@ -53,19 +47,19 @@ for scene in a.scenes.split(","):
     hits_p = abi.traverse(bvh, prim)
     sets = {"primary": (prim, False), "random": (raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, scenes.RANDOM_TMAX), False),
             "ao": (raygen.shadow_rays(scenes.LIGHTS[scene.split("/")[0]], prim, hits_p["t"], 0.0, 0.999), True)}
-    rec = {"triangles": int((tris["prim_id"] >= 0).sum() + (tris["prim_id"] < 0).sum()), "unique_triangles": int(len(np.unique(tris["prim_id"] & 0x7FFFFFFF))),
+    rec = {"references": len(tris), "triangles": int(len(np.unique(tris["prim_id"] & 0x7FFFFFFF))),
            "nodes": len(nodes), "bvh_MB": round((nodes.nbytes + tris.nbytes) / 1e6, 1), "build_or_load_s": round(build_s, 1)}
-    if not a.pmc:
-        print(f"== {scene}: {rec['unique_triangles']} triangles, {rec['triangles']} references, {rec['nodes']} nodes, {rec['bvh_MB']} MB ({build_s:.1f} s to build / load)", flush=True)
+    if not pmc:
+        say(f"== {scene}: {rec['triangles']} triangles, {rec['references']} references, {rec['nodes']} nodes, {rec['bvh_MB']} MB ({build_s:.1f} s to build / load)", flush=True)
     for kind, (rays, any_hit) in sets.items():
         n = len(rays)
         rd = abi.to_device(rays, 0); hd = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
-        if a.pmc:
+        if pmc:
             abi.traverse_async(bvh, rd, hd, n, any_hit, 0, st); torch.cuda.synchronize()
             continue
         cell = {}
-        for vname in a.variants.split(","):
-            cell[vname + "_ms"] = round(timed(bvh, rd, hd, n, any_hit, names.index(vname), a.steps), 4)
+        for vname in variants:
+            cell[vname + "_ms"] = round(timed(bvh, rd, hd, n, any_hit, names.index(vname), steps), 4)
         abi.read_stats()
         abi.traverse_async(bvh, rd, hd, n, any_hit, 0, st); torch.cuda.synchronize()
         cell["spilled_blocks"] = int(abi.read_stats()[7])
@@ -74,17 +68,28 @@ for scene in a.scenes.split(","):
         ref, stt = O.traverse(2, nodes, tris, rays[sample], any_hit=any_hit)
         cell["sample_parity"] = bool(got[sample].tobytes() == ref.tobytes()) if not any_hit else bool(np.array_equal(got[sample]["tri_id"] >= 0, ref["tri_id"] >= 0))
         depth = O.ray_depths(nodes, tris, rays[sample], any_hit=any_hit)
-        cell.update({"Mrays_s": round(n / cell["top_ms"] / 1e3, 1), "hit_share": round(float((got["tri_id"] >= 0).mean()), 4),
+        cell.update({"Mrays_s": round(n / cell[variants[0] + "_ms"] / 1e3, 1), "hit_share": round(float((got["tri_id"] >= 0).mean()), 4),
                      "inner_per_ray": round(stt["inner_per_ray"], 2), "prims_per_ray": round(stt["prims_per_ray"], 2),
                      "stack_mean": round(float(depth.mean()), 2), "stack_max": int(depth.max()), "beyond_window_share": round(float((depth >= 15).mean()), 5),
                      "stack_histogram": np.bincount(depth, minlength=1).tolist()})
         rec[kind] = cell
-        print(f"  {kind:8s} {cell['Mrays_s']:8.1f} Mrays/s  " + "  ".join(f"{v} {cell[v + '_ms']:.4f} ms" for v in a.variants.split(",")) +
-              f"  parity {cell['sample_parity']}  visits/ray {cell['inner_per_ray']:.1f} + {cell['prims_per_ray']:.1f}  stack mean {cell['stack_mean']:.1f} max {cell['stack_max']} "
-              f"beyond window {cell['beyond_window_share']:.3%} spilled {cell['spilled_blocks']}  hits {cell['hit_share']:.3f}", flush=True)
+        say(f"  {kind:8s} {cell['Mrays_s']:8.1f} Mrays/s  " + "  ".join(f"{v} {cell[v + '_ms']:.4f} ms" for v in variants) +
+            f"  parity {cell['sample_parity']}  visits/ray {cell['inner_per_ray']:.1f} + {cell['prims_per_ray']:.1f}  stack mean {cell['stack_mean']:.1f} max {cell['stack_max']} "
+            f"beyond window {cell['beyond_window_share']:.3%} spilled {cell['spilled_blocks']}  hits {cell['hit_share']:.3f}", flush=True)
         del rd, hd
     abi.check_errors(0)
-    out[scene] = rec
     del bvh
-if a.json and not a.pmc:
-    Path(a.json).write_text(json.dumps(out, indent=1))
+    return rec
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenes", default="atrium,gallery,crown,plant")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--variants", default="top,fast,refill")
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--pmc", action="store_true")
+    a = ap.parse_args()
+    out = {scene: measure(scene, a.steps, tuple(a.variants.split(",")), a.pmc) for scene in a.scenes.split(",")}
+    if a.json and not a.pmc:
+        Path(a.json).write_text(json.dumps(out, indent=1))

@@ -417,6 +417,9 @@ def test_bench_py_contract(native_build):
     assert rf["bound"] != "valu_issue" or (rf["peak"] == 1162.0 and 0 < rf["frac_of_measured_loop_mix_ceiling"] <= 1.0 and 0 < rf["lane_utilisation"] <= 1.0)
     assert rf["hbm_algorithmic_frac"] > 0 and "cache-served" in rf["hbm_algorithmic_frac_is"] and (rf["traffic"] is None or 0 < rf["hbm_measured_frac"] < 1.0)
     assert "random_Mrays_s" in d["config"] and "random_with_kind_hint_Mrays_s" in d["config"]
+    # the other scene classes and the any-hit ray class ride along: every cell's sample checked against the oracle inside bench.py
+    assert d["config"]["scene_classes_parity"] is True and d["config"]["ao_Mrays_s"] > 500 and set(d["extra"]["scenes"]) >= {"gallery", "crown", "plant"}
+    assert all(d["extra"]["scenes"][k][c]["beyond_window_share"] < 0.5 for k in ("gallery", "crown", "plant") for c in ("primary", "random", "ao"))
     assert rf["hbm_algorithmic"]["bound"] == "hbm" and rf["hbm_algorithmic"]["peak_GBps"] == 8000.0 and rf["hbm_algorithmic"]["bytes_per_ray"] > 48
     assert 0 < rf["binding"]["vmem_node_fetch"]["frac"] < 1.0 and 0 < rf["random"]["binding"]["vmem_node_fetch"]["frac"] < 1.2
     # counter-derived figures are quoted only from a profile of THESE kernel sources (rodent_amd/provenance.py)
