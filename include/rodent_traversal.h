@@ -134,7 +134,9 @@ int32_t rodent_hip_check_errors(int32_t dev, void* stream);
 /* Introspection / plumbing. */
 /* anydsl_get_kernel_time() of the AnyDSL runtime, which the reference's bench_traversal brackets its GPU calls with
  * (tools/bench_traversal/bench_traversal.cpp:125-133): microseconds of KERNEL time accumulated over the synchronous entry points above
- * (HIP events around what a call enqueues; launch gaps, the call's synchronisation and its flag read-back are not in it). */
+ * (HIP events around what a call enqueues, after the context's buffers have been allocated: the call's synchronisation is not in it; where a mapping
+ * is two kernels -- launches under rodent_hip_top_min_rays: the one-chunk kernel and its follow-up -- the microsecond between them is.  One sum per
+ * process over all devices, like the reference's; one synchronous call at a time per (device, null stream). */
 uint64_t    rodent_hip_get_kernel_time(void);
 int32_t     rodent_hip_device_count(void);              /* 0 when no GPU is visible */
 int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2, 4 or 8 */
