@@ -21,7 +21,7 @@ st = torch.cuda.current_stream()
 
 
 def timed(bvh, rd, hd, n, any_hit, v, steps):
-    for _ in range(3):
+    for _ in range(5):
         abi.traverse_async(bvh, rd, hd, n, any_hit, v, st)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -58,8 +58,10 @@ def measure(scene, steps=20, variants=("top", "fast", "refill"), pmc=False, quie
             abi.traverse_async(bvh, rd, hd, n, any_hit, 0, st); torch.cuda.synchronize()
             continue
         cell = {}
-        for vname in variants:
-            cell[vname + "_ms"] = round(timed(bvh, rd, hd, n, any_hit, names.index(vname), steps), 4)
+        for rep in range(2):                                   # two rounds over the mappings, the better one counts: whoever is measured first on fresh buffers runs cold
+            for vname in variants:
+                ms = round(timed(bvh, rd, hd, n, any_hit, names.index(vname), steps), 4)
+                cell[vname + "_ms"] = min(ms, cell.get(vname + "_ms", ms))
         abi.read_stats()
         abi.traverse_async(bvh, rd, hd, n, any_hit, 0, st); torch.cuda.synchronize()
         cell["spilled_blocks"] = int(abi.read_stats()[7])
