@@ -59,15 +59,15 @@ public:
         int version = 0;
         if (ncclGetVersion(&version) == ncclSuccess) rccl_version_ = version;
         const char* inject = getenv("RODENT_FORCE_RCCL_INIT_FAILURE");
-        std::string why;
-        if (shared && have < count) why = "RODENT_SHARE_GPUS: " + std::to_string(count) + " ranks on " + std::to_string(have) + " device(s)";
-        else if (inject && atoi(inject) != 0) why = "RODENT_FORCE_RCCL_INIT_FAILURE";
-        else {
+        const bool injected = inject && atoi(inject) != 0;
+        std::string init_error;
+        if (rccl_unused_reason(count, have, shared, injected, "").empty()) {          // nothing rules RCCL out beforehand: bring it up
             comms_.resize(count);
             const ncclResult_t r = ncclCommInitAll(comms_.data(), count, devs_.data());
-            if (r != ncclSuccess) { comms_.clear(); why = std::string("ncclCommInitAll: ") + ncclGetErrorString(r); }
+            if (r != ncclSuccess) { comms_.clear(); init_error = ncclGetErrorString(r); }
             else if (ncclCommCount(comms_[0], &comm_ranks_) != ncclSuccess) comm_ranks_ = -1;
         }
+        const std::string why = rccl_unused_reason(count, have, shared, injected, init_error);
         if (!why.empty()) {
             fallback_ = why;
             std::cerr << "rodent: WARNING: RCCL is not used (" << why << "); the gather to the first device falls back to one hipMemcpyPeerAsync per piece" << std::endl;

@@ -4,6 +4,7 @@
 // renderer.impala:28-33, so any partition reproduces the frame).  Rays: contiguous ranges keep coherent rays coherent.
 // The same arithmetic as rodent_amd/parallel.py (row_band, ray_range); tests/test_distributed.py compares the two.
 #pragma once
+#include <string>
 
 namespace rodent {
 
@@ -32,6 +33,19 @@ inline int tile_rows_of_rank(int height, int rank, int world, int tile_rows) {
     int rows = 0;
     for_each_tile(height, rank, world, tile_rows, [&](Part p) { rows += p.size(); });
     return rows;
+}
+
+// Which transport the ONE gather of a K-GPU run uses (host/multi_gpu.h DeviceGroup::init): RCCL when it comes up, otherwise one peer copy per piece -- a
+// run on several GPUs must not fail for want of a collective library, and must say what it did.  Pure decision logic (no HIP / RCCL here) so that the CPU
+// suite can test the fallback branch with an injected failure: returns the reason RCCL is NOT used, empty = it is.
+//   ranks > devices (RODENT_SHARE_GPUS: ranks share devices; RCCL cannot place two ranks on one device), an injected failure
+//   (RODENT_FORCE_RCCL_INIT_FAILURE), or ncclCommInitAll's own error string.
+inline std::string rccl_unused_reason(int ranks, int devices, bool shared, bool injected_failure, const std::string& init_error) {
+    if (ranks <= 1) return "";
+    if (shared && devices < ranks) return "RODENT_SHARE_GPUS: " + std::to_string(ranks) + " ranks on " + std::to_string(devices) + " device(s)";
+    if (injected_failure) return "RODENT_FORCE_RCCL_INIT_FAILURE";
+    if (!init_error.empty()) return "ncclCommInitAll: " + init_error;
+    return "";
 }
 
 } // namespace rodent
