@@ -707,7 +707,7 @@ def main():
         ref_hits, st = O.traverse(width, nodes, tris, prim, algo=algo)
         ref_rnd, st_r = O.traverse(width, nodes, tris, rnd, algo=algo)
         lds_p = lds_r = 0.0
-        if width == 2 and abi.variants(2)[variant] == "top" and n >= 9216 * 64:
+        if width == 2 and abi.variants(2)[variant] == "top" and n >= 6144 * 64:
             # the share of the node visits that the default mapping serves from its LDS image (host restatement of the image's node set)
             from rodent_amd import topimage
             ids = topimage.image_nodes(nodes)

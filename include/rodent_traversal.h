@@ -145,7 +145,7 @@ int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2, 4 or 8 
  * every launch phased (tests). */
 void        rodent_hip_phased_min_rays(int32_t rays);
 /* The default BVH2 mapping ("top": top of the tree staged in LDS, persistent workgroups) takes the one-chunk-per-workgroup
- * kernel ("fast") for launches of fewer than this many rays (default 589 824: the measured cross-over of the two kernels --
+ * kernel ("fast") for launches of fewer than this many rays (default 393 216: the measured cross-over of the two kernels, 589 824 until round 4 --
  * staging and validating the image in every workgroup does not pay below that); < 0 restores the default, 0 sends every launch through the LDS-image kernel (tests).
  * The default BVH4 / BVH8 mapping ("top": persistent workgroups that stage the top 85 / 73 nodes themselves) switches to ITS one-chunk kernel
  * ("single") at the same size. */

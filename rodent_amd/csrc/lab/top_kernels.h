@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     if (root != 1 && threadIdx.x == 0) atomicAdd(&ctl->stats[6], 1ull);
     const int total_chunks = (n + kWave - 1) / kWave, stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
     int* counter = tickets + stripe * kCounterStride;
-    int t = (blockIdx.x / kStripes) * WAVES + wave;
+    int t = stripe_rank(wave);
     lds_int* const sp_limit = col + LDS_N * kWave;
     const Bases base = make_bases(nodes, tris);
     const unsigned long long below = (1ull << lane) - 1ull;

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     const bool paired = total_chunks == 2 * stripe_waves * kStripes && stripe_waves == 128;
     lds_int* const sp_limit = col + LDS_N * kWave;
     const Bases base = make_bases(nodes, tris);
-    int t = (blockIdx.x / kStripes) * WAVES + wave;
+    int t = stripe_rank(wave);
     for (;;) {
         int chunk;
         if (paired) {

@@ -479,7 +479,7 @@ void k_trace_persist(SceneDev sc, PrimaryStream p, int n_primary, SecondaryStrea
     const int chunks_p = (np + kWave - 1) / kWave, total_chunks = chunks_p + (ns + kWave - 1) / kWave;
     const int stripe = blockIdx.x % kTraceStripes, stripe_waves = (gridDim.x / kTraceStripes) * kPersistWaves;
     int* counter = tickets + stripe * kTraceCounterStride;
-    int t = (blockIdx.x / kTraceStripes) * kPersistWaves + wave;
+    int t = wave * ((int)gridDim.x / kTraceStripes) + (int)blockIdx.x / kTraceStripes;     // the wave's rank in its stripe, wave-major (traversal_top.h stripe_rank)
     lds_int* col = (lds_int*)lds + wave * (kTopStack + 1) * kWave + lane;
     __syncthreads();
     if (MODE != 1 && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)np);
@@ -592,7 +592,7 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
         if (more && idle >= need_idle && idle > 0) {
             retire();
             int first;
-            if (first_draw) { first = ((blockIdx.x / kTraceStripes) * kPersistWaves + wave) * kWave; first_draw = false; }
+            if (first_draw) { first = (wave * ((int)gridDim.x / kTraceStripes) + (int)blockIdx.x / kTraceStripes) * kWave; first_draw = false; }      // rank in the stripe, wave-major
             else {
                 int f = 0;
                 if (lane == 0) f = atomicAdd(counter, idle);

@@ -14,7 +14,7 @@
 //  * the default mapping (k_bvh2_top_persist): the top 255 nodes of the caller's hierarchy are staged in LDS as an image
 //    that every workgroup validates against the node array before using it (the ABI passes a pointer, not a handle); the
 //    grid is one resident generation of 16-wave workgroups whose waves draw chunks from 64 striped ticket counters;
-//    launches under 576 Ki rays take k_bvh2_single (64-lane workgroups = one wavefront, one chunk each);
+//    launches under 384 Ki rays take k_bvh2_single (64-lane workgroups = one wavefront, one chunk each);
 //  * the traversal stack is an LDS-only window of 15 / 16 entries, laid out [entry][lane] (bank = lane % 32 for
 //    ds_read/write_b32: conflict free whatever each lane's depth is) and walked with a cursor pointer; a ray that
 //    needs more is finished by the one-wave follow-up kernel (k_bvh2_finish / k_bvh2_top_finish) with the reference's
@@ -866,7 +866,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool S
 // the single kernel (256 Ki rays: 0.099 ms against 0.117 ms, 512 Ki: 0.138 against 0.144, 768 Ki: 0.181 against 0.155 --
 // staging and validating the image does not pay yet), and so do
 // launches whose node array the runtime cannot give a mapped range for (nothing bounds the ids of an older image then).
-constexpr int kTopMinRays = 9216 * kWave;      // the measured cross-over lies between 512 Ki and 768 Ki rays (profiles/r02_threshold_sweep.txt)
+constexpr int kTopMinRays = 6144 * kWave;      // 384 Ki rays: the measured cross-over with wave-major first tickets (profiles/r05_spread_tickets.txt; 576 Ki until round 4, profiles/r02_threshold_sweep.txt)
 int g_top_min_rays = kTopMinRays;               // rodent_hip_top_min_rays()
 // rodent_hip_ray_kind_hint() / RODENT_HIP_KIND_HINT: 1 = the default mapping remembers what its kernels saw of a ray list and sends one that was incoherent throughout to
 // k_bvh2_top_refill from its second launch on (+2 ... 4 % on random segments).  OFF by default from round 5 on: which kernel a launch gets must not depend on earlier launches

@@ -47,6 +47,12 @@ __global__ __launch_bounds__(kWave) void k_bvh2_top_finish(const Node2* __restri
 // (lab build: lab/top_kernels.h holds the forms that were measured and superseded -- one chunk per workgroup wave with the image, the refill kernel under a pinned
 // register budget, work stealing inside the wave)
 
+// A wave's rank among the waves of its stripe = its first, static ticket.  WAVE-major (round 5): consecutive ranks belong to DIFFERENT workgroups of the stripe (all on
+// one XCD), so a launch of few chunks spreads over the chip instead of filling two workgroups per stripe with sixteen busy waves each while the others idle
+// (workgroup-major until round 4; 128 Ki rays through the persistent kernel 0.113 -> 0.096 ms, 384 Ki random segments 0.163 -> 0.141, 1 Mi and more unchanged:
+// profiles/r05_spread_tickets.txt).  The default mapping's switch from the one-chunk kernel moved from 576 Ki to 384 Ki rays with it.
+__device__ __forceinline__ int stripe_rank(int wave) { return wave * ((int)gridDim.x / kStripes) + (int)blockIdx.x / kStripes; }
+
 struct History { const int* order; int* cost; int stride; const int* agree; };   // order[stripe * stride + ticket] = chunk (may be null); cost may be null; agree: see below
 // chunks of stripe s under the default order: its complete 32-chunk groups plus, for one stripe, the ragged last group
 __device__ __forceinline__ int stripe_chunks(int total_chunks, int stripe) {
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     // counter hands out the tickets behind those
     const int total_chunks = (n + kWave - 1) / kWave, stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
     int* counter = tickets + stripe * kCounterStride;
-    int t = (blockIdx.x / kStripes) * WAVES + wave;
+    int t = stripe_rank(wave);
     lds_int* const sp_limit = col + LDS_N * kWave;
     const Bases base = make_bases(nodes, tris);
     const int my_chunks = HISTORY ? stripe_chunks(total_chunks, stripe) : 0;
@@ -324,7 +330,7 @@ __device__ __forceinline__ void top_refill_body(const Node2* __restrict__ nodes,
     const Bases base = make_bases(nodes, tris);
     Lane L;
     {
-        const int r = ray_of(((blockIdx.x / kStripes) * WAVES + wave) * kWave + lane);
+        const int r = ray_of(stripe_rank(wave) * kWave + lane);
         L = start_lane(rays, hits, r < n ? r : -1, 0, col);
         if (L.top != 0) L.top = root;
     }
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     const auto ray_of = [&](int t) { return ((t / kGroupRays) * kStripes + stripe) * kGroupRays + t % kGroupRays; };
     lds_int* const sp_limit = col + LDS_N * kWave;
     const Bases base = make_bases(nodes, tris);
-    int t = ((blockIdx.x / kStripes) * WAVES + wave) * kWave;               // the wave's first 64 tickets are its rank in the stripe; the counter hands out those behind
+    int t = stripe_rank(wave) * kWave;                                       // the wave's first 64 tickets are its rank in the stripe; the counter hands out those behind
     bool coherent = MODE != 2;
     if (MODE == 0 && ray_of(t) < n) {                                        // (ray_of grows with the ticket: otherwise this stripe's share is used up already)
         // one origin or one direction for all of the wave's first 64 rays?

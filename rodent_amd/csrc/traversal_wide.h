@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kWave * WAVES) void k_wide_top_persist(const char* 
     __syncthreads();
     const int total_chunks = (n + kWave - 1) / kWave, stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
     int* counter = tickets + stripe * kCounterStride;
-    int t = (blockIdx.x / kStripes) * WAVES + wave;                          // a wave's first ticket: its rank inside the stripe
+    int t = stripe_rank(wave);                                               // a wave's first ticket: its rank inside the stripe (wave-major, traversal_top.h)
     for (;;) {
         const int group_first = ((t / kGroup) * kStripes + stripe) * kGroup, chunk = group_first + t % kGroup;
         if (group_first >= total_chunks) break;                              // this stripe's share is used up

@@ -63,7 +63,7 @@ def test_all_benchmark_rays_bit_exact(gpu, oracle, dumps, width, kind):
 
 @pytest.mark.parametrize("scene,limit", [("atrium", 1.10), ("refbuilt", 1.10), ("cornell", 1.35)])
 def test_default_mapping_is_not_slower_than_the_one_chunk_kernel_where_it_is_selected(gpu, scene, limit, tmp_path):
-    """The default BVH2 mapping switches from the one-chunk kernel ("fast") to the persistent LDS-image kernel at 589 824 rays, with
+    """The default BVH2 mapping switches from the one-chunk kernel ("fast") to the persistent LDS-image kernel at 393 216 rays (589 824 until round 4), with
     a 255-record image and 15-entry stack windows -- constants tuned on the atrium's primary camera (profiles/r02_threshold_sweep.txt).
     From that size on it must not lose to "fast" by more than 10 %: on the benchmark scene, on the decimated atrium as the
     REFERENCE's builder lays it out (tests/golden/atrium-decimated-refbuilt.bvh.gz), primary and random rays.  On a tree that
@@ -95,7 +95,7 @@ def test_default_mapping_is_not_slower_than_the_one_chunk_kernel_where_it_is_sel
         return float(np.median([s.elapsed_time(e) for s, e in ev]))
 
     try:                                                               # (this module runs on the shipped switch point throughout)
-        for w, h in ((1024, 576), (1024, 1024)):
+        for w, h in ((1024, 384), (1024, 576), (1024, 1024)):
             n = w * h
             for kind, rays in (("primary", raygen.primary_rays(*cam, w, h, 0.0, 5000.0)), ("random", raygen.random_rays(lo, hi, n, 42, 0.0, 1.0))):
                 rd = gpu.to_device(rays, 0); hd = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
@@ -243,6 +243,33 @@ def test_atrium_joint_traversal_launch_renders_the_same_frame(R, atrium_scene, s
         assert (c["primary_rays"], c["shadow_rays"], c["generated"]) == (c0["primary_rays"], c0["shadow_rays"], W * H * SPP), mode
         assert np.allclose(f, f0, rtol=FILM_RTOL, atol=FILM_ATOL), mode
     assert f0.mean() > 1e-3
+
+
+def test_atrium_deep_stacks_in_the_renderer(R, atrium_scene):
+    """The renderer's traversal kernels on a hierarchy whose stacks outgrow the lanes' 15-row LDS windows (the atrium under ten padding levels,
+    conftest.pad_bvh2_depth: every ray's deepest stack + 10, hits unchanged): the persistent kernels spill in place (k_trace_refill: the per-scene
+    default; k_trace_persist: whole chunks), the one-chunk kernels hand such rays to k_trace_deep (64 workgroups), the megakernel keeps its scratch
+    stack.  Same ray counts as the unpadded scene, the same film up to the order of the atomic adds, no overflow."""
+    import copy
+    from conftest import pad_bvh2_depth
+    W, H, SPP, MAXLEN = 640, 360, 8, 8                                    # 1.8 M paths, 700 000-ray streams: above the persistent kernels' threshold
+    cam = atrium_camera(W, H)
+    r = R.Renderer(atrium_scene, W, H, SPP, MAXLEN, mapping="streaming", capacity=700_000)
+    r.render(cam, 3)
+    c0, f0 = r.counters(), r.film(); r.close()
+    deep = copy.copy(atrium_scene)
+    deep.nodes = pad_bvh2_depth(atrium_scene.nodes, 10)                  # (a stack of 5 entries on the plain scene -- a fifth of the rays -- now needs 15)
+    assert len(deep.nodes) == len(atrium_scene.nodes) + 11
+    for label, opts in (("joint launch, lane refill (the default for this scene)", dict(mapping="streaming")),
+                        ("joint launch, whole chunks", dict(mapping="streaming", trace_persistent=2, trace_refill=(0, 0))),
+                        ("two persistent launches, lane refill", dict(mapping="streaming", trace_persistent=1, trace_refill=(32, 32))),
+                        ("one-chunk kernels + k_trace_deep", dict(mapping="streaming", trace_persistent=0)),
+                        ("megakernel", dict(mapping="megakernel"))):
+        r = R.Renderer(deep, W, H, SPP, MAXLEN, capacity=700_000, **opts)
+        r.render(cam, 3)
+        c, f = r.counters(), r.film(); r.close()
+        assert (c["primary_rays"], c["shadow_rays"], c["generated"]) == (c0["primary_rays"], c0["shadow_rays"], W * H * SPP), label
+        assert np.allclose(f, f0, rtol=FILM_RTOL, atol=FILM_ATOL), label
 
 
 def test_atrium_lane_refill_renders_the_same_frame(R, atrium_scene):

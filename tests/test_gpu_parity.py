@@ -521,7 +521,7 @@ def test_schedule_history_only_reorders_the_chunks(gpu, oracle, cornell, cornell
 
 
 def test_default_mapping_switches_kernels_at_its_size_threshold(gpu, oracle, cornell, cornell_dev):
-    """With the shipped threshold (rodent_hip_top_min_rays(-1): 589 824 rays) launches just under it take the one-chunk kernel and
+    """With the shipped threshold (rodent_hip_top_min_rays(-1): 393 216 rays) launches just under it take the one-chunk kernel and
     launches from it on the persistent LDS-image kernel (stats[6]: workgroups that ran on the image); the hits are the oracle's."""
     import torch
     top = gpu.variants(2).index("top")
@@ -529,7 +529,7 @@ def test_default_mapping_switches_kernels_at_its_size_threshold(gpu, oracle, cor
     nodes, tris = cornell.blocks[2]
     gpu.lib().rodent_hip_top_min_rays(-1)
     try:
-        for n, persistent in ((9216 * 64 - 1, False), (9216 * 64, True), (9216 * 64 + 1, True)):
+        for n, persistent in ((6144 * 64 - 1, False), (6144 * 64, True), (6144 * 64 + 1, True)):
             rays = np.tile(base, (n + len(base) - 1) // len(base))[:n].copy()
             rays["org"][:, 1] += (np.arange(n, dtype=np.float32) % 613) * 1e-4
             rd = gpu.to_device(rays, 0)
