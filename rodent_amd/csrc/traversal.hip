@@ -756,7 +756,7 @@ void ensure_deep_list(DeviceState& s, int n) {
 }
 
 // The blocks the traversal stacks spill into beyond their LDS windows: one per wave slot of a resident generation of the persistent
-// kernels (num_cus x 32 waves = 8192), which the one-chunk kernels' launches below rodent_hip_top_min_rays (9216 chunks) fit as well.
+// kernels (num_cus x 32 waves = 8192), which the one-chunk kernels' launches below rodent_hip_top_min_rays (6144 chunks; 9216 until round 4) fit as well.
 // 113 MB per (device, stream) context, allocated with the context's first launch, touched only by rays deeper than their window.
 constexpr int kSpillSlots = 9216;
 void ensure_spill(DeviceState& s) {
