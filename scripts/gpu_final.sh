@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/r05; export TMPDIR=/tmp
 timeout 3000 python -m pytest tests -m gpu -x -q > gpurun_out/r05/tests_final.txt 2>&1; tail -4 gpurun_out/r05/tests_final.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-/usr/bin/time -f "bench wall %e s" timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r05/bench_final.json 2> gpurun_out/r05/bench_final.err; tail -2 gpurun_out/r05/bench_final.err
+SECONDS=0; timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r05/bench_final.json 2> gpurun_out/r05/bench_final.err; echo "bench wall $SECONDS s"; tail -2 gpurun_out/r05/bench_final.err
 python - <<'PY'
 import json
 d = json.loads([l for l in open("gpurun_out/r05/bench_final.json") if l.startswith("{")][0])
