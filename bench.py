@@ -560,6 +560,16 @@ def main():
         hint_rec = {"Mrays_s": round(len(rnd) * steps_r / wall_n / 1e6, 3), "kernels_ms": round(kn_mean, 5), "identical_to_default": bool(torch.equal(hits_hint_dev, hits_rnd_dev)),
                     "what": "rodent_hip_ray_kind_hint(1): the list goes to k_bvh2_top_refill from its second launch on; the default (random_Mrays_s) is k_bvh2_top_auto alone, whose waves "
                             "find their rays incoherent and run the refill loop -- no state between launches"}
+    # the default WITHOUT the tile mapping (rodent_hip_ray_grid(0): camera rays traced in list order, 64 pixels of a row per wavefront, as until round 4)
+    list_order_rec = None
+    if world == 1 and width == 2 and abi.variants(2)[variant] == "top" and args.only != "random":
+        abi.ray_grid(0)
+        hits_lo_dev = torch.zeros_like(hits_dev)
+        wall_l, kl_mean, _, _ = time_passes(abi, torch, bvh, prim_dev, hits_lo_dev, n, variant, steps_p, warm_p, None)
+        abi.ray_grid(-1)
+        list_order_rec = {"Mrays_s": round(n * steps_p / wall_l / 1e6, 3), "kernels_ms": round(kl_mean, 5), "identical_to_default": bool(torch.equal(hits_lo_dev, hits_dev)),
+                          "what": "rodent_hip_ray_grid(0): the same kernel with the wave's 64 rays in list order (64 pixels of an image row); the default recognises the image "
+                                  "width from 66 of the launch's rays and gives every wavefront an 8 x 8-pixel tile -- no state between launches, hit records identical"}
     abi.check_errors(dev)                                         # the asynchronous entry points report stack overflows through a flag
     # for information only (never `value`): independent batches in flight on two streams -- the fill of one launch
     # overlaps the drain of the other (every (device, stream) has its own launch state)
@@ -683,6 +693,9 @@ def main():
     out["config"]["random_Mrays_s"] = round(main_part["value_rnd"], 1)          # stateless: the in-kernel choice alone (the ray-kind hint is off by default)
     if hint_rec:
         out["config"]["random_with_kind_hint_Mrays_s"] = hint_rec["Mrays_s"]
+    if list_order_rec:
+        out["config"]["primary_in_list_order_Mrays_s"] = list_order_rec["Mrays_s"]
+        out["extra"]["primary_in_list_order"] = list_order_rec
     if world > 1:
         # what one GPU predicts for N (profiles/r04_range_costs.txt, r04_band_costs.txt: every rank's share timed alone): ONE 1 Mi-ray set does not shard its tail
         out["config"]["predicted_scaling_x"] = {"strong_1Mi_primary_contiguous_ranges": {"2": 1.31, "4": 1.78, "8": 2.21}, "strong_1Mi_random": {"2": 1.27, "4": 1.92, "8": 2.19},

@@ -163,6 +163,12 @@ void        rodent_hip_schedule_history(int32_t enable);
  * of the earlier launches found incoherent is traced by the kernel specialised for that ("refill") from its second launch on (+2 ... 4 % on random
  * segments): kernel selection then depends on earlier launches and, for asynchronous callers, on when they finished.  Hit records never depend on it. */
 void        rodent_hip_ray_kind_hint(int32_t enable);
+/* Camera rays in image order (round 5; RODENT_HIP_RAY_GRID).  The reference's primary-ray dumps are the pixels of an image row by row (tools/ray_gen/ray_gen.cpp:20-58:
+ * dir = d + kx r + ky u, not normalised).  Which rays share a wavefront is the callee's business: the default BVH2 kernel recognises such a list from 66 of its rays --
+ * no state between launches, no probe launch -- and gives every wavefront an 8 x 8-pixel tile instead of 64 pixels of one row (the rays of a tile finish closer together and
+ * share more nodes: 1 Mi camera rays on the atrium 0.178 -> 0.167 ms).  Hit records and their places in `hits` do not change.
+ * width: -1 = recognise (default), 0 = never (list order, as until round 4), > 0 = take this image width on trust (experiments; multiples of 8 only, others mean 0). */
+void        rodent_hip_ray_grid(int32_t width);
 int32_t     rodent_hip_is_lab_build(void);              /* 1 = librodent_hip_lab.so (-DRODENT_HIP_LAB: also the measured-and-lost kernels) */
 const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant);
 const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t any_hit);
@@ -172,7 +178,8 @@ const char* rodent_hip_version(void);
 const char* rodent_hip_source_digest(void);
 /* Debug aid: reads and clears the 8 phase counters of the instrumented "stats-*" variants
  * ([0] descent iterations, [1] lanes active in them, [2] leaf iterations, [3] lanes, [4] refills,
- * [5] lanes refilled, [6] outer iterations). */
+ * [5] lanes refilled, [6] outer iterations); from the shipped BVH2 mappings: [2] image width a launch traced 8 x 8 tiles of, [4] launches of the refill kernel by the
+ * ray-kind hint, [5] launches whose first wavefront chose the refill loop, [6] launches that ran on a validated LDS image, [7] stack blocks spilled + rays handed to the deep pass. */
 void        rodent_hip_read_stats(int32_t dev, uint64_t* out8);
 /* Debug aid: per-wave timeline of the instrumented variants.  First call (out may be NULL) arms it;
  * later calls copy 16384 x 4 words {start tick, end tick (100 MHz), hw_id | xcc_id << 32,

@@ -31,7 +31,7 @@ SYNC_ENTRY_POINTS = [
 ASYNC_ENTRY_POINTS = ["hip_traverse_bvh2_tri1_async", "hip_traverse_bvh4_tri4_async", "hip_traverse_bvh8_tri4_async"]
 EXPORTS = SYNC_ENTRY_POINTS + ASYNC_ENTRY_POINTS + [
     "rodent_hip_check_errors", "rodent_hip_get_kernel_time", "rodent_hip_device_count", "rodent_hip_num_variants", "rodent_hip_variant_name",
-    "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_source_digest", "rodent_hip_is_lab_build", "rodent_hip_phased_min_rays", "rodent_hip_top_min_rays", "rodent_hip_ray_kind_hint", "rodent_hip_schedule_history", "rodent_hip_read_stats", "rodent_hip_read_trace", "rodent_hip_debug_set_perm",
+    "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_source_digest", "rodent_hip_is_lab_build", "rodent_hip_phased_min_rays", "rodent_hip_top_min_rays", "rodent_hip_ray_kind_hint", "rodent_hip_ray_grid", "rodent_hip_schedule_history", "rodent_hip_read_stats", "rodent_hip_read_trace", "rodent_hip_debug_set_perm",
 ]
 BLOCK_OF_WIDTH = {2: F.BVH2_TRI1, 4: F.BVH4_TRI4, 8: F.BVH8_TRI4}
 
@@ -60,6 +60,7 @@ def lib():
         l.rodent_hip_top_min_rays.restype = None; l.rodent_hip_top_min_rays.argtypes = [i32]
         l.rodent_hip_get_kernel_time.restype = C.c_uint64; l.rodent_hip_get_kernel_time.argtypes = []
         l.rodent_hip_ray_kind_hint.restype = None; l.rodent_hip_ray_kind_hint.argtypes = [i32]
+        l.rodent_hip_ray_grid.restype = None; l.rodent_hip_ray_grid.argtypes = [i32]
         l.rodent_hip_schedule_history.restype = None; l.rodent_hip_schedule_history.argtypes = [i32]
         l.rodent_hip_device_count.restype = i32; l.rodent_hip_device_count.argtypes = []
         l.rodent_hip_num_variants.restype = i32; l.rodent_hip_num_variants.argtypes = [i32]
@@ -179,6 +180,12 @@ def ray_kind_hint(enable: bool):
     """rodent_hip_ray_kind_hint: may the default BVH2 mapping remember that a ray list (pointer, count) was incoherent and trace it with
     the refill kernel from its second launch on (default: no -- kernel selection is stateless; hit records do not depend on it)."""
     lib().rodent_hip_ray_kind_hint(int(bool(enable)))
+
+
+def ray_grid(width: int = -1):
+    """rodent_hip_ray_grid: -1 = the default BVH2 kernel recognises camera rays in image order and traces them as 8 x 8-pixel tiles (default),
+    0 = never, > 0 = that image width on trust (hit records do not depend on it)."""
+    lib().rodent_hip_ray_grid(int(width))
 
 
 def check_errors(dev=0, stream=None):

@@ -868,14 +868,27 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool S
 // launches whose node array the runtime cannot give a mapped range for (nothing bounds the ids of an older image then).
 constexpr int kTopMinRays = 6144 * kWave;      // 384 Ki rays: the measured cross-over with wave-major first tickets (profiles/r05_spread_tickets.txt; 576 Ki until round 4, profiles/r02_threshold_sweep.txt)
 int g_top_min_rays = kTopMinRays;               // rodent_hip_top_min_rays()
+// A tree that the runtime maps no more than an image's worth of node ids for (Cornell box: 16 nodes) is traced in a few dozen microseconds whatever the kernel; what differs is the
+// launch's fixed cost, and the one-chunk kernel's is ~12 us lower up to 1 Mi rays (profiles/r03_threshold_sweep.txt: 393 216 random segments 0.0345 against 0.0470 ms,
+// 1 Mi 0.0702 against 0.0745).  Such trees switch at 1 Mi rays (while the threshold is at its default).
+constexpr int kTinyTreeIds = 255, kTopMinRaysTinyTree = 16384 * kWave;
+// the node ids the persistent LDS-image kernel may assume mapped, or 0: this launch takes the one-chunk kernel
+int top_kernel_ids(const Node2* nodes, int n) {
+    if (n < g_top_min_rays) return 0;
+    const int ids = mapped_node_ids(nodes);
+    return ids <= kTinyTreeIds && g_top_min_rays == kTopMinRays && n < kTopMinRaysTinyTree ? 0 : ids;
+}
 // rodent_hip_ray_kind_hint() / RODENT_HIP_KIND_HINT: 1 = the default mapping remembers what its kernels saw of a ray list and sends one that was incoherent throughout to
 // k_bvh2_top_refill from its second launch on (+2 ... 4 % on random segments).  OFF by default from round 5 on: which kernel a launch gets must not depend on earlier launches
 // or on when an asynchronous caller's previous launch happened to finish; k_bvh2_top_auto's choice per wave needs no memory.
+// RODENT_HIP_RAY_GRID: -1 (default) = k_bvh2_top_auto recognises camera rays in image order by itself (detect_ray_grid) and traces them as 8 x 8-pixel tiles;
+// 0 = never (rays in list order, as until round 5); > 0 = the image's width, taken on trust (experiments)
+int g_ray_grid = [] { const char* e = getenv("RODENT_HIP_RAY_GRID"); return e ? atoi(e) : -1; }();
 int g_kind_hint = [] { const char* e = getenv("RODENT_HIP_KIND_HINT"); return e && atoi(e) ? 1 : 0; }();
 // FUSED = 2: the launch finishes itself (its last workgroup does the follow-up kernel's work; fences on the rare paths only): one
 // kernel per call instead of two, +1.1 % / +1.8 % on the benchmark's primary / random set in wall-clock terms (bench.py, 100 steps).
 template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, int FUSED = 2> void L_chunks(LAUNCH_ARGS) {
-    const int max_id = n < g_top_min_rays ? 0 : mapped_node_ids(nodes);
+    const int max_id = top_kernel_ids(nodes, n);
     if (max_id == 0) L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream);
     else launch_top_persist<ANY, LDS_N, TOPN, WAVES, PREFETCH, false, 32, false, 0, FUSED>(s, nodes, tris, rays, hits, n, stream, max_id);
 }
@@ -892,7 +905,7 @@ void ensure_top_buffers(DeviceState& s) {
     }
 }
 template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0, bool FUSED = true> void L_default(LAUNCH_ARGS) {
-    const int max_id = n < g_top_min_rays ? 0 : mapped_node_ids(nodes);
+    const int max_id = top_kernel_ids(nodes, n);
     if (max_id == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }
     if (g_schedule_history) { launch_top_persist<ANY, LDS_N, TOPN, WAVES, false, false, 32, false, 0, 2>(s, nodes, tris, rays, hits, n, stream, max_id); return; }
     ensure_deep_list(s, n);
@@ -918,7 +931,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0, bo
         return;
     }
     hipLaunchKernelGGL((k_bvh2_top_auto<ANY, LDS_N, TOPN, WAVES, REFILL, MODE, FUSED>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
-                       s.top_image, s.tickets, max_id, s.spill, report_to, id);
+                       s.top_image, s.tickets, max_id, s.spill, report_to, id, g_ray_grid);
     if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }
 
@@ -926,7 +939,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0, bo
 // benchmark's random segments +5 % at 1 Mi rays per launch, +13 % (closest hit) / +18 % (any hit) at 8 Mi, profiles/r03_sweep_refill_big_random.log;
 // coherent camera rays LOSE 13 ... 18 % (neighbouring rays stop being in step), which is why it is a variant the caller asks for and not the default.
 template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = false, bool FENCE = false> void L_top_refill(LAUNCH_ARGS) {
-    if (n < g_top_min_rays || mapped_node_ids(nodes) == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }      // (as L_default)
+    if (top_kernel_ids(nodes, n) == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }      // (as L_default)
     ensure_deep_list(s, n);
     if (!s.top_image || !s.tickets) {
         std::lock_guard<std::mutex> lock(g_mutex);
@@ -1167,6 +1180,7 @@ void rodent_hip_debug_set_perm(int32_t dev, const int32_t* device_perm) { device
 void rodent_hip_schedule_history(int32_t enable) { g_schedule_history = enable ? 1 : 0; }
 void rodent_hip_top_min_rays(int32_t rays) { g_top_min_rays = rays < 0 ? kTopMinRays : rays; }
 void rodent_hip_ray_kind_hint(int32_t enable) { g_kind_hint = enable ? 1 : 0; }
+void rodent_hip_ray_grid(int32_t width) { g_ray_grid = width; }
 int32_t rodent_hip_is_lab_build(void) {
 #ifdef RODENT_HIP_LAB
     return 1;

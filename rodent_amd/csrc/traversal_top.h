@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
     lds_int* image = (lds_int*)lds_raw + kStackInts;
     const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, (const int4*)top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;      // record 0 of the image, or node 1
-    if (root != 1 && threadIdx.x == 0) atomicAdd(&ctl->stats[6], 1ull);     // stats[6]: workgroups that ran on the image (read by the tests)
+    if (root != 1 && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&ctl->stats[6], 1ull);     // stats[6]: the launch ran on the image (read by the tests; workgroup 0 speaks for all, see k_bvh2_top_auto)
     // stripe = workgroup index mod 64 (its XCD = stripe mod 8); the first ticket of a wave is its rank inside the stripe, the
     // counter hands out the tickets behind those
     const int total_chunks = (n + kWave - 1) / kWave, stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
@@ -381,6 +381,33 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(c
     top_refill_body<ANY, LDS_N, TOPN, WAVES, REFILL, ADAPT, FENCE>(nodes, tris, rays, hits, n, ctl, deep_list, top_image, tickets, max_id, spill, host_kinds, launch_id);
 }
 
+// Are the rays the pixels of an image, row by row?  Then which rays share a wave is the kernel's choice, and an 8 x 8-pixel tile is a tighter bundle than 64 pixels of a row:
+// the wave's rays finish closer together (oracle step counts, atrium camera: mean over chunks of the longest ray 57.4 steps for row segments, 48.4 for tiles, mean ray 39.3)
+// and touch fewer distinct nodes per load.  What a ray visits and where its hit goes do not change: the hits stay bit-identical
+// (measured 1 Mi camera rays: atrium 0.1781 -> 0.1667 ms, gallery 0.295 -> 0.281, crown 0.1845 -> 0.1875; profiles/r05_grid_tiles.txt).
+// ray_gen writes dir = d + kx(column) r + ky(row) u, not normalised (the reference's tools/ray_gen/ray_gen.cpp:20-58): along a row the direction advances by a constant step e,
+// so (dir[i] - dir[0]) . e / |e|^2 is the column of ray i -- it climbs with i and falls back to 0 where the next row starts.  Every wave looks at rays 0, 64 and 128, 256, ... 8192
+// (one load per lane, in flight with the wave's first rays): the first probe whose column is less than half its index lies in the second row, width = index - column; the other probes
+// must then sit in the columns that width predicts.  Wave-uniform, and the same in every wave of a launch (same rays, same arithmetic).  0 = not recognised: rays in list order,
+// as until round 5.  A wrong answer would cost speed, never hits -- any width maps the launch's positions onto its rays one to one (k_bvh2_top_auto).
+__device__ __forceinline__ int detect_ray_grid(const Ray1* __restrict__ rays, int n) {
+    constexpr int kProbe = 128;
+    if (n <= 2 * kProbe) return 0;
+    const int lane = (int)threadIdx.x % kWave, i = kProbe * (lane + 1);
+    const bool valid = i < n;
+    const float4 d0 = reinterpret_cast<const float4*>(rays)[1], d1 = reinterpret_cast<const float4*>(rays + 64)[1], dp = reinterpret_cast<const float4*>(rays + (valid ? i : 0))[1];
+    const float ex = (d1.x - d0.x) * (1.0f / 64.0f), ey = (d1.y - d0.y) * (1.0f / 64.0f), ez = (d1.z - d0.z) * (1.0f / 64.0f);
+    const float q = ex * ex + ey * ey + ez * ez;
+    const float col = ((dp.x - d0.x) * ex + (dp.y - d0.y) * ey + (dp.z - d0.z) * ez) / q;
+    const unsigned long long wrapped = __ballot(valid && !(col >= 0.5f * (float)i));
+    if (!(q > 0.0f) || wrapped == 0ull) return 0;
+    const int first = __ffsll((long long)wrapped) - 1;
+    const int w = (int)rintf((float)(kProbe * (first + 1)) - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col), first)));
+    if (w < kProbe || w > kProbe * kWave) return 0;
+    if (__ballot(valid && !(fabsf(col - (float)(i % w)) < 0.25f)) != 0ull) return 0;
+    return w;
+}
+
 // The default from round 4 on: ONE persistent kernel that chooses per wave between the two loop forms above (compaction
 // that switches itself on -- the reference compacts unconditionally, render/mapping_gpu.impala:267-300; Aila's kernel refills unconditionally,
 // tools/bench_aila/kepler_dynamic_fetch.cu:116-127,361-362).  A wave draws 64 consecutive tickets of its stripe (ray-granular tickets, the
@@ -395,7 +422,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0 /* 
 __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_auto(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                   const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                                   Ctl* ctl, int* __restrict__ deep_list, int4* __restrict__ top_image, int* __restrict__ tickets, int max_id,
-                                                                  int* spill, int* host_kinds, int launch_id) {
+                                                                  int* spill, int* host_kinds, int launch_id, int grid_w) {
     constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroupRays = 32 * kWave;
     static_assert((kStackInts + TOPN * 16) * 4 * (32 / WAVES) <= 160 * 1024, "32 waves per CU must fit their stacks and images in LDS");
     __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
@@ -403,7 +430,9 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
     lds_int* image = (lds_int*)lds_raw + kStackInts;
     const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, (const int4*)top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;
-    if (root != 1 && threadIdx.x == 0) atomicAdd(&ctl->stats[6], 1ull);     // stats[6]: workgroups that ran on the image (read by the tests)
+    // stats[6]: this launch ran on the image; stats[5]: its first wave chose the refill loop (read by the tests).  Workgroup 0 speaks for all: every workgroup validates the
+    // same image, and 512 atomics on one address cost a launch of few rays 4 us (Cornell box, 64 ... 393 216 rays: 21.0 ... 24.5 us -> 16.7 ... 21.0, profiles/r05_fixed_costs.txt)
+    if (root != 1 && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&ctl->stats[6], 1ull);
     const int stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
     int* counter = tickets + stripe * kCounterStride;
     const auto ray_of = [&](int t) { return ((t / kGroupRays) * kStripes + stripe) * kGroupRays + t % kGroupRays; };
@@ -416,15 +445,26 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
         const int r = ray_of(t + lane);
         const float4* p = reinterpret_cast<const float4*>(rays + (r < n ? r : ray_of(t)));
         const float4 o = p[0], d = p[1];
+        if (grid_w < 0) grid_w = detect_ray_grid(rays, n);                   // (its loads travel with p[0], p[1])
         coherent = wave_rays_coherent(o.x, o.y, o.z, d.x, d.y, d.z, r < n);
         if (wave == 0) report_ray_kind(host_kinds, launch_id, coherent);
     }
-    if (!coherent && threadIdx.x == 0) atomicAdd(&ctl->stats[5], 1ull);      // stats[5]: workgroups whose first wave chose the refill loop (read by the tests)
+    if (!coherent && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&ctl->stats[5], 1ull);
+    // camera rays in image order: the wave's 64 rays are an 8 x 8-pixel tile, not 64 pixels of a row (see detect_ray_grid); rows behind the last whole band of 8 stay as they are
+    grid_w = __builtin_amdgcn_readfirstlane(grid_w > 0 && (grid_w & 7) == 0 ? grid_w : 0);
+    const int tiled_rays = __builtin_amdgcn_readfirstlane(grid_w > 0 ? (n / (8 * grid_w)) * (8 * grid_w) : 0);
+    const int tiles_per_row = grid_w >> 3;
+    if (grid_w > 0 && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&ctl->stats[2], (unsigned long long)grid_w);      // stats[2]: the image width the launch traced tiles of (read by the tests)
     if (MODE == 1 || (MODE == 0 && coherent)) {
         for (;;) {                                                           // k_bvh2_top_persist's loop on 64-ticket draws
-            const int first_ray = ray_of(t);
+            int first_ray = ray_of(t);
             if (first_ray >= n) break;
-            const int r = ray_of(t + lane);
+            int r = ray_of(t + lane);
+            if (first_ray < tiled_rays) {                                    // 8 x 8-pixel tile number first_ray / 64 of the image instead of 64 pixels of a row
+                const int tile = first_ray / kWave, band = __builtin_amdgcn_readfirstlane(tile / tiles_per_row), tx = tile - band * tiles_per_row;
+                first_ray = band * 8 * grid_w + tx * 8;
+                r = first_ray + (lane >> 3) * grid_w + (lane & 7);
+            }
             Lane L = start_lane(rays, hits, r < n ? r : -1, first_ray, col);
             if (L.top != 0) L.top = root;
             while (__ballot(L.top != 0)) {

@@ -545,6 +545,50 @@ def test_default_mapping_switches_kernels_at_its_size_threshold(gpu, oracle, cor
         gpu.lib().rodent_hip_top_min_rays(0)
 
 
+@pytest.mark.gpu
+def test_camera_rays_in_image_order_are_traced_as_tiles(gpu, oracle, cornell, cornell_dev):
+    """Round 5: the default BVH2 kernel recognises the pixels of an image, row by row (the reference's primary-ray dumps, tools/ray_gen/ray_gen.cpp:20-58), from 66 of
+    the rays and gives every wavefront an 8 x 8-pixel tile instead of 64 pixels of a row (detect_ray_grid, traversal_top.h; stats[2] = the width it used).  Whatever it
+    recognises -- widths that are no multiple of 8, heights that are not (the last rows stay in list order), two images in one list, normalised directions, segments in no order,
+    a width forced on rays that are no image at all -- every Hit1 record is the oracle's, in its ray's place."""
+    import torch
+    from rodent_amd import raygen, scenes
+    top = gpu.variants(2).index("top")
+    nodes, tris = cornell.blocks[2]
+    cam = scenes.CAMERAS["cornell"]
+    lo, hi = raygen.scene_bounds2(nodes)
+
+    def run(rays, expect_width, force=-1):
+        gpu.ray_grid(force)
+        try:
+            gpu.read_stats(0)
+            got = gpu.traverse(cornell_dev[2], rays, variant=top)
+            gpu.check_errors(0)
+            used = int(gpu.read_stats(0)[2])
+        finally:
+            gpu.ray_grid(-1)
+        ref, _ = oracle.traverse(2, nodes, tris, rays)
+        assert got.tobytes() == ref.tobytes(), (len(rays), expect_width, force)
+        if expect_width is not None:
+            assert used == expect_width, (len(rays), used, expect_width, force)
+
+    for w, h, expect in ((256, 64, 256), (1024, 24, 1024), (136, 50, 136), (1000, 16, 1000), (1004, 12, 0), (128, 40, 128), (120, 40, 0), (8192, 8, 8192), (8200, 8, 0), (1920, 33, 1920)):
+        run(raygen.primary_rays(*cam, w, h, 0.0, 5000.0), expect)
+    image = raygen.primary_rays(*cam, 256, 64, 0.0, 5000.0)
+    run(image, 0, force=0)                                               # switched off: list order
+    run(np.concatenate([image, image[::-1]]), 256)                      # a second image behind the first (here: the same pixels backwards) is traced by the first one's tiles
+    unit = image.copy()
+    unit["dir"] /= np.linalg.norm(unit["dir"], axis=1, keepdims=True)
+    run(unit, None)                                                      # normalised directions are no ray_gen dump: recognised or not, the hits are right
+    segments = raygen.random_rays(lo, hi, 40_000, 7, 0.0, 1.0)
+    run(segments, 0)
+    run(segments, 64, force=64)                                          # (no chunk loop for these: the width is noted and unused)
+    run(image, 64, force=64)                                             # a WRONG width on camera rays: any width is a one-to-one map of the launch's positions onto its rays
+    run(image, 1024, force=1024)
+    run(image, 0, force=1004)                                            # (no multiple of 8: unused)
+    run(image[:300], 0)                                                  # fewer rays than the probes span
+
+
 def test_default_mapping_chooses_chunks_or_refill_by_itself(gpu, oracle, cornell, cornell_dev):
     """BASELINE config 3 ("ray compaction on") without a variant argument: the default kernel (k_bvh2_top_auto) traces rays that share an
     origin as whole chunks and refills idle lanes otherwise (stats[5]: workgroups that chose the refill loop).  With the ray-kind hint ON
