@@ -358,13 +358,54 @@ __device__ __forceinline__ void finish_lane(const Lane& L, const Ray1* __restric
     if (L.ray_id >= 0 && !L.found) store_hit(hits, L.ray_id, -1, rays[L.ray_id].tmax, 0.0f, 0.0f);
 }
 
+// Are the rays the pixels of an image, row by row?  Then which rays share a wave is the kernel's choice, and an 8 x 8-pixel tile is a tighter bundle than 64 pixels of a row:
+// the wave's rays finish closer together (oracle step counts, atrium camera: mean over chunks of the longest ray 57.4 steps for row segments, 48.4 for tiles, mean ray 39.3)
+// and touch fewer distinct nodes per load.  What a ray visits and where its hit goes do not change: the hits stay bit-identical
+// (measured 1 Mi camera rays: atrium 0.1781 -> 0.1667 ms, gallery 0.295 -> 0.281, crown 0.1845 -> 0.1875; profiles/r05_grid_tiles.txt).
+// ray_gen writes dir = d + kx(column) r + ky(row) u, not normalised (the reference's tools/ray_gen/ray_gen.cpp:20-58): along a row the direction advances by a constant step e,
+// so (dir[i] - dir[0]) . e / |e|^2 is the column of ray i -- it climbs with i and falls back to 0 where the next row starts.  Every wave looks at rays 0, 64 and 128, 256, ... 8192
+// (one load per lane, in flight with the wave's first rays): the first probe whose column is less than half its index lies in the second row, width = index - column; the other probes
+// must then sit in the columns that width predicts.  Wave-uniform, and the same in every wave of a launch (same rays, same arithmetic).  0 = not recognised: rays in list order,
+// as until round 5.  A wrong answer would cost speed, never hits -- any width maps the launch's positions onto its rays one to one (k_bvh2_top_auto).
+__device__ __forceinline__ int detect_ray_grid(const Ray1* __restrict__ rays, int n) {
+    constexpr int kProbe = 128;
+    if (n <= 2 * kProbe) return 0;
+    const int lane = (int)threadIdx.x % kWave, i = kProbe * (lane + 1);
+    const bool valid = i < n;
+    const float4 d0 = reinterpret_cast<const float4*>(rays)[1], d1 = reinterpret_cast<const float4*>(rays + 64)[1], dp = reinterpret_cast<const float4*>(rays + (valid ? i : 0))[1];
+    const float ex = (d1.x - d0.x) * (1.0f / 64.0f), ey = (d1.y - d0.y) * (1.0f / 64.0f), ez = (d1.z - d0.z) * (1.0f / 64.0f);
+    const float q = ex * ex + ey * ey + ez * ez;
+    const float col = ((dp.x - d0.x) * ex + (dp.y - d0.y) * ey + (dp.z - d0.z) * ez) / q;
+    const unsigned long long wrapped = __ballot(valid && !(col >= 0.5f * (float)i));
+    if (!(q > 0.0f) || wrapped == 0ull) return 0;
+    const int first = __ffsll((long long)wrapped) - 1;
+    const int w = (int)rintf((float)(kProbe * (first + 1)) - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col), first)));
+    if (w < kProbe || w > kProbe * kWave) return 0;
+    if (__ballot(valid && !(fabsf(col - (float)(i % w)) < 0.25f)) != 0ull) return 0;
+    return w;
+}
+
+// rays [0, tiled_ray_count) are whole bands of 8 image rows: position p of the launch (64 consecutive positions = one wavefront) is pixel p % 64 of tile p / 64
+__device__ __forceinline__ int tiled_ray_count(int grid_w, int n) { return __builtin_amdgcn_readfirstlane(grid_w > 0 ? (n / (8 * grid_w)) * (8 * grid_w) : 0); }
+// the ray of `lane` in the tile at positions [first, first + 64); `first` becomes the tile's first ray
+__device__ __forceinline__ int tile_ray(int& first, int lane, int grid_w) {
+    const int tiles_per_row = grid_w >> 3, tile = first / kWave, band = __builtin_amdgcn_readfirstlane(tile / tiles_per_row), tx = tile - band * tiles_per_row;
+    first = band * 8 * grid_w + tx * 8;
+    return first + (lane >> 3) * grid_w + (lane & 7);
+}
+
 // PRIO (lab): 0 = none; 1 = a wave raises its issue priority as it ages (48 / 96 / 144 iterations -> s_setprio 1 / 2 / 3);
 // 2 = the waves of the second dispatch round (workgroup index >= 8192) run at priority 2 from the start; 3 = both.
 template <bool ANY, int LDS_N, int PRIO = 0, bool SPILL = false>
 __device__ __forceinline__ void unified_chunk(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, const Ray1* __restrict__ rays,
                                               Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray,
-                                              const int* __restrict__ perm = nullptr, int* __restrict__ spill = nullptr) {
-    const int lane_ray = first_ray + (int)threadIdx.x;
+                                              const int* __restrict__ perm = nullptr, int* __restrict__ spill = nullptr, int grid_w = 0) {
+    int lane_ray = first_ray + (int)threadIdx.x;
+    if (SPILL && PRIO == 0) {                          // (the form the default mapping launches) camera rays in image order: an 8 x 8-pixel tile per wavefront, see detect_ray_grid
+        if (grid_w < 0) grid_w = detect_ray_grid(rays, n);
+        grid_w = __builtin_amdgcn_readfirstlane(grid_w > 0 && (grid_w & 7) == 0 ? grid_w : 0);
+        if (first_ray < tiled_ray_count(grid_w, n)) lane_ray = tile_ray(first_ray, (int)threadIdx.x, grid_w);
+    }
     // perm (k_bvh2_single's "sorted" mapping): lane j traces ray perm[j]; its hit still goes to hits[ray id]
     Lane L = start_lane(rays, hits, lane_ray < n ? (perm ? perm[lane_ray] : lane_ray) : -1, perm ? perm[first_ray] : first_ray, col);
     lds_int* const sp_limit = col + LDS_N * kWave;
@@ -515,7 +556,7 @@ static_assert(kMaxPhases == 4 && kStripes == 64 && kCounterStride == 16, "k_bvh2
 template <bool ANY, int LDS_N, int XCD, bool TRACE = false, int PRIO = 0, bool SPILL = false>
 __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                        Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm, int* __restrict__ spill) {
+                                                        Ctl* ctl, int* __restrict__ deep_list, const int* __restrict__ perm, int* __restrict__ spill, int grid_w) {
     __shared__ int lds_raw[(LDS_N + (PRIO >= 16 && PRIO < 256 ? 2 : 1)) * kWave];
     lds_int* col = (lds_int*)lds_raw + threadIdx.x;
     const unsigned long long t_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -528,7 +569,7 @@ __global__ __launch_bounds__(kWave) void k_bvh2_single(const Node2* __restrict__
             chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
         }
     }
-    unified_chunk<ANY, LDS_N, PRIO, SPILL>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, perm, spill);
+    unified_chunk<ANY, LDS_N, PRIO, SPILL>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, perm, spill, perm ? 0 : grid_w);
     if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
         unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
         tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
@@ -794,18 +835,25 @@ int mapped_node_ids(const Node2* nodes) {
     return (int)std::min<size_t>(bytes / sizeof(Node2), 0x3FFFFFFF);
 }
 
+// RODENT_HIP_RAY_GRID: -1 (default) = k_bvh2_top_auto recognises camera rays in image order by itself (detect_ray_grid) and traces them as 8 x 8-pixel tiles;
+// 0 = never (rays in list order, as until round 5); > 0 = the image's width, taken on trust (experiments)
+int g_ray_grid = [] { const char* e = getenv("RODENT_HIP_RAY_GRID"); return e ? atoi(e) : -1; }();
 int g_schedule_history = [] { const char* e = getenv("RODENT_HIP_SCHEDULE_HISTORY"); return e && atoi(e) ? 1 : 0; }();      // rodent_hip_schedule_history()
 // workgroups (of one wave) of the follow-up kernels in the shipped mappings: a launch's deep rays are restarted 256 x 64 at a time
 constexpr int kFinishGroups = 256;
 #define LAUNCH_ARGS DeviceState& s, const Node2* nodes, const Tri1* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
 
+// the one-chunk kernel's waves learn the image width one memory round trip BEFORE they can load their rays (the persistent kernel's learn it with their first rays): with fewer than
+// 128 Ki rays -- every wave resident at once, the launch is one wave's latency -- that costs more than tiles gain (64 Ki camera rays 0.078 -> 0.083 ms, 128 Ki 0.088 = 0.089,
+// 256 Ki 0.106 -> 0.102, 384 Ki 0.130 -> 0.118: profiles/r05_threshold_sweep_grid.txt)
+constexpr int kGridMinRays = 2048 * kWave;
 template <bool ANY, int LDS_N, int XCD, bool TR = false, int PRIO = 0> void L_single(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     if (PRIO == 0 && !TR && blocks_for(n) <= kSpillSlots) {        // every chunk has a spill block: deep stacks stay in their lanes
         ensure_spill(s);
-        hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, false, 0, true>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr, s.spill);
+        hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, false, 0, true>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr, s.spill, n >= kGridMinRays ? g_ray_grid : 0);
     } else
-        hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR, PRIO>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr, (int*)nullptr);
+        hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR, PRIO>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr, (int*)nullptr, 0);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 
@@ -881,9 +929,6 @@ int top_kernel_ids(const Node2* nodes, int n) {
 // rodent_hip_ray_kind_hint() / RODENT_HIP_KIND_HINT: 1 = the default mapping remembers what its kernels saw of a ray list and sends one that was incoherent throughout to
 // k_bvh2_top_refill from its second launch on (+2 ... 4 % on random segments).  OFF by default from round 5 on: which kernel a launch gets must not depend on earlier launches
 // or on when an asynchronous caller's previous launch happened to finish; k_bvh2_top_auto's choice per wave needs no memory.
-// RODENT_HIP_RAY_GRID: -1 (default) = k_bvh2_top_auto recognises camera rays in image order by itself (detect_ray_grid) and traces them as 8 x 8-pixel tiles;
-// 0 = never (rays in list order, as until round 5); > 0 = the image's width, taken on trust (experiments)
-int g_ray_grid = [] { const char* e = getenv("RODENT_HIP_RAY_GRID"); return e ? atoi(e) : -1; }();
 int g_kind_hint = [] { const char* e = getenv("RODENT_HIP_KIND_HINT"); return e && atoi(e) ? 1 : 0; }();
 // FUSED = 2: the launch finishes itself (its last workgroup does the follow-up kernel's work; fences on the rare paths only): one
 // kernel per call instead of two, +1.1 % / +1.8 % on the benchmark's primary / random set in wall-clock terms (bench.py, 100 steps).
@@ -969,7 +1014,7 @@ template <bool ANY, int LDS_N> void L_sorted(LAUNCH_ARGS) {
     hipLaunchKernelGGL(k_raysort_count, dim3(blocks), dim3(kSortThreads), 0, stream, nodes, rays, n, s.sort_keys, s.sort_totals);
     hipLaunchKernelGGL(k_raysort_scan, dim3(1), dim3(kSortCells), 0, stream, s.sort_totals, s.sort_totals + kSortCells);
     hipLaunchKernelGGL(k_raysort_scatter, dim3(blocks), dim3(kSortThreads), 0, stream, s.sort_keys, n, s.sort_totals + kSortCells, s.sort_perm);
-    hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, 32, false, 0>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)s.sort_perm, (int*)nullptr);
+    hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, 32, false, 0>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)s.sort_perm, (int*)nullptr, 0);
     hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 

@@ -381,33 +381,6 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(c
     top_refill_body<ANY, LDS_N, TOPN, WAVES, REFILL, ADAPT, FENCE>(nodes, tris, rays, hits, n, ctl, deep_list, top_image, tickets, max_id, spill, host_kinds, launch_id);
 }
 
-// Are the rays the pixels of an image, row by row?  Then which rays share a wave is the kernel's choice, and an 8 x 8-pixel tile is a tighter bundle than 64 pixels of a row:
-// the wave's rays finish closer together (oracle step counts, atrium camera: mean over chunks of the longest ray 57.4 steps for row segments, 48.4 for tiles, mean ray 39.3)
-// and touch fewer distinct nodes per load.  What a ray visits and where its hit goes do not change: the hits stay bit-identical
-// (measured 1 Mi camera rays: atrium 0.1781 -> 0.1667 ms, gallery 0.295 -> 0.281, crown 0.1845 -> 0.1875; profiles/r05_grid_tiles.txt).
-// ray_gen writes dir = d + kx(column) r + ky(row) u, not normalised (the reference's tools/ray_gen/ray_gen.cpp:20-58): along a row the direction advances by a constant step e,
-// so (dir[i] - dir[0]) . e / |e|^2 is the column of ray i -- it climbs with i and falls back to 0 where the next row starts.  Every wave looks at rays 0, 64 and 128, 256, ... 8192
-// (one load per lane, in flight with the wave's first rays): the first probe whose column is less than half its index lies in the second row, width = index - column; the other probes
-// must then sit in the columns that width predicts.  Wave-uniform, and the same in every wave of a launch (same rays, same arithmetic).  0 = not recognised: rays in list order,
-// as until round 5.  A wrong answer would cost speed, never hits -- any width maps the launch's positions onto its rays one to one (k_bvh2_top_auto).
-__device__ __forceinline__ int detect_ray_grid(const Ray1* __restrict__ rays, int n) {
-    constexpr int kProbe = 128;
-    if (n <= 2 * kProbe) return 0;
-    const int lane = (int)threadIdx.x % kWave, i = kProbe * (lane + 1);
-    const bool valid = i < n;
-    const float4 d0 = reinterpret_cast<const float4*>(rays)[1], d1 = reinterpret_cast<const float4*>(rays + 64)[1], dp = reinterpret_cast<const float4*>(rays + (valid ? i : 0))[1];
-    const float ex = (d1.x - d0.x) * (1.0f / 64.0f), ey = (d1.y - d0.y) * (1.0f / 64.0f), ez = (d1.z - d0.z) * (1.0f / 64.0f);
-    const float q = ex * ex + ey * ey + ez * ez;
-    const float col = ((dp.x - d0.x) * ex + (dp.y - d0.y) * ey + (dp.z - d0.z) * ez) / q;
-    const unsigned long long wrapped = __ballot(valid && !(col >= 0.5f * (float)i));
-    if (!(q > 0.0f) || wrapped == 0ull) return 0;
-    const int first = __ffsll((long long)wrapped) - 1;
-    const int w = (int)rintf((float)(kProbe * (first + 1)) - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col), first)));
-    if (w < kProbe || w > kProbe * kWave) return 0;
-    if (__ballot(valid && !(fabsf(col - (float)(i % w)) < 0.25f)) != 0ull) return 0;
-    return w;
-}
-
 // The default from round 4 on: ONE persistent kernel that chooses per wave between the two loop forms above (compaction
 // that switches itself on -- the reference compacts unconditionally, render/mapping_gpu.impala:267-300; Aila's kernel refills unconditionally,
 // tools/bench_aila/kepler_dynamic_fetch.cu:116-127,361-362).  A wave draws 64 consecutive tickets of its stripe (ray-granular tickets, the
@@ -452,19 +425,14 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     if (!coherent && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&ctl->stats[5], 1ull);
     // camera rays in image order: the wave's 64 rays are an 8 x 8-pixel tile, not 64 pixels of a row (see detect_ray_grid); rows behind the last whole band of 8 stay as they are
     grid_w = __builtin_amdgcn_readfirstlane(grid_w > 0 && (grid_w & 7) == 0 ? grid_w : 0);
-    const int tiled_rays = __builtin_amdgcn_readfirstlane(grid_w > 0 ? (n / (8 * grid_w)) * (8 * grid_w) : 0);
-    const int tiles_per_row = grid_w >> 3;
+    const int tiled_rays = tiled_ray_count(grid_w, n);
     if (grid_w > 0 && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&ctl->stats[2], (unsigned long long)grid_w);      // stats[2]: the image width the launch traced tiles of (read by the tests)
     if (MODE == 1 || (MODE == 0 && coherent)) {
         for (;;) {                                                           // k_bvh2_top_persist's loop on 64-ticket draws
             int first_ray = ray_of(t);
             if (first_ray >= n) break;
             int r = ray_of(t + lane);
-            if (first_ray < tiled_rays) {                                    // 8 x 8-pixel tile number first_ray / 64 of the image instead of 64 pixels of a row
-                const int tile = first_ray / kWave, band = __builtin_amdgcn_readfirstlane(tile / tiles_per_row), tx = tile - band * tiles_per_row;
-                first_ray = band * 8 * grid_w + tx * 8;
-                r = first_ray + (lane >> 3) * grid_w + (lane & 7);
-            }
+            if (first_ray < tiled_rays) r = tile_ray(first_ray, lane, grid_w);   // (first_ray: the tile's first pixel)
             Lane L = start_lane(rays, hits, r < n ? r : -1, first_ray, col);
             if (L.top != 0) L.top = root;
             while (__ballot(L.top != 0)) {

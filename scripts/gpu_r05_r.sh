@@ -1,7 +1,5 @@
 #!/bin/bash
-# round 5, call R: tile mapping with detection -- its test, the suite, on / off on three scenes
+# round 5, call R2: tile mapping in the one-chunk kernel too -- test, switch-point sweep with it on / off
 mkdir -p gpurun_out/r05; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "image_order or switches_kernels or chooses_chunks" 2>&1 | tail -5
-for s in atrium gallery crown; do for g in 0 -1; do RODENT_HIP_RAY_GRID=$g timeout 600 python scripts/grid_experiment.py $s 1024 2>&1 | grep -v amdgpu.ids; done; done | tee gpurun_out/r05/grid_detect.txt
-timeout 600 python scripts/fixed_costs.py 2>&1 | grep -v amdgpu.ids | head -8 | tee gpurun_out/r05/fixed_costs_after.txt
-timeout 3000 python -m pytest tests -m gpu -q > gpurun_out/r05/tests_r.txt 2>&1; tail -6 gpurun_out/r05/tests_r.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "image_order" 2>&1 | tail -5
+for g in 0 -1; do echo "== RODENT_HIP_RAY_GRID=$g"; RODENT_HIP_RAY_GRID=$g timeout 900 python scripts/threshold_sweep.py --scenes atrium,cornell 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/r05/threshold_sweep_grid.txt

@@ -61,14 +61,16 @@ def test_all_benchmark_rays_bit_exact(gpu, oracle, dumps, width, kind):
     assert occ.tobytes() == ref_any.tobytes()
 
 
-@pytest.mark.parametrize("scene,limit", [("atrium", 1.10), ("refbuilt", 1.10), ("cornell", 1.35)])
+@pytest.mark.parametrize("scene,limit", [("atrium", 1.17), ("refbuilt", 1.17), ("cornell", 1.35)])
 def test_default_mapping_is_not_slower_than_the_one_chunk_kernel_where_it_is_selected(gpu, scene, limit, tmp_path):
     """The default BVH2 mapping switches from the one-chunk kernel ("fast") to the persistent LDS-image kernel at 393 216 rays (589 824 until round 4), with
     a 255-record image and 15-entry stack windows -- constants tuned on the atrium's primary camera (profiles/r02_threshold_sweep.txt).
-    From that size on it must not lose to "fast" by more than 10 %: on the benchmark scene, on the decimated atrium as the
-    REFERENCE's builder lays it out (tests/golden/atrium-decimated-refbuilt.bvh.gz), primary and random rays.  On a tree that
-    fits the image whole (Cornell, 16 nodes) the persistent launch's fixed cost (~8 us of a 50 us launch) shows at the switch
-    point: measured 16 % there (profiles/r03_threshold_sweep.txt has the table), 35 % allowed (these launches take 50 us)."""
+    From that size on it must not lose to "fast" by more than 17 %: on the benchmark scene, on the decimated atrium as the
+    REFERENCE's builder lays it out (tests/golden/atrium-decimated-refbuilt.bvh.gz), primary and random rays.  One switch point serves both ray
+    kinds (the host does not know which it got): at 393 216 rays camera rays are still 10 % faster through "fast" (0.118 against 0.130 ms, level
+    from 589 824 on) while segments are 18 % faster through the persistent kernel from 262 144 on (profiles/r05_threshold_sweep_grid.txt) --
+    the smaller loss decides.  On a tree that fits the image whole (Cornell, 16 nodes) the persistent launch's fixed cost (~3 us of a 23 us launch
+    since round 5, 12 us before: profiles/r05_fixed_costs.txt) shows at the switch point: measured 10 ... 15 % there, 35 % allowed."""
     import gzip
     import torch
     from rodent_amd import raygen, scenes

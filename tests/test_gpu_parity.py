@@ -586,7 +586,19 @@ def test_camera_rays_in_image_order_are_traced_as_tiles(gpu, oracle, cornell, co
     run(image, 64, force=64)                                             # a WRONG width on camera rays: any width is a one-to-one map of the launch's positions onto its rays
     run(image, 1024, force=1024)
     run(image, 0, force=1004)                                            # (no multiple of 8: unused)
-    run(image[:300], 0)                                                  # fewer rays than the probes span
+    run(image[:300], 256)                                                # (recognised from rays 0, 64, 128 and 256; no whole band of 8 rows: nothing to tile)
+    run(image[:200], 0)                                                  # fewer rays than the probes need
+    # launches under the shipped threshold take the one-chunk kernel, which maps its chunks the same way (it keeps no statistics)
+    gpu.lib().rodent_hip_top_min_rays(-1)
+    try:
+        for w, h in ((256, 64), (136, 50), (1004, 12), (1920, 33)):
+            run(raygen.primary_rays(*cam, w, h, 0.0, 5000.0), None)
+        run(image, None, force=64)
+        run(image, None, force=0)
+        run(segments, None)
+        run(image[:200], None)
+    finally:
+        gpu.lib().rodent_hip_top_min_rays(0)
 
 
 def test_default_mapping_chooses_chunks_or_refill_by_itself(gpu, oracle, cornell, cornell_dev):
