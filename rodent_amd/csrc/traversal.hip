@@ -389,6 +389,7 @@ __device__ __forceinline__ int detect_ray_grid(const Ray1* __restrict__ rays, in
 __device__ __forceinline__ int tiled_ray_count(int grid_w, int n) { return __builtin_amdgcn_readfirstlane(grid_w > 0 ? (n / (8 * grid_w)) * (8 * grid_w) : 0); }
 // the ray of `lane` in the tile at positions [first, first + 64); `first` becomes the tile's first ray
 __device__ __forceinline__ int tile_ray(int& first, int lane, int grid_w) {
+    asm volatile("" : "+s"(grid_w));                 // (the division below is redone per chunk: hoisted, its reciprocal would live in a VGPR through the step loop)
     const int tiles_per_row = grid_w >> 3, tile = first / kWave, band = __builtin_amdgcn_readfirstlane(tile / tiles_per_row), tx = tile - band * tiles_per_row;
     first = band * 8 * grid_w + tx * 8;
     return first + (lane >> 3) * grid_w + (lane & 7);
