@@ -697,10 +697,10 @@ def main():
         out["config"]["primary_in_list_order_Mrays_s"] = list_order_rec["Mrays_s"]
         out["extra"]["primary_in_list_order"] = list_order_rec
     if world > 1:
-        # what one GPU predicts for N (profiles/r04_range_costs.txt, r04_band_costs.txt: every rank's share timed alone): ONE 1 Mi-ray set does not shard its tail
-        out["config"]["predicted_scaling_x"] = {"strong_1Mi_primary_contiguous_ranges": {"2": 1.31, "4": 1.78, "8": 2.21}, "strong_1Mi_random": {"2": 1.27, "4": 1.92, "8": 2.19},
+        # what one GPU predicts for N (profiles/r05_range_costs.txt, r04_band_costs.txt: every rank's share timed alone): ONE 1 Mi-ray set does not shard its tail
+        out["config"]["predicted_scaling_x"] = {"strong_1Mi_primary_contiguous_ranges": {"2": 1.27, "4": 1.69, "8": 1.94}, "strong_1Mi_random": {"2": 1.33, "4": 1.74, "8": 1.97},
                                                 "cfg5_frame_interleaved_16_row_tiles": {"2": 1.99, "4": 3.99, "8": 7.94}, "weak": "1 Mi rays per GPU: ~N",
-                                                "source": "profiles/r04_range_costs.txt, profiles/r04_band_costs.txt"}
+                                                "source": "profiles/r05_range_costs.txt, profiles/r04_band_costs.txt"}
         out["config"]["world_size_seen_by_the_collective_backend"] = dist.get_world_size()
     if big:
         out["config"]["primary_16Mi_Mrays_s"] = big.get("Mrays_s")

@@ -61,6 +61,14 @@ static int env_capacity() {
     static const int v = [] { const char* e = getenv("RODENT_HIP_STREAM_CAPACITY"); const long c = e ? atol(e) : 0; return c >= 64 && c <= kMaxCapacity ? (int)c : kDefaultCapacity; }();
     return v;
 }
+// RODENT_HIP_PIXEL_BLOCK: the streaming renderer generates a frame's pixels in blocks of this many pixels squared (default 16; 0: row by row, the order of the reference's
+// gpu_generate_rays, mapping_gpu.impala:236-241).  Which pixel a stream slot carries is free -- a sample's seed depends on (sample, iter, x, y) only, renderer.impala:28-33 --
+// and the rays in flight together then start, and bounce, in a compact part of the scene instead of along a strip of rows: config 5's frame 1 790 -> 1 771 ms (+1.1 %; 8: +0.6 %,
+// 32 and 64 as 16), ray counts identical (profiles/r05_pixel_blocks.txt).
+inline int pixel_block() {
+    static const int v = [] { const char* e = getenv("RODENT_HIP_PIXEL_BLOCK"); const int b = e ? atoi(e) : 16; return b == 8 || b == 16 || b == 32 || b == 64 ? b : 0; }();
+    return v;
+}
 constexpr int kNumCounters = 100;              // [0..3] host-visible totals, [4..67] shadow rays (striped), [68..99] megakernel primary rays (striped)
 
 struct CameraDev { float eye[3], dir[3], up[3], right[3]; float w, h; };
@@ -84,12 +92,19 @@ __device__ __forceinline__ v3 emit_sample(const CameraDev& cam, int iter, int fi
 // Pixels of a call: [first_pixel, ...) contiguous (tile_pixels == 0: a row band), or interleaved row tiles -- local pixel q is pixel
 // first_pixel + (q / tile_pixels) * stride_pixels + q % tile_pixels (rodent_hip_render_tiles: the film's row tiles dealt round-robin to the GPUs).
 __global__ __launch_bounds__(kBlock) void k_generate(PrimaryStream p, int first_dst, int first_ray_id, int num_rays, CameraDev cam,
-                                                      int iter, int film_w, int film_h, int first_pixel, int spp, int tile_pixels, int stride_pixels) {
+                                                      int iter, int film_w, int film_h, int first_pixel, int spp, int tile_pixels, int stride_pixels,
+                                                      int block = 0, int band_rows = 0) {
     const int gid = blockIdx.x * kBlock + threadIdx.x;
     if (gid >= num_rays) return;
     const int ray_id = first_ray_id + gid, dst = first_dst + gid;
     const int sample = ray_id % spp, q = ray_id / spp;
-    const int pixel = first_pixel + (tile_pixels > 0 ? (q / tile_pixels) * stride_pixels + q % tile_pixels : q);
+    int tile = 0, local = q;                                         // local: the pixel's index in rows that are contiguous in the film (the call's band, or one of its tiles)
+    if (tile_pixels > 0) { tile = q / tile_pixels; local = q - tile * tile_pixels; }
+    if (block > 0) {                                                 // block x block pixels after one another instead of whole rows (pixel_block(), below); band_rows: rows of the band / a tile
+        const int strip = local / (block * film_w), i = local - strip * (block * film_w);
+        if ((strip + 1) * block <= band_rows) local = (strip * block + (i % (block * block)) / block) * film_w + (i / (block * block)) * block + i % block;
+    }
+    const int pixel = first_pixel + tile * stride_pixels + local;
     const int y = pixel / film_w, x = pixel - y * film_w;          // the reference uses fast_div (common.impala:19-35): same quotient
     uint32_t rnd;
     const v3 d = emit_sample(cam, iter, film_w, film_h, x, y, sample, &rnd);
@@ -1505,6 +1520,8 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
     // ray ids are 32-bit in the stream kernels (as in the reference, mapping_gpu.impala:236-241)
     if (num_rays > 0x7FFFFFFFll) { fprintf(stderr, "rodent_hip: spp x width x rows = %lld samples in one call exceeds 2^31 - 1; render fewer rows per call or more frames of fewer spp\n", num_rays); abort(); }
     const int first_pixel = y0 * r.film_w;
+    // pixels are generated block by block where the film allows it (whole blocks across, whole tiles down)
+    const int block = pixel_block() > 0 && r.film_w % pixel_block() == 0 && (tile_rows == 0 || (tile_rows % pixel_block() == 0 && r.film_h % tile_rows == 0)) ? pixel_block() : 0;
     long long id = 0; int size = 0;
     HIP_CHECK(hipMemsetAsync(r.ctl, 0, sizeof(int) * 8, stream));
     if (!r.counters_continue) { HIP_CHECK(hipMemsetAsync(r.counters, 0, sizeof(unsigned long long) * kNumCounters, stream)); r.call_iterations = r.call_generated = 0; }
@@ -1550,7 +1567,7 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
         if (size < kCapacity && id < num_rays) {                                         // regenerate (mapping_gpu.impala:332-336)
             const int n = (int)std::min<long long>(num_rays - id, kCapacity - size);
             hipLaunchKernelGGL(k_generate, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, *primary, size, (int)id, n, cam, iter,
-                               r.film_w, r.film_h, first_pixel, r.spp, tile_rows * r.film_w, stride_rows * r.film_w);
+                               r.film_w, r.film_h, first_pixel, r.spp, tile_rows * r.film_w, stride_rows * r.film_w, block, tile_rows > 0 ? tile_rows : y1 - y0);
             id += n; size += n; generated += n;
         }
         const int blocks = (size + kBlock - 1) / kBlock;

@@ -62,9 +62,14 @@ def measure(scene, steps=20, variants=("top", "fast", "refill"), pmc=False, quie
             for vname in variants:
                 ms = round(timed(bvh, rd, hd, n, any_hit, names.index(vname), steps), 4)
                 cell[vname + "_ms"] = min(ms, cell.get(vname + "_ms", ms))
+        if kind == "ao":                                       # these rays are pixels in image order too, but no ray_gen dump (dir = hit point - light): the width on trust
+            abi.ray_grid(1024)
+            cell["top_width_given_ms"] = min(round(timed(bvh, rd, hd, n, any_hit, 0, steps), 4) for rep in range(2))
+            abi.ray_grid(-1)
         abi.read_stats()
         abi.traverse_async(bvh, rd, hd, n, any_hit, 0, st); torch.cuda.synchronize()
-        cell["spilled_blocks"] = int(abi.read_stats()[7])
+        stats = abi.read_stats()
+        cell["spilled_blocks"], cell["tiles_of_width"] = int(stats[7]), int(stats[2])
         got = abi.from_device(hd, F.HIT1)
         sample = np.arange(0, n, 32)
         ref, stt = O.traverse(2, nodes, tris, rays[sample], any_hit=any_hit)
@@ -77,7 +82,8 @@ def measure(scene, steps=20, variants=("top", "fast", "refill"), pmc=False, quie
         rec[kind] = cell
         say(f"  {kind:8s} {cell['Mrays_s']:8.1f} Mrays/s  " + "  ".join(f"{v} {cell[v + '_ms']:.4f} ms" for v in variants) +
             f"  parity {cell['sample_parity']}  visits/ray {cell['inner_per_ray']:.1f} + {cell['prims_per_ray']:.1f}  stack mean {cell['stack_mean']:.1f} max {cell['stack_max']} "
-            f"beyond window {cell['beyond_window_share']:.3%} spilled {cell['spilled_blocks']}  hits {cell['hit_share']:.3f}", flush=True)
+            f"beyond window {cell['beyond_window_share']:.3%} spilled {cell['spilled_blocks']}  hits {cell['hit_share']:.3f}  tiles of width {cell['tiles_of_width']}" +
+            (f"  (width given: {cell['top_width_given_ms']:.4f} ms)" if "top_width_given_ms" in cell else ""), flush=True)
         del rd, hd
     abi.check_errors(0)
     del bvh
