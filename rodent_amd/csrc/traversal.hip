@@ -388,9 +388,14 @@ __device__ __forceinline__ int detect_ray_grid(const Ray1* __restrict__ rays, in
 // rays [0, tiled_ray_count) are whole bands of 8 image rows: position p of the launch (64 consecutive positions = one wavefront) is pixel p % 64 of tile p / 64
 __device__ __forceinline__ int tiled_ray_count(int grid_w, int n) { return __builtin_amdgcn_readfirstlane(grid_w > 0 ? (n / (8 * grid_w)) * (8 * grid_w) : 0); }
 // the ray of `lane` in the tile at positions [first, first + 64); `first` becomes the tile's first ray
-__device__ __forceinline__ int tile_ray(int& first, int lane, int grid_w) {
+__device__ __forceinline__ int tile_ray(int& first, int lane, int grid_w, int stack_bands = 1, int tiled_rays = 0) {
     asm volatile("" : "+s"(grid_w));                 // (the division below is redone per chunk: hoisted, its reciprocal would live in a VGPR through the step loop)
-    const int tiles_per_row = grid_w >> 3, tile = first / kWave, band = __builtin_amdgcn_readfirstlane(tile / tiles_per_row), tx = tile - band * tiles_per_row;
+    const int tiles_per_row = grid_w >> 3, tile = first / kWave;
+    int band = __builtin_amdgcn_readfirstlane(tile / tiles_per_row), tx = tile - band * tiles_per_row;
+    if (stack_bands > 1) {                           // experiment: consecutive tiles run DOWN a stack of `stack_bands` bands before they move right
+        const int per_stack = stack_bands * tiles_per_row, stack = __builtin_amdgcn_readfirstlane(tile / per_stack), c = tile - stack * per_stack;
+        if ((stack + 1) * per_stack * kWave <= tiled_rays) { band = stack * stack_bands + c % stack_bands; tx = c / stack_bands; }
+    }
     first = band * 8 * grid_w + tx * 8;
     return first + (lane >> 3) * grid_w + (lane & 7);
 }
