@@ -166,7 +166,8 @@ void        rodent_hip_ray_kind_hint(int32_t enable);
 /* Camera rays in image order (round 5; RODENT_HIP_RAY_GRID).  The reference's primary-ray dumps are the pixels of an image row by row (tools/ray_gen/ray_gen.cpp:20-58:
  * dir = d + kx r + ky u, not normalised).  Which rays share a wavefront is the callee's business: the default BVH2 kernel recognises such a list from 66 of its rays --
  * no state between launches, no probe launch -- and gives every wavefront an 8 x 8-pixel tile instead of 64 pixels of one row (the rays of a tile finish closer together and
- * share more nodes: 1 Mi camera rays on the atrium 0.178 -> 0.167 ms).  Hit records and their places in `hits` do not change.
+ * share more nodes: 1 Mi camera rays on the atrium 0.178 -> 0.167 ms).  Per-pixel lists that are no camera dump (ray_gen's shadow mode, tools/ray_gen/ray_gen.cpp:60-85;
+ * a renderer's shadow rays in pixel order) are recognised when the width is a multiple of 128 that divides the ray count.  Hit records and their places in `hits` do not change.
  * width: -1 = recognise (default), 0 = never (list order, as until round 4), > 0 = take this image width on trust (experiments; multiples of 8 only, others mean 0). */
 void        rodent_hip_ray_grid(int32_t width);
 int32_t     rodent_hip_is_lab_build(void);              /* 1 = librodent_hip_lab.so (-DRODENT_HIP_LAB: also the measured-and-lost kernels) */

@@ -362,40 +362,56 @@ __device__ __forceinline__ void finish_lane(const Lane& L, const Ray1* __restric
 // the wave's rays finish closer together (oracle step counts, atrium camera: mean over chunks of the longest ray 57.4 steps for row segments, 48.4 for tiles, mean ray 39.3)
 // and touch fewer distinct nodes per load.  What a ray visits and where its hit goes do not change: the hits stay bit-identical
 // (measured 1 Mi camera rays: atrium 0.1781 -> 0.1667 ms, gallery 0.295 -> 0.281, crown 0.1845 -> 0.1875; profiles/r05_grid_tiles.txt).
-// ray_gen writes dir = d + kx(column) r + ky(row) u, not normalised (the reference's tools/ray_gen/ray_gen.cpp:20-58): along a row the direction advances by a constant step e,
-// so (dir[i] - dir[0]) . e / |e|^2 is the column of ray i -- it climbs with i and falls back to 0 where the next row starts.  Every wave looks at rays 0, 64 and 128, 256, ... 8192
-// (one load per lane, in flight with the wave's first rays): the first probe whose column is less than half its index lies in the second row, width = index - column; the other probes
-// must then sit in the columns that width predicts.  Wave-uniform, and the same in every wave of a launch (same rays, same arithmetic).  0 = not recognised: rays in list order,
-// as until round 5.  A wrong answer would cost speed, never hits -- any width maps the launch's positions onto its rays one to one (k_bvh2_top_auto).
+// Every wave looks at rays 0, 64 and 128, 256, ... 8192 (one probe per lane, in flight with the wave's first rays) and reads them two ways:
+// 1. a ray_gen dump of camera rays (the reference's tools/ray_gen/ray_gen.cpp:20-58): dir = d + kx(column) r + ky(row) u, not normalised.  Along a row the direction advances by a
+//    constant step e, so (dir[i] - dir[0]) . e / |e|^2 is the column of ray i -- it climbs with i and falls back to 0 where the next row starts: the first probe whose column is
+//    less than half its index lies in the second row, width = index - column, and the other probes must sit in the columns that width predicts.  Any width, exactly.
+// 2. any other per-pixel list (ray_gen's shadow mode -- from a light to the camera rays' hit points, ray_gen.cpp:60-85, the suite's "ao" class --, normalised camera rays, a
+//    renderer's shadow or reflection rays in pixel order): probe k is 128 k pixels along the list; in an image of width 128 k* it is the pixel k* ... BELOW ray 0, a near neighbour,
+//    while the probes before it are 128, 256, ... pixels away along the row.  Distance = |org - org0|^2 and |dir - dir0|^2, each in units of probe 1's: the first probe closer than
+//    an eighth of probe 1 gives the width (a multiple of 128 that divides the ray count); the probe two rows down must be near as well and the probe after it about as far as
+//    probe 1.  Measured on the ao rays (1 Mi, profiles/r05_scene_matrix.txt): gallery 0.290 -> 0.217 ms, plant 0.095 -> 0.081, atrium 0.156 -> 0.151, crown level.
+// Wave-uniform, and the same in every wave of a launch (same rays, same arithmetic).  0 = not recognised: rays in list order, as until round 4.  A wrong answer would cost
+// speed, never hits -- any width maps the launch's positions onto its rays one to one (k_bvh2_top_auto).
 __device__ __forceinline__ int detect_ray_grid(const Ray1* __restrict__ rays, int n) {
     constexpr int kProbe = 128;
     if (n <= 2 * kProbe) return 0;
     const int lane = (int)threadIdx.x % kWave, i = kProbe * (lane + 1);
     const bool valid = i < n;
-    const float4 d0 = reinterpret_cast<const float4*>(rays)[1], d1 = reinterpret_cast<const float4*>(rays + 64)[1], dp = reinterpret_cast<const float4*>(rays + (valid ? i : 0))[1];
+    const float4* probe = reinterpret_cast<const float4*>(rays + (valid ? i : 0));
+    const float4 o0 = reinterpret_cast<const float4*>(rays)[0], d0 = reinterpret_cast<const float4*>(rays)[1], d1 = reinterpret_cast<const float4*>(rays + 64)[1], op = probe[0], dp = probe[1];
+    const auto lane_value = [](float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); };
+    // 1. constant step along the row
     const float ex = (d1.x - d0.x) * (1.0f / 64.0f), ey = (d1.y - d0.y) * (1.0f / 64.0f), ez = (d1.z - d0.z) * (1.0f / 64.0f);
     const float q = ex * ex + ey * ey + ez * ez;
     const float col = ((dp.x - d0.x) * ex + (dp.y - d0.y) * ey + (dp.z - d0.z) * ez) / q;
     const unsigned long long wrapped = __ballot(valid && !(col >= 0.5f * (float)i));
-    if (!(q > 0.0f) || wrapped == 0ull) return 0;
-    const int first = __ffsll((long long)wrapped) - 1;
-    const int w = (int)rintf((float)(kProbe * (first + 1)) - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col), first)));
-    if (w < kProbe || w > kProbe * kWave) return 0;
-    if (__ballot(valid && !(fabsf(col - (float)(i % w)) < 0.25f)) != 0ull) return 0;
+    if (q > 0.0f && wrapped != 0ull) {
+        const int first = __ffsll((long long)wrapped) - 1;
+        const int w = (int)rintf((float)(kProbe * (first + 1)) - lane_value(col, first));
+        if (w >= kProbe && w <= kProbe * kWave && __ballot(valid && !(fabsf(col - (float)(i % w)) < 0.25f)) == 0ull) return w;
+    }
+    // 2. the pixel below ray 0 is a near neighbour
+    const float far_o = (op.x - o0.x) * (op.x - o0.x) + (op.y - o0.y) * (op.y - o0.y) + (op.z - o0.z) * (op.z - o0.z);
+    const float far_d = (dp.x - d0.x) * (dp.x - d0.x) + (dp.y - d0.y) * (dp.y - d0.y) + (dp.z - d0.z) * (dp.z - d0.z);
+    const float unit_o = lane_value(far_o, 0), unit_d = lane_value(far_d, 0);
+    const float terms = (unit_o > 0.0f ? 1.0f : 0.0f) + (unit_d > 0.0f ? 1.0f : 0.0f);
+    const float dist = (unit_o > 0.0f ? far_o / unit_o : 0.0f) + (unit_d > 0.0f ? far_d / unit_d : 0.0f);      // probe 1: = terms
+    const unsigned long long near = __ballot(valid && lane > 0 && dist < terms * (1.0f / 64.0f));
+    if (near == 0ull) return 0;
+    const int k = __ffsll((long long)near), w = kProbe * k;                   // probe k = lane k - 1
+    if (n % w != 0) return 0;
+    if (2 * k <= kWave && kProbe * 2 * k < n && !(lane_value(dist, 2 * k - 1) < terms * (1.0f / 16.0f))) return 0;
+    if (k + 1 <= kWave && kProbe * (k + 1) < n) { const float next = lane_value(dist, k); if (!(next > 0.25f * terms && next < 4.0f * terms)) return 0; }
     return w;
 }
 
 // rays [0, tiled_ray_count) are whole bands of 8 image rows: position p of the launch (64 consecutive positions = one wavefront) is pixel p % 64 of tile p / 64
 __device__ __forceinline__ int tiled_ray_count(int grid_w, int n) { return __builtin_amdgcn_readfirstlane(grid_w > 0 ? (n / (8 * grid_w)) * (8 * grid_w) : 0); }
 // the ray of `lane` in the tile at positions [first, first + 64); `first` becomes the tile's first ray
-__device__ __forceinline__ int tile_ray(int& first, int lane, int grid_w, int stack_bands = 1, int tiled_rays = 0) {
+__device__ __forceinline__ int tile_ray(int& first, int lane, int grid_w) {
     asm volatile("" : "+s"(grid_w));                 // (the division below is redone per chunk: hoisted, its reciprocal would live in a VGPR through the step loop)
-    const int tiles_per_row = grid_w >> 3, tile = first / kWave;
-    int band = __builtin_amdgcn_readfirstlane(tile / tiles_per_row), tx = tile - band * tiles_per_row;
-    if (stack_bands > 1) {                           // experiment: consecutive tiles run DOWN a stack of `stack_bands` bands before they move right
-        const int per_stack = stack_bands * tiles_per_row, stack = __builtin_amdgcn_readfirstlane(tile / per_stack), c = tile - stack * per_stack;
-        if ((stack + 1) * per_stack * kWave <= tiled_rays) { band = stack * stack_bands + c % stack_bands; tx = c / stack_bands; }
-    }
+    const int tiles_per_row = grid_w >> 3, tile = first / kWave, band = __builtin_amdgcn_readfirstlane(tile / tiles_per_row), tx = tile - band * tiles_per_row;
     first = band * 8 * grid_w + tx * 8;
     return first + (lane >> 3) * grid_w + (lane & 7);
 }

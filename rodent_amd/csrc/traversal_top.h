@@ -413,14 +413,12 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     const Bases base = make_bases(nodes, tris);
     int t = stripe_rank(wave) * kWave;                                       // the wave's first 64 tickets are its rank in the stripe; the counter hands out those behind
     bool coherent = MODE != 2;
-    int stack_bands = 1;
     if (MODE == 0 && ray_of(t) < n) {                                        // (ray_of grows with the ticket: otherwise this stripe's share is used up already)
         // one origin or one direction for all of the wave's first 64 rays?
         const int r = ray_of(t + lane);
         const float4* p = reinterpret_cast<const float4*>(rays + (r < n ? r : ray_of(t)));
         const float4 o = p[0], d = p[1];
         if (grid_w < 0) grid_w = detect_ray_grid(rays, n);                   // (its loads travel with p[0], p[1])
-        else { stack_bands = grid_w >> 20; grid_w &= 0xFFFFF; }                // experiment: given width | stack << 20
         coherent = wave_rays_coherent(o.x, o.y, o.z, d.x, d.y, d.z, r < n);
         if (wave == 0) report_ray_kind(host_kinds, launch_id, coherent);
     }
@@ -434,7 +432,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
             int first_ray = ray_of(t);
             if (first_ray >= n) break;
             int r = ray_of(t + lane);
-            if (first_ray < tiled_rays) r = tile_ray(first_ray, lane, grid_w, stack_bands, tiled_rays);   // (first_ray: the tile's first pixel)
+            if (first_ray < tiled_rays) r = tile_ray(first_ray, lane, grid_w);   // (first_ray: the tile's first pixel)
             Lane L = start_lane(rays, hits, r < n ? r : -1, first_ray, col);
             if (L.top != 0) L.top = root;
             while (__ballot(L.top != 0)) {

@@ -582,6 +582,15 @@ def test_camera_rays_in_image_order_are_traced_as_tiles(gpu, oracle, cornell, co
     run(unit, None)                                                      # normalised directions are no ray_gen dump: recognised or not, the hits are right
     segments = raygen.random_rays(lo, hi, 40_000, 7, 0.0, 1.0)
     run(segments, 0)
+    # per-pixel lists that are no camera dump (the width is read from the pixel BELOW ray 0 being a near neighbour: multiples of 128 that divide the ray count)
+    light = np.array([0.0, 1.9, 0.0], np.float32)
+    for w, h, expect in ((256, 64, 256), (1024, 24, 1024), (384, 40, 384), (200, 64, 0)):
+        cam_rays = raygen.primary_rays(*cam, w, h, 0.0, 5000.0)
+        t = oracle.traverse(2, nodes, tris, cam_rays)[0]["t"]
+        run(raygen.shadow_rays(light, cam_rays, t, 0.0, 0.999), expect)                       # ray_gen's shadow mode: from a light to the hit points (the suite's "ao" class)
+        hit_points = cam_rays["org"] + t[:, None] * cam_rays["dir"]
+        run(F.make_rays(hit_points.astype(np.float32), (light - hit_points).astype(np.float32), 0.001, 0.999), expect)   # a renderer's: from the hit points to the light
+        run(raygen.shadow_rays(light, cam_rays, t, 0.0, 0.999)[: w * h - 7], 0 if expect else 0)   # a count the width does not divide: list order
     run(segments, 64, force=64)                                          # (no chunk loop for these: the width is noted and unused)
     run(image, 64, force=64)                                             # a WRONG width on camera rays: any width is a one-to-one map of the launch's positions onto its rays
     run(image, 1024, force=1024)
