@@ -54,9 +54,10 @@ __device__ __forceinline__ bool tri_pre(const RayX& r, float v0x, float v0y, flo
 template <bool ANY, int N, int LDS_N, bool TOP = false>
 __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const Tri4* __restrict__ tris, const Ray1* __restrict__ rays,
                                            Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray,
-                                           lds_int* image = nullptr, int root = 1) {
+                                           lds_int* image = nullptr, int root = 1, int grid_w = 0) {
     typedef WideLayout<N> L;
-    const int lane_ray = first_ray + (int)(threadIdx.x % kWave);
+    int lane_ray = first_ray + (int)(threadIdx.x % kWave);
+    if (first_ray < tiled_ray_count(grid_w, n)) lane_ray = tile_ray(first_ray, (int)(threadIdx.x % kWave), grid_w);      // per-pixel lists: an 8 x 8-pixel tile per wavefront (detect_ray_grid, traversal.hip)
     const int ray_id = lane_ray < n ? lane_ray : -1;
     RayX ray = load_ray(rays, ray_id >= 0 ? ray_id : first_ray);
     if (ray_id >= 0) store_hit(hits, ray_id, -1, ray.tmax, 0.0f, 0.0f);       // the miss record; accepted triangles overwrite it
@@ -147,11 +148,13 @@ __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const
 template <bool ANY, int N, int LDS_N, int XCD>
 __global__ __launch_bounds__(kWave) void k_wide_single(const char* __restrict__ nodes, const Tri4* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                        Ctl* ctl, int* __restrict__ deep_list) {
+                                                        Ctl* ctl, int* __restrict__ deep_list, int grid_w) {
     __shared__ int lds_raw[(LDS_N + N) * kWave];
     lds_int* col = (lds_int*)lds_raw + threadIdx.x;
     const int total_chunks = (n + kWave - 1) / kWave;
     int chunk = blockIdx.x;
+    if (grid_w < 0) grid_w = detect_ray_grid(rays, n);
+    grid_w = __builtin_amdgcn_readfirstlane(grid_w > 0 && (grid_w & 7) == 0 ? grid_w : 0);
     if (XCD > 0) {                                                            // as k_bvh2_single
         const int span = 8 * XCD, full = (total_chunks / span) * span;
         if ((int)blockIdx.x < full) {
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(kWave) void k_wide_single(const char* __restrict__ 
             chunk = ((l / XCD) * 8 + x) * XCD + l % XCD;
         }
     }
-    wide_chunk<ANY, N, LDS_N>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave);
+    wide_chunk<ANY, N, LDS_N>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, nullptr, 1, grid_w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -218,7 +221,7 @@ __device__ __forceinline__ void stage_wide_top(const char* __restrict__ nodes, l
 template <bool ANY, int N, int LDS_N, int WAVES>
 __global__ __launch_bounds__(kWave * WAVES) void k_wide_top_persist(const char* __restrict__ nodes, const Tri4* __restrict__ tris,
                                                                    const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                                   Ctl* ctl, int* __restrict__ deep_list, int* __restrict__ tickets) {
+                                                                   Ctl* ctl, int* __restrict__ deep_list, int* __restrict__ tickets, int grid_w) {
     constexpr int kStackInts = WAVES * (LDS_N + N) * kWave, kImageInts = WideTop<N>::kRecords * (int)WideLayout<N>::kNodeBytes / 4, kGroup = 32;
     static_assert((kStackInts + kImageInts + WideTop<N>::kRecords) * 4 <= 160 * 1024, "one workgroup per CU must fit its stacks and records in LDS");
     __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + kImageInts + WideTop<N>::kRecords];
@@ -230,10 +233,12 @@ __global__ __launch_bounds__(kWave * WAVES) void k_wide_top_persist(const char* 
     const int total_chunks = (n + kWave - 1) / kWave, stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
     int* counter = tickets + stripe * kCounterStride;
     int t = stripe_rank(wave);                                               // a wave's first ticket: its rank inside the stripe (wave-major, traversal_top.h)
+    if (grid_w < 0) grid_w = detect_ray_grid(rays, n);
+    grid_w = __builtin_amdgcn_readfirstlane(grid_w > 0 && (grid_w & 7) == 0 ? grid_w : 0);
     for (;;) {
         const int group_first = ((t / kGroup) * kStripes + stripe) * kGroup, chunk = group_first + t % kGroup;
         if (group_first >= total_chunks) break;                              // this stripe's share is used up
-        if (chunk < total_chunks) wide_chunk<ANY, N, LDS_N, true>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, image, kLdsTag);
+        if (chunk < total_chunks) wide_chunk<ANY, N, LDS_N, true>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, image, kLdsTag, grid_w);
         int t_next = 0;
         if (lane == 0) t_next = atomicAdd(counter, 1);
         t = stripe_waves + __builtin_amdgcn_readfirstlane(t_next);
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(kWave) void k_wide_finish(const char* __restrict__ 
 #define WIDE_LAUNCH_ARGS DeviceState& s, const void* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
 template <bool ANY, int N, int LDS_N, int XCD> void L_wide_single(WIDE_LAUNCH_ARGS) {
     ensure_deep_list(s, n);
-    hipLaunchKernelGGL((k_wide_single<ANY, N, LDS_N, XCD>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
+    hipLaunchKernelGGL((k_wide_single<ANY, N, LDS_N, XCD>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, n, s.ctl(), s.deep_list, n >= kGridMinRays ? g_ray_grid : 0);
     hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(kFinishGroups), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
 }
 // "top": the persistent form with the staged top levels for launches that fill the chip (as the BVH2 default: rodent_hip_top_min_rays),
@@ -338,6 +343,6 @@ template <bool ANY, int N, int LDS_N> void L_wide_top(WIDE_LAUNCH_ARGS) {
     }
     constexpr int kWaves = 16;
     const int groups = ((s.num_cus + kStripes - 1) / kStripes) * kStripes;   // one workgroup per CU, the same number in every stripe
-    hipLaunchKernelGGL((k_wide_top_persist<ANY, N, LDS_N, kWaves>), dim3(groups), dim3(kWave * kWaves), 0, stream, (const char*)nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.tickets);
+    hipLaunchKernelGGL((k_wide_top_persist<ANY, N, LDS_N, kWaves>), dim3(groups), dim3(kWave * kWaves), 0, stream, (const char*)nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.tickets, g_ray_grid);
     hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(kFinishGroups), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets);
 }

@@ -571,6 +571,14 @@ def test_camera_rays_in_image_order_are_traced_as_tiles(gpu, oracle, cornell, co
         assert got.tobytes() == ref.tobytes(), (len(rays), expect_width, force)
         if expect_width is not None:
             assert used == expect_width, (len(rays), used, expect_width, force)
+        for wide in (4, 8):                                              # the BVH4 / BVH8 kernels map their chunks the same way
+            gpu.ray_grid(force)
+            try:
+                got = gpu.traverse(cornell_dev[wide], rays, variant=0)
+            finally:
+                gpu.ray_grid(-1)
+            ref, _ = oracle.traverse(wide, *cornell.blocks[wide], rays, algo="gpu")
+            assert got.tobytes() == ref.tobytes(), (wide, len(rays), expect_width, force)
 
     for w, h, expect in ((256, 64, 256), (1024, 24, 1024), (136, 50, 136), (1000, 16, 1000), (1004, 12, 0), (128, 40, 128), (120, 40, 0), (8192, 8, 8192), (8200, 8, 0), (1920, 33, 1920)):
         run(raygen.primary_rays(*cam, w, h, 0.0, 5000.0), expect)
