@@ -938,16 +938,8 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH = true, bool S
 // launches whose node array the runtime cannot give a mapped range for (nothing bounds the ids of an older image then).
 constexpr int kTopMinRays = 6144 * kWave;      // 384 Ki rays: the measured cross-over with wave-major first tickets (profiles/r05_spread_tickets.txt; 576 Ki until round 4, profiles/r02_threshold_sweep.txt)
 int g_top_min_rays = kTopMinRays;               // rodent_hip_top_min_rays()
-// A tree that the runtime maps no more than an image's worth of node ids for (Cornell box: 16 nodes) is traced in a few dozen microseconds whatever the kernel; what differs is the
-// launch's fixed cost, and the one-chunk kernel's is ~12 us lower up to 1 Mi rays (profiles/r03_threshold_sweep.txt: 393 216 random segments 0.0345 against 0.0470 ms,
-// 1 Mi 0.0702 against 0.0745).  Such trees switch at 1 Mi rays (while the threshold is at its default).
-constexpr int kTinyTreeIds = 255, kTopMinRaysTinyTree = 16384 * kWave;
 // the node ids the persistent LDS-image kernel may assume mapped, or 0: this launch takes the one-chunk kernel
-int top_kernel_ids(const Node2* nodes, int n) {
-    if (n < g_top_min_rays) return 0;
-    const int ids = mapped_node_ids(nodes);
-    return ids <= kTinyTreeIds && g_top_min_rays == kTopMinRays && n < kTopMinRaysTinyTree ? 0 : ids;
-}
+int top_kernel_ids(const Node2* nodes, int n) { return n < g_top_min_rays ? 0 : mapped_node_ids(nodes); }
 // rodent_hip_ray_kind_hint() / RODENT_HIP_KIND_HINT: 1 = the default mapping remembers what its kernels saw of a ray list and sends one that was incoherent throughout to
 // k_bvh2_top_refill from its second launch on (+2 ... 4 % on random segments).  OFF by default from round 5 on: which kernel a launch gets must not depend on earlier launches
 // or on when an asynchronous caller's previous launch happened to finish; k_bvh2_top_auto's choice per wave needs no memory.

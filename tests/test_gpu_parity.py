@@ -512,6 +512,7 @@ def test_schedule_history_only_reorders_the_chunks(gpu, oracle, cornell, cornell
                 rays = rays[::-1].copy()                       # same count, other rays: the history mispredicts, nothing else
             rd = gpu.to_device(rays, 0)
             hd = torch.full((n * 16,), 0xFF, dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()                            # (the fill runs on torch's stream, the launch on `st`: without this the fill can land on top of the hits)
             gpu.traverse_async(cornell_dev[2], rd, hd, n, False, top, st)
             gpu.check_errors(0, st)
             ref, _ = oracle.traverse(2, nodes, tris, rays)
