@@ -85,7 +85,29 @@ def scene_obj(scene: str) -> Path:
     out = DATA / f"{kind}-d{detail}.obj"
     if not out.exists():
         _run([_tool("scene_gen"), kind, out, 1, detail])
+        if kind in PANELS:                                  # the stress scenes are geometry only: the renderer needs something that emits
+            _append_panels(out, PANELS[kind])
     return out
+
+
+# Emissive panels ("light" of atrium.mtl, facing down) for the renderer's frames of the generated stress scenes: (centre x, y, z, half size).
+# Appended to the OBJ only -- the traversal matrix builds its .bvh straight from the generator (scene_bvh) and does not see them.
+PANELS = {"crown": [(0.0, 950.0, 0.0, 450.0)],
+          "plant": [(x, 1390.0, z, 150.0) for x in (-1300.0, 0.0, 1300.0) for z in (-600.0, 600.0)]}
+
+
+def _append_panels(obj: Path, panels):
+    count = 0
+    with open(obj) as f:
+        for line in f:
+            count += line.startswith("v ")
+    with open(obj, "a") as f:
+        f.write("usemtl light\n")
+        for cx, y, cz, r in panels:
+            for x, z in ((cx - r, cz - r), (cx + r, cz - r), (cx + r, cz + r), (cx - r, cz + r)):      # (b - a) x (c - a) points down
+                f.write(f"v {x} {y} {z}\n")
+            f.write(f"f {count + 1} {count + 2} {count + 3}\nf {count + 1} {count + 3} {count + 4}\n")
+            count += 4
 
 
 def primary_rays(scene: str, width=1024, height=1024) -> Path:
