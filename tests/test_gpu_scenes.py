@@ -49,3 +49,25 @@ def test_scene_classes_bit_exact(gpu, oracle, scene):
     finally:
         gpu.lib().rodent_hip_top_min_rays(-1)
     gpu.check_errors(0)
+
+
+@pytest.mark.parametrize("scene", ["crown/1", "plant/1"])
+@pytest.mark.parametrize("mapping", ["auto", "megakernel"])
+def test_stress_scenes_path_traced_match_oracle(native_build, oracle, scene, mapping, tmp_path):
+    """The renderer on the two stress scenes (lit by the panels scenes.PANELS appends to their OBJ: the generators make geometry only): a small frame through the
+    library's own choice of mapping and through the megakernel against the render oracle -- ray counts exact, film within the order of the atomic adds.  The full-size
+    frames are measured by scripts/refill_rule_check.py (profiles/r05_refill_rule_check.txt)."""
+    import torch
+    from rodent_amd import render as R, scene as S, scenes
+    assert torch.cuda.is_available()
+    sc = S.convert(scenes.scene_obj(scene), tmp_path / "scene.rscene")
+    assert len(sc.lights) >= 2 and len(sc.nodes) > 100000
+    W, H, SPP, MAXLEN, IT = 160, 90, 2, 6, 2
+    cam = S.camera_settings(*scenes.CAMERAS[scene.split("/")[0]], W, H)
+    film_o, counts = oracle.render(sc, cam, IT, SPP, MAXLEN, W, H, threads=32)
+    assert film_o.mean() > 1e-4 and counts[1] > 0                                      # lit: shadow rays were cast and some arrived
+    r = R.Renderer(sc, W, H, SPP, MAXLEN, mapping=mapping)
+    r.render(cam, IT)
+    c = r.counters(); film_g = r.film(); r.close()
+    assert (c["primary_rays"], c["shadow_rays"], c["generated"]) == (counts[0], counts[1], W * H * SPP)
+    assert np.allclose(film_g, film_o, rtol=1e-5, atol=1e-6)
