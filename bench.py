@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark: Mrays/s of the HIP BVH traversal (BASELINE.json), renderer frame rates beside it.
 
-  python bench.py --gpus N --steps K --warmup W [--weak]
+  python bench.py --gpus N --steps K --warmup W [--strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Step  = one closest-hit traversal pass over one 1 048 576-ray batch resident in HBM
@@ -11,12 +11,13 @@ Scene = "sponza" if data/sponza.{bvh,-primary.rays,-random.rays} were supplied, 
         regenerable procedural "atrium" (the reference checkout lacks the Sponza blobs).
 value = rays traced by all ranks per second / 1e6, kernel passes only (rays, BVH and hit
         buffers resident in HBM; H2D/D2H excluded like bench_traversal.cpp:124-135).
-N > 1 = no data-path collective: the BVH is replicated.  BOTH partitions are timed:
-        strong (`value`): ONE 1 Mi-ray set, rank r traces the contiguous range ray_range(n, r, N); after the
-        timed region one RCCL gather brings the Hit1 ranges to rank 0, which compares the assembled array with its own
-        trace of the whole set;
-        weak (`extra.weak_scaling`): rank r traces sub-pixel sample r of N through the same 1024 x 1024 pixel grid (primary) /
-        seed 42 + r (random): 1 Mi rays per GPU per step.  `--weak` makes this one `value` instead.
+N > 1 = no data-path collective: the BVH is replicated, rays are independent units.  BOTH partitions are timed:
+        weak (`value`, "scaling": "weak" -- the contract's reading of a path that shards into independent units: per-GPU work fixed): rank r
+        traces sub-pixel sample r of N through the same 1024 x 1024 pixel grid (primary) / seed 42 + r (random): 1 Mi rays per GPU per step;
+        strong (`extra.strong_scaling`, `config.strong_scaling_Mrays_s`): ONE 1 Mi-ray set, rank r traces the contiguous range
+        ray_range(n, r, N); after the timed region one RCCL gather brings the Hit1 ranges to rank 0, which compares the assembled array with
+        its own trace of the whole set.  ONE 1 Mi-ray launch is latency-bound (its longest rays do not shard): predicted 1.27 / 1.69 / 1.94 x at
+        2 / 4 / 8 GPUs (`config.predicted_scaling_x`).  `--strong` makes this one `value` instead.
 roofline: ONE bound, stated once: VALU issue.  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU of the committed counter
         pass of THIS kernel on THESE sources) / live kernel time / SIMDs; peak = the guide's 2 cycles per wave64 VALU instruction at the clock measured
         in the calibration loop (MI355X_MICROARCH.md: 1 162 wave-instructions per us per SIMD at 2 323 MHz); frac = achieved / peak.  Beside it, each
@@ -55,8 +56,8 @@ def parse_args():
     ap.add_argument("--scene", default=None)
     ap.add_argument("--bvh-width", type=int, default=int(os.environ.get("RODENT_BENCH_WIDTH", "2")), choices=(2, 4, 8))
     ap.add_argument("--variant", type=int, default=int(os.environ.get("RODENT_BENCH_VARIANT", "-1")))
-    ap.add_argument("--weak", action="store_true", help="N > 1: report the weak-scaling figure as `value` (default: strong, SURVEY 8e)")
-    ap.add_argument("--strong", action="store_true", help="accepted for compatibility: strong scaling is the default for N > 1")
+    ap.add_argument("--weak", action="store_true", help="accepted for compatibility: weak scaling (1 Mi rays per GPU) is the default for N > 1")
+    ap.add_argument("--strong", action="store_true", help="N > 1: report the strong-scaling figure (ONE 1 Mi-ray set in contiguous ranges, SURVEY 8e) as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="profiling aid: no oracle leg, no CPU baselines, no informational extras")
     ap.add_argument("--no-render", action="store_true", help="skip the renderer section (extra.render)")
     ap.add_argument("--no-scenes", action="store_true", help="skip the scene x ray-class matrix (extra.scenes: the gallery / crown / plant classes are generated and built first, ~80 s)")
@@ -508,7 +509,7 @@ def main():
         strong_rec = {"Mrays_s": round(strong["value"], 3), "ms_per_step": round(1e3 * strong["wall"] / steps_p, 5), "random_Mrays_s": round(strong["value_rnd"], 3),
                       "rays_per_gpu_per_step": len(strong["prim"]), "kernel_ms_per_rank[primary,random]": strong["kernel_ms_per_rank"],
                       "what": "ONE 1 Mi-ray set in contiguous ranges (SURVEY 8e), Hit1 gather to rank 0 after the timed region"}
-        main_part, scaling = (weak_part, "weak") if args.weak else (strong, "strong")
+        main_part, scaling = (strong, "strong") if args.strong and not args.weak else (weak_part, "weak")
     prim, rnd = main_part["prim"], main_part["rnd"]
     n = len(prim)
     prim_dev, rnd_dev, hits_dev, hits_rnd_dev = main_part["prim_dev"], main_part["rnd_dev"], main_part["hits_dev"], main_part["hits_rnd_dev"]
@@ -702,6 +703,8 @@ def main():
                                                 "cfg5_frame_interleaved_16_row_tiles": {"2": 1.99, "4": 3.99, "8": 7.94}, "weak": "1 Mi rays per GPU: ~N",
                                                 "source": "profiles/r05_range_costs.txt, profiles/r04_band_costs.txt"}
         out["config"]["world_size_seen_by_the_collective_backend"] = dist.get_world_size()
+        out["config"]["strong_scaling_Mrays_s[primary,random]"] = [strong_rec["Mrays_s"], strong_rec["random_Mrays_s"]]     # ONE 1 Mi-ray set over the N GPUs
+        out["config"]["weak_scaling_Mrays_s[primary,random]"] = [weak["Mrays_s"], weak["random_Mrays_s"]]
     if big:
         out["config"]["primary_16Mi_Mrays_s"] = big.get("Mrays_s")
     if big_random:

@@ -445,8 +445,8 @@ def test_bench_py_contract(native_build):
 
 
 def test_bench_py_with_two_ranks(native_build):
-    """The N > 1 code path of bench.py -- strong partition as `value` (one ray set in contiguous ranges, Hit1 gather to rank 0,
-    assembled array equal to a single-GPU trace), weak partition beside it, config 5 as interleaved 16-row tiles with a film gather -- with two
+    """The N > 1 code path of bench.py -- weak partition as `value` (1 Mi rays per GPU: independent units, per-GPU work fixed), strong partition beside it
+    (one ray set in contiguous ranges, Hit1 gather to rank 0, assembled array equal to a single-GPU trace), config 5 as interleaved 16-row tiles with a film gather -- with two
     ranks.  On a box with one GPU the ranks share it and the collectives go through gloo (RODENT_BENCH_SHARE_GPUS / _BACKEND);
     with two or more GPUs this is the driver's RCCL launch."""
     import json, os, sys
@@ -460,10 +460,12 @@ def test_bench_py_with_two_ranks(native_build):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rays_per_gpu_per_step"] == (1 << 19) and d["value"] > 1000
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rays_per_gpu_per_step"] == (1 << 20) and d["value"] > 1000 and "per GPU" in d["config"]["workload"]
     e = d["extra"]
     assert e["strong_scaling_check"] == {"primary_equal_to_single_gpu": True, "random_equal_to_single_gpu": True}
-    assert e["weak_scaling"]["rays_per_gpu_per_step"] == (1 << 20) and e["weak_scaling"]["Mrays_s"] > 1000 and len(e["weak_scaling"]["kernel_ms_per_rank[primary,random]"]) == 2
+    assert e["weak_scaling"]["rays_per_gpu_per_step"] == (1 << 20) and e["weak_scaling"]["Mrays_s"] == d["value"] and len(e["weak_scaling"]["kernel_ms_per_rank[primary,random]"]) == 2
+    assert e["strong_scaling"]["rays_per_gpu_per_step"] == (1 << 19) and e["strong_scaling"]["Mrays_s"] > 1000
+    assert d["config"]["strong_scaling_Mrays_s[primary,random]"][0] == e["strong_scaling"]["Mrays_s"] and "predicted_scaling_x" in d["config"]
     assert e["all_rays_bit_exact_vs_oracle"] == {"primary": True, "random": True}          # rank 0's range against the oracle
     c5 = e["render"]["cfg5_atrium_3840x2160_256spp_len8"]
     # rank 0: tiles 0, 2, ..., 134 of 135
