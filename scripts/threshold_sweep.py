@@ -37,15 +37,17 @@ def scene_inputs(name):
         tmp = Path(tempfile.gettempdir()) / "atrium-decimated-refbuilt.bvh"
         tmp.write_bytes(gzip.decompress((scenes.GOLDEN / "atrium-decimated-refbuilt.bvh.gz").read_bytes()))
         return tmp, scenes.CAMERAS["atrium"]
-    return scenes.scene_bvh(name), scenes.CAMERAS[name]
+    return scenes.scene_bvh(name), scenes.CAMERAS[name.split("/")[0]]
 
 
 abi.lib().rodent_hip_top_min_rays(0)
 for scene in a.scenes.split(","):
     path, (eye, d, up, fov) = scene_inputs(scene)
     bvh = abi.DeviceBvh.load(path, 2, 0)
-    n4, _ = F.read_bvh(path, F.BVH4_TRI4)
-    lo, hi = raygen.scene_bounds(n4)
+    if scene.split("/")[0] in scenes.GENERATED:              # gallery / crown / plant: a .bvh with a BVH2 block only
+        lo, hi = raygen.scene_bounds2(F.read_bvh(path, F.BVH2_TRI1)[0])
+    else:
+        lo, hi = raygen.scene_bounds(F.read_bvh(path, F.BVH4_TRI4)[0])
     print(f"== {scene}: {bvh.num_nodes} nodes, {bvh.num_tris} triangles")
     print(f"{'rays':>10s} {'primary: fast ms':>17s} {'top ms':>9s} {'top/fast':>9s}   {'random: fast ms':>16s} {'top ms':>9s} {'top/fast':>9s}")
     for w, h in ((256, 256), (512, 256), (512, 512), (768, 512), (1024, 576), (1024, 768), (1024, 1024), (2048, 1024)):
