@@ -563,7 +563,7 @@ def main():
                             "find their rays incoherent and run the refill loop -- no state between launches"}
     # the default WITHOUT the tile mapping (rodent_hip_ray_grid(0): camera rays traced in list order, 64 pixels of a row per wavefront, as until round 4)
     list_order_rec = None
-    if world == 1 and width == 2 and abi.variants(2)[variant] == "top" and args.only != "random":
+    if world == 1 and width == 2 and abi.variants(2)[variant] == "top" and args.only != "random" and not args.no_cpu_baseline:      # (not in the profiling runs: the same kernel name in another mode would mix into their per-kernel means)
         abi.ray_grid(0)
         hits_lo_dev = torch.zeros_like(hits_dev)
         wall_l, kl_mean, _, _ = time_passes(abi, torch, bvh, prim_dev, hits_lo_dev, n, variant, steps_p, warm_p, None)
