@@ -546,11 +546,47 @@ constexpr int kFoundBit = 1 << 29, kIndexMask = (1 << 28) - 1;
 // 2 = the FARTHER child first (the light's side: a shadow ray runs from the surface to the light).  Occlusion does not depend on the order, so films and counts
 // do not (checked: scripts/render_rules_check.py).  Measured on config 5's frame (profiles/r05_render_rules_check.txt): 1 = +3.0 ... 4.1 %, 2 = +2.7 ... 3.7 % -- an
 // any-hit ray wants an occluder, not the nearest one, and the builder orders a node's children by decreasing reference count (bvh.h:215): child 0 is the bigger subtree.
+// joint_fetch with the memory records addressed as ONE wave-uniform base (an SGPR pair) + a 32-bit byte offset per lane (global_load ... vaddr32, saddr):
+// (traversal_device.h joint_fetch is the form for two arrays anywhere): the scene's node and triangle arrays lie in one allocation less than 4 GiB long -- no 64-bit
+// address per lane, no array bases in VGPRs: six registers fewer around the step.
+__device__ __forceinline__ void joint_fetch_off(vf4& q0, vf4& q1, vf4& q2, vi2& ids, int& popped, bool in_lds, unsigned lds_addr, gbytes base, unsigned off, unsigned off_ids, lds_int* sp) {
+    const unsigned long long lds_mask = __ballot(in_lds);
+    const unsigned sp_addr = (unsigned)(size_t)sp;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %[save], exec\n\t"
+                 "s_andn2_b64 exec, exec, %[lm]\n\t"
+                 "s_cbranch_execz .Ljoint_c_%=\n\t"
+                 "global_load_dwordx4 %[q1], %[o], %[sb] offset:16\n\t"
+                 "global_load_dwordx4 %[q0], %[o], %[sb]\n\t"
+                 "global_load_dwordx4 %[q2], %[o], %[sb] offset:32\n\t"
+                 "global_load_dwordx2 %[ch], %[oc], %[sb]\n"
+                 ".Ljoint_c_%=:\n\t"
+                 "s_and_b64 exec, %[save], %[lm]\n\t"
+                 "s_cbranch_execz .Ljoint_d_%=\n\t"
+                 "ds_read_b128 %[q0], %[l]\n\t"
+                 "ds_read_b128 %[q1], %[l] offset:16\n\t"
+                 "ds_read_b128 %[q2], %[l] offset:32\n\t"
+                 "ds_read_b64 %[ch], %[l] offset:48\n"
+                 ".Ljoint_d_%=:\n\t"
+                 "s_mov_b64 exec, %[save]\n\t"
+                 "ds_read_b32 %[pop], %[sp]\n\t"
+                 "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [ch] "=&v"(ids), [pop] "=&v"(popped), [save] "=&s"(save)
+                 : [o] "v"(off), [oc] "v"(off_ids), [sb] "s"(base), [l] "v"(lds_addr), [sp] "v"(sp_addr), [lm] "s"(lds_mask)
+                 : "memory");
+}
+
+// The streams arrive as SLABS: one base pointer and the capacity -- array k of a stream is base + k * capacity (carve_primary / carve_secondary: 0 id, 1..3 org, 4..6 dir,
+// 7 tmin, 8 tmax; primary 9..13 geom_id, prim_id, t, u, v; secondary 9 prim_id, 10..12 colour).  As the ABI's structs of 20 + 13 pointers this kernel kept ~45 SGPR pairs
+// alive around its loop, 51 of its SGPRs lived in the lanes of a VGPR and came back with v_readlane (VALU instructions) at every refill and every accepted triangle;
+// an array's address is now two SALU instructions away from three registers.  The host checks that a stream IS a slab (stream_slab) and sends any other one through
+// k_trace_persist.  flags: kHitRecordsAoS (primary).
+struct StreamSlab { float* base; int cap; int flags; };
 template <int SHADOW_ORDER = 0>
 __global__ __launch_bounds__(kWave * kPersistWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_from, SecondaryStream s, const int* size_ptr, int n_value, float* film, float inv_spp,
+void k_trace_refill(SceneDev sc, StreamSlab pslab, int n_primary, int coherent_from, StreamSlab sslab, const int* size_ptr, int n_value, float* film, float inv_spp,
                     int* deep_count_primary, int* deep_count_secondary, unsigned long long* counters, int* deep_list_primary, int* deep_list_secondary, int* tickets,
-                    int idle_bounce, int idle_shadow, int* spill, int* err) {
+                    int idle_bounce, int idle_shadow, int* spill, int* err, unsigned tri_delta) {
     constexpr int kStackInts = kPersistWaves * (kTopStack + 1) * kWave, kGroupRays = 32 * kWave;
     __shared__ __attribute__((aligned(16))) int lds[kStackInts + kPersistTopNodes * 16];
     const int lane = threadIdx.x % kWave, wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -558,7 +594,20 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     for (int j = threadIdx.x; j < kPersistTopNodes * 4; j += kWave * kPersistWaves)
         reinterpret_cast<__attribute__((address_space(3))) i32x4*>(image)[j] = reinterpret_cast<const i32x4*>(sc.top_image_large)[j];
-    const int np = n_primary, ns = s.rays.id ? stream_size(size_ptr, n_value) : 0;
+    const int np = n_primary, ns = sslab.base ? stream_size(size_ptr, n_value) : 0;
+    const auto P_ = [&](int k) { return pslab.base + (size_t)k * (size_t)pslab.cap; };
+    const auto S_ = [&](int k) { return sslab.base + (size_t)k * (size_t)sslab.cap; };
+    const auto stream_ray = [&](const float* base, size_t cap, int i) {
+        return make_rayx(base[cap + i], base[2 * cap + i], base[3 * cap + i], base[4 * cap + i], base[5 * cap + i], base[6 * cap + i], base[7 * cap + i], base[8 * cap + i]);
+    };
+    const auto hit_record = [&](unsigned i, int geom, int prim, float t, float u, float v) {               // store_hit_record on the slab
+        int* g = reinterpret_cast<int*>(P_(9));
+        if (pslab.flags & kHitRecordsAoS) {
+            int* rec = g + 5u * i;
+            *reinterpret_cast<i32x4_dword_aligned*>(rec) = i32x4_dword_aligned{geom, prim, __float_as_int(t), __float_as_int(u)};
+            rec[4] = __float_as_int(v);
+        } else { g[i] = geom; reinterpret_cast<int*>(P_(10))[i] = prim; P_(11)[i] = t; P_(12)[i] = u; P_(13)[i] = v; }
+    };
     const int P = (np + kWave - 1) / kWave * kWave, total = P + ns;
     const int stripe = blockIdx.x % kTraceStripes, stripe_waves = (gridDim.x / kTraceStripes) * kPersistWaves;
     int* counter = tickets + stripe * kTraceCounterStride;
@@ -567,10 +616,10 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
     lds_int* const wave_limit = wave_stack + kTopStack * kWave;                        // sp >= wave_limit  <=>  the lane's cursor is at entry kTopStack (l < kWave)
     __syncthreads();
     if (np && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)np);
+    // the scene's nodes and triangles lie in ONE allocation (rodent_hip_scene_create): one wave-uniform base, 32-bit byte offsets per lane (joint_fetch_off).
+    // tri_delta = bytes from node id 0's (fictitious) record to triangle 0, checked by the host (bvh_offsets_ok) together with the 24-bit index range of the multiply below
     typedef const __attribute__((address_space(1))) char* gptr;
-    unsigned long long node_bits = reinterpret_cast<unsigned long long>(sc.nodes - 1), tri_bits = reinterpret_cast<unsigned long long>(sc.tris);   // node ids are 1-based
-    asm volatile("" : "+v"(node_bits), "+v"(tri_bits));
-    const gptr node_base = (gptr)node_bits, tri_base = (gptr)tri_bits;
+    const gptr bvh_base = (gptr)reinterpret_cast<const char*>(sc.nodes - 1);                       // node ids are 1-based
 
     RefillLane L; L.top = 0; L.g = -1; L.sp = wave_stack + lane;
     // rays that ended since the last refill leave the wave: wave-uniform control flow (film_add_wave shuffles)
@@ -579,19 +628,19 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
         const int i = (L.g & kIndexMask) - P;
         const bool lit = done && i >= 0 && !(L.g & kFoundBit);
         if (__ballot(lit))
-            film_add_wave(film, lit ? s.rays.id[i] : -1, lit, lit ? s.color_r[i] * inv_spp : 0.0f, lit ? s.color_g[i] * inv_spp : 0.0f, lit ? s.color_b[i] * inv_spp : 0.0f);
+            film_add_wave(film, lit ? reinterpret_cast<const int*>(S_(0))[i] : -1, lit, lit ? S_(10)[i] * inv_spp : 0.0f, lit ? S_(11)[i] * inv_spp : 0.0f, lit ? S_(12)[i] * inv_spp : 0.0f);
         if (done) L.g = -1;
     };
     const auto start = [&](int g) {
         RayX ray;
         if (g < P) {
             if (g >= np) return;
-            ray = load_stream_ray(p.rays, g);
-            store_hit_record(p, (unsigned)g, sc.num_materials, -1, ray.tmax, 0.0f, 0.0f);     // the miss record; hits overwrite it
+            ray = stream_ray(pslab.base, (size_t)pslab.cap, g);
+            hit_record((unsigned)g, sc.num_materials, -1, ray.tmax, 0.0f, 0.0f);             // the miss record; hits overwrite it
         } else {
             const int i = g - P;
-            if (i >= ns || s.rays.id[i] < 0) return;
-            ray = load_stream_ray(s.rays, i);
+            if (i >= ns || reinterpret_cast<const int*>(S_(0))[i] < 0) return;
+            ray = stream_ray(sslab.base, (size_t)sslab.cap, i);
         }
         ray.tmin = canonical(ray.tmin); ray.tmax = canonical(ray.tmax);
         L.ray = ray; L.g = g;
@@ -635,10 +684,10 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
             i32x2 ch;
             int popped;
             {
-                // both kinds of fetch -- LDS image, memory -- and the word under the cursor in flight together (joint_fetch, traversal_device.h)
+                // both kinds of fetch -- LDS image, memory -- and the word under the cursor in flight together (joint_fetch_off, traversal_device.h)
                 const unsigned idx = (unsigned)(is_node ? top : ~top), stride = is_node ? (unsigned)sizeof(Node2) : (unsigned)sizeof(Tri1);
-                const gptr addr = (is_node ? node_base : tri_base) + (size_t)idx * stride;
-                joint_fetch(q0, q1, q2, ch, popped, top >= kLdsTag, (unsigned)(size_t)image + (unsigned)(top - kLdsTag), addr, addr + (is_node ? 48u : 40u), L.sp);
+                const unsigned off = __umul24(idx, stride) + (is_node ? 0u : tri_delta);           // (idx < 2^24: bvh_offsets_ok; a lane on an image link computes an offset nobody loads)
+                joint_fetch_off(q0, q1, q2, ch, popped, top >= kLdsTag, (unsigned)(size_t)image + (unsigned)(top - kLdsTag), bvh_base, off, off + (is_node ? 48u : 40u), L.sp);
             }
             if (is_node) {
                 float te0, te1;
@@ -664,7 +713,7 @@ void k_trace_refill(SceneDev sc, PrimaryStream p, int n_primary, int coherent_fr
                     if (!any) {
                         unsigned k = (unsigned)L.g & (unsigned)kIndexMask;
                         asm volatile("" : "+v"(k));
-                        store_hit_record(p, k, __float_as_int(q1.w), prim_id & 0x7FFFFFFF, t, u, v);
+                        hit_record(k, __float_as_int(q1.w), prim_id & 0x7FFFFFFF, t, u, v);
                     }
                     L.ray.tmax = t; found = true; L.g |= kFoundBit;
                 }
@@ -1220,6 +1269,7 @@ __global__ __launch_bounds__(kBinBlock) void k_scatter(PrimaryStream p, PrimaryS
 struct DevScene {
     bool loaded = false;
     int num_nodes = 0;
+    unsigned tri_delta = 0;                    // k_trace_refill's addressing of nodes and triangles from one base (rodent_hip_scene_create); 0 = not possible for this scene
     SceneDev dev{};
     std::vector<void*> allocs;
 };
@@ -1365,8 +1415,8 @@ void ensure_deep(RenderDevice& r, int which, int rays) {
 }
 int persistent_grid(RenderDevice& r);
 int shadow_order() { static const int v = [] { const char* e = getenv("RODENT_HIP_SHADOW_ORDER"); return e ? std::min(2, std::max(0, atoi(e))) : 1; }(); return v; }
-#define LAUNCH_TRACE_REFILL(...) do { const int so_ = shadow_order(); \
-        if (so_ == 1) hipLaunchKernelGGL(k_trace_refill<1>, __VA_ARGS__); else if (so_ == 2) hipLaunchKernelGGL(k_trace_refill<2>, __VA_ARGS__); else hipLaunchKernelGGL(k_trace_refill<0>, __VA_ARGS__); } while (0)
+#define LAUNCH_TRACE_REFILL(...) do { const int so_ = shadow_order(); const unsigned td_ = r.scene.tri_delta; \
+        if (so_ == 1) hipLaunchKernelGGL(k_trace_refill<1>, __VA_ARGS__, td_); else if (so_ == 2) hipLaunchKernelGGL(k_trace_refill<2>, __VA_ARGS__, td_); else hipLaunchKernelGGL(k_trace_refill<0>, __VA_ARGS__, td_); } while (0)
 // the spill blocks of a persistent launch on stream `which` (103 MB for the 8192 resident waves of this chip, allocated with the first such launch)
 int* ensure_spill(RenderDevice& r, int which) {
     if (!r.spill[which]) {
@@ -1391,6 +1441,29 @@ int persistent_grid(RenderDevice& r) {
 }
 // k_trace_refill keeps a ray's index in 28 bits of a lane register (the renderer's own streams hold at most 64 Mi rays each; a caller's stage-level
 // streams may be larger: those go through k_trace_persist)
+// A stream as k_trace_refill takes it (StreamSlab): the base and the capacity of a stream whose arrays lie `cap` words apart in carve order, or ok = false
+// (a caller's stage-level struct may point anywhere: such a stream goes through k_trace_persist).  An empty struct (all null) is the slab {null, 0}.
+bool stream_slab(const PrimaryStream& p, StreamSlab& out) {
+    float* base = (float*)p.rays.id;
+    const ptrdiff_t cap = p.rays.org_x - base;
+    const float* arrays[20] = {(float*)p.rays.id, p.rays.org_x, p.rays.org_y, p.rays.org_z, p.rays.dir_x, p.rays.dir_y, p.rays.dir_z, p.rays.tmin, p.rays.tmax, (float*)p.geom_id, (float*)p.prim_id,
+                               p.t, p.u, p.v, (float*)p.rnd, p.mis, p.contrib_r, p.contrib_g, p.contrib_b, (float*)p.depth};
+    out = StreamSlab{base, (int)cap, p.pad & kHitRecordsAoS};
+    if (!base) return true;
+    if (cap <= 0 || cap > 0x7FFFFFFF) return false;
+    for (int k = 0; k < 20; k++) if (arrays[k] != base + (size_t)k * (size_t)cap) return false;
+    return true;
+}
+bool stream_slab(const SecondaryStream& s, StreamSlab& out) {
+    float* base = (float*)s.rays.id;
+    const ptrdiff_t cap = s.rays.org_x - base;
+    const float* arrays[13] = {(float*)s.rays.id, s.rays.org_x, s.rays.org_y, s.rays.org_z, s.rays.dir_x, s.rays.dir_y, s.rays.dir_z, s.rays.tmin, s.rays.tmax, (float*)s.prim_id, s.color_r, s.color_g, s.color_b};
+    out = StreamSlab{base, (int)cap, 0};
+    if (!base) return true;
+    if (cap <= 0 || cap > 0x7FFFFFFF) return false;
+    for (int k = 0; k < 13; k++) if (arrays[k] != base + (size_t)k * (size_t)cap) return false;
+    return true;
+}
 bool refill_indexable(long long n_primary, long long n_secondary) { return n_primary + kWave + n_secondary <= (long long)kIndexMask; }
 // coherent_from: the rays [coherent_from, n) were generated for this launch (camera rays), the ones in front of them are what the last bounce left;
 // < 0 = the caller does not know (the stage-level hip_traverse_primary): whole chunks through k_trace_persist -- with coherent_from = 0 every draw of
@@ -1400,8 +1473,9 @@ void launch_trace_primary(RenderDevice& r, hipStream_t stream, const PrimaryStre
     int* tickets = nullptr;
     if (r.trace_persistent && n >= kPersistMinRays) {
         ensure_tickets(r); tickets = r.tickets[0];
-        if (r.trace_refill > 0 && coherent_from >= 0 && refill_indexable(n, 0))
-            LAUNCH_TRACE_REFILL(dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
+        StreamSlab ps, none{nullptr, 0, 0};
+        if (r.trace_refill > 0 && r.scene.tri_delta && coherent_from >= 0 && refill_indexable(n, 0) && stream_slab(p, ps))
+            LAUNCH_TRACE_REFILL(dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, ps, n, coherent_from, none, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
                                r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow, ensure_spill(r, 0), r.ctl + 2);
         else hipLaunchKernelGGL(k_trace_persist<0>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, SecondaryStream{}, (const int*)nullptr, 0, (float*)nullptr, 0.0f,
                            r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, ensure_spill(r, 0), r.ctl + 2);
@@ -1414,8 +1488,9 @@ void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const Secondary
     int* tickets = nullptr;
     if (r.trace_persistent && max_n >= kPersistMinRays) {
         ensure_tickets(r); tickets = r.tickets[1];
-        if (r.trace_refill > 0 && refill_indexable(0, max_n))
-            LAUNCH_TRACE_REFILL(dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, 0, s, size_ptr, max_n, r.film, inv_spp,
+        StreamSlab ss, none{nullptr, 0, 0};
+        if (r.trace_refill > 0 && r.scene.tri_delta && refill_indexable(0, max_n) && stream_slab(s, ss))
+            LAUNCH_TRACE_REFILL(dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, none, 0, 0, ss, size_ptr, max_n, r.film, inv_spp,
                                r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, r.trace_refill, r.trace_refill_shadow, ensure_spill(r, 1), r.ctl + 2);
         else hipLaunchKernelGGL(k_trace_persist<1>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, PrimaryStream{}, 0, s, size_ptr, max_n, r.film, inv_spp,
                            r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], tickets, ensure_spill(r, 1), r.ctl + 2);
@@ -1429,8 +1504,9 @@ void launch_trace_secondary(RenderDevice& r, hipStream_t stream, const Secondary
 void launch_trace_joint(RenderDevice& r, hipStream_t stream, const PrimaryStream& p, int n, int coherent_from, const SecondaryStream& s, const int* size_ptr, int max_n, float inv_spp) {
     ensure_deep(r, 0, n); ensure_deep(r, 1, max_n);
     ensure_tickets(r);
-    if (r.trace_refill > 0 && refill_indexable(n, max_n))
-        LAUNCH_TRACE_REFILL(dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, coherent_from, s, size_ptr, max_n, r.film, inv_spp,
+    StreamSlab ps, ss;
+    if (r.trace_refill > 0 && r.scene.tri_delta && refill_indexable(n, max_n) && stream_slab(p, ps) && stream_slab(s, ss))
+        LAUNCH_TRACE_REFILL(dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, ps, n, coherent_from, ss, size_ptr, max_n, r.film, inv_spp,
                            r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0], r.trace_refill, r.trace_refill_shadow, ensure_spill(r, 0), r.ctl + 2);
     else hipLaunchKernelGGL(k_trace_persist<2>, dim3(persistent_grid(r)), dim3(kWave * kPersistWaves), 0, stream, r.scene.dev, p, n, s, size_ptr, max_n, r.film, inv_spp,
                        r.ctl + 3, r.ctl + 4, r.counters, r.deep_list[0], r.deep_list[1], r.tickets[0], ensure_spill(r, 0), r.ctl + 2);
@@ -1737,8 +1813,19 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
     s.dev.normals = upload(s, d->normals, 4 * (size_t)d->num_vertices);
     s.dev.face_normals = upload(s, d->face_normals, 4 * (size_t)d->num_tris);
     s.dev.indices = upload(s, d->indices, 4 * (size_t)d->num_tris);
-    s.dev.nodes = upload(s, d->nodes, (size_t)d->num_nodes);
-    s.dev.tris = upload(s, d->tris, (size_t)d->num_bvh_tris);
+    {   // nodes and triangles in ONE allocation: k_trace_refill addresses both from one base with 32-bit offsets (joint_fetch_off)
+        const size_t node_bytes = sizeof(Node2) * (size_t)d->num_nodes, tri_bytes = sizeof(Tri1) * (size_t)d->num_bvh_tris;
+        char* bvh = nullptr;
+        HIP_CHECK(hipMalloc(&bvh, std::max<size_t>(node_bytes + tri_bytes, 16)));
+        s.allocs.push_back(bvh);
+        if (node_bytes) HIP_CHECK(hipMemcpy(bvh, d->nodes, node_bytes, hipMemcpyHostToDevice));
+        if (tri_bytes) HIP_CHECK(hipMemcpy(bvh + node_bytes, d->tris, tri_bytes, hipMemcpyHostToDevice));
+        s.dev.nodes = reinterpret_cast<const Node2*>(bvh);
+        s.dev.tris = reinterpret_cast<const Tri1*>(bvh + node_bytes);
+        // tri_delta: bytes from the record a node id of 0 would have to triangle 0; 0 = not addressable this way (offsets beyond 32 bits, or an index beyond the 24-bit multiply)
+        const unsigned long long delta = sizeof(Node2) + node_bytes, end = delta + tri_bytes;
+        s.tri_delta = (end < (1ull << 32) && d->num_nodes < (1 << 24) - 1 && d->num_bvh_tris < (1 << 24)) ? (unsigned)delta : 0u;
+    }
     s.dev.materials = upload(s, d->materials, (size_t)d->num_materials);
     s.dev.lights = upload(s, d->lights, (size_t)d->num_lights);
     s.dev.light_ids = upload(s, d->light_ids, (size_t)d->num_tris);

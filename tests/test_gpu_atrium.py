@@ -369,3 +369,46 @@ def test_atrium_hit_record_layouts_render_the_same_frame(R, atrium_scene, atrium
         c = r.counters(); film_g = r.film(); r.close()
         assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1]), (aos, sort, capacity)
         assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL), (aos, sort, capacity)
+
+
+def test_stage_level_streams_that_are_no_slabs_take_the_chunk_kernel(R, atrium_scene):
+    """k_trace_refill takes its streams as slabs (one base + k x capacity: what rodent_gpu_get_*_stream hands out); a caller's struct may point anywhere
+    (driver.impala:24-61 is a struct of pointers), and such a stream must go through k_trace_persist with the same result.  600 000 shadow rays of the atrium
+    (above the persistent kernels' minimum) through hip_traverse_secondary with lane refill on: once as the library's slab, once with tmin / tmax / colour arrays
+    moved to other allocations -- the film gets exactly the same contributions (compared per pixel to the order of the atomic adds)."""
+    import ctypes as C
+    import torch
+    W, H, SPP = 640, 480, 2
+    cam = atrium_camera(W, H)
+    r = R.Renderer(atrium_scene, W, H, SPP, 8, mapping="streaming", trace_persistent=1, trace_refill=32)
+    assert r.trace_refill() == (32, 32)
+    l = R.stage_lib()
+    cap = W * H * SPP
+    assert cap >= 8192 * 64                                      # kPersistMinRays
+    p, s = R.PrimaryStream(), R.SecondaryStream()
+    l.rodent_gpu_get_first_primary_stream(0, C.byref(p), cap)
+    l.rodent_gpu_get_secondary_stream(0, C.byref(s), cap)
+    st = R.make_settings(cam)
+    l.hip_generate_rays(0, C.byref(p), cap, 0, cap, C.byref(st), 1, W, H, 0, SPP, None)
+    l.hip_traverse_primary(0, C.byref(p), None)
+    l.hip_shade(0, C.byref(p), C.byref(s), p.size, None)
+    n = s.size
+    assert n == cap and (R.read_stream_array(s.rays.id, n, "<i4") >= 0).sum() > cap // 4      # shadow rays were cast
+    r.clear()
+    l.hip_traverse_secondary(0, C.byref(s), None)                # the slab: k_trace_refill
+    film_slab = r.film()
+    assert film_slab.sum() > 0
+    # the same stream with four of its arrays elsewhere
+    moved = {}
+    s2 = R.SecondaryStream.from_buffer_copy(s)
+    for holder, name in ((s2.rays, "tmin"), (s2.rays, "tmax"), (s2, "color_r"), (s2, "color_b")):
+        t = torch.empty(n * 4, dtype=torch.uint8, device="cuda")
+        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(getattr(holder, name)), C.c_size_t(n * 4), 3)
+        moved[name] = t
+        setattr(holder, name, t.data_ptr())
+    torch.cuda.synchronize()
+    r.clear()
+    l.hip_traverse_secondary(0, C.byref(s2), None)               # not a slab: k_trace_persist
+    film_moved = r.film()
+    r.close()
+    assert np.allclose(film_moved, film_slab, rtol=FILM_RTOL, atol=FILM_ATOL) and not np.array_equal(film_slab, np.zeros_like(film_slab))
