@@ -182,3 +182,16 @@ def test_converter_builder_parameters(tmp_path, native_build, oracle):
         assert np.array_equal(got["tri_id"] >= 0, ref["tri_id"] >= 0)
         hit = ref["tri_id"] >= 0
         assert np.allclose(got["t"][hit], ref["t"][hit], rtol=1e-5, atol=0)                 # another hierarchy: the same surfaces (ties may name another triangle)
+
+
+def test_stress_scenes_get_emissive_panels_for_the_renderer(native_build, tmp_path):
+    """scene_gen's crown and plant are geometry only; scenes.scene_obj appends emissive panels (material "light", facing down) so that the renderer
+    has something that emits -- the converter must find them as lights, and the panels must not touch the .bvh route of the traversal matrix."""
+    from rodent_amd import scene as S, scenes
+    for kind, panels in scenes.PANELS.items():
+        obj = scenes.scene_obj(f"{kind}/1")
+        text = obj.read_text().splitlines()
+        tail = [l for l in text[-(6 * len(panels) + 1):]]
+        assert tail[0] == "usemtl light" and sum(l.startswith("f ") for l in tail) == 2 * len(panels)
+        sc = S.convert(obj, tmp_path / f"{kind}.rscene")
+        assert len(sc.lights) == 2 * len(panels)
