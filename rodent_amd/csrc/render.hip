@@ -1878,6 +1878,23 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
     };
     s.dev.top_image = build_image(kSceneTopNodes);
     s.dev.top_image_large = build_image(kPersistTopNodes);
+    {   // SceneDev::tri_shade: per triangle face normal + its three vertex normals, gathered (RODENT_HIP_TRI_SHADE=0: not built, the shader goes through indices -> normals)
+        static const bool on = [] { const char* e = getenv("RODENT_HIP_TRI_SHADE"); return !e || atoi(e) != 0; }();
+        s.dev.tri_shade = nullptr;
+        if (on && d->num_tris > 0) {
+            std::vector<float> rec(12 * (size_t)d->num_tris);
+            for (int32_t t = 0; t < d->num_tris; t++) {
+                float* o = rec.data() + 12 * (size_t)t;
+                const float* fn = d->face_normals + 4 * (size_t)t;
+                o[0] = fn[0]; o[1] = fn[1]; o[2] = fn[2];
+                for (int k = 0; k < 3; k++) {
+                    const float* n = d->normals + 4 * (size_t)d->indices[4 * (size_t)t + k];
+                    o[3 + 3 * k] = n[0]; o[4 + 3 * k] = n[1]; o[5 + 3 * k] = n[2];
+                }
+            }
+            s.dev.tri_shade = reinterpret_cast<const float4*>(upload(s, rec.data(), rec.size()));
+        }
+    }
     s.num_nodes = d->num_nodes;
     s.loaded = true;
     r.mapping = resolve_mapping(r);

@@ -21,6 +21,10 @@ struct SceneDev {                 // device pointers (uploaded by rodent_hip_sce
     const float* texcoords; const RodentTexture* textures; const uint32_t* texels;
     const int4* top_image;        // the first kSceneTopNodes inner nodes, breadth first, as LDS-image records (traversal_device.h); built at scene creation
     const int4* top_image_large;  // the same with kPersistTopNodes records (persistent stream traversal kernels)
+    // What a hit needs of its triangle, gathered once at scene creation into ONE 48-byte record per triangle: face normal, then the three vertex normals
+    // (12 floats; rodent_hip_scene_create).  Through indices -> normals the shader waits for two dependent fetches (16 + 12 bytes, then 3 x 12 bytes
+    // scattered over the vertex array); the record is one fetch of three consecutive 16-byte words.  Same values, same arithmetic.  May be null (old path).
+    const float4* tri_shade;
 };
 
 #define FLT_MAX_REF 3.4028234664e+38f
@@ -199,10 +203,18 @@ RD_FN BsdfSample bsdf_sample(const RodentMaterial* m, const Surf* s, uint32_t* r
 
 /* geometry.impala:21-54 */
 RD_FN Surf surface_element(const SceneDev* sc, v3 org, v3 dir, int32_t prim, float t, float u, float v) {
-    const int32_t* idx = sc->indices + 4 * prim;
-    const v3 fn = LD3(sc->face_normals + 4 * prim);
-    const float* n0 = sc->normals + 4 * idx[0]; const float* n1 = sc->normals + 4 * idx[1]; const float* n2 = sc->normals + 4 * idx[2];
-    const v3 nrm = normalize(V(lerp2(n0[0], n1[0], n2[0], u, v), lerp2(n0[1], n1[1], n2[1], u, v), lerp2(n0[2], n1[2], n2[2], u, v)));
+    v3 fn, nrm;
+    if (sc->tri_shade) {                                       /* wave-uniform: the gathered record (see SceneDev::tri_shade) */
+        const float4* rec = sc->tri_shade + 3 * (size_t)prim;
+        const float4 a = rec[0], b = rec[1], c = rec[2];       /* fn.xyz n0.x | n0.yz n1.xy | n1.z n2.xyz */
+        fn = V(a.x, a.y, a.z);
+        nrm = normalize(V(lerp2(a.w, b.z, c.y, u, v), lerp2(b.x, b.w, c.z, u, v), lerp2(b.y, c.x, c.w, u, v)));
+    } else {
+        const int32_t* idx = sc->indices + 4 * prim;
+        fn = LD3(sc->face_normals + 4 * prim);
+        const float* n0 = sc->normals + 4 * idx[0]; const float* n1 = sc->normals + 4 * idx[1]; const float* n2 = sc->normals + 4 * idx[2];
+        nrm = normalize(V(lerp2(n0[0], n1[0], n2[0], u, v), lerp2(n0[1], n1[1], n2[1], u, v), lerp2(n0[2], n1[2], n2[2], u, v)));
+    }
     Surf s; s.entering = dot(dir, fn) <= 0.0f; s.point = add(org, mulf(dir, t));
     s.face_normal = s.entering ? fn : neg(fn); s.local = orthonormal(dot(dir, nrm) <= 0.0f ? nrm : neg(nrm)); return s;
 }

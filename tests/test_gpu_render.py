@@ -496,3 +496,16 @@ def test_mid_size_textured_scene_gets_the_rules_it_should(R, oracle, textured_ha
         ms[mapping] = min(t) * 1e3
         r.close()
     assert ms["streaming"] <= 1.15 * ms["megakernel"], ms
+
+
+def test_shading_through_indices_and_normals_still_matches_oracle(native_build):
+    """The shader reads a hit's face normal and vertex normals from ONE gathered 48-byte record per triangle (SceneDev::tri_shade, built at scene creation);
+    RODENT_HIP_TRI_SHADE=0 keeps the reference's path through indices -> normals (geometry.impala:21-54).  The switch is read once per process, so the
+    oracle comparisons of this module run again in a process that has it off."""
+    import os, sys
+    from conftest import ROOT
+    env = dict(os.environ, RODENT_HIP_TRI_SHADE="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_gpu_render.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "test_film_matches_oracle or test_textured_scene_matches_oracle or test_every_bsdf_matches_oracle or test_megakernel_matches_oracle"],
+                       capture_output=True, text=True, cwd=ROOT, env=env)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
