@@ -45,6 +45,7 @@ namespace {
 using namespace rodent_dev;
 
 constexpr int kBlock = 256;                    // workgroup of the streaming (non-traversal) kernels
+constexpr int kShadeBlockDefault = 512;        // ... of the shader (shade_block(): measured 256 / 512 / 1024, profiles/r05_shade_block.txt)
 // Rays per workgroup of the binning kernels (k_bin_count, k_scatter).  A workgroup's rays of one bin land in ONE contiguous
 // run of the output: with 1024 rays and ten bins a run is ~400 bytes per array instead of ~100 -- whole cache lines instead
 // of lines shared with the neighbouring workgroup (which usually runs on another XCD, behind another L2) -- and the per-block
@@ -891,6 +892,7 @@ __device__ __forceinline__ unsigned lookback_exclusive(unsigned* status, int blo
 // stable order the separate compaction produced, without reading and writing the 15-word stream once more per bounce (the
 // compaction's copy was 38 % of the summed kernel time of BASELINE config 4, profiles/r02_render_pmc_digest.txt); the
 // new stream size goes to *alive_total.
+template <int kBlock /* threads per workgroup = rays per compaction slot request (shade_block()) */>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shade(SceneDev sc, PrimaryStream p, PrimaryStream q, const int* __restrict__ perm, SecondaryStream s, const int* size_ptr, int n_value, float* film,
                                                    float inv_spp, int max_path_len, int unsorted, unsigned* scan, int* alive_total) {
     __shared__ unsigned wave_total[kBlock / kWave + 1];
@@ -1464,6 +1466,17 @@ bool stream_slab(const SecondaryStream& s, StreamSlab& out) {
     for (int k = 0; k < 13; k++) if (arrays[k] != base + (size_t)k * (size_t)cap) return false;
     return true;
 }
+// Threads per workgroup of the shader = rays per slot request of its fused compaction.  The request is one returning atomic on ONE word (the new stream size), and one
+// word serves ~88 atomics per microsecond: at 256 rays per request (until round 5) a full 32 Mi-ray stream asks 131 072 times, 77 per microsecond of the shader's 1.7 ms.
+// 512: config 5 +1.4 ... 2.0 %, crown +1.8 %, gallery +0.7 %, the Cornell box through the streaming loop +8.6 %; 1024 gives half of that back to its two barriers over
+// sixteen waves (profiles/r05_shade_block.txt).  RODENT_HIP_SHADE_BLOCK=256|512|1024.
+int shade_block() { static const int v = [] { const char* e = getenv("RODENT_HIP_SHADE_BLOCK"); const int b = e ? atoi(e) : kShadeBlockDefault; return b == 256 || b == 512 || b == 1024 ? b : kShadeBlockDefault; }(); return v; }
+template <typename... Args> void launch_k_shade(hipStream_t stream, int rays, Args... args) {
+    const int b = shade_block(), blocks = (rays + b - 1) / b;
+    if (b == 256) hipLaunchKernelGGL(k_shade<256>, dim3(blocks), dim3(256), 0, stream, args...);
+    else if (b == 512) hipLaunchKernelGGL(k_shade<512>, dim3(blocks), dim3(512), 0, stream, args...);
+    else hipLaunchKernelGGL(k_shade<1024>, dim3(blocks), dim3(1024), 0, stream, args...);
+}
 bool refill_indexable(long long n_primary, long long n_secondary) { return n_primary + kWave + n_secondary <= (long long)kIndexMask; }
 // coherent_from: the rays [coherent_from, n) were generated for this launch (camera rays), the ones in front of them are what the last bounce left;
 // < 0 = the caller does not know (the stage-level hip_traverse_primary): whole chunks through k_trace_persist -- with coherent_from = 0 every draw of
@@ -1635,8 +1648,8 @@ void render_rows(RenderDevice& r, const Settings* settings, int iter, int y0, in
             if (r.fused_compact != 2) HIP_CHECK(hipMemsetAsync(r.scan, 0, sizeof(unsigned) * (size_t)blocks, stream));
             // (d_alive was zeroed by the primary pass's follow-up kernel, k_trace_deep<false>)
         }
-        hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kBlock), 0, stream, r.scene.dev, from, to, perm, sec, size_ptr, n_value, r.film, inv_spp, r.max_path_len, unsorted,
-                           fused ? (r.fused_compact == 2 ? kScanAtomic : r.scan) : (unsigned*)nullptr, d_alive);
+        launch_k_shade(stream, blocks * kBlock, r.scene.dev, from, to, perm, sec, size_ptr, n_value, r.film, inv_spp, r.max_path_len, unsorted,
+                       fused ? (r.fused_compact == 2 ? kScanAtomic : r.scan) : (unsigned*)nullptr, d_alive);
     };
     while (id < num_rays || size > 0) {
         const int survivors = size;                                                      // [0, survivors): what the last bounce left; behind them the rays generated now
@@ -2069,8 +2082,8 @@ void hip_shade(int32_t dev, PrimaryStream* primary, SecondaryStream* secondary, 
     RenderDevice& r = rdev(dev); HIP_CHECK(hipSetDevice(dev)); ensure_film(r); require_scene(r);
     primary->size = num_rays; secondary->size = num_rays; primary->pad = 0;
     if (num_rays <= 0) return;
-    hipLaunchKernelGGL(k_shade, dim3((num_rays + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, r.scene.dev, *primary, *primary, (const int*)nullptr, *secondary, (const int*)nullptr, num_rays, r.film,
-                       1.0f / (float)r.spp, r.max_path_len, /* a ray that missed ends here instead of indexing the material table with the miss id: */ 1, (unsigned*)nullptr, (int*)nullptr);
+    launch_k_shade((hipStream_t)stream, num_rays, r.scene.dev, *primary, *primary, (const int*)nullptr, *secondary, (const int*)nullptr, num_rays, r.film,
+                   1.0f / (float)r.spp, r.max_path_len, /* a ray that missed ends here instead of indexing the material table with the miss id: */ 1, (unsigned*)nullptr, (int*)nullptr);
     HIP_CHECK(hipGetLastError());
 }
 
