@@ -1907,6 +1907,16 @@ void rodent_hip_scene_create(int32_t dev, const RodentSceneDesc* d) {
             }
             s.dev.tri_shade = reinterpret_cast<const float4*>(upload(s, rec.data(), rec.size()));
         }
+        s.dev.tri_tex = nullptr;
+        if (on && textured && d->num_tris > 0) {                 // SceneDev::tri_tex: the corners' texture coordinates, for resolve_material
+            std::vector<float> tc(6 * (size_t)d->num_tris);
+            for (int32_t t = 0; t < d->num_tris; t++)
+                for (int k = 0; k < 3; k++) {
+                    const float* c = d->texcoords + 4 * (size_t)d->indices[4 * (size_t)t + k];
+                    tc[6 * (size_t)t + 2 * k] = c[0]; tc[6 * (size_t)t + 2 * k + 1] = c[1];
+                }
+            s.dev.tri_tex = upload(s, tc.data(), tc.size());
+        }
     }
     s.num_nodes = d->num_nodes;
     s.loaded = true;

@@ -25,6 +25,7 @@ struct SceneDev {                 // device pointers (uploaded by rodent_hip_sce
     // (12 floats; rodent_hip_scene_create).  Through indices -> normals the shader waits for two dependent fetches (16 + 12 bytes, then 3 x 12 bytes
     // scattered over the vertex array); the record is one fetch of three consecutive 16-byte words.  Same values, same arithmetic.  May be null (old path).
     const float4* tri_shade;
+    const float* tri_tex;         // textured scenes: the three corners' texture coordinates per triangle, gathered the same way (6 floats); null otherwise
 };
 
 #define FLT_MAX_REF 3.4028234664e+38f
@@ -239,9 +240,15 @@ RD_FN v3 tex_lookup(const SceneDev* sc, const RodentTexture* t, float tu, float 
  * and the diffuse/Phong mix weight follows the looked-up colours (converter.cpp:881-906, geometry.impala:30-40). */
 RD_FN const RodentMaterial* resolve_material(const SceneDev* sc, const RodentMaterial* m, RodentMaterial* tmp, int32_t prim, float u, float v) {
     if (!(m->tex_kd | m->tex_ks)) return m;
-    const int32_t* idx = sc->indices + 4 * prim;
-    const float* t0 = sc->texcoords + 4 * idx[0]; const float* t1 = sc->texcoords + 4 * idx[1]; const float* t2 = sc->texcoords + 4 * idx[2];
-    const float tu = lerp2(t0[0], t1[0], t2[0], u, v), tv = lerp2(t0[1], t1[1], t2[1], u, v);
+    float tu, tv;
+    if (sc->tri_tex) {                                         /* wave-uniform: the gathered corners (SceneDev::tri_tex) */
+        const float* tc = sc->tri_tex + 6 * (size_t)prim;
+        tu = lerp2(tc[0], tc[2], tc[4], u, v); tv = lerp2(tc[1], tc[3], tc[5], u, v);
+    } else {
+        const int32_t* idx = sc->indices + 4 * prim;
+        const float* t0 = sc->texcoords + 4 * idx[0]; const float* t1 = sc->texcoords + 4 * idx[1]; const float* t2 = sc->texcoords + 4 * idx[2];
+        tu = lerp2(t0[0], t1[0], t2[0], u, v); tv = lerp2(t0[1], t1[1], t2[1], u, v);
+    }
     *tmp = *m;
     if (m->tex_kd) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_kd - 1), tu, tv); tmp->kd[0] = c.x; tmp->kd[1] = c.y; tmp->kd[2] = c.z; }
     if (m->tex_ks) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_ks - 1), tu, tv); tmp->ks[0] = c.x; tmp->ks[1] = c.y; tmp->ks[2] = c.z; }
