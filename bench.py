@@ -12,19 +12,20 @@ Scene = "sponza" if data/sponza.{bvh,-primary.rays,-random.rays} were supplied, 
 value = rays traced by all ranks per second / 1e6, kernel passes only (rays, BVH and hit
         buffers resident in HBM; H2D/D2H excluded like bench_traversal.cpp:124-135).
 N > 1 = no data-path collective: the BVH is replicated, rays are independent units.  BOTH partitions are timed:
-        weak (`value`, "scaling": "weak" -- the contract's reading of a path that shards into independent units: per-GPU work fixed): rank r
-        traces sub-pixel sample r of N through the same 1024 x 1024 pixel grid (primary) / seed 42 + r (random): 1 Mi rays per GPU per step;
-        strong (`extra.strong_scaling`, `config.strong_scaling_Mrays_s`): ONE 1 Mi-ray set, rank r traces the contiguous range
-        ray_range(n, r, N); after the timed region one RCCL gather brings the Hit1 ranges to rank 0, which compares the assembled array with
-        its own trace of the whole set.  ONE 1 Mi-ray launch is latency-bound (its longest rays do not shard): predicted 1.27 / 1.69 / 1.94 x at
-        2 / 4 / 8 GPUs (`config.predicted_scaling_x`).  `--strong` makes this one `value` instead.
+        strong (`value`, "scaling": "strong" -- BASELINE's metric is ONE 1 Mi-ray dump at 1 / 2 / 4 / 8 GPUs): rank r traces the
+        contiguous range ray_range(n, r, N) of the SAME set the N = 1 run traces; after the timed region one RCCL gather brings the Hit1 ranges
+        to rank 0, which compares the assembled array with its own trace of the whole set (`extra.strong_scaling_check`);
+        weak (`extra.weak_scaling`, `config.weak_scaling_Mrays_s`; `--weak` makes it `value`): rank r traces sub-pixel sample r of N through the
+        same 1024 x 1024 pixel grid (primary) / seed 42 + r (random): 1 Mi rays per GPU per step, per-GPU work fixed.
+        ONE 1 Mi-ray launch is latency-bound (its longest rays do not shard): `config.predicted_scaling_x` holds what one GPU predicts.
 roofline: ONE bound, stated once: VALU issue.  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU of the committed counter
         pass of THIS kernel on THESE sources) / live kernel time / SIMDs; peak = the guide's 2 cycles per wave64 VALU instruction at the clock measured
         in the calibration loop (MI355X_MICROARCH.md: 1 162 wave-instructions per us per SIMD at 2 323 MHz); frac = achieved / peak.  Beside it, each
         one division away from a file under profiles/: `frac_of_measured_loop_mix_ceiling` (the same rate against the microbenchmarked ceiling of the
-        loop's own instruction classes), `lane_utilisation`, `hbm_measured_frac` (= `traffic`, the FETCH_SIZE x 2 + WRITE_SIZE bytes of separate --pmc
-        passes, / kernel time / 8 TB/s) and `hbm_algorithmic_frac` (SURVEY 8(d)'s bytes per ray x rays / kernel time / 8 TB/s: > 1, because the 22 MB BVH
-        is served by LDS / L1 / L2 / MALL -- a count of cache hits, labelled so).  Counter-derived figures are only quoted while the profile's source
+        loop's own instruction classes), `lane_utilisation`, `roofline.hbm` (BASELINE's "fraction of HBM roofline": `traffic`, the FETCH_SIZE x 2 +
+        WRITE_SIZE bytes of separate --pmc passes, / kernel time / 8 TB/s = measured_frac; compulsory_frac, traffic_over_compulsory, write_amplification) and
+        `cache_served_bytes_over_hbm_peak` (SURVEY 8(d)'s bytes per ray x rays / kernel time / 8 TB/s: > 1, because the 22 MB BVH is served by LDS / L1 / L2 /
+        MALL -- a count of cache hits, no fraction, labelled so).  Counter-derived figures are only quoted while the profile's source
         hash matches the kernels' sources (rodent_amd/provenance.py); a stale profile is reported as such and the live node-fetch bound stands in.
 render  (`extra.render`): BASELINE configs 4 and 5 through the renderer ABI -- Cornell 1920 x 1080, 64 spp, path length 4 and the
         config-5 scene at 3840 x 2160, 256 spp, path length 8 (one GPU: the whole frame; N GPUs: row bands + one film gather
@@ -56,8 +57,8 @@ def parse_args():
     ap.add_argument("--scene", default=None)
     ap.add_argument("--bvh-width", type=int, default=int(os.environ.get("RODENT_BENCH_WIDTH", "2")), choices=(2, 4, 8))
     ap.add_argument("--variant", type=int, default=int(os.environ.get("RODENT_BENCH_VARIANT", "-1")))
-    ap.add_argument("--weak", action="store_true", help="accepted for compatibility: weak scaling (1 Mi rays per GPU) is the default for N > 1")
-    ap.add_argument("--strong", action="store_true", help="N > 1: report the strong-scaling figure (ONE 1 Mi-ray set in contiguous ranges, SURVEY 8e) as `value`")
+    ap.add_argument("--weak", action="store_true", help="N > 1: report the weak-scaling figure (1 Mi rays per GPU) as `value` instead")
+    ap.add_argument("--strong", action="store_true", help="accepted for compatibility: strong scaling (ONE 1 Mi-ray set in contiguous ranges, SURVEY 8e) is the default for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="profiling aid: no oracle leg, no CPU baselines, no informational extras")
     ap.add_argument("--no-render", action="store_true", help="skip the renderer section (extra.render)")
     ap.add_argument("--no-scenes", action="store_true", help="skip the scene x ray-class matrix (extra.scenes: the gallery / crown / plant classes are generated and built first, ~80 s)")
@@ -484,7 +485,7 @@ def main():
     strong_check = weak = None
     if world == 1:
         main_part = run_partition(prim_all, rnd_all)
-        scaling = "weak"
+        scaling = "strong"                                        # (N = 1 of the fixed 1 Mi-ray workload: the same set the N > 1 runs split)
     else:
         # strong: ONE ray set in contiguous ranges -- contiguous keeps coherent rays coherent
         a, b = parallel.ray_range(len(prim_all), rank, world)
@@ -509,7 +510,7 @@ def main():
         strong_rec = {"Mrays_s": round(strong["value"], 3), "ms_per_step": round(1e3 * strong["wall"] / steps_p, 5), "random_Mrays_s": round(strong["value_rnd"], 3),
                       "rays_per_gpu_per_step": len(strong["prim"]), "kernel_ms_per_rank[primary,random]": strong["kernel_ms_per_rank"],
                       "what": "ONE 1 Mi-ray set in contiguous ranges (SURVEY 8e), Hit1 gather to rank 0 after the timed region"}
-        main_part, scaling = (strong, "strong") if args.strong and not args.weak else (weak_part, "weak")
+        main_part, scaling = (weak_part, "weak") if args.weak and not args.strong else (strong, "strong")
     prim, rnd = main_part["prim"], main_part["rnd"]
     n = len(prim)
     prim_dev, rnd_dev, hits_dev, hits_rnd_dev = main_part["prim_dev"], main_part["rnd_dev"], main_part["hits_dev"], main_part["hits_rnd_dev"]
@@ -745,9 +746,16 @@ def main():
             "traffic": None if traffic is None else traffic["bytes"],
             "kernel": kname, "kernel_ms": round(k_mean, 5),
             "frac_of_measured_loop_mix_ceiling": vi.get("frac_of_measured_loop_mix_ceiling"), "lane_utilisation": vi.get("lane_utilisation"),
+            # BASELINE's "fraction of HBM roofline", one key: fabric bytes of the committed --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE) / live kernel time / 8 TB/s, beside the
+            # compulsory bytes (rays in, hits out, the BVH once) and the write amplification (WRITE_SIZE / the 16-byte Hit1 array)
+            "hbm": {"measured_frac": None if traffic is None else round(traffic["bytes"] / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "compulsory_frac": round(compulsory / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "traffic_over_compulsory": None if traffic is None else round(traffic["bytes"] / compulsory, 3),
+                    "write_amplification": None if traffic is None else round(traffic["write_bytes"] / (16.0 * n), 3),
+                    "peak_GBps": HBM_PEAK_GBPS, "source": None if traffic is None else traffic["source"]},
             "hbm_measured_frac": None if traffic is None else round(traffic["bytes"] / (k_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            "hbm_algorithmic_frac": round(hbm_alg, 4),
-            "hbm_algorithmic_frac_is": "cache-served, not a fraction: SURVEY 8(d)'s bytes per ray count every node / triangle visit although the BVH is served by LDS / L1 / L2 / MALL (> 1 is expected)",
+            "cache_served_bytes_over_hbm_peak": round(hbm_alg, 4),
+            "cache_served_bytes_over_hbm_peak_is": "NOT a fraction: SURVEY 8(d)'s bytes per ray count every node / triangle visit although the BVH is served by LDS / L1 / L2 / MALL (> 1 is expected)",
             "what": "VALU issue: wave-instructions per us per SIMD of this kernel (SQ_INSTS_VALU of the committed counter pass / live kernel time / SIMDs) against the guide's 2-cycle rate at the "
                     "measured clock.  At 1 Mi rays per launch the launch is a tail (LAB_NOTES.md 3.1.1); the same kernel at 16 Mi rays is in extra.primary_16Mi_rays_per_launch"
                     + ("" if top and top[0] == "valu_issue" else "  [the committed counter pass does not belong to the running sources: the live node-fetch bound stands in]"),
@@ -766,7 +774,7 @@ def main():
                        "bound": (pick_bound(binding_r) or [None])[0], "frac": (pick_bound(binding_r) or [None, {"frac": None}])[1]["frac"], "binding": binding_r}})
         out["roofline"] = roof
         out["config"]["hbm_measured_frac"] = roof["hbm_measured_frac"]
-        out["config"]["hbm_algorithmic_frac_cache_served"] = roof["hbm_algorithmic_frac"]
+        out["config"]["cache_served_bytes_over_hbm_peak"] = roof["cache_served_bytes_over_hbm_peak"]
         # parity on every ray of both sets (bit-exact for the order-preserving kernels)
         out["extra"]["all_rays_bit_exact_vs_oracle"] = {"primary": bool(hits.tobytes() == ref_hits.tobytes()), "random": bool(hits_rnd.tobytes() == ref_rnd.tobytes())}
     if world == 1 and not args.no_cpu_baseline:

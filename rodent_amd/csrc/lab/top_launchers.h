@@ -34,8 +34,8 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL> void L_top_refil
     ensure_deep_list(s, n);
     ensure_top_buffers(s);
     s.top_image_nodes = nullptr;
-    ensure_spill(s);
     const int groups = spill_checked(((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);
+    ensure_spill(s, groups * WAVES);
     hipLaunchKernelGGL((k_bvh2_top_refill_wpe<ANY, LDS_N, TOPN, WAVES, REFILL>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
                        (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes), s.spill);
     hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);

@@ -574,7 +574,7 @@ __device__ __forceinline__ void joint_fetch_off(vf4& q0, vf4& q1, vf4& q2, vi2& 
                  "s_waitcnt vmcnt(0) lgkmcnt(0)"
                  : [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [ch] "=&v"(ids), [pop] "=&v"(popped), [save] "=&s"(save)
                  : [o] "v"(off), [oc] "v"(off_ids), [sb] "s"(base), [l] "v"(lds_addr), [sp] "v"(sp_addr), [lm] "s"(lds_mask)
-                 : "memory");
+                 : "memory", "scc");               // (s_andn2_b64 / s_and_b64 write SCC)
 }
 
 // The streams arrive as SLABS: one base pointer and the capacity -- array k of a stream is base + k * capacity (carve_primary / carve_secondary: 0 id, 1..3 org, 4..6 dir,

@@ -415,6 +415,12 @@ __device__ __forceinline__ int tile_ray(int& first, int lane, int grid_w) {
     first = band * 8 * grid_w + tx * 8;
     return first + (lane >> 3) * grid_w + (lane & 7);
 }
+// the same map for ONE position (< tiled_ray_count), per lane: the refill loops draw positions that are not a wave's 64 consecutive ones
+__device__ __forceinline__ int tile_ray_at(int pos, int grid_w) {
+    asm volatile("" : "+s"(grid_w));
+    const unsigned tiles_per_row = (unsigned)grid_w >> 3, tile = (unsigned)pos / kWave, band = tile / tiles_per_row, tx = tile - band * tiles_per_row, l = (unsigned)pos % kWave;
+    return (int)(band * 8u * (unsigned)grid_w + tx * 8u + (l >> 3) * (unsigned)grid_w + (l & 7u));
+}
 
 // PRIO (lab): 0 = none; 1 = a wave raises its issue priority as it ages (48 / 96 / 144 iterations -> s_setprio 1 / 2 / 3);
 // 2 = the waves of the second dispatch round (workgroup index >= 8192) run at priority 2 from the start; 3 = both.
@@ -709,7 +715,7 @@ struct DeviceState {
     // (pinned host memory the kernels store into); hint_* = the ray list the hint is about and the first launch that traced it.
     int*  host_kinds = nullptr; int launch_id = 0; const void* hint_rays = nullptr; int hint_n = 0, hint_first_id = 0;
     int*  tickets = nullptr;                   // persistent "top*p" mappings: chunk tickets per XCD (zero between launches)
-    int*  spill = nullptr;                     // out-of-window stack entries: kSpillSlots wave blocks of kSpillWaveInts ints (stack_spill, traversal_device.h)
+    int*  spill = nullptr; int spill_slots = 0; // out-of-window stack entries: spill_slots wave blocks of kSpillWaveInts ints (stack_spill, traversal_device.h; ensure_spill)
     Ctl*  ctl() const { return reinterpret_cast<Ctl*>(scratch + 16); }
 };
 // One DeviceState per (device, stream): launches enqueued on different streams of a device may overlap, so each
@@ -820,13 +826,24 @@ void ensure_deep_list(DeviceState& s, int n) {
 
 // The blocks the traversal stacks spill into beyond their LDS windows: one per wave slot of a resident generation of the persistent
 // kernels (num_cus x 32 waves = 8192), which the one-chunk kernels' launches below rodent_hip_top_min_rays (6144 chunks; 9216 until round 4) fit as well.
-// 113 MB per (device, stream) context, allocated with the context's first launch, touched only by rays deeper than their window.
+// Sized to what the context's launches need (until round 5 every context took all 9 216 blocks = 113 MB with its first launch, a 64-ray one included, and a
+// process may hold 64 contexts per device): `slots` wave blocks of 12.5 KB, rounded up to a power of two from 64 on, grown -- behind a device synchronisation, like the
+// deep list -- when a later launch needs more; a persistent launch takes num_cus x 32 = 8 192 (100 MB).  Touched only by rays deeper than their window.
 constexpr int kSpillSlots = 9216;
-void ensure_spill(DeviceState& s) {
-    if (s.spill) return;
+void ensure_spill(DeviceState& s, int slots) {
+    if (slots <= s.spill_slots) return;
     std::lock_guard<std::mutex> lock(g_mutex);
-    if (!s.spill) HIP_CHECK(hipMalloc(&s.spill, sizeof(int) * (size_t)kSpillSlots * kSpillWaveInts));
+    if (slots <= s.spill_slots) return;
+    int want = 64;
+    while (want < slots) want *= 2;
+    want = std::min(want, kSpillSlots);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (s.spill) HIP_CHECK(hipFree(s.spill));
+    HIP_CHECK(hipMalloc(&s.spill, sizeof(int) * (size_t)want * kSpillWaveInts));
+    s.spill_slots = want;
 }
+// the wave slots of one resident generation of 16-wave workgroups (what every persistent BVH2 kernel launches)
+int resident_wave_slots(const DeviceState& s) { return ((s.num_cus * 2 + kStripes - 1) / kStripes) * kStripes * 16; }
 
 // a persistent grid's wave slots must fit the context's spill blocks (they do on every gfx950 part: 256 CUs x 32 waves)
 int spill_checked(int groups, int waves) {
@@ -872,7 +889,7 @@ constexpr int kGridMinRays = 2048 * kWave;
 template <bool ANY, int LDS_N, int XCD, bool TR = false, int PRIO = 0> void L_single(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     if (PRIO == 0 && !TR && blocks_for(n) <= kSpillSlots) {        // every chunk has a spill block: deep stacks stay in their lanes
-        ensure_spill(s);
+        ensure_spill(s, blocks_for(n));
         hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, false, 0, true>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr, s.spill, n >= kGridMinRays ? g_ray_grid : 0);
     } else
         hipLaunchKernelGGL((k_bvh2_single<ANY, LDS_N, XCD, TR, PRIO>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, (const int*)nullptr, (int*)nullptr, 0);
@@ -882,7 +899,7 @@ template <bool ANY, int LDS_N, int XCD, bool TR = false, int PRIO = 0> void L_si
 
 template <bool ANY, int LDS_N, int TOPN, int WAVES, bool PREFETCH, bool SORTED, int OCC, bool TRACE = false, int PRIO = 0, int FUSED = 0, bool LAZY = false> void launch_top_persist(LAUNCH_ARGS, int max_id) {
     ensure_deep_list(s, n);
-    ensure_spill(s);
+    ensure_spill(s, ((s.num_cus * (OCC / WAVES) + kStripes - 1) / kStripes) * kStripes * WAVES);
     if (!s.top_image || !s.tickets) {
         std::lock_guard<std::mutex> lock(g_mutex);
         if (!s.top_image) { HIP_CHECK(hipMalloc(&s.top_image, kMaxTopNodes * sizeof(Node2))); HIP_CHECK(hipMemset(s.top_image, 0, kMaxTopNodes * sizeof(Node2))); }
@@ -969,9 +986,9 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0, bo
     if (g_schedule_history) { launch_top_persist<ANY, LDS_N, TOPN, WAVES, false, false, 32, false, 0, 2>(s, nodes, tris, rays, hits, n, stream, max_id); return; }
     ensure_deep_list(s, n);
     ensure_top_buffers(s);
-    ensure_spill(s);
-    s.top_image_nodes = nullptr; s.order_rays = 0;
-    const int groups = spill_checked(((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);   // one resident generation, the same number in every stripe
+    const int groups = spill_checked(((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);
+    ensure_spill(s, groups * WAVES);
+    s.top_image_nodes = nullptr; s.order_rays = 0;   // one resident generation, the same number in every stripe
     // Which kernel?  k_bvh2_top_auto decides per wave and is right for any list; but its refill loop, compiled under the chunk loop's
     // register budget, runs a few per cent behind k_bvh2_top_refill's (profiles/r04_sweep_auto.log).  With the ray-kind hint ON (off by default, see
     // g_kind_hint) every workgroup reports what its first wave saw (report_ray_kind) and a list that earlier launches found incoherent throughout goes
@@ -1009,8 +1026,8 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, bool ADAPT = fal
         }
     }
     s.top_image_nodes = nullptr;
-    ensure_spill(s);
     const int groups = spill_checked(((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);
+    ensure_spill(s, groups * WAVES);
     hipLaunchKernelGGL((k_bvh2_top_refill<ANY, LDS_N, TOPN, WAVES, REFILL, ADAPT, FENCE>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
                        (const int4*)s.top_image, s.tickets, mapped_node_ids(nodes), s.spill, (int*)nullptr, 0);
     hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
@@ -1057,6 +1074,7 @@ int wide_top_min_rays() { return g_top_min_rays; }
 #ifdef RODENT_HIP_LAB
 #include "lab/top_kernels.h"         // lab build only: superseded forms of the LDS-image kernels
 #include "lab/top_launchers.h"
+#include "lab/defer_kernels.h"       // lab build only: deferred leaves (round 6)
 #include "lab/traversal_variants.h"  // lab build only: the kernels that were measured and lost, instrumented builds
 #endif
 
@@ -1183,7 +1201,10 @@ template <typename Launch> void timed_sync_call(int32_t dev, int32_t num_rays, L
     DeviceState& s = device_state(dev, nullptr);
     std::lock_guard<std::mutex> one_call(s.sync_mutex);
     if (!s.timer[0]) { HIP_CHECK(hipEventCreate(&s.timer[0])); HIP_CHECK(hipEventCreate(&s.timer[1])); }
-    if (num_rays > 0) { ensure_deep_list(s, num_rays); ensure_spill(s); ensure_top_buffers(s); }       // every lazy allocation of the default mappings
+    if (num_rays > 0) {                                                   // every lazy allocation of the default mappings
+        ensure_deep_list(s, num_rays); ensure_top_buffers(s);
+        ensure_spill(s, num_rays < g_top_min_rays && blocks_for(num_rays) <= kSpillSlots ? blocks_for(num_rays) : resident_wave_slots(s));
+    }
     HIP_CHECK(hipEventRecord(s.timer[0], nullptr));
     launch(s);
     HIP_CHECK(hipEventRecord(s.timer[1], nullptr));

@@ -216,7 +216,7 @@ __device__ __forceinline__ void joint_fetch(vf4& q0, vf4& q1, vf4& q2, vi2& ids,
                  "s_waitcnt vmcnt(0) lgkmcnt(0)"
                  : [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [ch] "=&v"(ids), [pop] "=&v"(popped), [save] "=&s"(save)
                  : [a] "v"(addr), [ac] "v"(addr_ids), [l] "v"(lds_addr), [sp] "v"(sp_addr), [lm] "s"(lds_mask)
-                 : "memory");
+                 : "memory", "scc");               // (s_andn2_b64 / s_and_b64 write SCC)
 }
 
 __device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }

@@ -443,9 +443,12 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
             t = stripe_waves * kWave + __builtin_amdgcn_readfirstlane(t_next);
         }
     } else if (MODE != 1) {
+        // The launch's positions map to rays the SAME way in both loops (`coherent` is per wave; a list that holds an image and segments -- a recognised
+        // width, waves of both kinds -- traced tiles in the chunk loop and list order here: rays of the band both kinds share were traced twice or never).
+        const auto ray_at = [&](int pos) { return pos < tiled_rays ? tile_ray_at(pos, grid_w) : pos; };
         Lane L;
         {
-            const int r = ray_of(t + lane);
+            const int r = ray_at(ray_of(t + lane));
             L = start_lane(rays, hits, r < n ? r : -1, 0, col);
             if (L.top != 0) L.top = root;
         }
@@ -460,8 +463,9 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
                 first = stripe_waves * kWave + __builtin_amdgcn_readfirstlane(first);
                 more = ray_of(first) < n;
                 if (L.top == 0) {
-                    const int rr = ray_of(first + __popcll(~live & ((1ull << lane) - 1ull)));
-                    if (rr < n) {
+                    const int pos = ray_of(first + __popcll(~live & ((1ull << lane) - 1ull)));
+                    if (pos < n) {                                               // (tiled positions lie below n and map below n: one test for both)
+                        const int rr = ray_at(pos);
                         L = start_lane(rays, hits, rr, rr, col);
                         L.top = root;
                     }

@@ -21,6 +21,8 @@
 #include <cmath>
 #include <cstring>
 #include <iostream>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "../multi_gpu.h"
@@ -128,6 +130,7 @@ int main(int argc, char** argv) {
     clear_pixels();
 
     std::vector<double> samples_sec, rank_ms(ngpu, 0.0);
+    std::mutex device_lock[16];
     uint32_t iter = 0;
     while (samples_sec.size() < bench_iter) {
         const auto ticks = std::chrono::high_resolution_clock::now();
@@ -135,6 +138,9 @@ int main(int argc, char** argv) {
         else {
             // every GPU its share of this frame, all at once; the call returns when the share is in the device's film
             group.run([&](int r) {
+                // RODENT_SHARE_GPUS maps several ranks onto one device: its RenderDevice (control words, slabs, counters, film) serves ONE render call at a time
+                // (K threads on one RenderDevice raced).  With one rank per device -- every real run -- nobody ever waits here.
+                std::lock_guard<std::mutex> one_call(device_lock[group.device(r) & 15]);
                 const auto t0 = std::chrono::high_resolution_clock::now();
                 if (bands) { const Part band = split_range((int)height, r, ngpu); rodent_hip_render_rows(group.device(r), &settings, (int32_t)iter, band.begin, band.end, nullptr); }
                 else rodent_hip_render_tiles(group.device(r), &settings, (int32_t)iter, kTileRows, r, ngpu, nullptr);
@@ -202,8 +208,8 @@ int main(int argc, char** argv) {
               << " (min/med/max Msamples/s)" << std::endl;
     if (ngpu > 1) {
         const int own_rows = bands ? split_range((int)height, 0, ngpu).size() : tile_rows_of_rank((int)height, 0, ngpu, kTileRows);
-        std::cout << "# GPUs: " << ngpu << " (devices " << dev << ".." << dev + ngpu - 1 << "), " << (bands ? "bands of " + std::to_string(own_rows) + " row(s)" : "interleaved tiles of " + std::to_string(kTileRows) + " rows")
-                  << "; film gather to device " << dev << ": " << double(height - own_rows) * width * 12 / 1e6 << " MB in " << gather_s * 1e3 << " ms" << std::endl;
+        std::cout << "# GPUs: " << ngpu << " (devices" << [&] { std::string l; for (int r = 0; r < ngpu; r++) l += " " + std::to_string(group.device(r)); return l; }() << "), " << (bands ? "bands of " + std::to_string(own_rows) + " row(s)" : "interleaved tiles of " + std::to_string(kTileRows) + " rows")
+                  << "; film gather to device " << group.device(0) << ": " << double(height - own_rows) * width * 12 / 1e6 << " MB in " << gather_s * 1e3 << " ms" << std::endl;
         std::cout << "# Collective: " << group.describe() << std::endl;
         std::cout << "# Render ms per rank (last frame):";
         for (double ms : rank_ms) std::cout << " " << ms;

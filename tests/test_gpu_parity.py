@@ -415,7 +415,10 @@ def test_bench_py_contract(native_build):
     # never above 1; the measured and the algorithmic HBM fractions side by side at the top level, the latter labelled as a count of cache hits
     assert rf["bound"] in ("valu_issue", "vmem_node_fetch") and 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3
     assert rf["bound"] != "valu_issue" or (rf["peak"] == 1162.0 and 0 < rf["frac_of_measured_loop_mix_ceiling"] <= 1.0 and 0 < rf["lane_utilisation"] <= 1.0)
-    assert rf["hbm_algorithmic_frac"] > 0 and "cache-served" in rf["hbm_algorithmic_frac_is"] and (rf["traffic"] is None or 0 < rf["hbm_measured_frac"] < 1.0)
+    # BASELINE's "fraction of HBM roofline" is ONE key: roofline.hbm (measured fabric bytes of the committed --pmc passes / kernel time / 8 TB/s); the survey's
+    # bytes-per-visit figure is a count of cache hits and is named so (it is no fraction: > 1 on a cache-resident tree)
+    assert rf["cache_served_bytes_over_hbm_peak"] > 0 and "hbm_algorithmic_frac" not in rf and "compulsory_frac" in rf["hbm"]
+    assert rf["traffic"] is None or (0 < rf["hbm"]["measured_frac"] < 1.0 and rf["hbm"]["traffic_over_compulsory"] > 0.9 and rf["hbm"]["write_amplification"] > 0.9)
     assert "random_Mrays_s" in d["config"] and "random_with_kind_hint_Mrays_s" in d["config"]
     # the other scene classes and the any-hit ray class ride along: every cell's sample checked against the oracle inside bench.py
     assert d["config"]["scene_classes_parity"] is True and d["config"]["ao_Mrays_s"] > 500 and set(d["extra"]["scenes"]) >= {"gallery", "crown", "plant"}
@@ -445,8 +448,8 @@ def test_bench_py_contract(native_build):
 
 
 def test_bench_py_with_two_ranks(native_build):
-    """The N > 1 code path of bench.py -- weak partition as `value` (1 Mi rays per GPU: independent units, per-GPU work fixed), strong partition beside it
-    (one ray set in contiguous ranges, Hit1 gather to rank 0, assembled array equal to a single-GPU trace), config 5 as interleaved 16-row tiles with a film gather -- with two
+    """The N > 1 code path of bench.py -- strong partition as `value` (BASELINE's metric: ONE 1 Mi-ray set, contiguous ranges, Hit1 gather to rank 0 after the
+    timed region, assembled array equal to a single-GPU trace), weak partition beside it (1 Mi rays per GPU), config 5 as interleaved 16-row tiles with a film gather -- with two
     ranks.  On a box with one GPU the ranks share it and the collectives go through gloo (RODENT_BENCH_SHARE_GPUS / _BACKEND);
     with two or more GPUs this is the driver's RCCL launch."""
     import json, os, sys
@@ -460,11 +463,11 @@ def test_bench_py_with_two_ranks(native_build):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rays_per_gpu_per_step"] == (1 << 20) and d["value"] > 1000 and "per GPU" in d["config"]["workload"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rays_per_gpu_per_step"] == (1 << 19) and d["value"] > 1000 and "per GPU" not in d["config"]["workload"]
     e = d["extra"]
     assert e["strong_scaling_check"] == {"primary_equal_to_single_gpu": True, "random_equal_to_single_gpu": True}
-    assert e["weak_scaling"]["rays_per_gpu_per_step"] == (1 << 20) and e["weak_scaling"]["Mrays_s"] == d["value"] and len(e["weak_scaling"]["kernel_ms_per_rank[primary,random]"]) == 2
-    assert e["strong_scaling"]["rays_per_gpu_per_step"] == (1 << 19) and e["strong_scaling"]["Mrays_s"] > 1000
+    assert e["weak_scaling"]["rays_per_gpu_per_step"] == (1 << 20) and e["weak_scaling"]["Mrays_s"] > 1000 and len(e["weak_scaling"]["kernel_ms_per_rank[primary,random]"]) == 2
+    assert e["strong_scaling"]["rays_per_gpu_per_step"] == (1 << 19) and e["strong_scaling"]["Mrays_s"] == d["value"]
     assert d["config"]["strong_scaling_Mrays_s[primary,random]"][0] == e["strong_scaling"]["Mrays_s"] and "predicted_scaling_x" in d["config"]
     assert e["all_rays_bit_exact_vs_oracle"] == {"primary": True, "random": True}          # rank 0's range against the oracle
     c5 = e["render"]["cfg5_atrium_3840x2160_256spp_len8"]
@@ -593,6 +596,11 @@ def test_camera_rays_in_image_order_are_traced_as_tiles(gpu, oracle, cornell, co
     run(unit, None)                                                      # normalised directions are no ray_gen dump: recognised or not, the hits are right
     segments = raygen.random_rays(lo, hi, 40_000, 7, 0.0, 1.0)
     run(segments, 0)
+    # An image AND segments in one list: the width is recognised, the image's waves trace tiles, the segments' waves refill lanes -- and both must map the
+    # launch's positions onto its rays the same way.  Heights that are no multiple of 8: the image's last rows share a band of 8 rows with segments.
+    for w, h in ((256, 60), (1024, 20), (136, 53)):
+        run(np.concatenate([raygen.primary_rays(*cam, w, h, 0.0, 5000.0), segments]), w)
+    run(np.concatenate([segments[:1000], image]), None)               # (segments first: whatever is recognised, the hits are right)
     # per-pixel lists that are no camera dump (the width is read from the pixel BELOW ray 0 being a near neighbour: multiples of 128 that divide the ray count)
     light = np.array([0.0, 1.9, 0.0], np.float32)
     for w, h, expect in ((256, 64, 256), (1024, 24, 1024), (384, 40, 384), (200, 64, 0)):
