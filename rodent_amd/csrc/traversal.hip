@@ -358,6 +358,16 @@ __device__ __forceinline__ void finish_lane(const Lane& L, const Ray1* __restric
     if (L.ray_id >= 0 && !L.found) store_hit(hits, L.ray_id, -1, rays[L.ray_id].tmax, 0.0f, 0.0f);
 }
 
+// finish_lane without the load: a ray that no triangle was accepted for still holds the tmax it was loaded with -- canonicalised (start_lane), which changes the bits of a
+// signalling NaN only: those lanes re-read theirs.
+__device__ __forceinline__ void finish_lane_reg(const Lane& L, const Ray1* __restrict__ rays, Hit1* __restrict__ hits) {
+    if (L.ray_id >= 0 && !L.found) {
+        float tmax = L.ray.tmax;
+        if (tmax != tmax) tmax = rays[L.ray_id].tmax;
+        store_hit(hits, L.ray_id, -1, tmax, 0.0f, 0.0f);
+    }
+}
+
 // Are the rays the pixels of an image, row by row?  Then which rays share a wave is the kernel's choice, and an 8 x 8-pixel tile is a tighter bundle than 64 pixels of a row:
 // the wave's rays finish closer together (oracle step counts, atrium camera: mean over chunks of the longest ray 57.4 steps for row segments, 48.4 for tiles, mean ray 39.3)
 // and touch fewer distinct nodes per load.  What a ray visits and where its hit goes do not change: the hits stay bit-identical
@@ -980,7 +990,7 @@ void ensure_top_buffers(DeviceState& s) {
         HIP_CHECK(hipMemset(s.tickets, 0, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
     }
 }
-template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0, bool FUSED = true> void L_default(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0, bool FUSED = true, bool LAZY = false> void L_default(LAUNCH_ARGS) {
     const int max_id = top_kernel_ids(nodes, n);
     if (max_id == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }
     if (g_schedule_history) { launch_top_persist<ANY, LDS_N, TOPN, WAVES, false, false, 32, false, 0, 2>(s, nodes, tris, rays, hits, n, stream, max_id); return; }
@@ -1006,7 +1016,7 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0, bo
         hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
         return;
     }
-    hipLaunchKernelGGL((k_bvh2_top_auto<ANY, LDS_N, TOPN, WAVES, REFILL, MODE, FUSED>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+    hipLaunchKernelGGL((k_bvh2_top_auto<ANY, LDS_N, TOPN, WAVES, REFILL, MODE, FUSED, LAZY>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
                        s.top_image, s.tickets, max_id, s.spill, report_to, id, g_ray_grid);
     if (!FUSED) hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
 }

@@ -391,7 +391,10 @@ __global__ __launch_bounds__(kWave * WAVES, 32 / WAVES) void k_bvh2_top_refill(c
 // allocation: the chunk loop then reloaded the spilled tmax in every iteration), costs ~25 instructions, and needs no probe launch: a list
 // of camera rays runs as it did, a list of incoherent segments as through "refill".
 // The launch finishes itself like k_bvh2_top_persist<FUSED = 2> (last workgroup: deep rays, counters, stale image).
-template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0 /* lab: 1 = whole chunks whatever the rays, 2 = refill whatever the rays */, bool FUSED = true /* lab: false = a follow-up kernel finishes the launch */>
+// LAZY (round 6): no miss record up front -- a ray's record is stored when a triangle is accepted, and the miss record when the ray ends without one, from the tmax the lane
+// still holds (finish_lane_reg): nearly every camera ray finds a triangle, and the record stored up front was written back to memory before the hit overwrote it
+// (WRITE_SIZE 1.64 x the Hit1 array, profiles/r05_traffic.json).  Round 3's lazy form re-read the ray at the end of every chunk (a dependent load on the critical path: -4 %).
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int MODE = 0 /* lab: 1 = whole chunks whatever the rays, 2 = refill whatever the rays */, bool FUSED = true /* lab: false = a follow-up kernel finishes the launch */, bool LAZY = false>
 __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_auto(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                   const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
                                                                   Ctl* ctl, int* __restrict__ deep_list, int4* __restrict__ top_image, int* __restrict__ tickets, int max_id,
@@ -433,11 +436,12 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
             if (first_ray >= n) break;
             int r = ray_of(t + lane);
             if (first_ray < tiled_rays) r = tile_ray(first_ray, lane, grid_w);   // (first_ray: the tile's first pixel)
-            Lane L = start_lane(rays, hits, r < n ? r : -1, first_ray, col);
+            Lane L = start_lane<LAZY>(rays, hits, r < n ? r : -1, first_ray, col);
             if (L.top != 0) L.top = root;
             while (__ballot(L.top != 0)) {
-                if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N, WAVES>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill);
+                if (L.top != 0) bvh2_step<ANY, false, true, LAZY, false, false, LDS_N, WAVES>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill);
             }
+            if (LAZY) finish_lane_reg(L, rays, hits);
             int t_next = 0;
             if (lane == 0) t_next = atomicAdd(counter, kWave);
             t = stripe_waves * kWave + __builtin_amdgcn_readfirstlane(t_next);
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
         Lane L;
         {
             const int r = ray_at(ray_of(t + lane));
-            L = start_lane(rays, hits, r < n ? r : -1, 0, col);
+            L = start_lane<LAZY>(rays, hits, r < n ? r : -1, 0, col);
             if (L.top != 0) L.top = root;
         }
         // One flat loop, deliberately (see k_bvh2_top_refill).
@@ -463,18 +467,20 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
                 first = stripe_waves * kWave + __builtin_amdgcn_readfirstlane(first);
                 more = ray_of(first) < n;
                 if (L.top == 0) {
+                    if (LAZY) { finish_lane_reg(L, rays, hits); L.ray_id = -1; }  // the ray that ended in this lane
                     const int pos = ray_of(first + __popcll(~live & ((1ull << lane) - 1ull)));
                     if (pos < n) {                                               // (tiled positions lie below n and map below n: one test for both)
                         const int rr = ray_at(pos);
-                        L = start_lane(rays, hits, rr, rr, col);
+                        L = start_lane<LAZY>(rays, hits, rr, rr, col);
                         L.top = root;
                     }
                 }
                 continue;
             }
             if (live == 0) break;
-            if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N, WAVES>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill);
+            if (L.top != 0) bvh2_step<ANY, false, true, LAZY, false, false, LDS_N, WAVES>(L, base, hits, sp_limit, ctl, deep_list, false, nullptr, image, nullptr, spill);
         }
+        if (LAZY) finish_lane_reg(L, rays, hits);
     }
     // the workgroup that finishes last does the follow-up work (k_bvh2_top_persist, FUSED == 2)
     if (!FUSED) return;
