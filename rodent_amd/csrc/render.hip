@@ -583,7 +583,10 @@ __device__ __forceinline__ void joint_fetch_off(vf4& q0, vf4& q1, vf4& q2, vi2& 
 // an array's address is now two SALU instructions away from three registers.  The host checks that a stream IS a slab (stream_slab) and sends any other one through
 // k_trace_persist.  flags: kHitRecordsAoS (primary).
 struct StreamSlab { float* base; int cap; int flags; };
-template <int SHADOW_ORDER = 0>
+// LAZY_MISS (RODENT_HIP_LAZY_MISS): no miss record when a closest-hit ray starts -- it is stored when the ray retires without an accepted triangle
+// (kFoundBit), from the tmax the lane still holds.  In a closed scene nearly every ray finds a triangle and the record stored up front was 20 of the ~43 bytes this
+// kernel wrote per ray.
+template <int SHADOW_ORDER = 0, bool LAZY_MISS = false>
 __global__ __launch_bounds__(kWave * kPersistWaves) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_trace_refill(SceneDev sc, StreamSlab pslab, int n_primary, int coherent_from, StreamSlab sslab, const int* size_ptr, int n_value, float* film, float inv_spp,
                     int* deep_count_primary, int* deep_count_secondary, unsigned long long* counters, int* deep_list_primary, int* deep_list_secondary, int* tickets,
@@ -630,6 +633,7 @@ void k_trace_refill(SceneDev sc, StreamSlab pslab, int n_primary, int coherent_f
         const bool lit = done && i >= 0 && !(L.g & kFoundBit);
         if (__ballot(lit))
             film_add_wave(film, lit ? reinterpret_cast<const int*>(S_(0))[i] : -1, lit, lit ? S_(10)[i] * inv_spp : 0.0f, lit ? S_(11)[i] * inv_spp : 0.0f, lit ? S_(12)[i] * inv_spp : 0.0f);
+        if (LAZY_MISS && done && i < 0 && !(L.g & kFoundBit)) hit_record((unsigned)L.g, sc.num_materials, -1, L.ray.tmax, 0.0f, 0.0f);     // (tmax: as loaded, canonicalised)
         if (done) L.g = -1;
     };
     const auto start = [&](int g) {
@@ -637,7 +641,7 @@ void k_trace_refill(SceneDev sc, StreamSlab pslab, int n_primary, int coherent_f
         if (g < P) {
             if (g >= np) return;
             ray = stream_ray(pslab.base, (size_t)pslab.cap, g);
-            hit_record((unsigned)g, sc.num_materials, -1, ray.tmax, 0.0f, 0.0f);             // the miss record; hits overwrite it
+            if (!LAZY_MISS) hit_record((unsigned)g, sc.num_materials, -1, ray.tmax, 0.0f, 0.0f);             // the miss record; hits overwrite it
         } else {
             const int i = g - P;
             if (i >= ns || reinterpret_cast<const int*>(S_(0))[i] < 0) return;
@@ -1417,8 +1421,12 @@ void ensure_deep(RenderDevice& r, int which, int rays) {
 }
 int persistent_grid(RenderDevice& r);
 int shadow_order() { static const int v = [] { const char* e = getenv("RODENT_HIP_SHADOW_ORDER"); return e ? std::min(2, std::max(0, atoi(e))) : 1; }(); return v; }
+// 1 (default from round 6 on): films and ray counts identical, frame rates +0.1 ... 0.3 % on atrium / gallery / Cornell box (profiles/r06_lazy_miss_render.txt), 20 bytes per
+// closest-hit ray less to write; 0 = the record up front (until round 5).  (Through the traversal ABI the same idea LOSES 2 ... 8 %: profiles/r06_lazy_miss_traversal.txt.)
+int lazy_miss() { static const int v = [] { const char* e = getenv("RODENT_HIP_LAZY_MISS"); return e ? (atoi(e) != 0) : 1; }(); return v; }
 #define LAUNCH_TRACE_REFILL(...) do { const int so_ = shadow_order(); const unsigned td_ = r.scene.tri_delta; \
-        if (so_ == 1) hipLaunchKernelGGL(k_trace_refill<1>, __VA_ARGS__, td_); else if (so_ == 2) hipLaunchKernelGGL(k_trace_refill<2>, __VA_ARGS__, td_); else hipLaunchKernelGGL(k_trace_refill<0>, __VA_ARGS__, td_); } while (0)
+        if (lazy_miss() && so_ == 1) hipLaunchKernelGGL((k_trace_refill<1, true>), __VA_ARGS__, td_); \
+        else if (so_ == 1) hipLaunchKernelGGL(k_trace_refill<1>, __VA_ARGS__, td_); else if (so_ == 2) hipLaunchKernelGGL(k_trace_refill<2>, __VA_ARGS__, td_); else hipLaunchKernelGGL(k_trace_refill<0>, __VA_ARGS__, td_); } while (0)
 // the spill blocks of a persistent launch on stream `which` (103 MB for the 8192 resident waves of this chip, allocated with the first such launch)
 int* ensure_spill(RenderDevice& r, int which) {
     if (!r.spill[which]) {
