@@ -1085,6 +1085,7 @@ int wide_top_min_rays() { return g_top_min_rays; }
 #include "lab/top_kernels.h"         // lab build only: superseded forms of the LDS-image kernels
 #include "lab/top_launchers.h"
 #include "lab/defer_kernels.h"       // lab build only: deferred leaves (round 6)
+#include "lab/coop8_kernel.h"        // lab build only: wave-cooperative BVH8 for any-hit rays (round 6)
 #include "lab/traversal_variants.h"  // lab build only: the kernels that were measured and lost, instrumented builds
 #endif
 

@@ -13,6 +13,8 @@ from rodent_amd import abi, formats as F, parallel, raygen, scenes
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--variants", default="top", help="comma-separated mapping names (lab build: e.g. top,fast-pf0,fast-pf48): one table per mapping")
+ap.add_argument("--worlds", default="2,4,8")
 a = ap.parse_args()
 path = scenes.scene_bvh("atrium")
 bvh = abi.DeviceBvh.load(path, 2, 0)
@@ -22,26 +24,32 @@ lo, hi = raygen.scene_bounds(n4)
 sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0), "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
 
 
+VARIANT = 0
+
+
 def timed(rays):
     n = len(rays)
     rd = abi.to_device(rays, 0); hd = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
     st = torch.cuda.current_stream()
     for _ in range(5):
-        abi.traverse_async(bvh, rd, hd, n, False, 0, st)
+        abi.traverse_async(bvh, rd, hd, n, False, VARIANT, st)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     for s, e in ev:
-        s.record(st); abi.traverse_async(bvh, rd, hd, n, False, 0, st); e.record(st)
+        s.record(st); abi.traverse_async(bvh, rd, hd, n, False, VARIANT, st); e.record(st)
     torch.cuda.synchronize()
     return float(np.median([s.elapsed_time(e) for s, e in ev]))
 
 
-for name, rays in sets.items():
+for vname, name, rays in [(v, k, r) for v in a.variants.split(",") for k, r in sets.items()]:
+    VARIANT = abi.variants(2).index(vname)
     n = len(rays)
     one = timed(rays)
+    if vname != "top":
+        print(f"== mapping {vname}")
     print(f"{name}: {n} rays on one GPU {one:.4f} ms = {n / one / 1e3:.0f} Mrays/s")
     print(f"  {'GPUs':>4s} {'partition':>24s} | per-rank ms" + " " * 52 + "| mean / max      | predicted Mrays/s (Hit1 gather outside the timed region)")
-    for world in (2, 4, 8):
+    for world in [int(x) for x in a.worlds.split(",")]:
         for kind in ("contiguous ranges", "interleaved 2048-ray groups"):
             ms = []
             for r in range(world):
