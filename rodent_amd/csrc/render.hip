@@ -786,10 +786,29 @@ struct ShadeOut {
 };
 constexpr float kRayOffset = 0.001f;           // renderer.impala:46
 
+// RODENT_SHADE_HOIST_LIGHT (compile time): 0 = the light record is fetched where it is used, behind the material (until round 5); 1 = fetched into
+// registers in front of the hit's gathers; 2 = its two cache lines touched from k_shade (global_load ... lds into a sink row: no register) as soon as the path's random
+// state is in (what ships: k_shade 916 -> 851 us per call at 16 spp, frames +0.2 %; mode 1 spills ten VGPRs and is 11 % slower).  profiles/r06_shade_*.txt
+#ifndef RODENT_SHADE_HOIST_LIGHT
+#define RODENT_SHADE_HOIST_LIGHT 2
+#endif
 __device__ __forceinline__ ShadeOut shade_vertex(const SceneDev& sc, const PathVertex& pv, int max_path_len) {
     ShadeOut o;
     const float pdf_lightpick = 1.0f / (float)sc.num_lights;
     uint32_t rnd = pv.rnd;
+#if RODENT_SHADE_HOIST_LIGHT == 1
+    // The light that next-event estimation will sample depends on the path's random state only (renderer.impala:76-78), not on what was hit: its record is fetched HERE,
+    // beside the hit's own gathers (material, triangle record), instead of behind them -- one dependent fetch less in the chain this kernel waits for.
+    // Same values, same arithmetic; a specular hit fetches a record it does not use.
+    typedef float lf4 __attribute__((ext_vector_type(4)));
+    lf4 lv0, lv1, lv2, lnrm, lcol;
+    {
+        uint32_t peek = rnd;
+        const RodentLight* Lh = sc.lights + (int)(xorshift(&peek) & 0x7FFFFFFFu) % sc.num_lights;
+        lv0 = *reinterpret_cast<const lf4*>(Lh->v0); lv1 = *reinterpret_cast<const lf4*>(Lh->v1); lv2 = *reinterpret_cast<const lf4*>(Lh->v2);
+        lnrm = *reinterpret_cast<const lf4*>(Lh->n); lcol = *reinterpret_cast<const lf4*>(Lh->color);
+    }
+#endif
     RodentMaterial textured;
     const RodentMaterial* m = resolve_material(&sc, sc.materials + pv.geom, &textured, pv.prim, pv.u, pv.v);
     const Surf sf = surface_element(&sc, pv.org, pv.dir, pv.prim, pv.t, pv.u, pv.v);
@@ -812,12 +831,20 @@ __device__ __forceinline__ ShadeOut shade_vertex(const SceneDev& sc, const PathV
     o.shadow = false;
     if (!bsdf_is_specular(m)) {
         const int light_id = (int)(xorshift(&rnd) & 0x7FFFFFFFu) % sc.num_lights;
-        const RodentLight* L = sc.lights + light_id;
         const float lu = randf(&rnd), lv = randf(&rnd);
+#if RODENT_SHADE_HOIST_LIGHT == 1
+        (void)light_id;
+        const v3 pos = sample_triangle(lu, lv, V(lv0.x, lv0.y, lv0.z), V(lv1.x, lv1.y, lv1.z), V(lv2.x, lv2.y, lv2.z));
+        const v3 from_dir = sub(sf.point, pos);
+        float lcos = dot(from_dir, V(lnrm.x, lnrm.y, lnrm.z)) / len(from_dir);
+        v3 intensity = V(lcol.x, lcol.y, lcol.z); float pdf_area = lnrm.w;
+#else
+        const RodentLight* L = sc.lights + light_id;
         const v3 pos = sample_triangle(lu, lv, LD3(L->v0), LD3(L->v1), LD3(L->v2));
         const v3 from_dir = sub(sf.point, pos);
         float lcos = dot(from_dir, LD3(L->n)) / len(from_dir);
         v3 intensity = LD3(L->color); float pdf_area = L->inv_area;
+#endif
         if (!(pdf_area > 0.0f && cosine_hemisphere_pdf(lcos) > 0.0f && lcos > 0.0f)) { intensity = V(0, 0, 0); pdf_area = 1.0f; lcos = 0.0f; }
         const v3 light_dir = sub(pos, sf.point);
         const float vis = dot(light_dir, sf.local.c2);
@@ -900,6 +927,9 @@ template <int kBlock /* threads per workgroup = rays per compaction slot request
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shade(SceneDev sc, PrimaryStream p, PrimaryStream q, const int* __restrict__ perm, SecondaryStream s, const int* size_ptr, int n_value, float* film,
                                                    float inv_spp, int max_path_len, int unsorted, unsigned* scan, int* alive_total) {
     __shared__ unsigned wave_total[kBlock / kWave + 1];
+#if RODENT_SHADE_HOIST_LIGHT == 2
+    __shared__ int light_sink[kBlock];
+#endif
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int n_valid = stream_size(size_ptr, n_value);
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
@@ -918,6 +948,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         const HitRecord hit = load_hit_record(p, (unsigned)src);
         pv.prim = hit.prim; pv.geom = hit.geom; pv.t = hit.t; pv.u = hit.u; pv.v = hit.v;
         pv.rnd = p.rnd[src]; pv.mis = p.mis[src];
+#if RODENT_SHADE_HOIST_LIGHT == 2
+        {
+            uint32_t peek = pv.rnd;
+            const char* lp = reinterpret_cast<const char*>(sc.lights + (int)(xorshift(&peek) & 0x7FFFFFFFu) % sc.num_lights);
+            __attribute__((address_space(3))) void* sink = (__attribute__((address_space(3))) void*)(light_sink + (threadIdx.x / kWave) * kWave);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)lp, sink, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lp + 64), sink, 4, 0, 0);
+        }
+#endif
         pv.contrib = V(p.contrib_r[src], p.contrib_g[src], p.contrib_b[src]);
         pv.depth = p.depth[src];
         o = shade_vertex(sc, pv, max_path_len);
