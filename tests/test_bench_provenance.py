@@ -13,9 +13,9 @@ ROOT = Path(__file__).resolve().parents[1]
 
 @pytest.fixture()
 def bench(tmp_path, monkeypatch):
-    spec = importlib.util.spec_from_file_location("bench_under_test", ROOT / "bench.py")
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    """benchlib/profiles.py (what bench.py reads committed profiles with), looking at an empty profiles/ directory."""
+    sys.path.insert(0, str(ROOT))
+    import benchlib.profiles as mod
     (tmp_path / "profiles").mkdir()
     monkeypatch.setattr(mod, "ROOT", tmp_path)
     return mod
