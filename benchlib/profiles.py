@@ -33,7 +33,8 @@ def current_profile(pattern, kind):
         return None, None, f"no profiles/{pattern}"
     name, data = found
     if not provenance.is_current(data.get("_meta"), kind):
-        return name, None, f"profiles/{name} was taken on other {kind} sources (source_sha {data.get('_meta', {}).get('source_sha')} != {provenance.source_sha(kind)}): not quoted"
+        return name, None, f"profiles/{name} was taken on other {kind} sources (source_sha {data.get('_meta', {}).get('source_sha')} != " \
+            f"{provenance.source_sha(kind)}): not quoted"
     return name, data, None
 
 
@@ -66,7 +67,8 @@ def measured_traffic(kernel):
         return None, why
     for k, t in data.items():
         if k != "_meta" and k.replace(" ", "").startswith(kernel.replace(" ", "").rstrip(">")) and "hbm_bytes_fetch_x2" in t:
-            return {"bytes": int(t["hbm_bytes_fetch_x2"]), "fetch_bytes_x2": int(2 * t["FETCH_SIZE"] * 1024), "write_bytes": int(t["WRITE_SIZE"] * 1024), "source": name}, None
+            return {"bytes": int(t["hbm_bytes_fetch_x2"]), "fetch_bytes_x2": int(2 * t["FETCH_SIZE"] * 1024),
+                "write_bytes": int(t["WRITE_SIZE"] * 1024), "source": name}, None
     return None, f"profiles/{name} holds no pass of kernel {kernel}"
 
 
@@ -83,45 +85,61 @@ def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms, lds_steps_pe
     c, stale = kernel_counters(kernel, ray_set)
     fetches_per_ns = (steps_per_ray - lds_steps_per_ray) * rays / (kernel_ms * 1e6)
     if ray_set == "primary":
-        peak, peak_kind = cal["node_fetch_peak_coherent"], "64-byte node per lane, neighbouring lanes share nodes, L1/L2-resident (vmem_peak 'coherent')"
+        peak, peak_kind = cal["node_fetch_peak_coherent"], "64-byte node per lane, neighbouring lanes share nodes, L1/L2-resident " \
+            "(vmem_peak 'coherent')"
     else:
         # incoherent rays: every lane its own node; blend of the scattered-L2 and scattered-MALL rates by the measured L2 hit rate
         hit = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if "TCC_HIT_sum" in c else 0.85
         peak = 1.0 / (hit / cal["node_fetch_peak_scattered_l2"] + (1.0 - hit) / cal["node_fetch_peak_scattered_mall"])
-        peak_kind = f"64-byte node per lane, scattered: L2 rate x {hit:.3f} + MALL rate x {1 - hit:.3f} ({'measured' if 'TCC_HIT_sum' in c else 'assumed'} TCC hit rate; vmem_peak 'scattered')"
-    out = {"vmem_node_fetch": {"bound": "vector-memory pipeline (TA/L1/L2), node fetches", "unit": "fetches/ns", "achieved": round(fetches_per_ns, 2), "peak": round(peak, 2),
-                               "frac": round(fetches_per_ns / peak, 4), "peak_kind": peak_kind, "steps_per_ray": round(steps_per_ray - lds_steps_per_ray, 3), "peak_source": cal_name}}
+        peak_kind = f"64-byte node per lane, scattered: L2 rate x {hit:.3f} + MALL rate x {1 - hit:.3f} " \
+            f"({'measured' if 'TCC_HIT_sum' in c else 'assumed'} TCC hit rate; vmem_peak 'scattered')"
+    out = {"vmem_node_fetch": {"bound": "vector-memory pipeline (TA/L1/L2), node fetches", "unit": "fetches/ns",
+        "achieved": round(fetches_per_ns, 2), "peak": round(peak, 2),
+                               "frac": round(fetches_per_ns / peak, 4), "peak_kind": peak_kind,
+                                   "steps_per_ray": round(steps_per_ray - lds_steps_per_ray, 3), "peak_source": cal_name}}
     if lds_steps_per_ray:
-        # MI355X_MICROARCH.md, LDS table: ds_read_b128 4 and ds_read_b64 2 LDS cycles per wave-instruction when conflict-free -> 3 x 4 + 2 per 64 node records
+        # MI355X_MICROARCH.md, LDS table: ds_read_b128 4 and ds_read_b64 2 LDS cycles per wave-instruction when conflict-free -> 3 x 4 + 2
+        # per 64 node records
         lds_peak = LDS_CLOCK_GHZ * cal["cus"] * 64 / 14.0
         lds_per_ns = lds_steps_per_ray * rays / (kernel_ms * 1e6)
-        out["lds_fetch"] = {"bound": "LDS (top-of-tree image: 3 x ds_read_b128 + ds_read_b64 per node)", "unit": "fetches/ns", "achieved": round(lds_per_ns, 2),
-                            "peak": round(lds_peak, 1), "frac": round(lds_per_ns / lds_peak, 4), "steps_per_ray": round(lds_steps_per_ray, 3),
-                            "peak_kind": "conflict-free rate of the guide's LDS table at 2.4 GHz; distinct records on one bank quarter serialise"}
+        out["lds_fetch"] = {"bound": "LDS (top-of-tree image: 3 x ds_read_b128 + ds_read_b64 per node)", "unit": "fetches/ns",
+            "achieved": round(lds_per_ns, 2),
+                            "peak": round(lds_peak, 1), "frac": round(lds_per_ns / lds_peak, 4),
+                                "steps_per_ray": round(lds_steps_per_ray, 3),
+                            "peak_kind": "conflict-free rate of the guide's LDS table at 2.4 GHz; distinct records on one bank quarter "
+                                "serialise"}
     if stale:
         out["counters_not_quoted"] = stale
     if "SQ_INSTS_VALU" in c:
         per_simd_us = c["SQ_INSTS_VALU"] / (kernel_ms * 1e3) / cal["simds"]
         lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
-        peak = cal["valu_issue_guide_2_cycle_rate"]           # MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD, at the clock measured in the calibration loop
+        # MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD, at the clock measured in the calibration loop
+        peak = cal["valu_issue_guide_2_cycle_rate"]
         out["valu_issue"] = {"bound": "VALU issue", "unit": "wave-instructions/us/SIMD", "achieved": round(per_simd_us, 1), "peak": peak,
                              "frac": round(per_simd_us / peak, 4), "valu_instructions_per_launch": int(c["SQ_INSTS_VALU"]),
                              "lane_utilisation": round(lane_util, 4), "useful_lane_frac": round(per_simd_us / peak * lane_util, 4),
-                             # scripts/ubench/valu_rate.hip: the same rate against the measured ceiling of the loop's own instruction classes
-                             "frac_of_measured_loop_mix_ceiling": round(per_simd_us / cal["valu_issue_peak_loop_mix_r04"], 4), "measured_loop_mix_ceiling": cal["valu_issue_peak_loop_mix_r04"],
-                             "ceilings": "peak = the guide's 2 cycles per wave64 instruction at the clock measured in the calibration loop (2 323 MHz -> 1 162); it holds for mul / add / fma with <= 2 VGPR "
-                                         "sources only -- min / max / cndmask / compares / 3-source fma issue every ~4 cycles, so the loop's own mix tops out at 645 (profiles/r04_ubench_valu_rate.txt)",
+                             # scripts/ubench/valu_rate.hip: the same rate against the measured ceiling of the loop's own instruction
+                             # classes
+                             "frac_of_measured_loop_mix_ceiling": round(per_simd_us / cal["valu_issue_peak_loop_mix_r04"], 4),
+                                 "measured_loop_mix_ceiling": cal["valu_issue_peak_loop_mix_r04"],
+                             "ceilings": "peak = the guide's 2 cycles per wave64 instruction at the clock measured in the calibration loop "
+                                 "(2 323 MHz -> 1 162); it holds for mul / add / fma with <= 2 VGPR "
+                                         "sources only -- min / max / cndmask / compares / 3-source fma issue every ~4 cycles, so the "
+                                             "loop's own mix tops out at 645 (profiles/r04_ubench_valu_rate.txt)",
                              "peak_source": cal_name, "counter_source": c.get("source")}
     if "TA_TA_BUSY_sum" in c and "GRBM_GUI_ACTIVE" in c:
-        out["ta_busy_frac_profiled"] = round(c["TA_TA_BUSY_sum"] / cal["cus"] / (c["GRBM_GUI_ACTIVE"] / 8.0), 4)     # mean over the 256 TAs / cycles of one XCD
+        # mean over the 256 TAs / cycles of one XCD
+        out["ta_busy_frac_profiled"] = round(c["TA_TA_BUSY_sum"] / cal["cus"] / (c["GRBM_GUI_ACTIVE"] / 8.0), 4)
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
         out["wave_cycles_waiting_frac_profiled"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
     if "SQ_WAVE_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
-        # wavefront occupancy: SQ_WAVE_CYCLES counts quad-cycles of resident waves (MI355X_MICROARCH.md), GRBM_GUI_ACTIVE the busy cycles of the
+        # wavefront occupancy: SQ_WAVE_CYCLES counts quad-cycles of resident waves (MI355X_MICROARCH.md), GRBM_GUI_ACTIVE the busy cycles of
+        # the
         # eight XCDs -> resident waves per SIMD averaged over the launch, against the 8 the hardware holds (the kernel's 64 VGPRs and
         # 80 KB of LDS per 16-wave workgroup admit all 8: what is missing from 8 is the launch's fill and drain)
         waves = 4.0 * c["SQ_WAVE_CYCLES"] / ((c["GRBM_GUI_ACTIVE"] / 8.0) * cal["simds"])
-        out["occupancy"] = {"resident_waves_per_simd_time_averaged_profiled": round(waves, 2), "max_waves_per_simd": 8, "frac": round(waves / 8.0, 4),
+        out["occupancy"] = {"resident_waves_per_simd_time_averaged_profiled": round(waves, 2), "max_waves_per_simd": 8,
+            "frac": round(waves / 8.0, 4),
                             "waves_per_simd_the_kernel_admits": 8}
     return out
 
@@ -150,7 +168,8 @@ def render_profile(config_name):
             continue
         rows = {}
         for k, v in kernels.items():
-            row = {"calls_per_frame": v.get("calls_per_frame"), "avg_ms": round(v["avg_us"] / 1e3, 4), "ms_per_frame": round(v["avg_us"] * v.get("calls_per_frame", 0) / 1e3, 3)}
+            row = {"calls_per_frame": v.get("calls_per_frame"), "avg_ms": round(v["avg_us"] / 1e3, 4),
+                "ms_per_frame": round(v["avg_us"] * v.get("calls_per_frame", 0) / 1e3, 3)}
             if "hbm_TBps_fetch_x2" in v:
                 row["hbm_frac"] = round(v["hbm_TBps_fetch_x2"] * 1e3 / HBM_PEAK_GBPS, 4)
                 row["hbm_GBps"] = round(v["hbm_TBps_fetch_x2"] * 1e3, 1)
@@ -186,7 +205,8 @@ def traversal_roofline(b, part, hits, hits_rnd, kname):
     # (the ray-kind hint is off by default: both sets run through the same kernel)
     binding_r = binding_bounds(kname, "random", len(rnd), st_r["inner_per_ray"] + st_r["prims_per_ray"], kr_mean, lds_r)
     top = pick_bound(binding)
-    roof = {"bound": top[0], "achieved": top[1]["achieved"], "peak": top[1]["peak"], "unit": top[1]["unit"], "frac": top[1]["frac"]} if top else \
+    roof = {"bound": top[0], "achieved": top[1]["achieved"], "peak": top[1]["peak"], "unit": top[1]["unit"],
+        "frac": top[1]["frac"]} if top else \
            {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "note": "no calibration under profiles/"}
     compulsory = 48 * n + nodes.nbytes + tris.nbytes
     vi = (binding or {}).get("valu_issue") or {}
@@ -209,21 +229,24 @@ def traversal_roofline(b, part, hits, hits_rnd, kname):
                 "peak_GBps": HBM_PEAK_GBPS, "source": None if traffic is None else traffic["source"]},
         "hbm_measured_frac": None if traffic is None else round(traffic["bytes"] * per_s, 4),
         "cache_served_bytes_over_hbm_peak": round(hbm_alg, 4),
-        "cache_served_bytes_over_hbm_peak_is": "NOT a fraction: SURVEY 8(d)'s bytes per ray count every node / triangle visit although the BVH is "
+        "cache_served_bytes_over_hbm_peak_is": "NOT a fraction: SURVEY 8(d)'s bytes per ray count every node / triangle visit although the "
+            "BVH is "
                                                "served by LDS / L1 / L2 / MALL (> 1 is expected)",
-        "what": "VALU issue: wave-instructions per us per SIMD of this kernel (SQ_INSTS_VALU of the committed counter pass / live kernel time / "
-                "SIMDs) against the guide's 2-cycle rate at the measured clock.  At 1 Mi rays per launch the launch is a tail (LAB_NOTES.md "
-                "3.1.1); the same kernel at 16 Mi rays is in extra.primary_16Mi_rays_per_launch" + stand_in,
+        "what": "VALU issue: wave-instructions per us per SIMD of this kernel (SQ_INSTS_VALU of the committed counter pass / live kernel "
+                "time / SIMDs) against the guide's 2-cycle rate at the measured clock.  At 1 Mi rays per launch the launch is a tail "
+                "(LAB_NOTES.md 3.1.1); the same kernel at 16 Mi rays is in extra.primary_16Mi_rays_per_launch" + stand_in,
         "hbm_algorithmic": {"bound": "hbm", "GBps": round(achieved, 2), "peak_GBps": HBM_PEAK_GBPS, "frac": round(hbm_alg, 5),
                             "bytes_per_ray": round(bytes_per_ray, 2),
                             "visits_per_ray": {"inner": round(st["inner_per_ray"], 3), "prim": round(st["prims_per_ray"], 3)},
-                            "note": "SURVEY 8(d): 32 + 16 + 64 N_inner + 48 N_tri bytes per ray x rays / kernel time: a count of cache hits, not a "
+                            "note": "SURVEY 8(d): 32 + 16 + 64 N_inner + 48 N_tri bytes per ray x rays / kernel time: a count of cache "
+                                "hits, not a "
                                     "fraction of anything"},
         # FETCH_SIZE x 2 = 128-byte line fills, calibrated on scattered 64-byte node fetches as well
         # (profiles/r04_fetch_size_calibration.txt): bytes between the L2s and the fabric, Infinity-Cache hits included -- an upper bound on
         # DRAM bytes
         "l2_fabric_traffic": {"not_quoted": traffic_why} if traffic is None else
-                             {"what": "FETCH_SIZE x 2 + WRITE_SIZE of separate --pmc passes: bytes between the L2s and the fabric, Infinity-Cache "
+                             {"what": "FETCH_SIZE x 2 + WRITE_SIZE of separate --pmc passes: bytes between the L2s and the fabric, "
+                                 "Infinity-Cache "
                                       "hits included (an upper bound on HBM bytes)",
                               "bytes_per_launch": traffic["bytes"], "GBps": round(traffic["bytes"] / (k_mean * 1e-3) / 1e9, 1),
                               "frac": round(traffic["bytes"] * per_s, 4), "compulsory_bytes_per_launch": int(compulsory),

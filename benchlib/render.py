@@ -49,7 +49,8 @@ def render_section(args, torch, dist, rank, world, dev):
         sc = S.Scene(rscene)
         eye, d, up, fov = scenes.CAMERAS[scene_name]
         cam = S.camera_settings(eye, d, up, fov, w, h)
-        # N GPUs: rank r renders the interleaved 16-row tiles r, r + N, ... (bands of the atrium frame differ by 27 % in cost, tile shares by 1 %: profiles/r04_band_costs.txt)
+        # N GPUs: rank r renders the interleaved 16-row tiles r, r + N, ... (bands of the atrium frame differ by 27 % in cost, tile shares
+        # by 1 %: profiles/r04_band_costs.txt)
         my_rows = sum(b - a for a, b in parallel.row_tiles(h, rank, world)) if world > 1 else h
 
         def render_share(r, it):
@@ -58,7 +59,8 @@ def render_section(args, torch, dist, rank, world, dev):
             else:
                 r.render_rows(cam, it, 0, h)
         frames = 3 if spp * w * h < (1 << 28) else 1
-        entry = {"scene": f"{scene_name} ({sc.num_tris} triangles, {len(sc.materials)} materials)", "width": w, "height": h, "spp": spp, "max_path_len": max_len,
+        entry = {"scene": f"{scene_name} ({sc.num_tris} triangles, {len(sc.materials)} materials)", "width": w, "height": h, "spp": spp,
+            "max_path_len": max_len,
                  "samples_per_frame": spp * w * h, "timed_frames": frames, "rows_per_gpu": my_rows,
                  "partition": f"interleaved {parallel.TILE_ROWS}-row tiles" if world > 1 else "whole frame"}
         # auto = what the library chooses for this scene; streaming = the wavefront loop with the library's defaults (shading in stream
@@ -68,10 +70,12 @@ def render_section(args, torch, dist, rank, world, dev):
         for mapping in mappings:
             if world > 1 and mapping != "auto":                        # N GPUs: only the mapping the library chooses
                 continue
-            r = R.Renderer(sc, w, h, spp=4, max_path_len=max_len, dev=dev, mapping=mapping.split("_")[0], sort=True if mapping.endswith("_sorted") else None)
+            r = R.Renderer(sc, w, h, spp=4, max_path_len=max_len, dev=dev, mapping=mapping.split("_")[0],
+                sort=True if mapping.endswith("_sorted") else None)
             if mapping == "auto":
                 chosen = r.mapping_name()
-                entry["auto_trace_refill_idle_lanes[bounce,shadow]"] = list(r.trace_refill())      # lane refill in the persistent traversal launches (0 = whole chunks)
+                # lane refill in the persistent traversal launches (0 = whole chunks)
+                entry["auto_trace_refill_idle_lanes[bounce,shadow]"] = list(r.trace_refill())
             elif mapping == chosen:
                 r.close()
                 entry[mapping] = {"same_as": "auto"}
@@ -89,7 +93,8 @@ def render_section(args, torch, dist, rank, world, dev):
                 secs.append(time.perf_counter() - t0)
             secs = [max_over_ranks(torch, dist, dev, [s])[0] for s in secs]
             best = float(np.median(secs))
-            res = {"Msamples_s": round(spp * w * h / best / 1e6, 2), "frame_ms": round(best * 1e3, 2), "frame_ms_all": [round(s * 1e3, 2) for s in secs], "rays": r.counters()}
+            res = {"Msamples_s": round(spp * w * h / best / 1e6, 2), "frame_ms": round(best * 1e3, 2),
+                "frame_ms_all": [round(s * 1e3, 2) for s in secs], "rays": r.counters()}
             if world > 1:
                 # the one collective of the path: every peer's rows into rank 0's device film, then the frame is complete there
                 film = parallel.device_film(dev)
@@ -102,7 +107,8 @@ def render_section(args, torch, dist, rank, world, dev):
                 res["film_gather_MB"] = round((h - my_rows) * w * 12 / 1e6, 2) if rank == 0 else None
                 res["Msamples_s_including_gather"] = round(spp * w * h / (best + g) / 1e6, 2)
                 if rank == 0:
-                    res["film_complete_on_root"] = bool(torch.isfinite(full).all() and float(full[h - 1].abs().sum()) > 0 and float(full[0].abs().sum()) > 0)
+                    res["film_complete_on_root"] = bool(torch.isfinite(full).all() and float(full[h - 1].abs().sum()) > 0
+                        and float(full[0].abs().sum()) > 0)
             r.close()
             entry[mapping] = res
             if mapping == "auto":
@@ -122,7 +128,8 @@ def render_cpu_baseline(threads):
     for name, (scene_name, w, h, spp, max_len) in RENDER_CONFIGS.items():
         obj, rscene = scene_file(scene_name)
         sc = S.Scene(rscene)
-        n8, t8 = F.read_bvh(scenes.scene_bvh(scene_name), F.BVH8_TRI4)      # the reference's CPU targets trace a BVH8 / Tri4 (converter.cpp:152-259)
+        # the reference's CPU targets trace a BVH8 / Tri4 (converter.cpp:152-259)
+        n8, t8 = F.read_bvh(scenes.scene_bvh(scene_name), F.BVH8_TRI4)
         # bounded samples (seconds, not minutes, of CPU work): config 4 whole (133 M samples), config 5 at a quarter of the pixels and 8 spp
         sw, sh, sspp = (w, h, spp) if scene_name == "cornell" else (w // 2, h // 2, 8)
         eye, d, up, fov = scenes.CAMERAS[scene_name]
@@ -132,6 +139,7 @@ def render_cpu_baseline(threads):
         O.render_wavefront(sc, n8, t8, cam, 0, sspp, max_len, sw, sh, None, threads=threads)
         dt = time.perf_counter() - t0
         out[name] = {"Msamples_s": round(sspp * sw * sh / dt / 1e6, 2), "cores": threads, "kind": "port",
-                     "sample": f"{sw}x{sh}, {sspp} spp, path length {max_len}: {sspp * sw * sh} samples in {dt:.2f} s; reference's CPU wavefront mapping restated "
+                     "sample": f"{sw}x{sh}, {sspp} spp, path length {max_len}: {sspp * sw * sh} samples in {dt:.2f} s; reference's CPU "
+                         f"wavefront mapping restated "
                                "(render/mapping_cpu.impala:352-473; scalar shading instead of RV-vectorised)"}
     return out

@@ -11,10 +11,14 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, dist, any_hit=False):
-    """W untimed + K timed launches, back to back on one stream.  Returns (wall seconds for the K steps [max over ranks is taken by the caller],
-    average launch duration in ms from ONE pair of HIP events around the timed region on the launch stream, ... and, from a second, untimed pass with an
-    event pair around every single launch, the median and minimum of those).  Until round 4 the timed region itself carried an event pair per step:
-    two marker packets between every two kernels cost 17 us per 0.18 ms step (profiles/r05_host_call_costs.txt: 174.9 us per launch back to back
+    """W untimed + K timed launches, back to back on one stream.  Returns (wall seconds for the K steps [max over ranks is taken by the
+    caller],
+    average launch duration in ms from ONE pair of HIP events around the timed region on the launch stream, ... and, from a second, untimed
+    pass with an
+    event pair around every single launch, the median and minimum of those).  Until round 4 the timed region itself carried an event pair
+    per step:
+    two marker packets between every two kernels cost 17 us per 0.18 ms step (profiles/r05_host_call_costs.txt: 174.9 us per launch back to
+    back
     against 192.3 with them) -- time the benchmark spent measuring itself."""
     stream = torch.cuda.current_stream()
     for _ in range(warmup):
@@ -35,7 +39,8 @@ def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, 
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     region_ms = first.elapsed_time(last) / max(1, steps)
-    # per-launch spread (not part of the timed region): every launch between its own two events, which adds the dispatch latency the back-to-back region hides
+    # per-launch spread (not part of the timed region): every launch between its own two events, which adds the dispatch latency the
+    # back-to-back region hides
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     for i in range(steps):

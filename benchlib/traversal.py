@@ -40,7 +40,8 @@ class Bench:
 
 
 def ray_sets(b: Bench, sample, samples):
-    """(camera rays, random segments): 1024 x 1024 pixels through sub-pixel sample `sample` of `samples`, 1 Mi segments with seed 42 + sample."""
+    """(camera rays, random segments): 1024 x 1024 pixels through sub-pixel sample `sample` of `samples`, 1 Mi segments with seed 42 +
+    sample."""
     from rodent_amd import formats as F, raygen, scenes
     if b.scene == "sponza":
         return (F.read_rays(scenes.DATA / "sponza-primary.rays", 0.0, scenes.PRIMARY_TMAX),
@@ -104,7 +105,8 @@ def timed_partitions(b: Bench):
             "random_Mrays_s": round(weak_part["value_rnd"], 3), "rays_per_gpu_per_step": len(pw),
             "kernel_ms_per_rank[primary,random]": weak_part["kernel_ms_per_rank"],
             "hit_counts_per_rank[primary,random]": [[int(c[0]), int(c[1])] for c in counts],
-            "what": "rank r traces sub-pixel sample r of N through the same 1024 x 1024 pixel grid (random: seed 42 + r): per-GPU work fixed"}
+            "what": "rank r traces sub-pixel sample r of N through the same 1024 x 1024 pixel grid (random: seed 42 + r): per-GPU work "
+                "fixed"}
     strong_rec = {"Mrays_s": round(strong["value"], 3), "ms_per_step": round(1e3 * strong["wall"] / steps_p, 5),
                   "random_Mrays_s": round(strong["value_rnd"], 3), "rays_per_gpu_per_step": len(strong["prim"]),
                   "kernel_ms_per_rank[primary,random]": strong["kernel_ms_per_rank"],
@@ -142,14 +144,16 @@ def side_measurements(b: Bench, part):
         out["with_schedule_history"] = {
             "primary_Mrays_s": vp, "primary_ms_per_step": msp, "primary_kernels_ms": kp, "random_Mrays_s": vr, "random_ms_per_step": msr,
             "random_kernels_ms": kr, "identical_hits": bool(torch.equal(hp, hits_dev) and torch.equal(hr, hits_rnd_dev)),
-            "what": "rodent_hip_schedule_history(1): every launch records the wave iterations of each 64-ray chunk, the next launch of the same "
+            "what": "rodent_hip_schedule_history(1): every launch records the wave iterations of each 64-ray chunk, the next launch of the "
+                "same "
                     "size traces its chunks longest first; off by default, not the headline value"}
     # BASELINE config 3 ("ray compaction/sorting on"): the random set through "sorted" (the permutation by origin cell is rebuilt inside
     # every timed launch) and through "refill" (continuous compaction inside the persistent kernel)
     if args.only != "primary":
         for name, key, same_key, what in (
                 ("sorted", "random_sorted", "identical_to_unsorted",
-                 "sorted: counting sort of the rays on 512 Morton cells of their origin inside every launch, then the default kernel through "
+                 "sorted: counting sort of the rays on 512 Morton cells of their origin inside every launch, then the default kernel "
+                     "through "
                  "the permutation"),
                 ("refill", "random_refill", "identical_to_default",
                  "refill: the default's persistent workgroups; a wave whose idle lanes reach 32 draws that many new rays from its stripe's "
@@ -157,7 +161,8 @@ def side_measurements(b: Bench, part):
             if name in abi.variants(width):
                 h, v, ms, k = timed(rnd_dev, n_r, abi.variants(width).index(name), steps_r, warm_r)
                 out[key] = {"Mrays_s": v, "ms_per_step": ms, "kernels_ms": k, "variant": what, same_key: bool(torch.equal(h, hits_rnd_dev))}
-        # the default WITH the ray-kind hint (rodent_hip_ray_kind_hint(1); off by default from round 5 on): state carried from launch to launch
+        # the default WITH the ray-kind hint (rodent_hip_ray_kind_hint(1); off by default from round 5 on): state carried from launch to
+        # launch
         if b.default_top:
             abi.ray_kind_hint(True)
             h, v, _, k = timed(rnd_dev, n_r, variant, steps_r, warm_r)
@@ -165,7 +170,8 @@ def side_measurements(b: Bench, part):
             out["random_with_kind_hint"] = {
                 "Mrays_s": v, "kernels_ms": k, "identical_to_default": bool(torch.equal(h, hits_rnd_dev)),
                 "what": "rodent_hip_ray_kind_hint(1): the list goes to k_bvh2_top_refill from its second launch on; the default "
-                        "(random_Mrays_s) is k_bvh2_top_auto alone, whose waves find their rays incoherent and run the refill loop -- no state "
+                        "(random_Mrays_s) is k_bvh2_top_auto alone, whose waves find their rays incoherent and run the refill loop -- no "
+                            "state "
                         "between launches"}
     # the default WITHOUT the tile mapping (rodent_hip_ray_grid(0): camera rays in list order, 64 pixels of a row per wavefront, as until
     # round 4).  Not in the profiling runs: the same kernel name in another mode would mix into their per-kernel means.
@@ -175,9 +181,9 @@ def side_measurements(b: Bench, part):
         abi.ray_grid(-1)
         out["primary_in_list_order"] = {
             "Mrays_s": v, "kernels_ms": k, "identical_to_default": bool(torch.equal(h, hits_dev)),
-            "what": "rodent_hip_ray_grid(0): the same kernel with the wave's 64 rays in list order (64 pixels of an image row); the default "
-                    "recognises the image width from 66 of the launch's rays and gives every wavefront an 8 x 8-pixel tile -- no state between "
-                    "launches, hit records identical"}
+            "what": "rodent_hip_ray_grid(0): the same kernel with the wave's 64 rays in list order (64 pixels of an image row); the "
+                    "default recognises the image width from 66 of the launch's rays and gives every wavefront an 8 x 8-pixel tile -- no "
+                    "state between launches, hit records identical"}
     abi.check_errors(dev)                                         # the asynchronous entry points report stack overflows through a flag
     if not b.info:
         return out
@@ -219,7 +225,8 @@ def side_measurements(b: Bench, part):
             h_d, v_d, _, k_d = timed(rnd8_dev, len(rnd8), variant, 10, 3)
             h_f, v_f, _, k_f = timed(rnd8_dev, len(rnd8), abi.variants(width).index("refill"), 10, 3)
             out["random_8Mi_rays_per_launch"] = {"rays_per_launch": len(rnd8), "default_Mrays_s": v_d, "default_kernels_ms": k_d,
-                                                 "refill_Mrays_s": v_f, "refill_kernels_ms": k_f, "identical_hits": bool(torch.equal(h_d, h_f))}
+                                                 "refill_Mrays_s": v_f, "refill_kernels_ms": k_f,
+                                                     "identical_hits": bool(torch.equal(h_d, h_f))}
             del rnd8_dev, h_d, h_f, rnd8
     except Exception as e:
         print(f"bench.py: 8 Mi random-ray measurement skipped ({e})", file=sys.stderr)

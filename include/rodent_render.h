@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 struct Vec3 { float x, y, z; };
-struct Settings { struct Vec3 eye, dir, up, right; float width, height; };   /* width/height = tan(fov/2), that / ratio (driver.cpp:37-38) */
+/* width/height = tan(fov/2), that / ratio (driver.cpp:37-38) */
+struct Settings { struct Vec3 eye, dir, up, right; float width, height; };
 
 struct RayStream { int32_t* id; float *org_x, *org_y, *org_z, *dir_x, *dir_y, *dir_z, *tmin, *tmax; };
 struct PrimaryStream {
@@ -46,7 +47,8 @@ struct RodentMaterial {            /* 64 B; one per geometry id (converter.cpp:8
     float kd[3]; int32_t type; float ks[3]; float ns; float tf[3]; float ni;
     float mix_k;                   /* lum(ks) / (lum(ks) + lum(kd)) (converter.cpp:900-906); recomputed per hit when textured */
     int32_t emissive;
-    int32_t tex_kd, tex_ks;        /* 0: kd / ks are the constants above; else 1 + index of the map_Kd / map_Ks texture (converter.cpp:881-893) */
+    /* 0: kd / ks are the constants above; else 1 + index of the map_Kd / map_Ks texture (converter.cpp:881-893) */
+    int32_t tex_kd, tex_ks;
 };
 struct RodentTexture {             /* RGBA8 image, row 0 = bottom row of the file, gamma-corrected (src/driver/image.cpp:10-18,85) */
     int32_t width, height; uint32_t offset /* first texel in the pool */; int32_t pad;
@@ -78,7 +80,8 @@ void    rodent_hip_render_config(int32_t dev, int32_t spp, int32_t max_path_len)
  * -1 (default) = chosen per scene when the scene is created: the megakernel for hierarchies of at most
  * RODENT_HIP_AUTO_MEGA_MAX_NODES inner nodes (default 128: the whole tree sits in the traversal kernels' LDS image and the
  * wavefront formulation's stream traffic is all that is left to save; the Cornell box renders 1.45 x faster that way), the
- * streaming loop for larger scenes (1.05 x faster at 306 nodes, 1.4-1.5 x from 5 000 nodes on: profiles/r03_mapping_sweep.txt).  The initial value can also be set with the environment variable
+ * streaming loop for larger scenes (1.05 x faster at 306 nodes, 1.4-1.5 x from 5 000 nodes on: profiles/r03_mapping_sweep.txt).  The
+ * initial value can also be set with the environment variable
  * RODENT_HIP_MAPPING=auto|streaming|mega.  rodent_hip_render_mapping_in_effect: 0 / 1, what the next frame will use. */
 void    rodent_hip_render_mapping(int32_t dev, int32_t mapping);
 int32_t rodent_hip_render_mapping_in_effect(int32_t dev);
@@ -95,9 +98,12 @@ void    rodent_hip_render_capacity(int32_t dev, int32_t rays);
  * every BSDF kind on neighbouring walls, a textured room) the unsorted loop is 5 ... 22 % faster, so it is the default; the sort
  * stays one call away.  Same paths, same ray counts; RODENT_HIP_SORT=0|1 sets the initial value, `rodent --sort` / `--no-sort`. */
 void    rodent_hip_render_sort(int32_t dev, int32_t enable);
-/* Hit records inside the library's own wavefront loop: 1 (default) = one 20-byte record per ray in the memory of the stream's geom_id / prim_id /
- * t / u / v arrays (one 16-byte + one 4-byte store per record instead of five scattered 4-byte stores: the traversal launches' write traffic),
- * 0 = the ABI's five arrays.  The stage-level entry points (hip_traverse_primary, hip_shade, ...) always use the five arrays, and so does the
+/* Hit records inside the library's own wavefront loop: 1 (default) = one 20-byte record per ray in the memory of the stream's geom_id /
+ * prim_id /
+ * t / u / v arrays (one 16-byte + one 4-byte store per record instead of five scattered 4-byte stores: the traversal launches' write
+ * traffic),
+ * 0 = the ABI's five arrays.  The stage-level entry points (hip_traverse_primary, hip_shade, ...) always use the five arrays, and so does
+ * the
  * loop when the sort by material is on.  RODENT_HIP_HIT_AOS. */
 void    rodent_hip_render_hit_records(int32_t dev, int32_t aos);
 /* 1 (default): the shadow rays of a bounce are traced on a second HIP stream beside the compaction, regeneration and the
@@ -147,7 +153,8 @@ void    rodent_hip_render_trace_persistent(int32_t dev, int32_t enable);
  * (every ray is short there: -4 ... -11 %).  Same paths, same ray counts, same film up to the order of the atomic adds.
  * RODENT_HIP_TRACE_REFILL=<both> or <bounce>,<shadow>. */
 void    rodent_hip_render_trace_refill(int32_t dev, int32_t idle_bounce, int32_t idle_shadow);
-int32_t rodent_hip_render_trace_refill_in_effect(int32_t dev);      /* idle_bounce | idle_shadow << 8 for the scene that is loaded (0 = whole chunks) */
+/* idle_bounce | idle_shadow << 8 for the scene that is loaded (0 = whole chunks) */
+int32_t rodent_hip_render_trace_refill_in_effect(int32_t dev);
 
 /* ---- the reference's renderer ABI ---- */
 int32_t get_spp(void);
@@ -166,11 +173,14 @@ void    rodent_present(int32_t dev);                                 /* film dev
  * reference converter's files onto device `dev` and return DEVICE pointers.  Results are cached by (dev, file name), owned
  * by the library and valid until cleanup_interface(); a missing or malformed file prints a message and abort()s like the
  * reference's error().  `dev` is the HIP device index (there is no host device 0 here: nothing is computed on the CPU). */
-uint8_t* rodent_load_buffer(int32_t dev, const char* file);           /* one LZ4 buffer file (data/vertices.bin, ...; src/driver/buffer.h) */
-void    rodent_load_bvh2_tri1(int32_t dev, const char* file, struct Node2** nodes, struct Tri1** tris);   /* the matching layout of data/bvh.bin */
+/* one LZ4 buffer file (data/vertices.bin, ...; src/driver/buffer.h) */
+uint8_t* rodent_load_buffer(int32_t dev, const char* file);
+/* the matching layout of data/bvh.bin */
+void    rodent_load_bvh2_tri1(int32_t dev, const char* file, struct Node2** nodes, struct Tri1** tris);
 void    rodent_load_bvh4_tri4(int32_t dev, const char* file, struct Node4** nodes, struct Tri4** tris);
 void    rodent_load_bvh8_tri4(int32_t dev, const char* file, struct Node8** nodes, struct Tri4** tris);
-void    rodent_load_png(int32_t dev, const char* file, uint8_t** pixels, int32_t* width, int32_t* height); /* RGBA8, rows flipped, gamma 2.2 (image.cpp:10-18,85) */
+/* RGBA8, rows flipped, gamma 2.2 (image.cpp:10-18,85) */
+void    rodent_load_png(int32_t dev, const char* file, uint8_t** pixels, int32_t* width, int32_t* height);
 void    rodent_load_jpg(int32_t dev, const char* file, uint8_t** pixels, int32_t* width, int32_t* height);
 /* Host-side stream slabs with the device slabs' carving, one per calling thread (interface.cpp:341-342,367-373,621-629). */
 void    rodent_cpu_get_primary_stream(struct PrimaryStream* primary, int32_t size);
@@ -192,7 +202,8 @@ void    rodent_hip_render_rows(int32_t dev, const struct Settings* settings, int
  * shorter): GPU k of K takes first_tile = k, tile_stride = K, which balances the GPUs where contiguous bands do not (SURVEY 8e;
  * the reference deals ~1024-sample tiles dynamically, render/mapping_gpu.impala:374-420).  Same samples, same film as
  * rodent_hip_render_rows over the same rows; synchronous like it. */
-void    rodent_hip_render_tiles(int32_t dev, const struct Settings* settings, int32_t iter, int32_t tile_rows, int32_t first_tile, int32_t tile_stride, void* stream);
+void    rodent_hip_render_tiles(int32_t dev, const struct Settings* settings, int32_t iter, int32_t tile_rows, int32_t first_tile,
+    int32_t tile_stride, void* stream);
 /* Counters of the last render call on this device (render, rodent_hip_render_rows, rodent_hip_render_tiles -- the whole call, however
  * many launches it took): [0] primary rays traced, [1] shadow rays traced, [2] wavefront iterations, [3] rays generated. */
 void    rodent_hip_render_counters(int32_t dev, uint64_t* out4);

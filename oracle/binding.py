@@ -140,17 +140,20 @@ def brute_force(tris, rays):
 # ---- renderer oracle (oracle/render_oracle.c) ------------------------------------------------
 
 class _Scene(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")] + \
+    _fields_ = [(n, C.c_void_p) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights",
+        "light_ids")] + \
                [("num_tris", C.c_int32), ("num_materials", C.c_int32), ("num_lights", C.c_int32), ("pad", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("texcoords", "textures", "texels")]
 
 
 class _Settings(C.Structure):
-    _fields_ = [("eye", C.c_float * 3), ("dir", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3), ("w", C.c_float), ("h", C.c_float)]
+    _fields_ = [("eye", C.c_float * 3), ("dir", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3), ("w", C.c_float),
+        ("h", C.c_float)]
 
 
 def _scene_struct(scene):
-    keep = [np.ascontiguousarray(getattr(scene, n)) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")]
+    keep = [np.ascontiguousarray(getattr(scene, n)) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris",
+        "materials", "lights", "light_ids")]
     tex = [np.ascontiguousarray(getattr(scene, n)) for n in ("texcoords", "textures", "texels")]
     s = _Scene(*[_ptr(a) for a in keep], scene.num_tris, len(scene.materials), len(scene.lights), 0, *[_ptr(a) for a in tex])
     return s, keep + tex
@@ -218,10 +221,12 @@ def baseline_lib():
     if _base is None:
         out = HERE / "libcpu_baseline.so"
         src = HERE / "hybrid_baseline.cpp"
-        lib()                                                    # liboracle.so first: the baseline library links it (shading of the CPU wavefront renderer)
+        # liboracle.so first: the baseline library links it (shading of the CPU wavefront renderer)
+        lib()
         deps = [src, HERE / "cpu_wavefront.inc", LIB_PATH]
         if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
-            subprocess.run(["g++", "-O3", "-std=c++17", "-march=x86-64-v3", "-fPIC", "-shared", "-pthread", str(src), f"-L{HERE}", "-l:liboracle.so", "-Wl,-rpath,$ORIGIN",
+            subprocess.run(["g++", "-O3", "-std=c++17", "-march=x86-64-v3", "-fPIC", "-shared", "-pthread", str(src), f"-L{HERE}",
+                "-l:liboracle.so", "-Wl,-rpath,$ORIGIN",
                             "-o", str(out)], check=True)
         _base = C.CDLL(str(out))
         _base.cpu_baseline_traverse.restype = None
@@ -235,7 +240,8 @@ def cpu_baseline(nodes8, tris4, rays, any_hit=False, mode="hybrid", threads=1):
     nodes8 = np.ascontiguousarray(nodes8); tris4 = np.ascontiguousarray(tris4); rays = np.ascontiguousarray(rays)
     n = len(rays) // 8 * 8
     hits = np.zeros(n, HIT1)
-    baseline_lib().cpu_baseline_traverse(_ptr(nodes8), _ptr(tris4), _ptr(rays), _ptr(hits), n, int(any_hit), 0 if mode == "hybrid" else 1, int(threads))
+    baseline_lib().cpu_baseline_traverse(_ptr(nodes8), _ptr(tris4), _ptr(rays), _ptr(hits), n, int(any_hit), 0 if mode == "hybrid" else 1,
+        int(threads))
     return hits
 
 
@@ -247,8 +253,10 @@ def cpu_baseline_bench(nodes8, tris4, rays, threads, passes, any_hit=False, mode
     secs = np.zeros(passes, np.float64)
     l = baseline_lib()
     l.cpu_baseline_bench.restype = None
-    l.cpu_baseline_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
-    l.cpu_baseline_bench(_ptr(nodes8), _ptr(tris4), _ptr(rays), _ptr(hits), n, int(any_hit), 0 if mode == "hybrid" else 1, int(threads), int(passes), _ptr(secs))
+    l.cpu_baseline_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+        C.c_void_p]
+    l.cpu_baseline_bench(_ptr(nodes8), _ptr(tris4), _ptr(rays), _ptr(hits), n, int(any_hit), 0 if mode == "hybrid" else 1, int(threads),
+        int(passes), _ptr(secs))
     return secs, hits
 
 
@@ -257,16 +265,19 @@ def render_wavefront(scene, nodes8, tris4, cam, iter_, spp, max_path_len, width,
     ray8 x BVH8 traversal (oracle/cpu_wavefront.inc).  Returns (film, [primary rays, shadow rays])."""
     l = baseline_lib()
     l.cpu_wavefront_render.restype = None
-    l.cpu_wavefront_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(_Settings), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+    l.cpu_wavefront_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(_Settings), C.c_int32,
+        C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_int32, C.c_void_p]
     if film is None:
         film = np.zeros((height, width, 3), "<f4")
     s, keep = _scene_struct(scene)
     nodes8 = np.ascontiguousarray(nodes8); tris4 = np.ascontiguousarray(tris4)
     indices = np.ascontiguousarray(scene.indices)
-    st = _Settings((C.c_float * 3)(*cam["eye"]), (C.c_float * 3)(*cam["dir"]), (C.c_float * 3)(*cam["up"]), (C.c_float * 3)(*cam["right"]), float(cam["w"]), float(cam["h"]))
+    st = _Settings((C.c_float * 3)(*cam["eye"]), (C.c_float * 3)(*cam["dir"]), (C.c_float * 3)(*cam["up"]), (C.c_float * 3)(*cam["right"]),
+        float(cam["w"]), float(cam["h"]))
     counts = np.zeros(2, np.uint64)
-    l.cpu_wavefront_render(C.byref(s), _ptr(indices), len(scene.materials), _ptr(nodes8), _ptr(tris4), C.byref(st), iter_, spp, max_path_len, width, height,
+    l.cpu_wavefront_render(C.byref(s), _ptr(indices), len(scene.materials), _ptr(nodes8), _ptr(tris4), C.byref(st), iter_, spp,
+        max_path_len, width, height,
                            _ptr(film), int(threads), _ptr(counts))
     return film, counts
 

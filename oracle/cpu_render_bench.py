@@ -61,7 +61,8 @@ def main(argv=None):
         rates.append(a.spp * a.width * a.height / dt / 1e6)
         rays += int(counts.sum())
     rates.sort()
-    print(f"# {rates[0]:g}/{rates[len(rates) // 2]:g}/{rates[-1]:g} (min/med/max Msamples/s)  [{a.mapping} mapping, {a.threads} threads, {rays} rays]")
+    print(f"# {rates[0]:g}/{rates[len(rates) // 2]:g}/{rates[-1]:g} (min/med/max Msamples/s)  [{a.mapping} mapping, {a.threads} threads, "
+        f"{rays} rays]")
     assert np.isfinite(film).all()
     return 0
 

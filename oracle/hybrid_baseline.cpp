@@ -38,7 +38,8 @@ static inline v8f imin(v8f a, v8f b) { return ((v8i)a < (v8i)b) ? a : b; }      
 static inline v8f imax(v8f a, v8f b) { return ((v8i)a > (v8i)b) ? a : b; }
 static inline int movemask(v8i m) { return __builtin_ia32_movmskps256((v8f)m); }
 static inline v8f loadu(const float* p) { v8f r; std::memcpy(&r, p, 32); return r; }
-static inline float prodsign1(float x, float y) { uint32_t a, b; std::memcpy(&a, &x, 4); std::memcpy(&b, &y, 4); a ^= b & 0x80000000u; std::memcpy(&x, &a, 4); return x; }
+static inline float prodsign1(float x, float y) { uint32_t a, b; std::memcpy(&a, &x, 4); std::memcpy(&b, &y, 4); a ^= b & 0x80000000u;
+    std::memcpy(&x, &a, 4); return x; }
 static inline float safe_rcp1(float x) { return ((x > 0 ? x : -x) < 1e-8f) ? prodsign1(kFltMax, x) : 1.0f / x; }
 
 struct Ray1X { float o[3], d[3], id[3], io[3], tmin, tmax; int octant; };
@@ -67,7 +68,8 @@ static inline bool tri_scalar(const Ray1X& r, const Tri4& P, int k, float& t, fl
 }
 
 static void sort_desc(Ent1* a, int n) {      // what the sorting networks compute: farthest first (sort.impala:3-66)
-    for (int i = 1; i < n; i++) { Ent1 x = a[i]; int j = i - 1; while (j >= 0 && a[j].tmin < x.tmin) { a[j + 1] = a[j]; j--; } a[j + 1] = x; }
+    for (int i = 1; i < n; i++) { Ent1 x = a[i]; int j = i - 1; while (j >= 0 && a[j].tmin < x.tmin) { a[j + 1] = a[j]; j--;
+        } a[j + 1] = x; }
 }
 
 // mapping_cpu.impala:138-256, SIMD lanes = children
@@ -153,7 +155,8 @@ static void hybrid_packet(const Node8* nodes, const Tri4* tris, const Ray1* rays
                         r.id[0] = idx[l]; r.id[1] = idy[l]; r.id[2] = idz[l]; r.io[0] = iox[l]; r.io[1] = ioy[l]; r.io[2] = ioz[l];
                         r.tmin = tmin[l]; r.tmax = tmax[l]; r.octant = octant[l];
                         Hit1 h;
-                        if (single_ray(nodes, tris, r, any_hit, top.node, h)) { hits[l] = h; if (!any_hit) tmax[l] = h.t; else terminated |= 1 << l; }
+                        if (single_ray(nodes, tris, r, any_hit, top.node, h)) { hits[l] = h; if (!any_hit) tmax[l] = h.t;
+                            else terminated |= 1 << l; }
                     }
                 } else break;
             }
@@ -213,9 +216,10 @@ static void hybrid_packet(const Node8* nodes, const Tri4* tris, const Ray1* rays
 
 extern "C" {
 
-// Traces n rays (tail beyond a multiple of 8 is dropped like load_rays.h:74) on `threads` host threads
-// (the reference's bench loop is sequential, mapping_cpu.impala:397; the all-cores figure mirrors results_par.txt).  mode: 0 = hybrid ray8 x bvh8, 1 = single-ray bvh8.
-void cpu_baseline_traverse(const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t n, int32_t any_hit, int32_t mode, int32_t threads) {
+// Traces n rays (tail beyond a multiple of 8 is dropped like load_rays.h:74) on `threads` host threads (the reference's bench loop is
+// sequential, mapping_cpu.impala:397; the all-cores figure mirrors results_par.txt).  mode: 0 = hybrid ray8 x bvh8, 1 = single-ray bvh8.
+void cpu_baseline_traverse(const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t n, int32_t any_hit, int32_t mode,
+    int32_t threads) {
     const int packets = n / 8;
     if (threads < 1) threads = 1;
     auto work = [&](int p0, int p1) {
@@ -234,7 +238,8 @@ void cpu_baseline_traverse(const Node8* nodes, const Tri4* tris, const Ray1* ray
     std::atomic<int> next{0};
     const int chunk = 256;
     std::vector<std::thread> pool;
-    for (int t = 0; t < threads; t++) pool.emplace_back([&] { for (;;) { const int p0 = next.fetch_add(chunk); if (p0 >= packets) break; work(p0, std::min(packets, p0 + chunk)); } });
+    for (int t = 0; t < threads; t++) pool.emplace_back([&] { for (;;) { const int p0 =
+        next.fetch_add(chunk); if (p0 >= packets) break; work(p0, std::min(packets, p0 + chunk)); } });
     for (auto& th : pool) th.join();
 }
 
@@ -242,17 +247,21 @@ void cpu_baseline_traverse(const Node8* nodes, const Tri4* tris, const Ray1* ray
 // (one warm-up pass first); thread creation is outside the timed region, every pass starts and ends at a barrier and is
 // timed on its own.  seconds[p] = wall time of pass p.  (The one-shot entry point above spawns its threads inside the call:
 // at 256 threads that is a third of a 12 ms pass.)
-void cpu_baseline_bench(const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t n, int32_t any_hit, int32_t mode, int32_t threads,
+void cpu_baseline_bench(const Node8* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int32_t n, int32_t any_hit, int32_t mode,
+    int32_t threads,
                         int32_t passes, double* seconds) {
     const int packets = n / 8, chunk = 128;
     if (threads < 1) threads = 1;
     std::atomic<int> next{0};
     std::mutex m; std::condition_variable cv; int arrived = 0, generation = 0;
     std::vector<std::chrono::steady_clock::time_point> tripped(2 * (passes + 1));
-    auto barrier = [&]() {                                   // sleeping barrier (256 yield-spinning threads starve the workers); the last arriver resets the work
-        std::unique_lock<std::mutex> lock(m);                // counter and stamps the time: a pass lasts from the trip of its start barrier to the trip of its end barrier
+    // sleeping barrier (256 yield-spinning threads starve the workers); the last arriver resets the work
+    auto barrier = [&]() {
+        // counter and stamps the time: a pass lasts from the trip of its start barrier to the trip of its end barrier
+        std::unique_lock<std::mutex> lock(m);
         const int gen = generation;
-        if (++arrived == threads) { arrived = 0; next.store(0); tripped[generation] = std::chrono::steady_clock::now(); generation++; cv.notify_all(); }
+        if (++arrived == threads) { arrived = 0; next.store(0); tripped[generation] = std::chrono::steady_clock::now(); generation++;
+            cv.notify_all(); }
         else cv.wait(lock, [&] { return generation != gen; });
     };
     auto one_pass = [&]() {
@@ -271,10 +280,12 @@ void cpu_baseline_bench(const Node8* nodes, const Tri4* tris, const Ray1* rays, 
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 1; t < threads; t++) pool.emplace_back([&] { for (int pass = 0; pass < passes + 1; pass++) { barrier(); one_pass(); barrier(); } });
+    for (int t = 1; t < threads; t++) pool.emplace_back([&] { for (int pass =
+        0; pass < passes + 1; pass++) { barrier(); one_pass(); barrier(); } });
     for (int pass = 0; pass < passes + 1; pass++) { barrier(); one_pass(); barrier(); }      // the calling thread is worker 0
     for (auto& th : pool) th.join();
-    for (int pass = 1; pass < passes + 1; pass++) seconds[pass - 1] = std::chrono::duration<double>(tripped[2 * pass + 1] - tripped[2 * pass]).count();
+    for (int pass = 1; pass < passes + 1; pass++) seconds[pass - 1] =
+        std::chrono::duration<double>(tripped[2 * pass + 1] - tripped[2 * pass]).count();
 }
 
 int32_t cpu_baseline_hardware_threads(void) { return (int32_t)std::thread::hardware_concurrency(); }

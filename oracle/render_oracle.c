@@ -45,7 +45,8 @@ int oracle_bvh2_tri1(const struct Node2*, const struct Tri1*, const struct Ray1*
 
 /* Scene tables (same layout as include/rodent_render.h) */
 enum { MAT_BLACK = 0, MAT_DIFFUSE = 1, MAT_PHONG = 2, MAT_MIX = 3, MAT_MIRROR = 4, MAT_GLASS = 5 };
-struct Material { float kd[3]; int32_t type; float ks[3]; float ns; float tf[3]; float ni; float mix_k; int32_t emissive; int32_t tex_kd, tex_ks; };
+struct Material { float kd[3]; int32_t type; float ks[3]; float ns; float tf[3]; float ni; float mix_k; int32_t emissive;
+    int32_t tex_kd, tex_ks; };
 struct Texture  { int32_t width, height; uint32_t offset; int32_t pad; };
 struct Light    { float v0[4], v1[4], v2[4]; float n[3]; float inv_area; float color[4]; };
 struct Scene {
@@ -80,13 +81,15 @@ static inline float lerp1(float a, float b, float k) { return (1.0f - k) * a + k
 static inline float lerp2(float a, float b, float c, float k1, float k2) { return (1.0f - k1 - k2) * a + k1 * b + k2 * c; }
 static inline float positive_cos(v3 a, v3 b) { const float c = dot(a, b); return c >= 0.0f ? c : 0.0f; }
 static inline float luminance(v3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }  /* color.impala:33 */
-static inline v3 color_lerp(v3 a, v3 b, float t) { return V((1.0f - t) * a.x + t * b.x, (1.0f - t) * a.y + t * b.y, (1.0f - t) * a.z + t * b.z); }
+static inline v3 color_lerp(v3 a, v3 b, float t) {
+    return V((1.0f - t) * a.x + t * b.x, (1.0f - t) * a.y + t * b.y, (1.0f - t) * a.z + t * b.z); }
 
 static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
 static inline float u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
 
 /* random.impala:22-30, 7-11 */
-static inline uint32_t xorshift(uint32_t* seed) { uint32_t x = *seed; x = x == 0u ? 1u : x; x ^= x << 13; x ^= x >> 17; x ^= x << 5; *seed = x; return x; }
+static inline uint32_t xorshift(uint32_t* seed) { uint32_t x = *seed; x = x == 0u ? 1u : x; x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    *seed = x; return x; }
 static inline float randf(uint32_t* rnd) { return u2f((127u << 23) | (xorshift(rnd) & 0x7FFFFFu)) - 1.0f; }
 /* random.impala:116-126 */
 static inline uint32_t fnv_hash(uint32_t h, uint32_t d) {
@@ -116,7 +119,8 @@ static inline void sincos_2pi(float u, float* c_out, float* s_out) {
     const float a = (x - (float)k) * 1.57079632679f;
     const float a2 = a * a;
     const float s = a * (1.0f + a2 * (-0.16666667163f + a2 * (0.0083333337680f + a2 * (-0.00019841270114f + a2 * 2.7557314297e-6f))));
-    const float c = 1.0f + a2 * (-0.5f + a2 * (0.041666667908f + a2 * (-0.0013888889225f + a2 * (2.4801587642e-5f + a2 * -2.7557314297e-7f))));
+    const float c = 1.0f + a2
+        * (-0.5f + a2 * (0.041666667908f + a2 * (-0.0013888889225f + a2 * (2.4801587642e-5f + a2 * -2.7557314297e-7f))));
     switch (k & 3) {
         case 0: *c_out = c;  *s_out = s;  break;
         case 1: *c_out = -s; *s_out = c;  break;
@@ -132,7 +136,8 @@ static inline m3 orthonormal(v3 n) {
     m3 m; m.c0 = V(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x); m.c1 = V(b, sign + n.y * n.y * a, -n.y); m.c2 = n; return m;
 }
 static inline v3 m3_mul(m3 m, v3 v) {   /* matrix.impala mat3x3_mul: rows dotted with v */
-    return V(m.c0.x * v.x + m.c1.x * v.y + m.c2.x * v.z, m.c0.y * v.x + m.c1.y * v.y + m.c2.y * v.z, m.c0.z * v.x + m.c1.z * v.y + m.c2.z * v.z);
+    return V(m.c0.x * v.x + m.c1.x * v.y + m.c2.x * v.z, m.c0.y * v.x + m.c1.y * v.y + m.c2.y * v.z,
+        m.c0.z * v.x + m.c1.z * v.y + m.c2.z * v.z);
 }
 
 typedef struct { v3 dir; float pdf; } DirSample;
@@ -248,7 +253,8 @@ static Surf surface_element(const struct Scene* sc, v3 org, v3 dir, int32_t prim
 /* image.impala:24-38 (RGBA8 -> colour), :48-54 (repeat border), :64-86 (bilinear filter) */
 static inline v3 texel(const struct Scene* sc, const struct Texture* t, int32_t x, int32_t y) {
     const uint32_t p = sc->texels[t->offset + (uint32_t)y * (uint32_t)t->width + (uint32_t)x];
-    return V((float)(p & 0xFFu) * (1.0f / 255.0f), (float)((p >> 8) & 0xFFu) * (1.0f / 255.0f), (float)((p >> 16) & 0xFFu) * (1.0f / 255.0f));
+    return V((float)(p & 0xFFu) * (1.0f / 255.0f), (float)((p >> 8) & 0xFFu) * (1.0f / 255.0f),
+        (float)((p >> 16) & 0xFFu) * (1.0f / 255.0f));
 }
 static v3 tex_lookup(const struct Scene* sc, const struct Texture* t, float tu, float tv) {
     const float ru = tu - floorf(tu), rv = tv - floorf(tv);
@@ -263,14 +269,18 @@ static v3 tex_lookup(const struct Scene* sc, const struct Texture* t, float tu, 
 }
 /* The material of a hit: map_Kd / map_Ks replace kd / ks with texture lookups at the interpolated texture coordinates,
  * and the diffuse/Phong mix weight follows the looked-up colours (converter.cpp:881-906, geometry.impala:30-40). */
-static const struct Material* resolve_material(const struct Scene* sc, const struct Material* m, struct Material* tmp, int32_t prim, float u, float v) {
+static const struct Material* resolve_material(const struct Scene* sc, const struct Material* m, struct Material* tmp, int32_t prim,
+    float u, float v) {
     if (!(m->tex_kd | m->tex_ks)) return m;
     const int32_t* idx = sc->indices + 4 * prim;
-    const float* t0 = sc->texcoords + 4 * idx[0]; const float* t1 = sc->texcoords + 4 * idx[1]; const float* t2 = sc->texcoords + 4 * idx[2];
+    const float* t0 = sc->texcoords + 4 * idx[0]; const float* t1 = sc->texcoords + 4 * idx[1];
+    const float* t2 = sc->texcoords + 4 * idx[2];
     const float tu = lerp2(t0[0], t1[0], t2[0], u, v), tv = lerp2(t0[1], t1[1], t2[1], u, v);
     *tmp = *m;
-    if (m->tex_kd) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_kd - 1), tu, tv); tmp->kd[0] = c.x; tmp->kd[1] = c.y; tmp->kd[2] = c.z; }
-    if (m->tex_ks) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_ks - 1), tu, tv); tmp->ks[0] = c.x; tmp->ks[1] = c.y; tmp->ks[2] = c.z; }
+    if (m->tex_kd) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_kd - 1), tu, tv); tmp->kd[0] = c.x; tmp->kd[1] = c.y;
+        tmp->kd[2] = c.z; }
+    if (m->tex_ks) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_ks - 1), tu, tv); tmp->ks[0] = c.x; tmp->ks[1] = c.y;
+        tmp->ks[2] = c.z; }
     if (m->type == MAT_MIX) {
         const float ls = luminance(LD3(tmp->ks)), ld = luminance(LD3(tmp->kd));
         tmp->mix_k = (ls + ld == 0.0f) ? 0.0f : ls / (ls + ld);
@@ -326,7 +336,8 @@ void oracle_shade_vertex(const struct Scene* sc, const struct OracleVertex* pv, 
         const v3 from_dir = sub(s.point, pos);
         float lcos = dot(from_dir, LD3(L->n)) / len(from_dir);                    /* light.impala:124-128 */
         v3 intensity = LD3(L->color); float pdf_area = L->inv_area;
-        if (!(pdf_area > 0.0f && cosine_hemisphere_pdf(lcos) > 0.0f && lcos > 0.0f)) { intensity = V(0, 0, 0); pdf_area = 1.0f; lcos = 0.0f; }
+        if (!(pdf_area > 0.0f && cosine_hemisphere_pdf(lcos) > 0.0f && lcos > 0.0f)) { intensity = V(0, 0, 0); pdf_area = 1.0f;
+            lcos = 0.0f; }
         const v3 light_dir = sub(pos, s.point);
         const float vis = dot(light_dir, s.local.c2);
         if (vis > 0.0f && lcos > 0.0f) {
@@ -354,7 +365,8 @@ void oracle_shade_vertex(const struct Scene* sc, const struct OracleVertex* pv, 
 }
 
 /* on_emit (renderer.impala:26-40, camera.impala:35-44): the sample's seed state and camera ray direction */
-void oracle_emit_sample(const struct Settings* st, int32_t iter, int32_t width, int32_t height, int32_t x, int32_t y, int32_t sample, uint32_t* rnd_out, float* dir3) {
+void oracle_emit_sample(const struct Settings* st, int32_t iter, int32_t width, int32_t height, int32_t x, int32_t y, int32_t sample,
+    uint32_t* rnd_out, float* dir3) {
     const v3 cdir = LD3(st->dir), cup = LD3(st->up), cright = LD3(st->right);
     uint32_t rnd = fnv_hash(fnv_hash(fnv_hash(fnv_hash(0x811C9DC5u, (uint32_t)sample), (uint32_t)iter), (uint32_t)x), (uint32_t)y);
     const float kx = 2.0f * ((float)x + randf(&rnd)) / (float)width - 1.0f;
@@ -401,7 +413,8 @@ void oracle_render(const struct Scene* sc, const struct Settings* st, int32_t it
 void oracle_sincos_2pi(const float* u, float* c, float* s, int32_t n) { for (int32_t i = 0; i < n; i++) sincos_2pi(u[i], &c[i], &s[i]); }
 /* probes for the tests: texture lookup and the per-hit material of a textured scene */
 void oracle_tex_lookup(const struct Scene* sc, int32_t tex, const float* uv, float* rgb, int32_t n) {
-    for (int32_t i = 0; i < n; i++) { const v3 c = tex_lookup(sc, sc->textures + tex, uv[2 * i], uv[2 * i + 1]); rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z; }
+    for (int32_t i = 0; i < n; i++) { const v3 c = tex_lookup(sc, sc->textures + tex, uv[2 * i], uv[2 * i + 1]); rgb[3 * i] = c.x;
+        rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z; }
 }
 void oracle_hit_material(const struct Scene* sc, int32_t prim, float u, float v, struct Material* out) {
     struct Material tmp; *out = *resolve_material(sc, sc->materials + sc->indices[4 * prim + 3], &tmp, prim, u, v);
@@ -418,7 +431,8 @@ void oracle_bsdf_samples(const struct Material* m, const float* out_dir3, uint32
     for (int32_t i = 0; i < n; i++) {
         const BsdfSample b = bsdf_sample(m, &s, &seed, od);
         float* o = out8 + 10 * i;
-        o[0] = b.in_dir.x; o[1] = b.in_dir.y; o[2] = b.in_dir.z; o[3] = b.pdf; o[4] = b.cos; o[5] = b.color.x; o[6] = b.color.y; o[7] = b.color.z;
+        o[0] = b.in_dir.x; o[1] = b.in_dir.y; o[2] = b.in_dir.z; o[3] = b.pdf; o[4] = b.cos; o[5] = b.color.x; o[6] = b.color.y;
+        o[7] = b.color.z;
         o[8] = bsdf_pdf(m, &s, b.in_dir, od); const v3 e = bsdf_eval(m, &s, b.in_dir, od); o[9] = e.x;
     }
 }

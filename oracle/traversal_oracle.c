@@ -224,7 +224,8 @@ int oracle_bvh2_tri1(const struct Node2* nodes, const struct Tri1* tris,
         }
         hits[i].tri_id = hit_id; hits[i].t = hit_t; hits[i].u = hit_u; hits[i].v = hit_v;
         st.hits += hit_id >= 0;
-        if (g_ray_steps) { g_ray_steps[2 * i] = (uint32_t)(st.inner_nodes - inner_before); g_ray_steps[2 * i + 1] = (uint32_t)(st.prim_packets - prims_before); }
+        if (g_ray_steps) { g_ray_steps[2 * i] = (uint32_t)(st.inner_nodes - inner_before);
+            g_ray_steps[2 * i + 1] = (uint32_t)(st.prim_packets - prims_before); }
         if (g_ray_depth) g_ray_depth[i] = (uint8_t)deepest;
     }
     st.rays = (uint64_t)n;

@@ -20,7 +20,8 @@ from . import formats as F
 # and the instrumented builds; made by `RODENT_HIP_LAB=1 python -m rodent_amd.build`).  Default: the product library.
 LAB = os.environ.get("RODENT_HIP_LAB", "0") not in ("", "0")
 LIB_PATH = Path(__file__).resolve().parent / "lib" / ("librodent_hip_lab.so" if LAB else "librodent_hip.so")
-if os.environ.get("RODENT_HIP_LIB"):               # lab: another build of the library (A/B runs of compiler options, scripts/flags_experiment.sh)
+# lab: another build of the library (A/B runs of compiler options, scripts/flags_experiment.sh)
+if os.environ.get("RODENT_HIP_LIB"):
     LIB_PATH = Path(os.environ["RODENT_HIP_LIB"]).resolve()
 
 SYNC_ENTRY_POINTS = [
@@ -30,8 +31,11 @@ SYNC_ENTRY_POINTS = [
 ]
 ASYNC_ENTRY_POINTS = ["hip_traverse_bvh2_tri1_async", "hip_traverse_bvh4_tri4_async", "hip_traverse_bvh8_tri4_async"]
 EXPORTS = SYNC_ENTRY_POINTS + ASYNC_ENTRY_POINTS + [
-    "rodent_hip_check_errors", "rodent_hip_get_kernel_time", "rodent_hip_device_count", "rodent_hip_num_variants", "rodent_hip_variant_name",
-    "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_source_digest", "rodent_hip_is_lab_build", "rodent_hip_phased_min_rays", "rodent_hip_top_min_rays", "rodent_hip_ray_kind_hint", "rodent_hip_ray_grid", "rodent_hip_schedule_history", "rodent_hip_read_stats", "rodent_hip_read_trace", "rodent_hip_debug_set_perm",
+    "rodent_hip_check_errors", "rodent_hip_get_kernel_time", "rodent_hip_device_count", "rodent_hip_num_variants",
+        "rodent_hip_variant_name",
+    "rodent_hip_kernel_name", "rodent_hip_version", "rodent_hip_source_digest", "rodent_hip_is_lab_build", "rodent_hip_phased_min_rays",
+        "rodent_hip_top_min_rays", "rodent_hip_ray_kind_hint", "rodent_hip_ray_grid", "rodent_hip_schedule_history",
+        "rodent_hip_read_stats", "rodent_hip_read_trace", "rodent_hip_debug_set_perm",
 ]
 BLOCK_OF_WIDTH = {2: F.BVH2_TRI1, 4: F.BVH4_TRI4, 8: F.BVH8_TRI4}
 
@@ -86,7 +90,8 @@ def variants(width):
     return [l.rodent_hip_variant_name(width, i).decode() for i in range(l.rodent_hip_num_variants(width))]
 
 
-# Mappings that do NOT keep the reference's per-ray visit order (lab build only: work stealing inside the wave, measured and lost): last-bit ties in t
+# Mappings that do NOT keep the reference's per-ray visit order (lab build only: work stealing inside the wave, measured and lost): last-bit
+# ties in t
 # resolve to another triangle.  Every shipped mapping reproduces the reference kernel bit for bit (tests/).
 ORDER_CHANGING = ("steal",)
 
@@ -137,7 +142,8 @@ def traverse_async(bvh: DeviceBvh, rays_dev, hits_dev, num_rays, any_hit=False, 
     import torch
     if stream is None:
         stream = torch.cuda.current_stream(bvh.dev)
-    fn = getattr(lib(), {2: "hip_traverse_bvh2_tri1_async", 4: "hip_traverse_bvh4_tri4_async", 8: "hip_traverse_bvh8_tri4_async"}[bvh.width])
+    fn = getattr(lib(), {2: "hip_traverse_bvh2_tri1_async", 4: "hip_traverse_bvh4_tri4_async",
+        8: "hip_traverse_bvh8_tri4_async"}[bvh.width])
     fn(bvh.dev, bvh.nodes.data_ptr(), bvh.tris.data_ptr(), rays_dev.data_ptr(), hits_dev.data_ptr(),
        int(num_rays), int(any_hit), int(variant), C.c_void_p(stream.cuda_stream))
 
@@ -155,7 +161,8 @@ def traverse(bvh: DeviceBvh, rays: np.ndarray, any_hit=False, variant=None) -> n
         torch.cuda.synchronize(bvh.dev)
         name = {(2, False): "amdgpu_intersect_single_ray1_bvh2_tri1", (2, True): "amdgpu_occluded_single_ray1_bvh2_tri1",
                 (4, False): "hip_intersect_single_ray1_bvh4_tri4", (4, True): "hip_occluded_single_ray1_bvh4_tri4",
-                (8, False): "hip_intersect_single_ray1_bvh8_tri4", (8, True): "hip_occluded_single_ray1_bvh8_tri4"}[(bvh.width, bool(any_hit))]
+                (8, False): "hip_intersect_single_ray1_bvh8_tri4",
+                    (8, True): "hip_occluded_single_ray1_bvh8_tri4"}[(bvh.width, bool(any_hit))]
         getattr(lib(), name)(bvh.dev, bvh.nodes.data_ptr(), bvh.tris.data_ptr(), rays_dev.data_ptr(), hits_dev.data_ptr(), n)
     else:
         traverse_async(bvh, rays_dev, hits_dev, n, any_hit, variant)
@@ -183,7 +190,8 @@ def ray_kind_hint(enable: bool):
 
 
 def ray_grid(width: int = -1):
-    """rodent_hip_ray_grid: -1 = the default BVH2 kernel recognises camera rays in image order and traces them as 8 x 8-pixel tiles (default),
+    """rodent_hip_ray_grid: -1 = the default BVH2 kernel recognises camera rays in image order and traces them as 8 x 8-pixel tiles
+    (default),
     0 = never, > 0 = that image width on trust (hit records do not depend on it)."""
     lib().rodent_hip_ray_grid(int(width))
 

@@ -186,7 +186,8 @@ def build_oracle(force: bool = False) -> Path:
         out2 = ORACLE / "libcpu_baseline.so"
         if force or _newer(out2, *cpp, *sorted(ORACLE.glob("*.inc")), out):
             # links the parity oracle for its shading functions (cpu_wavefront.inc); both are test infrastructure
-            _run([CXX, "-O3", "-std=c++17", "-march=x86-64-v3", "-fPIC", "-shared", "-pthread", *cpp, f"-L{ORACLE}", "-l:liboracle.so", "-Wl,-rpath,$ORIGIN", "-o", out2])
+            _run([CXX, "-O3", "-std=c++17", "-march=x86-64-v3", "-fPIC", "-shared", "-pthread", *cpp, f"-L{ORACLE}", "-l:liboracle.so",
+                "-Wl,-rpath,$ORIGIN", "-o", out2])
     return out
 
 

@@ -1,23 +1,26 @@
 // lab/defer_kernels.h -- LAB BUILD ONLY: deferred leaves.
 //
-// The single-step schedule issues the triangle half of the step (~65 of ~132 VALU instructions) in ~99 % of a refilled wave's iterations for
-// ~6 % of its lanes (profiles/r05_tri_turns_experiment.txt).  "Triangle turns" (lanes WAIT for a common triangle iteration) lost because a
-// waiting lane keeps its lane slot.  Here a lane that reaches a leaf does not wait: it notes the leaf in a small FIFO of its own (PEND words of
-// LDS behind its stack window) and goes on traversing against the tmax it has; when DRAIN lanes of the wave hold pending leaves -- or nobody
-// can take a node step any more -- the whole wave runs triangle steps only, every lane on ITS OWN pending leaves, in the order it met them,
-// until all FIFOs are empty.  The triangle code then runs for >= DRAIN / 64 of the lanes in its first round instead of ~6 %.
+// The single-step schedule issues the triangle half of the step (~65 of ~132 VALU instructions) in ~99 % of a refilled wave's iterations
+// for ~6 % of its lanes (profiles/r05_tri_turns_experiment.txt).  "Triangle turns" (lanes WAIT for a common triangle iteration) lost
+// because a waiting lane keeps its lane slot.  Here a lane that reaches a leaf does not wait: it notes the leaf in a small FIFO of its own
+// (PEND words of LDS behind its stack window) and goes on traversing against the tmax it has; when DRAIN lanes of the wave hold pending
+// leaves -- or nobody can take a node step any more -- the whole wave runs triangle steps only, every lane on ITS OWN pending leaves, in
+// the order it met them, until all FIFOs are empty.  The triangle code then runs for >= DRAIN / 64 of the lanes in its first round instead
+// of ~6 %.
 //
 // What changes for a ray: nothing about the ORDER of its triangle tests (its leaves are met in the reference's depth-first order, entry
-// distances do not depend on tmax, and a lane tests its own leaves first in, first out against its running tmax: mapping_gpu.impala:156-174,
-// intersection.impala:181-182) -- but between noting a leaf and testing it the ray walks on against a STALE tmax, so it may enter nodes the
-// reference prunes: a superset of the reference's visits, in the same order.  A triangle of such an extra leaf is accepted only where the
-// slab test (with the tmax the triangle before it set) and the triangle test disagree in the last bit -- a hit on a shared edge or vertex, a
-// coplanar duplicate.  Any-hit rays: the first accepted triangle is the reference's (nothing is pruned before it): bit-identical records.
-// Closest-hit rays: identical up to such ties; scripts/defer_experiment.py counts them against the oracle on all 2 x 1 Mi benchmark rays.
+// distances do not depend on tmax, and a lane tests its own leaves first in, first out against its running tmax:
+// mapping_gpu.impala:156-174, intersection.impala:181-182) -- but between noting a leaf and testing it the ray walks on against a STALE
+// tmax, so it may enter nodes the reference prunes: a superset of the reference's visits, in the same order.  A triangle of such an extra
+// leaf is accepted only where the slab test (with the tmax the triangle before it set) and the triangle test disagree in the last bit -- a
+// hit on a shared edge or vertex, a coplanar duplicate.  Any-hit rays: the first accepted triangle is the reference's (nothing is pruned
+// before it): bit-identical records. Closest-hit rays: identical up to such ties; scripts/defer_experiment.py counts them against the
+// oracle on all 2 x 1 Mi benchmark rays.
 #pragma once
 
 // joint_fetch (traversal_device.h) with a mask of its own for the memory kind: lanes that only pop (a leaf being noted) fetch nothing.
-__device__ __forceinline__ void joint_fetch3(vf4& q0, vf4& q1, vf4& q2, vi2& ids, int& popped, bool from_mem, bool from_lds, unsigned lds_addr, gbytes addr, gbytes addr_ids, lds_int* sp) {
+__device__ __forceinline__ void joint_fetch3(vf4& q0, vf4& q1, vf4& q2, vi2& ids, int& popped, bool from_mem, bool from_lds,
+    unsigned lds_addr, gbytes addr, gbytes addr_ids, lds_int* sp) {
     const unsigned long long mem_mask = __ballot(from_mem), lds_mask = __ballot(from_lds);
     const unsigned sp_addr = (unsigned)(size_t)sp;
     unsigned long long save;
@@ -44,16 +47,19 @@ __device__ __forceinline__ void joint_fetch3(vf4& q0, vf4& q1, vf4& q2, vi2& ids
                  : "memory", "scc");
 }
 
-// One step of a lane that can advance: a node step (mapping_gpu.impala:107-134) whose leaf children go to the lane's FIFO instead of becoming its top,
-// or -- a leaf that came off the stack -- noting that leaf and popping.  `fifo`: the lane's column of the PEND rows behind its window; `pend`: entries in it.
+// One step of a lane that can advance: a node step (mapping_gpu.impala:107-134) whose leaf children go to the lane's FIFO instead of
+// becoming its top, or -- a leaf that came off the stack -- noting that leaf and popping.  `fifo`: the lane's column of the PEND rows
+// behind its window; `pend`: entries in it.
 template <int LDS_N, int PEND, int WPG>
-__device__ __forceinline__ void defer_step(Lane& L, int& pend, const Bases& base, lds_int* sp_limit, lds_int* fifo, Ctl* ctl, lds_int* image, int* __restrict__ spill) {
+__device__ __forceinline__ void defer_step(Lane& L, int& pend, const Bases& base, lds_int* sp_limit, lds_int* fifo, Ctl* ctl,
+    lds_int* image, int* __restrict__ spill) {
     const bool is_node = L.top > 0, in_image = L.top >= kLdsTag;
     vf4 q0, q1, q2;
     vi2 ch;
     int popped;
     const gptr addr = base.node + (size_t)(unsigned)L.top * (unsigned)sizeof(Node2);
-    joint_fetch3(q0, q1, q2, ch, popped, is_node && !in_image, in_image, (unsigned)(size_t)image + (unsigned)(L.top - kLdsTag), addr, addr + 48u, L.sp);
+    joint_fetch3(q0, q1, q2, ch, popped, is_node && !in_image, in_image, (unsigned)(size_t)image + (unsigned)(L.top - kLdsTag), addr,
+        addr + 48u, L.sp);
     if (is_node) {
         float te0, te1;
         const bool h0 = slab_canonical(L.ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
@@ -71,7 +77,8 @@ __device__ __forceinline__ void defer_step(Lane& L, int& pend, const Bases& base
         L.top = pop ? popped : (note1 ? second : first);
         L.sp += push ? kWave : (pop ? -kWave : 0);
         if (push && L.sp >= sp_limit) stack_spill<LDS_N>(L.sp, L.top, sp_limit, spill, WPG, &ctl->err, &ctl->stats[7]);
-    } else {                                                                        // a leaf off the stack, and room for it (the caller holds back lanes without)
+    // a leaf off the stack, and room for it (the caller holds back lanes without)
+    } else {
         fifo[pend * kWave] = L.top; pend++;
         L.top = popped;
         L.sp -= kWave;
@@ -79,9 +86,11 @@ __device__ __forceinline__ void defer_step(Lane& L, int& pend, const Bases& base
     if (L.top >= kSpillMark) stack_reload<LDS_N>(L.sp, L.top, sp_limit, spill, WPG);
 }
 
-// Triangle steps only: every lane tests the leaves of its FIFO, oldest first, one triangle per round, until all FIFOs of the wave are empty.
+// Triangle steps only: every lane tests the leaves of its FIFO, oldest first, one triangle per round, until all FIFOs of the wave are
+// empty.
 template <bool ANY, int PEND>
-__device__ __forceinline__ void defer_drain(Lane& L, int& pend, const Bases& base, Hit1* __restrict__ hits, lds_int* fifo, unsigned long long* rounds = nullptr) {
+__device__ __forceinline__ void defer_drain(Lane& L, int& pend, const Bases& base, Hit1* __restrict__ hits, lds_int* fifo,
+    unsigned long long* rounds = nullptr) {
     static_assert(PEND >= 1 && PEND <= 4, "the FIFO is read into registers");
     int e[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -105,19 +114,23 @@ __device__ __forceinline__ void defer_drain(Lane& L, int& pend, const Bases& bas
                 L.ray.tmax = t; found = true;
             }
             const bool leave = prim_id < 0;
-            if (ANY && found) { L.top = 0; cur = 0; }                               // the ray is done: what is left of its stack and FIFO is dropped
+            // the ray is done: what is left of its stack and FIFO is dropped
+            if (ANY && found) { L.top = 0; cur = 0; }
             else if (leave) { cur = e[1]; e[1] = e[2]; e[2] = e[3]; e[3] = 0; }
             else cur -= 1;                                                          // ~(j + 1)
         }
     }
 }
 
-// k_bvh2_top_auto with deferred leaves.  LDS per wave: LDS_N + 1 window rows + PEND FIFO rows (LDS_N + 1 + PEND = 16: the shipped kernel's footprint).
-// MODE as k_bvh2_top_auto's (0: per wave, 1: whole chunks, 2: refill).  STATS: drain rounds / lane-rounds into stats[3] / stats[4] (instrumented build).
+// k_bvh2_top_auto with deferred leaves.  LDS per wave: LDS_N + 1 window rows + PEND FIFO rows (LDS_N + 1 + PEND = 16: the shipped kernel's
+// footprint). MODE as k_bvh2_top_auto's (0: per wave, 1: whole chunks, 2: refill).  STATS: drain rounds / lane-rounds into stats[3] /
+// stats[4] (instrumented build).
 template <bool ANY, int LDS_N, int PEND, int TOPN, int WAVES, int REFILL, int DRAIN, int MODE = 0, bool STATS = false>
-__global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_defer(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+__global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void
+    k_bvh2_top_defer(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                   const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                                  Ctl* ctl, int* __restrict__ deep_list, int4* __restrict__ top_image, int* __restrict__ tickets, int max_id,
+                                                                  Ctl* ctl, int* __restrict__ deep_list, int4* __restrict__ top_image,
+                                                                      int* __restrict__ tickets, int max_id,
                                                                   int* spill, int grid_w) {
     constexpr int kRows = LDS_N + 1 + PEND, kStackInts = WAVES * kRows * kWave, kGroupRays = 32 * kWave;
     static_assert((kStackInts + TOPN * 16) * 4 * (32 / WAVES) <= 160 * 1024, "32 waves per CU must fit their stacks and images in LDS");
@@ -126,7 +139,8 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     lds_int* col = (lds_int*)lds_raw + wave * kRows * kWave + lane;
     lds_int* const fifo = col + (LDS_N + 1) * kWave;
     lds_int* image = (lds_int*)lds_raw + kStackInts;
-    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, (const int4*)top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;
+    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, (const int4*)top_image, image, (lds_int*)lds_raw, ctl, max_id)
+        ? kLdsTag : 1;
     if (root != 1 && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&ctl->stats[6], 1ull);
     const int stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
     int* counter = tickets + stripe * kCounterStride;
@@ -160,7 +174,8 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
                 const bool stepping = L.top != 0 && !(L.top < 0 && pend == PEND);
                 const unsigned long long step_mask = __ballot(stepping), pend_mask = __ballot(pend != 0);
                 if ((step_mask | pend_mask) == 0ull) break;
-                if (__popcll(pend_mask) >= DRAIN || step_mask == 0ull) { defer_drain<ANY, PEND>(L, pend, base, hits, fifo, rounds); continue; }
+                if (__popcll(pend_mask) >= DRAIN || step_mask == 0ull) { defer_drain<ANY, PEND>(L, pend, base, hits, fifo, rounds);
+                    continue; }
                 if (stepping) defer_step<LDS_N, PEND, WAVES>(L, pend, base, sp_limit, fifo, ctl, image, spill);
             }
             int t_next = 0;
@@ -203,7 +218,8 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) lds_raw[0] = __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    if (threadIdx.x == 0) lds_raw[0] = __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     __syncthreads();
     if (!lds_raw[0] || wave != 0) return;
     const int deep = __hip_atomic_load(&ctl->deep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -216,7 +232,8 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     }
 }
 
-template <bool ANY, int LDS_N, int PEND, int TOPN, int WAVES, int REFILL, int DRAIN, int MODE = 0, bool STATS = false> void L_defer(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int PEND, int TOPN, int WAVES, int REFILL, int DRAIN, int MODE = 0,
+    bool STATS = false> void L_defer(LAUNCH_ARGS) {
     const int max_id = top_kernel_ids(nodes, n);
     if (max_id == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }
     ensure_deep_list(s, n);
@@ -224,6 +241,7 @@ template <bool ANY, int LDS_N, int PEND, int TOPN, int WAVES, int REFILL, int DR
     const int groups = spill_checked(((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);
     ensure_spill(s, groups * WAVES);
     s.top_image_nodes = nullptr; s.order_rays = 0;
-    hipLaunchKernelGGL((k_bvh2_top_defer<ANY, LDS_N, PEND, TOPN, WAVES, REFILL, DRAIN, MODE, STATS>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+    hipLaunchKernelGGL((k_bvh2_top_defer<ANY, LDS_N, PEND, TOPN, WAVES, REFILL, DRAIN, MODE, STATS>), dim3(groups), dim3(kWave * WAVES), 0,
+        stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
                        s.top_image, s.tickets, max_id, s.spill, g_ray_grid);
 }

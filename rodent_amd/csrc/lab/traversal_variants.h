@@ -154,7 +154,8 @@ __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ n
     unsigned c_n = 0, c_l = 0;                     // per-lane participations
     __shared__ unsigned wst[8];                    // wave-level counts, bumped by an elected lane
     if ((STATS || TRACE) && threadIdx.x < 8) wst[threadIdx.x] = 0;
-#define WAVE_COUNT(slot, amount) do { const unsigned long long m_ = __ballot(true); if ((int)threadIdx.x == __ffsll((long long)m_) - 1) atomicAdd(&wst[slot], (unsigned)(amount)); } while (0)
+#define WAVE_COUNT(slot, amount) do { const unsigned long long m_ = __ballot(true); \
+    if ((int)threadIdx.x == __ffsll((long long)m_) - 1) atomicAdd(&wst[slot], (unsigned)(amount)); } while (0)
 
     for (;;) {
         if (STATS) WAVE_COUNT(6, 1);
@@ -222,14 +223,16 @@ __global__ __launch_bounds__(kWave) void k_bvh2_fast(const Node2* __restrict__ n
     if (STATS) {
         for (int o = 32; o > 0; o >>= 1) { c_n += __shfl_xor((int)c_n, o); c_l += __shfl_xor((int)c_l, o); }
         if (threadIdx.x == 0) {
-            for (int k = 0; k < 7; k++) atomicAdd(&ctl->stats[k], (unsigned long long)(k == 1 ? c_n : (k == 3 ? c_l : atomicAdd(&wst[k], 0u))));
+            for (int k = 0; k < 7; k++) atomicAdd(&ctl->stats[k],
+                (unsigned long long)(k == 1 ? c_n : (k == 3 ? c_l : atomicAdd(&wst[k], 0u))));
         }
     }
 #undef WAVE_COUNT
     if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
         unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
         tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
-        tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+        tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4))
+            | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
         tr[3] = ((unsigned long long)atomicAdd(&wst[0], 0u) << 32) | atomicAdd(&wst[2], 0u);
     }
 }
@@ -263,7 +266,8 @@ __global__ __launch_bounds__(kWave) void k_bvh2_sched(const Node2* __restrict__ 
     if ((STATS || TRACE) && threadIdx.x < 8) wst[threadIdx.x] = 0;
     const unsigned long long t_start = (STATS || TRACE) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned traced_rays = 0;
-#define WAVE_COUNT(slot, amount) do { const unsigned long long m_ = __ballot(true); if ((int)threadIdx.x == __ffsll((long long)m_) - 1) atomicAdd(&wst[slot], (unsigned)(amount)); } while (0)
+#define WAVE_COUNT(slot, amount) do { const unsigned long long m_ = __ballot(true); \
+    if ((int)threadIdx.x == __ffsll((long long)m_) - 1) atomicAdd(&wst[slot], (unsigned)(amount)); } while (0)
 
     for (;;) {
         if (STATS) WAVE_COUNT(6, 1);
@@ -342,11 +346,13 @@ __global__ __launch_bounds__(kWave) void k_bvh2_sched(const Node2* __restrict__ 
     if (STATS) {
         for (int o = 32; o > 0; o >>= 1) { c_n += __shfl_xor((int)c_n, o); c_l += __shfl_xor((int)c_l, o); }
         if (threadIdx.x == 0) {
-            for (int k = 0; k < 7; k++) atomicAdd(&ctl->stats[k], (unsigned long long)(k == 1 ? c_n : (k == 3 ? c_l : atomicAdd(&wst[k], 0u))));
+            for (int k = 0; k < 7; k++) atomicAdd(&ctl->stats[k],
+                (unsigned long long)(k == 1 ? c_n : (k == 3 ? c_l : atomicAdd(&wst[k], 0u))));
             if (ctl->trace && blockIdx.x < 16384) {       // per-wave timeline: start, end (100 MHz ticks), hw id, xcc id, work
                 unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
                 tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
-                tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+                tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4))
+                    | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
                 tr[3] = ((unsigned long long)atomicAdd(&wst[5], 0u) << 32) | atomicAdd(&wst[6], 0u);
             }
         }
@@ -355,7 +361,8 @@ __global__ __launch_bounds__(kWave) void k_bvh2_sched(const Node2* __restrict__ 
     if (TRACE && threadIdx.x == 0 && ctl->trace && blockIdx.x < 16384) {
         unsigned long long* tr = ctl->trace + 4 * (size_t)blockIdx.x;
         tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
-        tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+        tr[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4))
+            | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
         tr[3] = (unsigned long long)traced_rays << 32;
     }
 }
@@ -386,21 +393,27 @@ bool needs_wide_offsets(const void* nodes, const void* tris) {
 }
 
 template <bool ANY, int LDS_N> void L_lane(LAUNCH_ARGS) {
-    hipLaunchKernelGGL((k_bvh2_lane<ANY, LDS_N>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.host_page + kHostErr);
+    hipLaunchKernelGGL((k_bvh2_lane<ANY, LDS_N>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n,
+        s.host_page + kHostErr);
 }
 template <bool ANY, int LDS_N, int NE> void L_ww(LAUNCH_ARGS) {
-    hipLaunchKernelGGL((k_bvh2_ww<ANY, LDS_N, NE>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.host_page + kHostErr);
+    hipLaunchKernelGGL((k_bvh2_ww<ANY, LDS_N, NE>), dim3(blocks_for(n)), dim3(kWave), 0, stream, nodes, tris, rays, hits, n,
+        s.host_page + kHostErr);
 }
-template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false, int XCD = 0, bool TR = false, bool SC = false> void L_fast(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, int NE, bool P, int RI, int CH, bool ST = false, int XCD = 0, bool TR = false,
+    bool SC = false> void L_fast(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     const int per_block = P ? CH : kWave;
     int grid = (n + per_block - 1) / per_block;
     if (P) grid = std::min(grid, s.num_cus * (SC ? static_waves_per_cu() : persistent_waves_per_cu()));
     if (needs_wide_offsets(nodes, tris))
-        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, TR, SC, true>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
+        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, TR, SC, true>), dim3(grid), dim3(kWave), 0, stream, nodes,
+            tris, rays, hits, n, s.ctl(), s.deep_list);
     else
-        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, TR, SC, false>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list);
-    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
+        hipLaunchKernelGGL((k_bvh2_fast<ANY, LDS_N, NE, P, RI, CH, ST, XCD, TR, SC, false>), dim3(grid), dim3(kWave), 0, stream, nodes,
+            tris, rays, hits, n, s.ctl(), s.deep_list);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack,
+        (int*)nullptr);
 }
 
 int coprime_stride(int count) {
@@ -411,15 +424,18 @@ int coprime_stride(int count) {
     return m % count;
 }
 
-template <bool ANY, int LDS_N, bool P, int RI, int CH, int TB, bool PERMUTE = false, bool ST = false, bool TR = false> void L_sched(LAUNCH_ARGS) {
+template <bool ANY, int LDS_N, bool P, int RI, int CH, int TB, bool PERMUTE = false, bool ST = false,
+    bool TR = false> void L_sched(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     const int per_block = P ? CH : kWave;
     const int chunks = (n + per_block - 1) / per_block;
     int grid = chunks;
     if (P) grid = std::min(grid, s.num_cus * persistent_waves_per_cu());
     const ChunkPerm perm{chunks, PERMUTE ? coprime_stride(chunks) : 1};
-    hipLaunchKernelGGL((k_bvh2_sched<ANY, LDS_N, P, RI, CH, TB, ST, TR>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list, perm);
-    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
+    hipLaunchKernelGGL((k_bvh2_sched<ANY, LDS_N, P, RI, CH, TB, ST, TR>), dim3(grid), dim3(kWave), 0, stream, nodes, tris, rays, hits, n,
+        s.ctl(), s.deep_list, perm);
+    hipLaunchKernelGGL((k_bvh2_finish<ANY>), dim3(1), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack,
+        (int*)nullptr);
 }
 
 
@@ -438,7 +454,8 @@ __global__ __launch_bounds__(kWave) void k_wide_lane(const char* __restrict__ no
     store_hit(hits, i, hit.id, hit.t, hit.u, hit.v);
 }
 template <bool ANY, int N, int LDS_N> void L_wide_lane(WIDE_LAUNCH_ARGS) {
-    hipLaunchKernelGGL((k_wide_lane<ANY, N, LDS_N>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, n, s.host_page + kHostErr);
+    hipLaunchKernelGGL((k_wide_lane<ANY, N, LDS_N>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, n,
+        s.host_page + kHostErr);
 }
 
 
@@ -455,17 +472,21 @@ template <bool ANY, int N, int LDS_N> void L_wide_lane(WIDE_LAUNCH_ARGS) {
 // Only for launches of exactly 2 x resident-waves chunks (1 Mi rays on 256 CUs); anything else takes the default order.
 // ---------------------------------------------------------------------------------------------
 template <bool ANY, int LDS_N, int TOPN, int WAVES, int HOT_ITER, int HOT_LANES>
-__global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh2_top_partner(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
+__global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void
+    k_bvh2_top_partner(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris,
                                                                      const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                                     Ctl* ctl, int* __restrict__ deep_list, int4* __restrict__ top_image, int* __restrict__ tickets, int max_id) {
+                                                                     Ctl* ctl, int* __restrict__ deep_list, int4* __restrict__ top_image,
+                                                                         int* __restrict__ tickets, int max_id) {
     constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave;
     __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
     lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
     lds_int* image = (lds_int*)lds_raw + kStackInts;
-    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, (const int4*)top_image, image, (lds_int*)lds_raw, ctl, max_id) ? kLdsTag : 1;
+    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, (const int4*)top_image, image, (lds_int*)lds_raw, ctl, max_id)
+        ? kLdsTag : 1;
     const int total_chunks = (n + kWave - 1) / kWave, stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
-    unsigned* state = reinterpret_cast<unsigned*>(tickets + stripe * kCounterStride);      // [1..4] hot mask, [5..8] claimed mask (word 0: the default order's counter)
+    // [1..4] hot mask, [5..8] claimed mask (word 0: the default order's counter)
+    unsigned* state = reinterpret_cast<unsigned*>(tickets + stripe * kCounterStride);
     const bool paired = total_chunks == 2 * stripe_waves * kStripes && stripe_waves == 128;
     lds_int* const sp_limit = col + LDS_N * kWave;
     const Bases base = make_bases(nodes, tris);
@@ -498,14 +519,16 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
         if (paired) {
             // the whole wave draws: lanes 0..3 read the hot words, 4..7 the claimed words (ONE round trip), lane 0 claims
             t_next = 1 << 20;                                                 // nothing left
-            const int start = (int)(((blockIdx.x / kStripes) * WAVES + wave) >> 5) & 3;         // waves look for hot partners from different words: fewer collisions
+            // waves look for hot partners from different words: fewer collisions
+            const int start = (int)(((blockIdx.x / kStripes) * WAVES + wave) >> 5) & 3;
             for (;;) {
                 const unsigned word = lane < 8 ? __hip_atomic_load(&state[1 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 const unsigned free_hot = word & ~(unsigned)__shfl((int)word, (lane & 3) + 4);          // lanes 0..3: hot and not taken
                 const unsigned long long any = __ballot(lane < 4 && free_hot != 0u);
                 int pick = -1;
                 if (any) {
-                    const unsigned rot = (unsigned)(((any | (any << 4)) >> start) & 15ull);            // first non-empty word from `start` on
+                    // first non-empty word from `start` on
+                    const unsigned rot = (unsigned)(((any | (any << 4)) >> start) & 15ull);
                     const int w = (start + __ffs((int)rot) - 1) & 3;
                     pick = 32 * w + __ffs(__shfl((int)free_hot, w)) - 1;
                 } else {
@@ -524,13 +547,15 @@ __global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8
     }
 }
 // the follow-up kernel's extra duty: the hot / claimed masks back to zero
-__global__ void k_partner_reset(int* tickets) { const int s = threadIdx.x; for (int w = 1; w <= 8; w++) tickets[s * kCounterStride + w] = 0; }
+__global__ void k_partner_reset(int* tickets) { const int s = threadIdx.x;
+    for (int w = 1; w <= 8; w++) tickets[s * kCounterStride + w] = 0; }
 
 template <bool ANY, int LDS_N, int TOPN, int WAVES, int HOT_ITER, int HOT_LANES> void L_top_partner(LAUNCH_ARGS) {
     ensure_deep_list(s, n);
     if (!s.top_image || !s.tickets) {
         std::lock_guard<std::mutex> lock(g_mutex);
-        if (!s.top_image) { HIP_CHECK(hipMalloc(&s.top_image, kMaxTopNodes * sizeof(Node2))); HIP_CHECK(hipMemset(s.top_image, 0, kMaxTopNodes * sizeof(Node2))); }
+        if (!s.top_image) { HIP_CHECK(hipMalloc(&s.top_image, kMaxTopNodes * sizeof(Node2)));
+            HIP_CHECK(hipMemset(s.top_image, 0, kMaxTopNodes * sizeof(Node2))); }
         if (!s.tickets) {
             HIP_CHECK(hipMalloc(&s.tickets, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
             HIP_CHECK(hipMemset(s.tickets, 0, sizeof(int) * kMaxPhases * kStripes * kCounterStride));
@@ -538,8 +563,10 @@ template <bool ANY, int LDS_N, int TOPN, int WAVES, int HOT_ITER, int HOT_LANES>
     }
     s.top_image_nodes = nullptr;
     const int groups = ((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes;
-    hipLaunchKernelGGL((k_bvh2_top_partner<ANY, LDS_N, TOPN, WAVES, HOT_ITER, HOT_LANES>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
+    hipLaunchKernelGGL((k_bvh2_top_partner<ANY, LDS_N, TOPN, WAVES, HOT_ITER, HOT_LANES>), dim3(groups), dim3(kWave * WAVES), 0, stream,
+        nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
                        s.top_image, s.tickets, mapped_node_ids(nodes));
-    hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
+    hipLaunchKernelGGL((k_bvh2_top_finish<ANY>), dim3(kFinishGroups), dim3(kWave), 0, stream, nodes, tris, rays, hits, s.ctl(),
+        s.deep_list, s.deep_stack, s.tickets, s.top_image, TOPN);
     hipLaunchKernelGGL(k_partner_reset, dim3(1), dim3(kStripes), 0, stream, s.tickets);
 }

@@ -54,7 +54,8 @@ std::mutex g_cache_mutex;
 
 void select_device(int dev) {
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || dev < 0 || dev >= count) { fprintf(stderr, "rodent_hip: no HIP device %d (%d visible)\n", dev, count); abort(); }
+    if (hipGetDeviceCount(&count) != hipSuccess || dev < 0 || dev >= count) {
+        fprintf(stderr, "rodent_hip: no HIP device %d (%d visible)\n", dev, count); abort(); }
     HIP_CHECK(hipSetDevice(dev));
 }
 
@@ -113,7 +114,8 @@ void rodent_services_cleanup() {
     int previous = 0;
     const bool have_device = hipGetDevice(&previous) == hipSuccess;
     for (auto& kv : g_cache.buffers) { (void)hipSetDevice(kv.first.first); (void)hipFree(kv.second.ptr); }
-    for (auto& kv : g_cache.bvhs) { (void)hipSetDevice(std::get<0>(kv.first)); (void)hipFree(kv.second.nodes.ptr); (void)hipFree(kv.second.tris.ptr); }
+    for (auto& kv : g_cache.bvhs) { (void)hipSetDevice(std::get<0>(kv.first)); (void)hipFree(kv.second.nodes.ptr);
+        (void)hipFree(kv.second.tris.ptr); }
     for (auto& kv : g_cache.images) { (void)hipSetDevice(kv.first.first); (void)hipFree(kv.second.pixels.ptr); }
     if (have_device) (void)hipSetDevice(previous);
     g_cache = Cache();
@@ -175,9 +177,11 @@ void rodent_load_jpg(int32_t dev, const char* file, uint8_t** pixels, int32_t* w
 #ifndef RODENT_HIP_SOURCE_DIGEST
 #define RODENT_HIP_SOURCE_DIGEST "unknown"
 #endif
-const char* rodent_hip_source_digest(void) { return RODENT_HIP_SOURCE_DIGEST; }      // rodent_amd/build.py source_digest(), passed by the build
+// rodent_amd/build.py source_digest(), passed by the build
+const char* rodent_hip_source_digest(void) { return RODENT_HIP_SOURCE_DIGEST; }
 
-int64_t clock_us(void) {                                                       // interface.cpp:665-673 (its non-x86 branch: a monotonic clock)
+// interface.cpp:665-673 (its non-x86 branch: a monotonic clock)
+int64_t clock_us(void) {
     return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 

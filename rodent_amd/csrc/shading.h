@@ -19,13 +19,16 @@ struct SceneDev {                 // device pointers (uploaded by rodent_hip_sce
     const RodentMaterial* materials; const RodentLight* lights; const int32_t* light_ids;
     int32_t num_tris, num_materials, num_lights, pad;
     const float* texcoords; const RodentTexture* textures; const uint32_t* texels;
-    const int4* top_image;        // the first kSceneTopNodes inner nodes, breadth first, as LDS-image records (traversal_device.h); built at scene creation
+    // the first kSceneTopNodes inner nodes, breadth first, as LDS-image records (traversal_device.h); built at scene creation
+    const int4* top_image;
     const int4* top_image_large;  // the same with kPersistTopNodes records (persistent stream traversal kernels)
-    // What a hit needs of its triangle, gathered once at scene creation into ONE 48-byte record per triangle: face normal, then the three vertex normals
-    // (12 floats; rodent_hip_scene_create).  Through indices -> normals the shader waits for two dependent fetches (16 + 12 bytes, then 3 x 12 bytes
-    // scattered over the vertex array); the record is one fetch of three consecutive 16-byte words.  Same values, same arithmetic.  May be null (old path).
+    // What a hit needs of its triangle, gathered once at scene creation into ONE 48-byte record per triangle: face normal, then the three
+    // vertex normals (12 floats; rodent_hip_scene_create).  Through indices -> normals the shader waits for two dependent fetches (16 + 12
+    // bytes, then 3 x 12 bytes scattered over the vertex array); the record is one fetch of three consecutive 16-byte words.  Same values,
+    // same arithmetic.  May be null (old path).
     const float4* tri_shade;
-    const float* tri_tex;         // textured scenes: the three corners' texture coordinates per triangle, gathered the same way (6 floats); null otherwise
+    // textured scenes: the three corners' texture coordinates per triangle, gathered the same way (6 floats); null otherwise
+    const float* tri_tex;
 };
 
 #define FLT_MAX_REF 3.4028234664e+38f
@@ -53,7 +56,8 @@ RD_FN uint32_t f2u(float x) { return __float_as_uint(x); }
 RD_FN float u2f(uint32_t u) { return __uint_as_float(u); }
 
 /* random.impala:22-30, 7-11 */
-RD_FN uint32_t xorshift(uint32_t* seed) { uint32_t x = *seed; x = x == 0u ? 1u : x; x ^= x << 13; x ^= x >> 17; x ^= x << 5; *seed = x; return x; }
+RD_FN uint32_t xorshift(uint32_t* seed) { uint32_t x = *seed; x = x == 0u ? 1u : x; x ^= x << 13; x ^= x >> 17; x ^= x << 5; *seed = x;
+    return x; }
 RD_FN float randf(uint32_t* rnd) { return u2f((127u << 23) | (xorshift(rnd) & 0x7FFFFFu)) - 1.0f; }
 /* random.impala:116-126 */
 RD_FN uint32_t fnv_hash(uint32_t h, uint32_t d) {
@@ -83,7 +87,8 @@ RD_FN void sincos_2pi(float u, float* c_out, float* s_out) {
     const float a = (x - (float)k) * 1.57079632679f;
     const float a2 = a * a;
     const float s = a * (1.0f + a2 * (-0.16666667163f + a2 * (0.0083333337680f + a2 * (-0.00019841270114f + a2 * 2.7557314297e-6f))));
-    const float c = 1.0f + a2 * (-0.5f + a2 * (0.041666667908f + a2 * (-0.0013888889225f + a2 * (2.4801587642e-5f + a2 * -2.7557314297e-7f))));
+    const float c = 1.0f + a2
+        * (-0.5f + a2 * (0.041666667908f + a2 * (-0.0013888889225f + a2 * (2.4801587642e-5f + a2 * -2.7557314297e-7f))));
     switch (k & 3) {
         case 0: *c_out = c;  *s_out = s;  break;
         case 1: *c_out = -s; *s_out = c;  break;
@@ -99,7 +104,8 @@ RD_FN m3 orthonormal(v3 n) {
     m3 m; m.c0 = V(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x); m.c1 = V(b, sign + n.y * n.y * a, -n.y); m.c2 = n; return m;
 }
 RD_FN v3 m3_mul(m3 m, v3 v) {   /* matrix.impala mat3x3_mul: rows dotted with v */
-    return V(m.c0.x * v.x + m.c1.x * v.y + m.c2.x * v.z, m.c0.y * v.x + m.c1.y * v.y + m.c2.y * v.z, m.c0.z * v.x + m.c1.z * v.y + m.c2.z * v.z);
+    return V(m.c0.x * v.x + m.c1.x * v.y + m.c2.x * v.z, m.c0.y * v.x + m.c1.y * v.y + m.c2.y * v.z,
+        m.c0.z * v.x + m.c1.z * v.y + m.c2.z * v.z);
 }
 
 typedef struct { v3 dir; float pdf; } DirSample;
@@ -223,7 +229,8 @@ RD_FN Surf surface_element(const SceneDev* sc, v3 org, v3 dir, int32_t prim, flo
 /* image.impala:24-38 (RGBA8 -> colour), :48-54 (repeat border), :64-86 (bilinear filter) */
 RD_FN v3 texel(const SceneDev* sc, const RodentTexture* t, int32_t x, int32_t y) {
     const uint32_t p = sc->texels[t->offset + (uint32_t)y * (uint32_t)t->width + (uint32_t)x];
-    return V((float)(p & 0xFFu) * (1.0f / 255.0f), (float)((p >> 8) & 0xFFu) * (1.0f / 255.0f), (float)((p >> 16) & 0xFFu) * (1.0f / 255.0f));
+    return V((float)(p & 0xFFu) * (1.0f / 255.0f), (float)((p >> 8) & 0xFFu) * (1.0f / 255.0f),
+        (float)((p >> 16) & 0xFFu) * (1.0f / 255.0f));
 }
 RD_FN v3 tex_lookup(const SceneDev* sc, const RodentTexture* t, float tu, float tv) {
     const float ru = tu - floorf(tu), rv = tv - floorf(tv);
@@ -238,7 +245,8 @@ RD_FN v3 tex_lookup(const SceneDev* sc, const RodentTexture* t, float tu, float 
 }
 /* The material of a hit: map_Kd / map_Ks replace kd / ks with texture lookups at the interpolated texture coordinates,
  * and the diffuse/Phong mix weight follows the looked-up colours (converter.cpp:881-906, geometry.impala:30-40). */
-RD_FN const RodentMaterial* resolve_material(const SceneDev* sc, const RodentMaterial* m, RodentMaterial* tmp, int32_t prim, float u, float v) {
+RD_FN const RodentMaterial* resolve_material(const SceneDev* sc, const RodentMaterial* m, RodentMaterial* tmp, int32_t prim, float u,
+    float v) {
     if (!(m->tex_kd | m->tex_ks)) return m;
     float tu, tv;
     if (sc->tri_tex) {                                         /* wave-uniform: the gathered corners (SceneDev::tri_tex) */
@@ -246,12 +254,15 @@ RD_FN const RodentMaterial* resolve_material(const SceneDev* sc, const RodentMat
         tu = lerp2(tc[0], tc[2], tc[4], u, v); tv = lerp2(tc[1], tc[3], tc[5], u, v);
     } else {
         const int32_t* idx = sc->indices + 4 * prim;
-        const float* t0 = sc->texcoords + 4 * idx[0]; const float* t1 = sc->texcoords + 4 * idx[1]; const float* t2 = sc->texcoords + 4 * idx[2];
+        const float* t0 = sc->texcoords + 4 * idx[0]; const float* t1 = sc->texcoords + 4 * idx[1];
+        const float* t2 = sc->texcoords + 4 * idx[2];
         tu = lerp2(t0[0], t1[0], t2[0], u, v); tv = lerp2(t0[1], t1[1], t2[1], u, v);
     }
     *tmp = *m;
-    if (m->tex_kd) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_kd - 1), tu, tv); tmp->kd[0] = c.x; tmp->kd[1] = c.y; tmp->kd[2] = c.z; }
-    if (m->tex_ks) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_ks - 1), tu, tv); tmp->ks[0] = c.x; tmp->ks[1] = c.y; tmp->ks[2] = c.z; }
+    if (m->tex_kd) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_kd - 1), tu, tv); tmp->kd[0] = c.x; tmp->kd[1] = c.y;
+        tmp->kd[2] = c.z; }
+    if (m->tex_ks) { const v3 c = tex_lookup(sc, sc->textures + (m->tex_ks - 1), tu, tv); tmp->ks[0] = c.x; tmp->ks[1] = c.y;
+        tmp->ks[2] = c.z; }
     if (m->type == RODENT_BSDF_MIX) {
         const float ls = luminance(LD3(tmp->ks)), ld = luminance(LD3(tmp->kd));
         tmp->mix_k = (ls + ld == 0.0f) ? 0.0f : ls / (ls + ld);

@@ -69,7 +69,8 @@ __device__ __forceinline__ bool slab(const RayX& r, float lox, float hix, float 
 // v_max_f32 x, x).  The two operations that touch them are therefore issued as plain v_max_f32 / v_min_f32, which on
 // canonical operands compute exactly fmaxf / fminf.
 __device__ __forceinline__ float canonical(float x) { return __builtin_canonicalizef(x); }
-__device__ __forceinline__ bool slab_canonical(const RayX& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float& tentry) {
+__device__ __forceinline__ bool slab_canonical(const RayX& r, float lox, float hix, float loy, float hiy, float loz, float hiz,
+    float& tentry) {
     const f32x2 tx = __builtin_elementwise_fma((f32x2){r.idx, r.idx}, (f32x2){lox, hix}, (f32x2){r.iox, r.iox});
     const f32x2 ty = __builtin_elementwise_fma((f32x2){r.idy, r.idy}, (f32x2){loy, hiy}, (f32x2){r.ioy, r.ioy});
     const f32x2 tz = __builtin_elementwise_fma((f32x2){r.idz, r.idz}, (f32x2){loz, hiz}, (f32x2){r.ioz, r.ioz});
@@ -131,13 +132,14 @@ constexpr int kSpillMark = 0x7F000000;          // above every node id (<= 0x3FF
 constexpr int kSpillRows = 7, kSpillBlocks = 7;
 constexpr int kSpillWaveInts = kSpillRows * kSpillBlocks * kWave;       // 12 544 bytes per resident wave
 
-// Both helpers run exec-masked on the rare path and take what they need in its cheapest loop-invariant form -- the lane's window LIMIT
-// (col + WINDOW rows, which the step compares against anyway), the launch's spill buffer and the workgroup's wave count -- and derive the rest
+// Both helpers run exec-masked on the rare path and take what they need in its cheapest loop-invariant form -- the lane's window LIMIT (col
+// + WINDOW rows, which the step compares against anyway), the launch's spill buffer and the workgroup's wave count -- and derive the rest
 // behind an opaque barrier: computed outside, the column base and the 64-bit address of the lane's spill words would be three more VGPRs
 // carried around a loop that is compiled under a 64-VGPR budget (measured: +2 ... 3 % on the benchmark launches).
 __device__ __forceinline__ int* spill_words(int* __restrict__ spill, int waves_per_group) {
     unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    int slot = (int)blockIdx.x * waves_per_group + __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);     // the wave's slot in the resident grid
+    // the wave's slot in the resident grid
+    int slot = (int)blockIdx.x * waves_per_group + __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
     asm volatile("" : "+v"(lane), "+s"(slot));
     return spill + (size_t)slot * kSpillWaveInts + lane;
 }
@@ -150,11 +152,13 @@ __device__ __forceinline__ lds_int* window_base(lds_int* limit) {
 // Called by a lane whose push filled row WINDOW (sp == limit).  `events` (may be null): a counter of blocks moved out, for the tests and
 // the per-scene reports (one atomic per block).
 template <int WINDOW>
-__device__ __forceinline__ void stack_spill(lds_int*& sp, int& top, lds_int* limit, int* __restrict__ spill, int waves_per_group, int* err, unsigned long long* events = nullptr) {
+__device__ __forceinline__ void stack_spill(lds_int*& sp, int& top, lds_int* limit, int* __restrict__ spill, int waves_per_group, int* err,
+    unsigned long long* events = nullptr) {
     static_assert(WINDOW > kSpillRows + 1, "something must stay in the window");
     lds_int* const col = window_base<WINDOW>(limit);
     const int mark = col[0], blocks = mark ? mark - kSpillMark : 0;
-    if (blocks >= kSpillBlocks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); top = 0; return; }        // more than the reference's 64 slots: the host reports it
+    // more than the reference's 64 slots: the host reports it
+    if (blocks >= kSpillBlocks) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); top = 0; return; }
     if (events) atomicAdd(events, 1ull);
     int* g = spill_words(spill, waves_per_group) + blocks * kSpillRows * kWave;
 #pragma unroll 1
@@ -164,9 +168,10 @@ __device__ __forceinline__ void stack_spill(lds_int*& sp, int& top, lds_int* lim
     col[0] = kSpillMark + blocks + 1;
     sp -= kSpillRows * kWave;
 }
-// Called at the end of a step by a lane that popped row 0 while blocks are out (its new top is the mark, >= kSpillMark): the newest block comes
-// back into rows 1..kSpillRows - 1, its newest entry is the new top.  (Measured beside the alternative -- testing the word UNDER the cursor at the
-// start of the step, off the dependency chain: 0.1857 against 0.1872 ms on the benchmark launch, profiles/r05_spill_experiment.txt.)
+// Called at the end of a step by a lane that popped row 0 while blocks are out (its new top is the mark, >= kSpillMark): the newest block
+// comes back into rows 1..kSpillRows - 1, its newest entry is the new top.  (Measured beside the alternative -- testing the word UNDER the
+// cursor at the start of the step, off the dependency chain: 0.1857 against 0.1872 ms on the benchmark launch,
+// profiles/r05_spill_experiment.txt.)
 template <int WINDOW>
 __device__ __forceinline__ void stack_reload(lds_int*& sp, int& top, lds_int* limit, int* __restrict__ spill, int waves_per_group) {
     lds_int* const col = window_base<WINDOW>(limit);
@@ -180,19 +185,20 @@ __device__ __forceinline__ void stack_reload(lds_int*& sp, int& top, lds_int* li
 }
 
 // ---------------------------------------------------------------------------------------------
-// One step's fetches, both kinds in flight TOGETHER.  A lane whose node is in the LDS image (in_lds: ds_read_b128 x 3 + ds_read_b64 at `lds_addr`)
-// and a lane whose node / triangle comes from memory (global_load_dwordx4 x 3 at `addr` + dwordx2 at `addr_ids`) write the same registers.
-// Compiled from the two branches of an if, the second kind's loads wait for the first kind's to LAND -- the compiler cannot know that the
-// two exec masks are disjoint and sees a write-after-write on q0 .. ids -- so every iteration in which a wave holds both kinds pays an LDS
-// round trip behind a memory round trip.  Here they are issued back to back under their own exec masks and waited for once, together with
-// the word under the stack cursor (`popped`).  A kind nobody in the wave needs is skipped (a memory instruction with an empty exec mask
-// still makes the round trip).  Measured on one MI355X (profiles/r05_joint_loads.txt): random segments -6 % (atrium) ... -13 % (crown,
-// plant), camera rays +1 % (atrium) ... -4 % (crown).  Results cannot change: the same loads, the same lanes.
+// One step's fetches, both kinds in flight TOGETHER.  A lane whose node is in the LDS image (in_lds: ds_read_b128 x 3 + ds_read_b64 at
+// `lds_addr`) and a lane whose node / triangle comes from memory (global_load_dwordx4 x 3 at `addr` + dwordx2 at `addr_ids`) write the same
+// registers. Compiled from the two branches of an if, the second kind's loads wait for the first kind's to LAND -- the compiler cannot know
+// that the two exec masks are disjoint and sees a write-after-write on q0 .. ids -- so every iteration in which a wave holds both kinds
+// pays an LDS round trip behind a memory round trip.  Here they are issued back to back under their own exec masks and waited for once,
+// together with the word under the stack cursor (`popped`).  A kind nobody in the wave needs is skipped (a memory instruction with an empty
+// exec mask still makes the round trip).  Measured on one MI355X (profiles/r05_joint_loads.txt): random segments -6 % (atrium) ... -13 %
+// (crown, plant), camera rays +1 % (atrium) ... -4 % (crown).  Results cannot change: the same loads, the same lanes.
 // ---------------------------------------------------------------------------------------------
 typedef float vf4 __attribute__((ext_vector_type(4)));
 typedef int vi2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) char* gbytes;
-__device__ __forceinline__ void joint_fetch(vf4& q0, vf4& q1, vf4& q2, vi2& ids, int& popped, bool in_lds, unsigned lds_addr, gbytes addr, gbytes addr_ids, lds_int* sp) {
+__device__ __forceinline__ void joint_fetch(vf4& q0, vf4& q1, vf4& q2, vi2& ids, int& popped, bool in_lds, unsigned lds_addr, gbytes addr,
+    gbytes addr_ids, lds_int* sp) {
     const unsigned long long lds_mask = __ballot(in_lds);
     const unsigned sp_addr = (unsigned)(size_t)sp;
     unsigned long long save;
@@ -220,9 +226,11 @@ __device__ __forceinline__ void joint_fetch(vf4& q0, vf4& q1, vf4& q2, vi2& ids,
 }
 
 __device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-// One wave (the LDS operations of a wave complete in program order: between one lane's write and another lane's read the
-// compiler only has to keep that order).  Record layout: ints 0..11 bounds, 12..13 child ids / links, 14 = the node's own 1-based id (0: slot unused), 15 = 0.
-__device__ __forceinline__ void build_top_image(const Node2* __restrict__ nodes, int4* __restrict__ image, int capacity, lds_int* slot_node /* [capacity]: 1-based node id held by each slot */) {
+// One wave (the LDS operations of a wave complete in program order: between one lane's write and another lane's read the compiler only has
+// to keep that order).  Record layout: ints 0..11 bounds, 12..13 child ids / links, 14 = the node's own 1-based id (0: slot unused), 15 =
+// 0.
+__device__ __forceinline__ void build_top_image(const Node2* __restrict__ nodes, int4* __restrict__ image, int capacity,
+    lds_int* slot_node /* [capacity]: 1-based node id held by each slot */) {
     const int lane = threadIdx.x;
     if (lane == 0) slot_node[0] = 1;
     wave_lds_sync();
@@ -233,7 +241,8 @@ __device__ __forceinline__ void build_top_image(const Node2* __restrict__ nodes,
             const int slot = first + lane;
             const bool on = slot < end;
             int4 r0 = {}, r1 = {}, r2 = {}, r3 = {};
-            if (on) { const int4* p = reinterpret_cast<const int4*>(nodes + (slot_node[slot] - 1)); r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3]; }
+            if (on) { const int4* p = reinterpret_cast<const int4*>(nodes + (slot_node[slot] - 1)); r0 = p[0]; r1 = p[1]; r2 = p[2];
+                r3 = p[3]; }
             const bool in0 = on && r3.x > 0, in1 = on && r3.y > 0;   // inner children (r3.x / r3.y = Node2::child)
             const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1), below = (1ull << lane) - 1ull;
             const int s0 = next + __popcll(m0 & below), s1 = next + __popcll(m0) + __popcll(m1 & below);

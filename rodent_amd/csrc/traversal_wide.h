@@ -53,11 +53,13 @@ __device__ __forceinline__ bool tri_pre(const RayX& r, float v0x, float v0y, flo
 // rewritten the same way), fetched with ds_read_b128 instead of through the vector-memory pipeline.
 template <bool ANY, int N, int LDS_N, bool TOP = false>
 __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const Tri4* __restrict__ tris, const Ray1* __restrict__ rays,
-                                           Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col, int first_ray,
+                                           Hit1* __restrict__ hits, int n, Ctl* ctl, int* __restrict__ deep_list, lds_int* col,
+                                               int first_ray,
                                            lds_int* image = nullptr, int root = 1, int grid_w = 0) {
     typedef WideLayout<N> L;
     int lane_ray = first_ray + (int)(threadIdx.x % kWave);
-    if (first_ray < tiled_ray_count(grid_w, n)) lane_ray = tile_ray(first_ray, (int)(threadIdx.x % kWave), grid_w);      // per-pixel lists: an 8 x 8-pixel tile per wavefront (detect_ray_grid, traversal.hip)
+    // per-pixel lists: an 8 x 8-pixel tile per wavefront (detect_ray_grid, traversal.hip)
+    if (first_ray < tiled_ray_count(grid_w, n)) lane_ray = tile_ray(first_ray, (int)(threadIdx.x % kWave), grid_w);
     const int ray_id = lane_ray < n ? lane_ray : -1;
     RayX ray = load_ray(rays, ray_id >= 0 ? ray_id : first_ray);
     if (ray_id >= 0) store_hit(hits, ray_id, -1, ray.tmax, 0.0f, 0.0f);       // the miss record; accepted triangles overwrite it
@@ -67,7 +69,9 @@ __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const
     lds_int* const sp_limit = col + LDS_N * kWave;
     col[0] = 0;
     typedef const __attribute__((address_space(1))) char* gptr;
-    unsigned long long node_bits = reinterpret_cast<unsigned long long>(nodes) - L::kNodeBytes, tri_bits = reinterpret_cast<unsigned long long>(tris);   // node ids are 1-based
+    // node ids are 1-based
+    unsigned long long node_bits = reinterpret_cast<unsigned long long>(nodes) - L::kNodeBytes,
+        tri_bits = reinterpret_cast<unsigned long long>(tris);
     asm volatile("" : "+v"(node_bits), "+v"(tri_bits));
     const gptr node_base = (gptr)node_bits, tri_base = (gptr)tri_bits;
     while (__ballot(top != 0)) {
@@ -75,7 +79,9 @@ __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const
             const bool is_node = top > 0;
             f32x4 d[L::kVecs];
             if (TOP && top >= kLdsTag) {
-                const __attribute__((address_space(3))) f32x4* p = (const __attribute__((address_space(3))) f32x4*)((__attribute__((address_space(3))) const char*)image + (unsigned)(top - kLdsTag));
+                const __attribute__((address_space(3))) f32x4* p =
+                    (const __attribute__((address_space(3))) f32x4*)((__attribute__((address_space(3))) const char*)image
+                    + (unsigned)(top - kLdsTag));
 #pragma unroll
                 for (int k = 0; k < L::kNodeVecs; k++) d[k] = p[k];
             } else {
@@ -95,9 +101,11 @@ __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const
             const int popped = *sp;
             // every load in flight before anything is consumed (see unified_chunk in traversal.hip)
             if constexpr (L::kVecs == 13)
-                asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]));
+                asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]),
+                    "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]));
             else
-                asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]));
+                asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]),
+                    "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]));
             if (is_node) {
                 // mapping_gpu.impala:136-153.  The pop frees the slot sp points at; hit children are written from there
                 // upwards, each write holding either the child (not nearer than the best so far) or the previous best.
@@ -108,7 +116,8 @@ __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const
                     float te;
                     const int child = __float_as_int(wide_bound<N>(d, 6, k));
                     const bool hit = slab_canonical(ray, wide_bound<N>(d, 0, k), wide_bound<N>(d, 1, k), wide_bound<N>(d, 2, k),
-                                                    wide_bound<N>(d, 3, k), wide_bound<N>(d, 4, k), wide_bound<N>(d, 5, k), te) && child != 0;
+                                                    wide_bound<N>(d, 3, k), wide_bound<N>(d, 4, k), wide_bound<N>(d, 5, k), te)
+                                                        && child != 0;
                     if (hit) {
                         const bool nearer = ANY || te < tnear;                // strict < (:145)
                         *wp = nearer ? cur : child; wp += kWave;
@@ -129,7 +138,8 @@ __device__ __forceinline__ void wide_chunk(const char* __restrict__ nodes, const
                 for (int k = 0; k < 4; k++) {
                     valid = valid && pid[k] != -1;                            // an unused slot ends the packet (mapping_cpu.impala:38)
                     float t, u, v, abs_det;
-                    const bool pre = tri_pre(ray, d[0][k], d[1][k], d[2][k], d[3][k], d[4][k], d[5][k], d[6][k], d[7][k], d[8][k], d[9][k], d[10][k], d[11][k], t, u, v, abs_det);
+                    const bool pre = tri_pre(ray, d[0][k], d[1][k], d[2][k], d[3][k], d[4][k], d[5][k], d[6][k], d[7][k], d[8][k], d[9][k],
+                        d[10][k], d[11][k], t, u, v, abs_det);
                     if (pre && valid && !(ANY && found) && t <= abs_det * ray.tmax) {
                         const float inv_det = 1.0f / abs_det;
                         const float th = t * inv_det;
@@ -221,9 +231,12 @@ __device__ __forceinline__ void stage_wide_top(const char* __restrict__ nodes, l
 template <bool ANY, int N, int LDS_N, int WAVES>
 __global__ __launch_bounds__(kWave * WAVES) void k_wide_top_persist(const char* __restrict__ nodes, const Tri4* __restrict__ tris,
                                                                    const Ray1* __restrict__ rays, Hit1* __restrict__ hits, int n,
-                                                                   Ctl* ctl, int* __restrict__ deep_list, int* __restrict__ tickets, int grid_w) {
-    constexpr int kStackInts = WAVES * (LDS_N + N) * kWave, kImageInts = WideTop<N>::kRecords * (int)WideLayout<N>::kNodeBytes / 4, kGroup = 32;
-    static_assert((kStackInts + kImageInts + WideTop<N>::kRecords) * 4 <= 160 * 1024, "one workgroup per CU must fit its stacks and records in LDS");
+                                                                   Ctl* ctl, int* __restrict__ deep_list, int* __restrict__ tickets,
+                                                                       int grid_w) {
+    constexpr int kStackInts = WAVES * (LDS_N + N) * kWave, kImageInts = WideTop<N>::kRecords * (int)WideLayout<N>::kNodeBytes / 4,
+        kGroup = 32;
+    static_assert((kStackInts + kImageInts + WideTop<N>::kRecords) * 4 <= 160 * 1024,
+        "one workgroup per CU must fit its stacks and records in LDS");
     __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + kImageInts + WideTop<N>::kRecords];
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
     lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + N) * kWave + lane;
@@ -232,13 +245,15 @@ __global__ __launch_bounds__(kWave * WAVES) void k_wide_top_persist(const char* 
     __syncthreads();
     const int total_chunks = (n + kWave - 1) / kWave, stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
     int* counter = tickets + stripe * kCounterStride;
-    int t = stripe_rank(wave);                                               // a wave's first ticket: its rank inside the stripe (wave-major, traversal_top.h)
+    // a wave's first ticket: its rank inside the stripe (wave-major, traversal_top.h)
+    int t = stripe_rank(wave);
     if (grid_w < 0) grid_w = detect_ray_grid(rays, n);
     grid_w = __builtin_amdgcn_readfirstlane(grid_w > 0 && (grid_w & 7) == 0 ? grid_w : 0);
     for (;;) {
         const int group_first = ((t / kGroup) * kStripes + stripe) * kGroup, chunk = group_first + t % kGroup;
         if (group_first >= total_chunks) break;                              // this stripe's share is used up
-        if (chunk < total_chunks) wide_chunk<ANY, N, LDS_N, true>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, image, kLdsTag, grid_w);
+        if (chunk < total_chunks) wide_chunk<ANY, N, LDS_N, true>(nodes, tris, rays, hits, n, ctl, deep_list, col, chunk * kWave, image,
+            kLdsTag, grid_w);
         int t_next = 0;
         if (lane == 0) t_next = atomicAdd(counter, 1);
         t = stripe_waves + __builtin_amdgcn_readfirstlane(t_next);
@@ -257,7 +272,8 @@ __device__ __forceinline__ HitAcc wide_ray_literal(const char* __restrict__ node
         float tnear = ray.tmax;
 #pragma unroll
         for (int q = 0; q < N / 4; q++) {
-            const float4 lx = p[0 * (N / 4) + q], hx = p[1 * (N / 4) + q], ly = p[2 * (N / 4) + q], hy = p[3 * (N / 4) + q], lz = p[4 * (N / 4) + q], hz = p[5 * (N / 4) + q];
+            const float4 lx = p[0 * (N / 4) + q], hx = p[1 * (N / 4) + q], ly = p[2 * (N / 4) + q], hy = p[3 * (N / 4) + q],
+                lz = p[4 * (N / 4) + q], hz = p[5 * (N / 4) + q];
             const int4 ch = *reinterpret_cast<const int4*>(p + 6 * (N / 4) + q);
             const float blx[4] = {lx.x, lx.y, lx.z, lx.w}, bhx[4] = {hx.x, hx.y, hx.z, hx.w};
             const float bly[4] = {ly.x, ly.y, ly.z, ly.w}, bhy[4] = {hy.x, hy.y, hy.z, hy.w};
@@ -285,7 +301,8 @@ __device__ __forceinline__ HitAcc wide_ray_literal(const char* __restrict__ node
                 for (int k = 0; k < 4; k++) {
                     if (ids[k] == -1) break;                                  // is_valid (mapping_cpu.impala:38)
                     float t, u, v;
-                    if (intersect_tri(ray, q[0][k], q[1][k], q[2][k], q[3][k], q[4][k], q[5][k], q[6][k], q[7][k], q[8][k], q[9][k], q[10][k], q[11][k], t, u, v)) {
+                    if (intersect_tri(ray, q[0][k], q[1][k], q[2][k], q[3][k], q[4][k], q[5][k], q[6][k], q[7][k], q[8][k], q[9][k],
+                        q[10][k], q[11][k], t, u, v)) {
                         hit.id = ids[k] & 0x7FFFFFFF; hit.t = t; hit.u = u; hit.v = v;
                         ray.tmax = t;
                         if (ANY) return hit;
@@ -298,14 +315,15 @@ __device__ __forceinline__ HitAcc wide_ray_literal(const char* __restrict__ node
     return hit;
 }
 
-// kFinishGroups one-wave workgroups, each taking every kFinishGroups-th batch of 64 deep rays (one wave until round 4: a launch with many deep rays
-// waited for a serial drain); the last workgroup to finish resets the launch's control words (finish_launch's protocol).
+// kFinishGroups one-wave workgroups, each taking every kFinishGroups-th batch of 64 deep rays (one wave until round 4: a launch with many
+// deep rays waited for a serial drain); the last workgroup to finish resets the launch's control words (finish_launch's protocol).
 template <bool ANY, int N>
 __global__ __launch_bounds__(kWave) void k_wide_finish(const char* __restrict__ nodes, const Tri4* __restrict__ tris,
                                                         const Ray1* __restrict__ rays, Hit1* __restrict__ hits,
                                                         Ctl* ctl, const int* __restrict__ deep_list, int* deep_stack, int* tickets) {
     __shared__ int stack_lds[kStackCap * kWave];                    // the reference's 64 entries per lane, in LDS (see DeepStack)
-    if (tickets && blockIdx.x == 0) for (int k = threadIdx.x; k < 4 * 64; k += kWave) tickets[k * 16] = 0;     // the persistent form's ticket counters, ready for the next launch
+    // the persistent form's ticket counters, ready for the next launch
+    if (tickets && blockIdx.x == 0) for (int k = threadIdx.x; k < 4 * 64; k += kWave) tickets[k * 16] = 0;
     const int count = ctl->deep_count;
     if (count > 0) {
         DeepStack st{(lds_int*)stack_lds + threadIdx.x, &ctl->err};
@@ -316,17 +334,21 @@ __global__ __launch_bounds__(kWave) void k_wide_finish(const char* __restrict__ 
         }
     }
     if (threadIdx.x == 0) {
-        // (every workgroup has read deep_count before it counts itself done, so the last one may zero it; no deep rays -- the usual case --: workgroup 0 rewrites the zeros)
+        // (every workgroup has read deep_count before it counts itself done, so the last one may zero it; no deep rays -- the usual case
+        // --: workgroup 0 rewrites the zeros)
         const bool last = gridDim.x == 1 || (count == 0 ? blockIdx.x == 0 : atomicAdd(&ctl->finish_done, 1) == (int)gridDim.x - 1);
-        if (last) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; ctl->finish_done = 0; report_error(ctl); }
+        if (last) { ctl->stats[7] += (unsigned long long)count; ctl->counter = 0; ctl->deep_count = 0; ctl->finish_done = 0;
+            report_error(ctl); }
     }
 }
 
 #define WIDE_LAUNCH_ARGS DeviceState& s, const void* nodes, const Tri4* tris, const Ray1* rays, Hit1* hits, int n, hipStream_t stream
 template <bool ANY, int N, int LDS_N, int XCD> void L_wide_single(WIDE_LAUNCH_ARGS) {
     ensure_deep_list(s, n);
-    hipLaunchKernelGGL((k_wide_single<ANY, N, LDS_N, XCD>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, n, s.ctl(), s.deep_list, n >= kGridMinRays ? g_ray_grid : 0);
-    hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(kFinishGroups), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, (int*)nullptr);
+    hipLaunchKernelGGL((k_wide_single<ANY, N, LDS_N, XCD>), dim3(blocks_for(n)), dim3(kWave), 0, stream, (const char*)nodes, tris, rays,
+        hits, n, s.ctl(), s.deep_list, n >= kGridMinRays ? g_ray_grid : 0);
+    hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(kFinishGroups), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(),
+        s.deep_list, s.deep_stack, (int*)nullptr);
 }
 // "top": the persistent form with the staged top levels for launches that fill the chip (as the BVH2 default: rodent_hip_top_min_rays),
 // the one-chunk kernel below that
@@ -343,6 +365,8 @@ template <bool ANY, int N, int LDS_N> void L_wide_top(WIDE_LAUNCH_ARGS) {
     }
     constexpr int kWaves = 16;
     const int groups = ((s.num_cus + kStripes - 1) / kStripes) * kStripes;   // one workgroup per CU, the same number in every stripe
-    hipLaunchKernelGGL((k_wide_top_persist<ANY, N, LDS_N, kWaves>), dim3(groups), dim3(kWave * kWaves), 0, stream, (const char*)nodes, tris, rays, hits, n, s.ctl(), s.deep_list, s.tickets, g_ray_grid);
-    hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(kFinishGroups), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(), s.deep_list, s.deep_stack, s.tickets);
+    hipLaunchKernelGGL((k_wide_top_persist<ANY, N, LDS_N, kWaves>), dim3(groups), dim3(kWave * kWaves), 0, stream, (const char*)nodes,
+        tris, rays, hits, n, s.ctl(), s.deep_list, s.tickets, g_ray_grid);
+    hipLaunchKernelGGL((k_wide_finish<ANY, N>), dim3(kFinishGroups), dim3(kWave), 0, stream, (const char*)nodes, tris, rays, hits, s.ctl(),
+        s.deep_list, s.deep_stack, s.tickets);
 }

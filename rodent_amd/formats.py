@@ -165,4 +165,5 @@ def read_bvh_bin(path, node_dtype=None, tri_dtype=None):
 
 def write_bvh_bin(path, nodes, tris, append=False):
     with open(path, "ab" if append else "wb") as f:
-        f.write(struct.pack("<II", nodes.dtype.itemsize, tris.dtype.itemsize) + _pack_buffer(nodes.tobytes()) + _pack_buffer(tris.tobytes()))
+        f.write(struct.pack("<II", nodes.dtype.itemsize,
+            tris.dtype.itemsize) + _pack_buffer(nodes.tobytes()) + _pack_buffer(tris.tobytes()))

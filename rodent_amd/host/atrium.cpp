@@ -68,7 +68,8 @@ void vase_with_plant(Builder& b, V3 base, float s, Rng& rng, int mat_vase, int m
     const V3 top = base + V3(0, 1.6f * s, 0);
     for (int i = 0; i < 1800 * b.detail * b.detail; i++) {      // foliage: tiny incoherent triangles
         const float a = rng.range(0, 6.2831853f), e = rng.range(0.1f, 1.5f), d = rng.range(0.2f, 1.0f) * 1.4f * s;
-        const V3 c = top + V3(d * (float)std::cos(a) * (float)std::cos(e), d * (float)std::sin(e) * 1.3f, d * (float)std::sin(a) * (float)std::cos(e));
+        const V3 c = top + V3(d * (float)std::cos(a) * (float)std::cos(e), d * (float)std::sin(e) * 1.3f,
+            d * (float)std::sin(a) * (float)std::cos(e));
         const float l = rng.range(0.04f, 0.12f) * s;
         const V3 t1(rng.range(-1, 1), rng.range(-1, 1), rng.range(-1, 1)), t2(rng.range(-1, 1), rng.range(-1, 1), rng.range(-1, 1));
         const uint32_t v0 = b.vert(c), v1 = b.vert(c + t1 * l), v2 = b.vert(c + t2 * l);
@@ -80,7 +81,8 @@ void relief(Builder& b, V3 c, float r, Rng& rng) {
     const float p1 = rng.range(0, 6.28f), p2 = rng.range(0, 6.28f);
     b.patch(128, 64, [&](float u, float v) {
         const double th = kPi * v, ph = 2 * kPi * u;
-        const float bump = 1.0f + 0.08f * (float)std::sin(9 * ph + p1) * (float)std::sin(7 * th + p2) + 0.04f * (float)std::sin(23 * ph) * (float)std::sin(19 * th);
+        const float bump = 1.0f + 0.08f * (float)std::sin(9 * ph + p1) * (float)std::sin(7 * th + p2) + 0.04f * (float)std::sin(23 * ph)
+            * (float)std::sin(19 * th);
         return c + V3((float)(std::sin(th) * std::cos(ph)), (float)std::cos(th), (float)(std::sin(th) * std::sin(ph)) * 0.5f) * (r * bump);
     });
 }
@@ -117,7 +119,8 @@ void generate_atrium(TriMesh& mesh, uint64_t seed, int detail) {
     for (int i = 0; i < 6; i++) {
         const float x = -1500.0f + 600.0f * i;
         const V3 lo(x - 120, Y - 20, -90), hi(x + 120, Y - 20, 90);
-        const uint32_t v0 = b.vert({lo.x, lo.y, lo.z}), v1 = b.vert({hi.x, lo.y, lo.z}), v2 = b.vert({hi.x, lo.y, hi.z}), v3 = b.vert({lo.x, lo.y, hi.z});
+        const uint32_t v0 = b.vert({lo.x, lo.y, lo.z}), v1 = b.vert({hi.x, lo.y, lo.z}), v2 = b.vert({hi.x, lo.y, hi.z}),
+            v3 = b.vert({lo.x, lo.y, hi.z});
         b.quad(v0, v1, v2, v3);
     }
 

@@ -23,7 +23,8 @@ template <typename T> bool read_buffer(FILE* f, std::vector<T>& v) {
     const long here = ftell(f);
     if (here < 0 || fseek(f, 0, SEEK_END) != 0) return false;
     const long end = ftell(f);
-    if (end < here || fseek(f, here, SEEK_SET) != 0 || (uint64_t)(end - here) < hdr[1] || (uint64_t)hdr[0] > 255ull * hdr[1] + 16) return false;
+    if (end < here || fseek(f, here, SEEK_SET) != 0 || (uint64_t)(end - here) < hdr[1]
+        || (uint64_t)hdr[0] > 255ull * hdr[1] + 16) return false;
     std::vector<uint8_t> c(hdr[1]);
     if (hdr[1] && fread(c.data(), 1, c.size(), f) != c.size()) return false;
     v.resize(hdr[0] / sizeof(T));
@@ -46,7 +47,8 @@ template <typename T> bool read_buffer_file(const std::string& path, std::vector
 }
 
 // appends one layout to data/bvh.bin
-template <typename Node, typename Tri> bool append_bvh_bin(const std::string& path, const std::vector<Node>& nodes, const std::vector<Tri>& tris) {
+template <typename Node,
+    typename Tri> bool append_bvh_bin(const std::string& path, const std::vector<Node>& nodes, const std::vector<Tri>& tris) {
     FILE* f = fopen(path.c_str(), "ab");
     if (!f) return false;
     const uint32_t sizes[2] = {(uint32_t)sizeof(Node), (uint32_t)sizeof(Tri)};

@@ -244,7 +244,8 @@ std::vector<Cand> expand(Cand&& c, int level, const std::vector<Triangle>& tris,
         kids[pick] = std::move(l);
         kids.push_back(std::move(r));
     }
-    if (kids.size() > 1) std::stable_sort(kids.begin(), kids.end(), [](const Cand& a, const Cand& b) { return a.refs.size() > b.refs.size(); });
+    if (kids.size() > 1) std::stable_sort(kids.begin(), kids.end(),
+        [](const Cand& a, const Cand& b) { return a.refs.size() > b.refs.size(); });
     return kids;
 }
 
@@ -255,7 +256,8 @@ std::vector<uint32_t> leaf_ids(const Cand& c) {
 }
 
 // The serial build of one subtree: a stack of tasks, depth first, child 0 first.
-void build_piece(Cand&& root, int root_level, const std::vector<Triangle>& tris, const BuildParams& p, float spatial_threshold, Piece& out) {
+void build_piece(Cand&& root, int root_level, const std::vector<Triangle>& tris, const BuildParams& p, float spatial_threshold,
+    Piece& out) {
     struct Task { Cand c; int parent, slot, level; };
     std::vector<Task> stack;
     stack.push_back({std::move(root), -1, 0, root_level});
@@ -292,8 +294,8 @@ void build_piece(Cand&& root, int root_level, const std::vector<Triangle>& tris,
 // Large inputs are built on several host threads WITHOUT changing the result: the serial builder works through a subtree completely before
 // it touches the next one, so a subtree's nodes and leaves are contiguous runs of its output.  The top of the tree (tasks above
 // `piece_limit` references) is expanded first, in the serial order, into a list of events -- node, leaf, or "a subtree goes here" --; the
-// subtrees are built independently, each numbering its nodes and leaves from zero; then the events are replayed and every subtree is spliced
-// in with its offsets.  Same nodes, same order, same leaves as one thread would produce (tests/test_builder.py).
+// subtrees are built independently, each numbering its nodes and leaves from zero; then the events are replayed and every subtree is
+// spliced in with its offsets.  Same nodes, same order, same leaves as one thread would produce (tests/test_builder.py).
 WideBvh build_wide_bvh(const std::vector<Triangle>& tris, const BuildParams& p) {
     WideBvh out; out.arity = p.arity;
     assert(p.arity >= 2 && p.arity <= 8);
@@ -320,7 +322,8 @@ WideBvh build_wide_bvh(const std::vector<Triangle>& tris, const BuildParams& p) 
         }
     } else {
         const size_t piece_limit = std::max(kMinPieceRefs, tris.size() / (size_t)(8 * threads));
-        struct Event { int kind; int parent, slot; WideNode node; std::vector<uint32_t> ids; int piece; };    // kind 0: node, 1: leaf, 2: piece; parent = index of the parent's node EVENT
+        // kind 0: node, 1: leaf, 2: piece; parent = index of the parent's node EVENT
+        struct Event { int kind; int parent, slot; WideNode node; std::vector<uint32_t> ids; int piece; };
         std::vector<Event> events;
         struct PieceIn { Cand c; int level; };
         std::vector<PieceIn> todo;
@@ -400,7 +403,8 @@ WideBvh build_wide_bvh(const std::vector<Triangle>& tris, const BuildParams& p) 
         }
     }
     out.nodes = std::move(whole.nodes); out.leaves = std::move(whole.leaves);
-    out.num_refs = whole.num_refs; out.object_splits = whole.object_splits; out.spatial_splits = whole.spatial_splits; out.depth = whole.depth;
+    out.num_refs = whole.num_refs; out.object_splits = whole.object_splits; out.spatial_splits = whole.spatial_splits;
+    out.depth = whole.depth;
 
     // SAH cost relative to the root area (traversal 1 per inner node, 1 per referenced triangle)
     Box rb; for (int i = 0; i < out.nodes[0].count; i++) rb.grow(out.nodes[0].box[i]);

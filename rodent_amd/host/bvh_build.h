@@ -36,11 +36,13 @@ struct WideBvh {
 struct BuildParams {
     int   arity = 2;
     int   leaf_threshold = 2;
-    float traversal_cost = 1.0f; // cost of visiting an inner node, in units of one triangle test, times its half area (the reference: 1, converter.cpp:120-127)
+    // cost of visiting an inner node, in units of one triangle test, times its half area (the reference: 1, converter.cpp:120-127)
+    float traversal_cost = 1.0f;
     float alpha = 1e-5f;
     bool  spatial_splits = true;
     int   max_depth = 56;        // keeps the traversal stacks (64 entries, stack.impala:53) safe
-    int   threads = 0;           // host threads for inputs of 65 536 triangles and more (0 = all hardware threads); the result does not depend on it
+    // host threads for inputs of 65 536 triangles and more (0 = all hardware threads); the result does not depend on it
+    int   threads = 0;
 };
 
 WideBvh build_wide_bvh(const std::vector<Triangle>& tris, const BuildParams& p);

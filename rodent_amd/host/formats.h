@@ -36,7 +36,8 @@ inline bool load_bvh(const std::string& file, BvhType type, std::vector<Node>& n
                 // the counts must agree with the block size and the block must fit in the file BEFORE anything is allocated
                 const uint64_t payload = sizeof(Node) * (uint64_t)hdr[0] + sizeof(Tri) * (uint64_t)hdr[1];
                 const long here = ftell(f);
-                ok = offset == 12 + payload && here >= 0 && fseek(f, 0, SEEK_END) == 0 && (uint64_t)(ftell(f) - here) >= payload && fseek(f, here, SEEK_SET) == 0;
+                ok = offset == 12 + payload && here >= 0 && fseek(f, 0, SEEK_END) == 0 && (uint64_t)(ftell(f) - here) >= payload
+                    && fseek(f, here, SEEK_SET) == 0;
             }
             if (ok) {
                 nodes.resize(hdr[0]); tris.resize(hdr[1]);

@@ -113,7 +113,8 @@ void png_convert_row(const PngInfo& info, const uint8_t* row, int count, uint8_t
                 bool same = true;
                 for (int c = 0; c < 3 && same; c++) {
                     const int key = (info.trns[2 * c] << 8) | info.trns[2 * c + 1];
-                    const int raw = info.depth == 16 ? (row[2 * ((size_t)x * 3 + c)] << 8) | row[2 * ((size_t)x * 3 + c) + 1] : row[(size_t)x * 3 + c];
+                    const int raw = info.depth == 16
+                        ? (row[2 * ((size_t)x * 3 + c)] << 8) | row[2 * ((size_t)x * 3 + c) + 1] : row[(size_t)x * 3 + c];
                     same = raw == key;
                 }
                 if (same) a = 0;
@@ -170,17 +171,21 @@ int decode_huff(BitReader& br, const Huff& h) {
 
 int extend(int v, int t) { return t == 0 ? 0 : (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v); }
 
-const int kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-                         35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+const int kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
+    28,
+                         35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54,
+                             47, 55, 62, 63};
 
 void idct8x8(const float* in, uint8_t* out, size_t stride) {
     static float c[8][8]; static bool init = false;
     if (!init) {
-        for (int x = 0; x < 8; x++) for (int u = 0; u < 8; u++) c[x][u] = (u == 0 ? 0.35355339059f : 0.5f) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
+        for (int x = 0; x < 8; x++) for (int u = 0; u < 8; u++) c[x][u] = (u == 0 ? 0.35355339059f
+            : 0.5f) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
         init = true;
     }
     float tmp[64];
-    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { float s = 0; for (int u = 0; u < 8; u++) s += c[x][u] * in[8 * y + u]; tmp[8 * y + x] = s; }
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { float s = 0; for (int u = 0; u < 8; u++) s += c[x][u] * in[8 * y + u];
+        tmp[8 * y + x] = s; }
     for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) {
         float s = 0; for (int v = 0; v < 8; v++) s += c[y][v] * tmp[8 * v + x];
         const int q = (int)std::lround(s + 128.0f);
@@ -204,7 +209,8 @@ bool load_png(const std::string& path, ImageRgba8& img, std::string* error) {
         if (pos + 12 + (size_t)len > file.size()) return fail(error, "truncated PNG chunk");
         const uint8_t* type = &file[pos + 4]; const uint8_t* data = &file[pos + 8];
         if (!memcmp(type, "IHDR", 4) && len >= 13) {
-            info.width = (int)be32(data); info.height = (int)be32(data + 4); info.depth = data[8]; info.ctype = data[9]; info.interlace = data[12];
+            info.width = (int)be32(data); info.height = (int)be32(data + 4); info.depth = data[8]; info.ctype = data[9];
+            info.interlace = data[12];
             have_ihdr = true;
         } else if (!memcmp(type, "PLTE", 4)) info.palette.assign(data, data + len);
         else if (!memcmp(type, "tRNS", 4)) info.trns.assign(data, data + len);
@@ -212,14 +218,16 @@ bool load_png(const std::string& path, ImageRgba8& img, std::string* error) {
         else if (!memcmp(type, "IEND", 4)) break;
         pos += 12 + (size_t)len;
     }
-    const bool depth_ok = info.depth == 8 || info.depth == 16 || ((info.ctype == 0 || info.ctype == 3) && (info.depth == 1 || info.depth == 2 || info.depth == 4));
+    const bool depth_ok = info.depth == 8 || info.depth == 16
+        || ((info.ctype == 0 || info.ctype == 3) && (info.depth == 1 || info.depth == 2 || info.depth == 4));
     if (!have_ihdr || info.width <= 0 || info.height <= 0 || info.width > 65536 || info.height > 65536 || !depth_ok ||
         !(info.ctype == 0 || info.ctype == 2 || info.ctype == 3 || info.ctype == 4 || info.ctype == 6) || info.interlace > 1 ||
         (info.ctype == 3 && info.depth == 16))
         return fail(error, "unsupported PNG header");
     const int bits = png_channels(info.ctype) * info.depth, bpp = std::max(1, bits / 8);
     auto stride_of = [&](int w) { return ((size_t)w * bits + 7) / 8; };
-    static const int xs[7] = {0, 4, 0, 2, 0, 1, 0}, ys[7] = {0, 0, 4, 0, 2, 0, 1}, dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4, 2, 2};
+    static const int xs[7] = {0, 4, 0, 2, 0, 1, 0}, ys[7] = {0, 0, 4, 0, 2, 0, 1}, dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4,
+        2, 2};
     size_t raw_size = 0;
     if (!info.interlace) raw_size = (stride_of(info.width) + 1) * (size_t)info.height;
     else for (int p = 0; p < 7; p++) {
@@ -228,13 +236,15 @@ bool load_png(const std::string& path, ImageRgba8& img, std::string* error) {
     }
     std::vector<uint8_t> raw(raw_size);
     uLongf got = (uLongf)raw_size;
-    if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw_size) return fail(error, "PNG data does not inflate to the image size");
+    if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw_size) return fail(error,
+        "PNG data does not inflate to the image size");
     img.width = info.width; img.height = info.height;
     std::vector<uint8_t> rgba((size_t)info.width * info.height * 4);
     if (!info.interlace) {
         const size_t stride = stride_of(info.width);
         if (!unfilter(raw.data(), info.height, stride, bpp)) return fail(error, "bad PNG filter type");
-        for (int y = 0; y < info.height; y++) png_convert_row(info, raw.data() + (stride + 1) * (size_t)y + 1, info.width, &rgba[(size_t)y * info.width * 4], 1);
+        for (int y = 0; y < info.height; y++) png_convert_row(info, raw.data() + (stride + 1) * (size_t)y + 1, info.width,
+            &rgba[(size_t)y * info.width * 4], 1);
     } else {
         size_t off = 0;
         for (int p = 0; p < 7; p++) {
@@ -243,7 +253,8 @@ bool load_png(const std::string& path, ImageRgba8& img, std::string* error) {
             const size_t stride = stride_of(w);
             if (!unfilter(raw.data() + off, h, stride, bpp)) return fail(error, "bad PNG filter type");
             for (int y = 0; y < h; y++)
-                png_convert_row(info, raw.data() + off + (stride + 1) * (size_t)y + 1, w, &rgba[((size_t)(ys[p] + y * dy[p]) * info.width + xs[p]) * 4], dx[p]);
+                png_convert_row(info, raw.data() + off + (stride + 1) * (size_t)y + 1, w,
+                    &rgba[((size_t)(ys[p] + y * dy[p]) * info.width + xs[p]) * 4], dx[p]);
             off += (stride + 1) * (size_t)h;
         }
     }
@@ -261,7 +272,8 @@ bool load_jpg(const std::string& path, ImageRgba8& img, std::string* error) {
     // reads its textures with libjpeg (src/driver/image.cpp:185-238), which decodes all of these.
     uint16_t qt[4][64] = {}; Huff dc[4], ac[4];
     std::vector<JpegComp> comps;
-    std::vector<std::vector<int16_t>> coef;                               // per component: blocks in raster order over the padded grid x 64, natural order
+    // per component: blocks in raster order over the padded grid x 64, natural order
+    std::vector<std::vector<int16_t>> coef;
     int width = 0, height = 0, restart_interval = 0, adobe_transform = -1, hmax = 1, vmax = 1, mcux = 0, mcuy = 0;
     bool progressive = false, any_scan = false;
     size_t pos = 2;
@@ -298,23 +310,28 @@ bool load_jpg(const std::string& path, ImageRgba8& img, std::string* error) {
             progressive = marker == 0xC2;
             height = (d[1] << 8) | d[2]; width = (d[3] << 8) | d[4];
             const int nc = d[5];
-            if ((nc != 1 && nc != 3) || n < 6 + 3 * (size_t)nc || width <= 0 || height <= 0) return fail(error, "unsupported JPEG component count");
+            if ((nc != 1 && nc != 3) || n < 6 + 3 * (size_t)nc || width <= 0 || height <= 0) return fail(error,
+                "unsupported JPEG component count");
             comps.resize(nc);
-            for (int c = 0; c < nc; c++) { comps[c].id = d[6 + 3 * c]; comps[c].h = d[7 + 3 * c] >> 4; comps[c].v = d[7 + 3 * c] & 15; comps[c].tq = d[8 + 3 * c] & 3; }
+            for (int c = 0; c < nc; c++) { comps[c].id = d[6 + 3 * c]; comps[c].h = d[7 + 3 * c] >> 4; comps[c].v = d[7 + 3 * c] & 15;
+                comps[c].tq = d[8 + 3 * c] & 3; }
             // a frame with ONE component is never interleaved: its MCU is a single 8x8 block whatever the sampling factors say
             // (ITU T.81 A.2.2; several encoders write greyscale files with 2x2 factors)
             if (nc == 1) comps[0].h = comps[0].v = 1;
-            for (auto& c : comps) { if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4) return fail(error, "bad JPEG component"); hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+            for (auto& c : comps) { if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4) return fail(error, "bad JPEG component");
+                hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
             mcux = (width + 8 * hmax - 1) / (8 * hmax); mcuy = (height + 8 * vmax - 1) / (8 * vmax);
             coef.resize(nc);
-            for (int c = 0; c < nc; c++) { comps[c].stride = (size_t)mcux * comps[c].h * 8; coef[c].assign((size_t)mcux * comps[c].h * mcuy * comps[c].v * 64, 0); }
+            for (int c = 0; c < nc; c++) { comps[c].stride = (size_t)mcux * comps[c].h * 8;
+                coef[c].assign((size_t)mcux * comps[c].h * mcuy * comps[c].v * 64, 0); }
         } else if (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC) {
             return fail(error, "arithmetic-coded / lossless / hierarchical JPEG is not supported");
         } else if (marker == 0xDD && n >= 2) restart_interval = (d[0] << 8) | d[1];
         else if (marker == 0xEE && n >= 12 && !memcmp(d, "Adobe", 5)) adobe_transform = d[11];
         else if (marker == 0xDA) {                                       // SOS: one scan
             const int ns = n ? d[0] : 0;
-            if (comps.empty() || ns < 1 || ns > (int)comps.size() || n < 1 + 2 * (size_t)ns + 3) return fail(error, "unsupported JPEG scan layout");
+            if (comps.empty() || ns < 1 || ns > (int)comps.size() || n < 1 + 2 * (size_t)ns + 3) return fail(error,
+                "unsupported JPEG scan layout");
             std::vector<int> in_scan;
             for (int k = 0; k < ns; k++) {
                 int found = -1;
@@ -324,10 +341,12 @@ bool load_jpg(const std::string& path, ImageRgba8& img, std::string* error) {
                 in_scan.push_back(found);
             }
             const int ss = d[1 + 2 * ns], se = d[2 + 2 * ns], ah = d[3 + 2 * ns] >> 4, al = d[3 + 2 * ns] & 15;
-            if (progressive ? (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13) : (ss != 0 || se != 63 || ah != 0 || al != 0))
+            if (progressive ? (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13) : (ss != 0 || se != 63
+                || ah != 0 || al != 0))
                 return fail(error, "bad JPEG scan parameters");
             for (int c : in_scan) {
-                if ((!progressive || ss == 0) && ah == 0 && !dc[comps[c].td & 3].defined) return fail(error, "JPEG scan without its DC table");
+                if ((!progressive || ss == 0) && ah == 0 && !dc[comps[c].td & 3].defined) return fail(error,
+                    "JPEG scan without its DC table");
                 if ((!progressive || ss > 0) && !ac[comps[c].ta & 3].defined) return fail(error, "JPEG scan without its AC table");
             }
             BitReader br{&file[pos + 2 + len], file.data() + file.size()};
@@ -337,9 +356,11 @@ bool load_jpg(const std::string& path, ImageRgba8& img, std::string* error) {
             // own blocks: ceil(its width / 8) x ceil(its height / 8) (A.2.2, A.2.3)
             const bool interleaved = ns > 1;
             const JpegComp& c0 = comps[in_scan[0]];
-            const int units_x = interleaved ? mcux : ((width * c0.h + hmax - 1) / hmax + 7) / 8, units_y = interleaved ? mcuy : ((height * c0.v + vmax - 1) / vmax + 7) / 8;
+            const int units_x = interleaved ? mcux : ((width * c0.h + hmax - 1) / hmax + 7) / 8,
+                units_y = interleaved ? mcuy : ((height * c0.v + vmax - 1) / vmax + 7) / 8;
             for (int uy = 0; uy < units_y; uy++) for (int ux = 0; ux < units_x; ux++) {
-                if (restart_interval && until_restart == 0) {            // RSTn: byte-align, skip the marker, reset predictors and the band run
+                // RSTn: byte-align, skip the marker, reset predictors and the band run
+                if (restart_interval && until_restart == 0) {
                     while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) br.p++;
                     if (br.p + 1 < br.end) br.p += 2;
                     br.restart();
@@ -451,7 +472,8 @@ bool load_jpg(const std::string& path, ImageRgba8& img, std::string* error) {
         const int dw = (width * c.h + hmax - 1) / hmax, dh = (height * c.v + vmax - 1) / vmax;      // downsampled size
         std::vector<uint8_t>& out = full[ci];
         out.resize((size_t)width * height);
-        auto in = [&](int x, int y) { return (int)c.plane[(size_t)std::min(std::max(y, 0), dh - 1) * c.stride + (size_t)std::min(std::max(x, 0), dw - 1)]; };
+        auto in = [&](int x, int y) {
+            return (int)c.plane[(size_t)std::min(std::max(y, 0), dh - 1) * c.stride + (size_t)std::min(std::max(x, 0), dw - 1)]; };
         if (hmax % c.h == 0 && vmax % c.v == 0 && fx == 2 && (fy == 1 || fy == 2) && dw >= 2) {
             for (int y = 0; y < height; y++) {
                 const int r = fy == 2 ? y / 2 : y, far = fy == 2 ? ((y & 1) ? r + 1 : r - 1) : r;
@@ -472,7 +494,8 @@ bool load_jpg(const std::string& path, ImageRgba8& img, std::string* error) {
                 }
             }
         } else {
-            for (int y = 0; y < height; y++) for (int x = 0; x < width; x++) out[(size_t)y * width + x] = (uint8_t)in(x * c.h / hmax, y * c.v / vmax);
+            for (int y = 0; y < height; y++) for (int x = 0; x < width; x++) out[(size_t)y * width + x] = (uint8_t)in(x * c.h / hmax,
+                y * c.v / vmax);
         }
     }
     std::vector<uint8_t> rgba((size_t)width * height * 4);
@@ -484,8 +507,10 @@ bool load_jpg(const std::string& path, ImageRgba8& img, std::string* error) {
         if (comps.size() == 1) { px[0] = px[1] = px[2] = (uint8_t)s[0]; }
         else if (ycc) {
             const float Y = (float)s[0], cb = (float)s[1] - 128.0f, cr = (float)s[2] - 128.0f;
-            const int r = (int)std::lround(Y + 1.402f * cr), g = (int)std::lround(Y - 0.344136f * cb - 0.714136f * cr), b = (int)std::lround(Y + 1.772f * cb);
-            px[0] = (uint8_t)std::min(255, std::max(0, r)); px[1] = (uint8_t)std::min(255, std::max(0, g)); px[2] = (uint8_t)std::min(255, std::max(0, b));
+            const int r = (int)std::lround(Y + 1.402f * cr), g = (int)std::lround(Y - 0.344136f * cb - 0.714136f * cr),
+                b = (int)std::lround(Y + 1.772f * cb);
+            px[0] = (uint8_t)std::min(255, std::max(0, r)); px[1] = (uint8_t)std::min(255, std::max(0, g));
+            px[2] = (uint8_t)std::min(255, std::max(0, b));
         } else { px[0] = (uint8_t)s[0]; px[1] = (uint8_t)s[1]; px[2] = (uint8_t)s[2]; }
         px[3] = 255;
     }
@@ -525,7 +550,8 @@ bool load_tga(const std::string& path, ImageRgba8& img, std::string* error) {
             for (int k = 0; k < run && i < count; k++) put(&file[pos]);
             pos += bytes;
         } else {
-            for (int k = 0; k < run && i < count; k++) { if (pos + bytes > file.size()) return fail(error, "truncated TGA"); put(&file[pos]); pos += bytes; }
+            for (int k = 0; k < run && i < count; k++) { if (pos + bytes > file.size()) return fail(error, "truncated TGA");
+                put(&file[pos]); pos += bytes; }
         }
     }
     img.width = width; img.height = height;

@@ -141,7 +141,8 @@ bool load_mtl(const std::string& path, std::unordered_map<std::string, Material>
     if (!in) { std::cerr << "Cannot open MTL file '" << path << "'" << std::endl; return false; }
     std::string line, cur;
     int errors = 0, line_no = 0;
-    auto rest = [](std::istringstream& ls) { std::string s; std::getline(ls, s); auto b = s.find_first_not_of(" \t"); auto e = s.find_last_not_of(" \t\r\n"); return b == std::string::npos ? std::string() : s.substr(b, e - b + 1); };
+    auto rest = [](std::istringstream& ls) { std::string s; std::getline(ls, s); auto b = s.find_first_not_of(" \t");
+        auto e = s.find_last_not_of(" \t\r\n"); return b == std::string::npos ? std::string() : s.substr(b, e - b + 1); };
     while (std::getline(in, line)) {
         line_no++;
         std::istringstream ls(line);
@@ -149,7 +150,8 @@ bool load_mtl(const std::string& path, std::unordered_map<std::string, Material>
         if (!(ls >> cmd) || cmd[0] == '#') continue;
         if (cmd == "newmtl") {
             ls >> cur;
-            if (lib.count(cur)) { std::cerr << "Material redefinition for '" << cur << "' (line " << line_no << ")." << std::endl; errors++; }
+            if (lib.count(cur)) { std::cerr << "Material redefinition for '" << cur << "' (line " << line_no << ")." << std::endl;
+                errors++; }
             lib[cur];
             continue;
         }

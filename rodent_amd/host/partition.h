@@ -27,7 +27,8 @@ inline Part split_range(int n, int rank, int world) {
 constexpr int kTileRows = 16;
 template <typename F>   // f(Part rows) for every tile of `rank`, top to bottom
 inline void for_each_tile(int height, int rank, int world, int tile_rows, F f) {
-    for (int t = rank; t * tile_rows < height; t += world) f(Part{t * tile_rows, (t + 1) * tile_rows < height ? (t + 1) * tile_rows : height});
+    for (int t = rank; t * tile_rows < height; t += world) f(Part{t * tile_rows,
+        (t + 1) * tile_rows < height ? (t + 1) * tile_rows : height});
 }
 inline int tile_rows_of_rank(int height, int rank, int world, int tile_rows) {
     int rows = 0;
@@ -35,14 +36,16 @@ inline int tile_rows_of_rank(int height, int rank, int world, int tile_rows) {
     return rows;
 }
 
-// Which transport the ONE gather of a K-GPU run uses (host/multi_gpu.h DeviceGroup::init): RCCL when it comes up, otherwise one peer copy per piece -- a
-// run on several GPUs must not fail for want of a collective library, and must say what it did.  Pure decision logic (no HIP / RCCL here) so that the CPU
-// suite can test the fallback branch with an injected failure: returns the reason RCCL is NOT used, empty = it is.
+// Which transport the ONE gather of a K-GPU run uses (host/multi_gpu.h DeviceGroup::init): RCCL when it comes up, otherwise one peer copy
+// per piece -- a run on several GPUs must not fail for want of a collective library, and must say what it did.  Pure decision logic (no HIP
+// / RCCL here) so that the CPU suite can test the fallback branch with an injected failure: returns the reason RCCL is NOT used, empty = it
+// is.
 //   ranks > devices (RODENT_SHARE_GPUS: ranks share devices; RCCL cannot place two ranks on one device), an injected failure
 //   (RODENT_FORCE_RCCL_INIT_FAILURE), or ncclCommInitAll's own error string.
 inline std::string rccl_unused_reason(int ranks, int devices, bool shared, bool injected_failure, const std::string& init_error) {
     if (ranks <= 1) return "";
-    if (shared && devices < ranks) return "RODENT_SHARE_GPUS: " + std::to_string(ranks) + " ranks on " + std::to_string(devices) + " device(s)";
+    if (shared && devices < ranks) return "RODENT_SHARE_GPUS: " + std::to_string(ranks) + " ranks on " + std::to_string(devices)
+        + " device(s)";
     if (injected_failure) return "RODENT_FORCE_RCCL_INIT_FAILURE";
     if (!init_error.empty()) return "ncclCommInitAll: " + init_error;
     return "";

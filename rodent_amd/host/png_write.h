@@ -11,7 +11,8 @@ namespace rodent {
 
 inline uint32_t png_crc(const uint8_t* p, size_t n, uint32_t crc = 0xFFFFFFFFu) {
     static uint32_t table[256]; static bool init = false;
-    if (!init) { for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; } init = true; }
+    if (!init) { for (uint32_t i = 0; i < 256; i++) { uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; } init = true; }
     for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
     return crc;
 }

@@ -68,7 +68,8 @@ bool build_scene_from_obj(const std::string& obj_path, SceneData& scene, const B
     lib[""] = dummy;
     std::vector<std::string> names = mesh.material_names;
     for (auto& n : names)
-        if (!n.empty() && !lib.count(n)) { std::clog << "Missing material definition for '" << n << "'. Replaced by dummy material." << std::endl; n = ""; }
+        if (!n.empty() && !lib.count(n)) {
+            std::clog << "Missing material definition for '" << n << "'. Replaced by dummy material." << std::endl; n = ""; }
 
     if (mesh.num_tris() == 0) { std::cerr << "The OBJ file '" << obj_path << "' has no faces" << std::endl; return false; }
     // merge identical materials, drop unused ones (first occurrence keeps its place)
@@ -116,11 +117,13 @@ bool build_scene_from_obj(const std::string& obj_path, SceneData& scene, const B
     for (size_t t = 0; t < nt; t++) mesh.indices[4 * t + 3] = (uint32_t)new_id[canon[mesh.indices[4 * t + 3]]];
 
     // mesh buffers
-    auto pad4 = [](const std::vector<V3>& v) { std::vector<float> o(v.size() * 4, 0.0f); for (size_t i = 0; i < v.size(); i++) { o[4 * i] = v[i].x; o[4 * i + 1] = v[i].y; o[4 * i + 2] = v[i].z; } return o; };
+    auto pad4 = [](const std::vector<V3>& v) { std::vector<float> o(v.size() * 4, 0.0f);
+        for (size_t i = 0; i < v.size(); i++) { o[4 * i] = v[i].x; o[4 * i + 1] = v[i].y; o[4 * i + 2] = v[i].z; } return o; };
     scene.vertices = pad4(mesh.vertices); scene.normals = pad4(mesh.normals); scene.face_normals = pad4(mesh.face_normals);
     scene.indices.assign(mesh.indices.begin(), mesh.indices.end());
     scene.texcoords.assign(mesh.vertices.size() * 4, 0.0f);
-    for (size_t i = 0; i < mesh.texcoords.size() && i < mesh.vertices.size(); i++) { scene.texcoords[4 * i] = mesh.texcoords[i].x; scene.texcoords[4 * i + 1] = mesh.texcoords[i].y; }
+    for (size_t i = 0; i < mesh.texcoords.size() && i < mesh.vertices.size(); i++) { scene.texcoords[4 * i] = mesh.texcoords[i].x;
+        scene.texcoords[4 * i + 1] = mesh.texcoords[i].y; }
 
     // lights (converter.cpp:770-851): one per emissive triangle
     scene.light_ids.assign(nt, 0);
@@ -186,7 +189,8 @@ bool validate_scene(const SceneData& s, std::string* why) {
         if ((uint32_t)s.indices[4 * t + 3] >= s.materials.size()) return bad("material index out of range");
         if (s.light_ids[t] < 0 || (s.light_ids[t] > 0 && (size_t)s.light_ids[t] >= s.lights.size())) return bad("light id out of range");
         // the shader looks an emitter's triangle up in the light table (light id 0 included): the entry must exist
-        if (s.materials[s.indices[4 * t + 3]].emissive && (size_t)s.light_ids[t] >= s.lights.size()) return bad("emissive triangle without an entry in the light table");
+        if (s.materials[s.indices[4 * t + 3]].emissive
+            && (size_t)s.light_ids[t] >= s.lights.size()) return bad("emissive triangle without an entry in the light table");
     }
     for (const Node2& n : s.nodes)
         for (int k = 0; k < 2; k++) {
@@ -200,9 +204,11 @@ bool validate_scene(const SceneData& s, std::string* why) {
         if ((uint32_t)t.geom_id >= s.materials.size()) return bad("BVH triangle refers to a material that does not exist");
     }
     for (const RodentMaterial& m : s.materials)
-        if (m.tex_kd < 0 || (size_t)m.tex_kd > s.textures.size() || m.tex_ks < 0 || (size_t)m.tex_ks > s.textures.size()) return bad("material refers to a texture that does not exist");
+        if (m.tex_kd < 0 || (size_t)m.tex_kd > s.textures.size() || m.tex_ks < 0
+            || (size_t)m.tex_ks > s.textures.size()) return bad("material refers to a texture that does not exist");
     for (const RodentTexture& t : s.textures)
-        if (t.width <= 0 || t.height <= 0 || (uint64_t)t.offset + (uint64_t)t.width * (uint64_t)t.height > s.texels.size()) return bad("texture outside the texel pool");
+        if (t.width <= 0 || t.height <= 0
+            || (uint64_t)t.offset + (uint64_t)t.width * (uint64_t)t.height > s.texels.size()) return bad("texture outside the texel pool");
     return true;
 }
 
@@ -214,13 +220,16 @@ bool load_scene(const std::string& path, SceneData& s) {
     if (ok) {
         // the header's counts must add up to the file's size before anything is allocated
         const uint64_t nv = hdr[4], nt = hdr[5];
-        const uint64_t expect = 48 + 16 * nv * 2 + 16 * nt * 2 + sizeof(Node2) * (uint64_t)hdr[6] + sizeof(Tri1) * (uint64_t)hdr[7] + sizeof(RodentMaterial) * (uint64_t)hdr[8] +
-                                sizeof(RodentLight) * (uint64_t)hdr[9] + 4 * nt + 16 * nv + sizeof(RodentTexture) * (uint64_t)hdr[10] + 4ull * hdr[11];
+        const uint64_t expect = 48 + 16 * nv * 2 + 16 * nt * 2 + sizeof(Node2) * (uint64_t)hdr[6] + sizeof(Tri1) * (uint64_t)hdr[7]
+            + sizeof(RodentMaterial) * (uint64_t)hdr[8] +
+                                sizeof(RodentLight) * (uint64_t)hdr[9] + 4 * nt + 16 * nv + sizeof(RodentTexture) * (uint64_t)hdr[10]
+                                    + 4ull * hdr[11];
         ok = fseek(f, 0, SEEK_END) == 0 && (uint64_t)ftell(f) == expect && fseek(f, 48, SEEK_SET) == 0;
     }
     if (ok) {
         s.default_spp = (int32_t)hdr[2]; s.default_max_path_len = (int32_t)hdr[3];
-        auto get = [&](auto& vec, size_t count) { vec.resize(count); ok = ok && (count == 0 || fread(vec.data(), sizeof(vec[0]), count, f) == count); };
+        auto get = [&](auto& vec, size_t count) { vec.resize(count);
+            ok = ok && (count == 0 || fread(vec.data(), sizeof(vec[0]), count, f) == count); };
         get(s.vertices, 4ull * hdr[4]); get(s.normals, 4ull * hdr[4]); get(s.face_normals, 4ull * hdr[5]); get(s.indices, 4ull * hdr[5]);
         get(s.nodes, hdr[6]); get(s.tris, hdr[7]); get(s.materials, hdr[8]); get(s.lights, hdr[9]); get(s.light_ids, hdr[5]);
         get(s.texcoords, 4ull * hdr[4]); get(s.textures, hdr[10]); get(s.texels, hdr[11]);

@@ -38,9 +38,11 @@ struct SceneData {
 };
 
 struct BuildParams;
-bool build_scene_from_obj(const std::string& obj_path, SceneData& scene, const BuildParams* bvh = nullptr);   // bvh: builder parameters other than the defaults (arity is always 2)
+// bvh: builder parameters other than the defaults (arity is always 2)
+bool build_scene_from_obj(const std::string& obj_path, SceneData& scene, const BuildParams* bvh = nullptr);
 bool save_scene(const std::string& path, const SceneData& scene);   // ".rscene" binary
-bool load_scene(const std::string& path, SceneData& scene);           // validates counts against the file size and every index (validate_scene)
+// validates counts against the file size and every index (validate_scene)
+bool load_scene(const std::string& path, SceneData& scene);
 bool validate_scene(const SceneData& scene, std::string* why = nullptr);
 
 // The reference converter's data directory (LZ4 buffer files, src/driver/buffer.h; converter.cpp:403-437,805-815,848):

@@ -10,7 +10,8 @@ namespace {
 struct Rng {                                   // splitmix64: portable, seedable
     uint64_t s;
     explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}
-    uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+    uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
     float uni() { return (float)((next() >> 40) * (1.0 / 16777216.0)); }           // [0,1)
     float range(float a, float b) { return a + (b - a) * uni(); }
 };
@@ -20,7 +21,8 @@ const double kPi = 3.14159265358979323846;
 struct Builder {
     TriMesh& m;
     int mat = 0;
-    int detail = 1;                               // every parametric patch is tessellated detail x detail times finer (the "gallery" scene: the atrium at detail 4)
+    // every parametric patch is tessellated detail x detail times finer (the "gallery" scene: the atrium at detail 4)
+    int detail = 1;
     uint32_t vert(V3 p) { m.vertices.push_back(p); return (uint32_t)m.vertices.size() - 1; }
     void tri(uint32_t a, uint32_t b, uint32_t c) { m.indices.insert(m.indices.end(), {a, b, c, (uint32_t)mat}); }
     void quad(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { tri(a, b, c); tri(a, c, d); }

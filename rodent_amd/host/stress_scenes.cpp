@@ -1,6 +1,6 @@
 // Procedural stand-ins for the other scene classes of the reference's benchmark suite (benchmarks/benchmark.py:16-21: sponza, crown,
-// san-miguel, powerplant -- 262 K ... 12.7 M triangles; none of them is in the checkout).  Every tuning constant of rounds 1-4 was fitted on
-// the atrium (Sponza class); these scenes exist so that the defaults are measured on trees of another character:
+// san-miguel, powerplant -- 262 K ... 12.7 M triangles; none of them is in the checkout).  Every tuning constant of rounds 1-4 was fitted
+// on the atrium (Sponza class); these scenes exist so that the defaults are measured on trees of another character:
 //   "crown"   one dense organic surface: a knotted tube with a carved, bumpy skin, 4.2 M small triangles of similar size at detail 4 --
 //             many leaves per unit of surface, rays graze a deep, regular tree (the reference's crown.obj, san-miguel's foliage);
 //   "plant"   a hall full of long thin triangles: pipe runs (eight-sided prisms hundreds of radii long, a third of them diagonal), gratings
@@ -33,7 +33,8 @@ void pipe(Builder& b, V3 a, V3 c, float radius, int sides) {
             const double ang = 2 * kPi * k / sides;
             b.vert((end ? c : a) + u * (radius * (float)std::cos(ang)) + v * (radius * (float)std::sin(ang)));
         }
-    for (int k = 0; k < sides; k++) {                                 // ONE segment along the whole run: two triangles per side, as long as the pipe
+    // ONE segment along the whole run: two triangles per side, as long as the pipe
+    for (int k = 0; k < sides; k++) {
         const uint32_t k1 = (uint32_t)((k + 1) % sides);
         b.quad(base + k, base + k1, base + sides + k1, base + sides + k);
     }
@@ -109,7 +110,8 @@ void generate_plant(TriMesh& mesh, uint64_t seed, int detail) {
             a = V3(rng.range(-X + 30, X - 30), rng.range(20, Y - 20), rng.range(-Z + 30, Z - 30));
             const V3 d = normalize(V3(rng.range(-1, 1), rng.range(-0.5f, 0.5f), rng.range(-1, 1)));
             c = a + d * rng.range(400, 2600);
-            c = V3(std::min(X - 10, std::max(-X + 10, c.x)), std::min(Y - 10, std::max(10.0f, c.y)), std::min(Z - 10, std::max(-Z + 10, c.z)));
+            c = V3(std::min(X - 10, std::max(-X + 10, c.x)), std::min(Y - 10, std::max(10.0f, c.y)),
+                std::min(Z - 10, std::max(-Z + 10, c.z)));
         }
         if (length(c - a) > 1.0f) pipe(b, a, c, r, 8);
     }
@@ -142,7 +144,8 @@ void generate_plant(TriMesh& mesh, uint64_t seed, int detail) {
     for (int t = 0; t < 6; t++) {
         const V3 base(-1500.0f + 600.0f * t, 0, (t & 1) ? 500.0f : -500.0f);
         const float r = rng.range(140, 220), h = rng.range(400, 800);
-        b.lathe(base, 48, 24, [&](float v) { return r * (float)std::sqrt(std::max(0.0, 1.0 - std::pow(2.0 * v - 1.0, 8.0))) + 1.0f; }, [&](float v) { return v * h; });
+        b.lathe(base, 48, 24, [&](float v) { return r * (float)std::sqrt(std::max(0.0, 1.0 - std::pow(2.0 * v - 1.0, 8.0))) + 1.0f; },
+            [&](float v) { return v * h; });
     }
     b.detail = 1;
 }

@@ -7,7 +7,8 @@
 #include "../buffer_io.h"
 
 int main(int argc, char** argv) {
-    if (argc != 4 || (strcmp(argv[1], "pack") && strcmp(argv[1], "unpack"))) { std::cerr << "usage: buffer_tool pack raw out.bin | unpack in.bin raw" << std::endl; return 1; }
+    if (argc != 4 || (strcmp(argv[1], "pack") && strcmp(argv[1], "unpack"))) {
+        std::cerr << "usage: buffer_tool pack raw out.bin | unpack in.bin raw" << std::endl; return 1; }
     std::vector<uint8_t> data;
     if (!strcmp(argv[1], "pack")) {
         FILE* f = fopen(argv[2], "rb");
@@ -18,7 +19,8 @@ int main(int argc, char** argv) {
     } else {
         if (!rodent::read_buffer_file(argv[2], data)) { std::cerr << "Invalid buffer file '" << argv[2] << "'" << std::endl; return 1; }
         FILE* f = fopen(argv[3], "wb");
-        if (!f || (data.size() && fwrite(data.data(), 1, data.size(), f) != data.size())) { std::cerr << "Cannot write '" << argv[3] << "'" << std::endl; return 1; }
+        if (!f || (data.size() && fwrite(data.data(), 1, data.size(), f) != data.size())) {
+            std::cerr << "Cannot write '" << argv[3] << "'" << std::endl; return 1; }
         fclose(f);
     }
     return 0;

@@ -54,13 +54,18 @@ int main(int argc, char** argv) {
     if (!rodent::build_scene_from_obj(obj, scene, &bvh)) { std::cerr << "Invalid OBJ file '" << obj << "'" << std::endl; return 1; }
     scene.default_spp = spp; scene.default_max_path_len = max_path_len;
     if (!rodent::save_scene(out, scene)) { std::cerr << "Cannot write '" << out << "'" << std::endl; return 1; }
-    if (!data_dir.empty() && !rodent::save_reference_data(data_dir, scene)) { std::cerr << "Cannot write the data files into '" << data_dir << "'" << std::endl; return 1; }
+    if (!data_dir.empty() && !rodent::save_reference_data(data_dir, scene)) {
+        std::cerr << "Cannot write the data files into '" << data_dir << "'" << std::endl; return 1; }
     if (!verify_dir.empty()) {
         rodent::SceneData back;
-        if (!rodent::load_reference_data(verify_dir, back)) { std::cerr << "Cannot read the data files in '" << verify_dir << "'" << std::endl; return 1; }
-        auto same = [](const auto& a, const auto& b) { return a.size() == b.size() && (a.empty() || !memcmp(a.data(), b.data(), a.size() * sizeof(a[0]))); };
-        const bool ok = same(back.vertices, scene.vertices) && same(back.normals, scene.normals) && same(back.face_normals, scene.face_normals) &&
-                        same(back.indices, scene.indices) && same(back.texcoords, scene.texcoords) && same(back.nodes, scene.nodes) && same(back.tris, scene.tris) &&
+        if (!rodent::load_reference_data(verify_dir, back)) {
+            std::cerr << "Cannot read the data files in '" << verify_dir << "'" << std::endl; return 1; }
+        auto same = [](const auto& a, const auto& b) {
+            return a.size() == b.size() && (a.empty() || !memcmp(a.data(), b.data(), a.size() * sizeof(a[0]))); };
+        const bool ok = same(back.vertices, scene.vertices) && same(back.normals, scene.normals)
+            && same(back.face_normals, scene.face_normals) &&
+                        same(back.indices, scene.indices) && same(back.texcoords, scene.texcoords) && same(back.nodes, scene.nodes)
+                            && same(back.tris, scene.tris) &&
                         same(back.light_ids, scene.light_ids) && same(back.lights, scene.lights);
         if (!ok) { std::cerr << "The data files in '" << verify_dir << "' differ from the converted scene" << std::endl; return 1; }
         std::cout << "Data files in '" << verify_dir << "' match the converted scene" << std::endl;

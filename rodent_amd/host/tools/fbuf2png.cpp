@@ -37,7 +37,8 @@ int main(int argc, char** argv) {
     std::ifstream in(files[0], std::ifstream::binary);
     if (!in) return 1;
     std::vector<float> img((size_t)width * height);
-    if (!in.read((char*)img.data(), img.size() * sizeof(float))) { std::cerr << "Not enough data in the float buffer" << std::endl; return 1; }
+    if (!in.read((char*)img.data(), img.size() * sizeof(float))) { std::cerr << "Not enough data in the float buffer" << std::endl;
+        return 1; }
     const float tmax = normalize ? *std::max_element(img.begin(), img.end()) : 1.0f;
     std::vector<uint8_t> px(img.size() * 4);
     for (size_t i = 0; i < img.size(); i++) {

@@ -7,9 +7,11 @@
 #include "../partition.h"
 
 int main(int argc, char** argv) {
-    // partition_check transport ranks devices shared injected [init error]: the gather's transport decision (host/partition.h rccl_unused_reason)
+    // partition_check transport ranks devices shared injected [init error]: the gather's transport decision (host/partition.h
+    // rccl_unused_reason)
     if (argc >= 6 && std::string(argv[1]) == "transport") {
-        const std::string why = rodent::rccl_unused_reason(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]) != 0, atoi(argv[5]) != 0, argc > 6 ? argv[6] : "");
+        const std::string why = rodent::rccl_unused_reason(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]) != 0, atoi(argv[5]) != 0,
+            argc > 6 ? argv[6] : "");
         std::cout << (why.empty() ? "rccl" : "peer copies: " + why) << "\n";
         return 0;
     }
@@ -17,9 +19,11 @@ int main(int argc, char** argv) {
     const int n = atoi(argv[1]), world = atoi(argv[2]), tile_rows = argc == 4 ? atoi(argv[3]) : 0;
     if (n < 0 || world < 1 || tile_rows < 0) { std::cerr << "Invalid arguments" << std::endl; return 1; }
     if (tile_rows > 0) {                                   // interleaved row tiles: one "rank begin end" line per tile
-        for (int r = 0; r < world; r++) rodent::for_each_tile(n, r, world, tile_rows, [&](rodent::Part p) { std::cout << r << " " << p.begin << " " << p.end << "\n"; });
+        for (int r = 0; r < world; r++) rodent::for_each_tile(n, r, world, tile_rows,
+            [&](rodent::Part p) { std::cout << r << " " << p.begin << " " << p.end << "\n"; });
         return 0;
     }
-    for (int r = 0; r < world; r++) { const rodent::Part p = rodent::split_range(n, r, world); std::cout << r << " " << p.begin << " " << p.end << "\n"; }
+    for (int r = 0; r < world; r++) { const rodent::Part p = rodent::split_range(n, r, world);
+        std::cout << r << " " << p.begin << " " << p.end << "\n"; }
     return 0;
 }

@@ -28,7 +28,8 @@ static void usage() {
 
 static void put(FILE* f, V3 o, V3 d) { const float r[6] = {o.x, o.y, o.z, d.x, d.y, d.z}; fwrite(r, 4, 6, f); }
 
-struct SplitMix { uint64_t s; uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+struct SplitMix { uint64_t s; uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
                   float uni() { return (float)(next() >> 40) * (1.0f / 16777216.0f); } };
 
 int main(int argc, char** argv) {
@@ -73,7 +74,8 @@ int main(int argc, char** argv) {
     } else if (!strcmp(argv[1], "random")) {
         if (argc != 6) { std::cerr << "Incorrect number of arguments in random mode" << std::endl; return 1; }
         std::vector<Node4> nodes; std::vector<Tri4> tris;
-        if (!load_bvh(argv[2], BvhType::BVH4_TRI4, nodes, tris) || nodes.empty()) { std::cerr << "Cannot extract scene bounds" << std::endl; return 1; }
+        if (!load_bvh(argv[2], BvhType::BVH4_TRI4, nodes, tris) || nodes.empty()) {
+            std::cerr << "Cannot extract scene bounds" << std::endl; return 1; }
         Box b;
         for (int i = 0; i < 4; i++) {
             b.lo = vmin(b.lo, V3(nodes[0].bounds[0][i], nodes[0].bounds[2][i], nodes[0].bounds[4][i]));

@@ -68,12 +68,17 @@ int main(int argc, char** argv) {
 
     for (int i = 1; i < argc; ++i) {
         if (argv[i][0] != '-') fail(std::string("Unexpected argument '") + argv[i] + "'");
-        auto need = [&](int n) { if (i + n >= argc) fail(std::string("Option '") + argv[i] + "' expects " + std::to_string(n) + " arguments, got " + std::to_string(argc - i)); };
+        auto need = [&](int n) {
+            if (i + n >= argc) fail(std::string("Option '") + argv[i] + "' expects " + std::to_string(n) + " arguments, got "
+            + std::to_string(argc - i)); };
         if (!strcmp(argv[i], "--width")) { need(1); width = strtoul(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "--height")) { need(1); height = strtoul(argv[++i], nullptr, 10); }
-        else if (!strcmp(argv[i], "--eye")) { need(3); eye = V3(strtof(argv[i + 1], nullptr), strtof(argv[i + 2], nullptr), strtof(argv[i + 3], nullptr)); i += 3; }
-        else if (!strcmp(argv[i], "--dir")) { need(3); dir = V3(strtof(argv[i + 1], nullptr), strtof(argv[i + 2], nullptr), strtof(argv[i + 3], nullptr)); i += 3; }
-        else if (!strcmp(argv[i], "--up")) { need(3); up = V3(strtof(argv[i + 1], nullptr), strtof(argv[i + 2], nullptr), strtof(argv[i + 3], nullptr)); i += 3; }
+        else if (!strcmp(argv[i], "--eye")) { need(3);
+            eye = V3(strtof(argv[i + 1], nullptr), strtof(argv[i + 2], nullptr), strtof(argv[i + 3], nullptr)); i += 3; }
+        else if (!strcmp(argv[i], "--dir")) { need(3);
+            dir = V3(strtof(argv[i + 1], nullptr), strtof(argv[i + 2], nullptr), strtof(argv[i + 3], nullptr)); i += 3; }
+        else if (!strcmp(argv[i], "--up")) { need(3);
+            up = V3(strtof(argv[i + 1], nullptr), strtof(argv[i + 2], nullptr), strtof(argv[i + 3], nullptr)); i += 3; }
         else if (!strcmp(argv[i], "--fov")) { need(1); fov = strtof(argv[++i], nullptr); }
         else if (!strcmp(argv[i], "--bench")) { need(1); bench_iter = strtoul(argv[++i], nullptr, 10); }
         else if (!strcmp(argv[i], "-o")) { need(1); out_file = argv[++i]; }
@@ -119,7 +124,8 @@ int main(int argc, char** argv) {
     }
     const RodentSceneDesc desc = scene.desc();
     setup_interface(width, height);
-    for (int r = ngpu - 1; r >= 0; r--) {                                // (the first device last: it stays the current one of render() / get_spp())
+    // (the first device last: it stays the current one of render() / get_spp())
+    for (int r = ngpu - 1; r >= 0; r--) {
         const int d = group.device(r);
         rodent_hip_set_device(d);
         rodent_hip_scene_create(d, &desc);
@@ -138,11 +144,13 @@ int main(int argc, char** argv) {
         else {
             // every GPU its share of this frame, all at once; the call returns when the share is in the device's film
             group.run([&](int r) {
-                // RODENT_SHARE_GPUS maps several ranks onto one device: its RenderDevice (control words, slabs, counters, film) serves ONE render call at a time
-                // (K threads on one RenderDevice raced).  With one rank per device -- every real run -- nobody ever waits here.
+                // RODENT_SHARE_GPUS maps several ranks onto one device: its RenderDevice (control words, slabs, counters, film) serves ONE
+                // render call at a time (K threads on one RenderDevice raced).  With one rank per device -- every real run --
+                // nobody ever waits here.
                 std::lock_guard<std::mutex> one_call(device_lock[group.device(r) & 15]);
                 const auto t0 = std::chrono::high_resolution_clock::now();
-                if (bands) { const Part band = split_range((int)height, r, ngpu); rodent_hip_render_rows(group.device(r), &settings, (int32_t)iter, band.begin, band.end, nullptr); }
+                if (bands) { const Part band = split_range((int)height, r, ngpu);
+                    rodent_hip_render_rows(group.device(r), &settings, (int32_t)iter, band.begin, band.end, nullptr); }
                 else rodent_hip_render_tiles(group.device(r), &settings, (int32_t)iter, kTileRows, r, ngpu, nullptr);
                 rank_ms[r] = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
             });
@@ -160,7 +168,9 @@ int main(int argc, char** argv) {
         for (int r = 1; r < ngpu; r++) {
             float* film = nullptr;
             rodent_get_film_data(group.device(r), &film, &fw, &fh);
-            const auto add = [&](Part rows) { pieces.push_back({r, film + (size_t)rows.begin * width * 3, root_film + (size_t)rows.begin * width * 3, (size_t)rows.size() * width * 3 * sizeof(float)}); };
+            const auto add = [&](Part rows) {
+                pieces.push_back({r, film + (size_t)rows.begin * width * 3, root_film + (size_t)rows.begin * width * 3,
+                (size_t)rows.size() * width * 3 * sizeof(float)}); };
             if (bands) add(split_range((int)height, r, ngpu));
             else for_each_tile((int)height, r, ngpu, kTileRows, add);
         }
@@ -184,7 +194,8 @@ int main(int argc, char** argv) {
             if (d > tol) off++;
             worst = std::max(worst, d / (std::fabs((double)alone[k]) + 1e-6 * iter));
         }
-        verdict = std::string("the gathered film ") + (off == 0 ? "EQUALS" : "DIFFERS FROM") + " the first device's own render of the whole frame(s) (1e-5 relative; largest relative difference "
+        verdict = std::string("the gathered film ") + (off == 0 ? "EQUALS"
+            : "DIFFERS FROM") + " the first device's own render of the whole frame(s) (1e-5 relative; largest relative difference "
                   + std::to_string(worst) + (off ? ", " + std::to_string(off) + " values off" : "") + ")";
         std::copy(gathered.begin(), gathered.end(), get_pixels());       // the image that is saved is the multi-GPU one
     }
@@ -194,7 +205,8 @@ int main(int argc, char** argv) {
         const float inv_iter = 1.0f / iter, inv_gamma = 1.0f / 2.2f;
         std::vector<uint8_t> px(width * height * 4);
         for (size_t k = 0; k < width * height; k++) {
-            for (int c = 0; c < 3; c++) px[4 * k + c] = (uint8_t)(std::min(std::max(std::pow(film[3 * k + c] * inv_iter, inv_gamma), 0.0f), 1.0f) * 255.0f);
+            for (int c = 0; c < 3; c++) px[4 * k + c] =
+                (uint8_t)(std::min(std::max(std::pow(film[3 * k + c] * inv_iter, inv_gamma), 0.0f), 1.0f) * 255.0f);
             px[4 * k + 3] = 255;
         }
         if (!write_png(out_file, px.data(), (int)width, (int)height, 4)) fail("Failed to save PNG file '" + out_file + "'");
@@ -208,8 +220,12 @@ int main(int argc, char** argv) {
               << " (min/med/max Msamples/s)" << std::endl;
     if (ngpu > 1) {
         const int own_rows = bands ? split_range((int)height, 0, ngpu).size() : tile_rows_of_rank((int)height, 0, ngpu, kTileRows);
-        std::cout << "# GPUs: " << ngpu << " (devices" << [&] { std::string l; for (int r = 0; r < ngpu; r++) l += " " + std::to_string(group.device(r)); return l; }() << "), " << (bands ? "bands of " + std::to_string(own_rows) + " row(s)" : "interleaved tiles of " + std::to_string(kTileRows) + " rows")
-                  << "; film gather to device " << group.device(0) << ": " << double(height - own_rows) * width * 12 / 1e6 << " MB in " << gather_s * 1e3 << " ms" << std::endl;
+        std::cout << "# GPUs: " << ngpu << " (devices" << [&] { std::string l;
+            for (int r = 0; r < ngpu; r++) l += " " + std::to_string(group.device(r)); return l;
+            }() << "), " << (bands ? "bands of " + std::to_string(own_rows) + " row(s)"
+            : "interleaved tiles of " + std::to_string(kTileRows) + " rows")
+                  << "; film gather to device " << group.device(0) << ": " << double(height - own_rows) * width * 12 / 1e6 << " MB in "
+                      << gather_s * 1e3 << " ms" << std::endl;
         std::cout << "# Collective: " << group.describe() << std::endl;
         std::cout << "# Render ms per rank (last frame):";
         for (double ms : rank_ms) std::cout << " " << ms;

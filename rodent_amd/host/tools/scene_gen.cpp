@@ -1,7 +1,8 @@
-// scene_gen -- writes the procedural benchmark scenes.  New tool: the reference ships its test scene (Sponza) as binary blobs that are absent
-// from the checkout, and its benchmark suite's other scenes (benchmarks/benchmark.py:16-21) not at all.
+// scene_gen -- writes the procedural benchmark scenes.  New tool: the reference ships its test scene (Sponza) as binary blobs that are
+// absent from the checkout, and its benchmark suite's other scenes (benchmarks/benchmark.py:16-21) not at all.
 //   scene_gen <atrium|gallery|crown|plant> out.obj [seed] [detail]          OBJ (+ atrium.mtl beside it)
-//   scene_gen <atrium|gallery|crown|plant> --bvh out.bvh [seed] [detail]    straight to a .bvh with a BVH2/Tri1 block (no OBJ round trip: the
+//   scene_gen <atrium|gallery|crown|plant> --bvh out.bvh [seed] [detail]    straight to a .bvh with a BVH2/Tri1 block (no OBJ round trip:
+//                                                                           the
 //                                                                           multi-million-triangle scenes are built where they are needed)
 // gallery = the atrium at detail 4 (4.2 M triangles); crown / plant: stress_scenes.cpp.  detail defaults: atrium 1, the others 4.
 #include <chrono>
@@ -51,10 +52,12 @@ int main(int argc, char** argv) {
     std::vector<Node2> n2; std::vector<Tri1> t1;
     layout_bvh2_tri1(b2, tris, geom.data(), n2, t1);
     FILE* f = fopen(out.c_str(), "wb");
-    if (!f || !begin_bvh_file(f) || !append_bvh_block(f, BvhType::BVH2_TRI1, n2, t1)) { std::cerr << "Cannot write " << out << std::endl; return 1; }
+    if (!f || !begin_bvh_file(f) || !append_bvh_block(f, BvhType::BVH2_TRI1, n2, t1)) { std::cerr << "Cannot write " << out << std::endl;
+        return 1; }
     fclose(f);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::cout << "BVH2 successfully built (" << b2.nodes.size() << " nodes, " << b2.leaves.size() << " leaves, " << b2.num_refs << " refs, "
-              << b2.object_splits << " object + " << b2.spatial_splits << " spatial splits, depth " << b2.depth << ", SAH " << b2.sah_cost << ") in " << secs << " s" << std::endl;
+              << b2.object_splits << " object + " << b2.spatial_splits << " spatial splits, depth " << b2.depth << ", SAH " << b2.sah_cost
+                  << ") in " << secs << " s" << std::endl;
     return 0;
 }

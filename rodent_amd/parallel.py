@@ -30,7 +30,8 @@ TILE_ROWS = 16          # host/partition.h kTileRows
 
 def row_tiles(height: int, rank: int, world: int, tile_rows: int = TILE_ROWS):
     """Interleaved row tiles of rank `rank`: [(y0, y1), ...] = tiles rank, rank + world, ... of `tile_rows` rows each, top to bottom
-    (the film's last tile may be shorter).  host/partition.h for_each_tile; what rodent_hip_render_tiles(dev, ..., tile_rows, rank, world) renders."""
+    (the film's last tile may be shorter).  host/partition.h for_each_tile; what rodent_hip_render_tiles(dev, ..., tile_rows, rank, world)
+    renders."""
     return [(t * tile_rows, min((t + 1) * tile_rows, height)) for t in range(rank, (height + tile_rows - 1) // tile_rows, world)]
 
 

@@ -22,19 +22,27 @@ class Settings(C.Structure):
 
 
 class SceneDesc(C.Structure):
-    _fields_ = [(n, vp) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")] + \
+    _fields_ = [(n, vp) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights",
+        "light_ids")] + \
                [(n, i32) for n in ("num_vertices", "num_tris", "num_nodes", "num_bvh_tris", "num_materials", "num_lights")] + \
                [(n, vp) for n in ("texcoords", "textures", "texels")] + [("num_textures", i32), ("num_texels", C.c_uint32)]
 
 
-RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping", "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_hit_records", "rodent_hip_render_overlap", "rodent_hip_render_fused_sort", "rodent_hip_render_fused_compact", "rodent_hip_render_mapping_in_effect", "rodent_hip_render_defaults", "rodent_hip_render_lds_image", "rodent_hip_render_mega_joint", "rodent_hip_render_trace_persistent", "rodent_hip_render_trace_refill", "rodent_hip_render_trace_refill_in_effect", "get_spp", "render",
+RENDER_EXPORTS = ["rodent_hip_scene_create", "rodent_hip_scene_destroy", "rodent_hip_render_config", "rodent_hip_render_mapping",
+    "rodent_hip_render_capacity", "rodent_hip_render_sort", "rodent_hip_render_hit_records", "rodent_hip_render_overlap",
+    "rodent_hip_render_fused_sort", "rodent_hip_render_fused_compact", "rodent_hip_render_mapping_in_effect", "rodent_hip_render_defaults",
+    "rodent_hip_render_lds_image", "rodent_hip_render_mega_joint", "rodent_hip_render_trace_persistent", "rodent_hip_render_trace_refill",
+    "rodent_hip_render_trace_refill_in_effect", "get_spp", "render",
                   "setup_interface", "get_pixels", "clear_pixels", "cleanup_interface", "rodent_get_film_data",
                   "rodent_gpu_get_first_primary_stream", "rodent_gpu_get_second_primary_stream", "rodent_gpu_get_secondary_stream",
-                  "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows", "rodent_hip_render_tiles",
+                  "rodent_gpu_get_tmp_buffer", "rodent_present", "rodent_hip_set_device", "rodent_hip_render_rows",
+                      "rodent_hip_render_tiles",
                   "rodent_hip_render_counters", "hip_generate_rays", "hip_traverse_primary", "hip_sort_primary", "hip_shade",
                   "hip_traverse_secondary", "hip_compact_primary",
-                  "rodent_load_buffer", "rodent_load_bvh2_tri1", "rodent_load_bvh4_tri4", "rodent_load_bvh8_tri4", "rodent_load_png", "rodent_load_jpg",
-                  "rodent_cpu_get_primary_stream", "rodent_cpu_get_secondary_stream", "clock_us", "rodent_hip_buffer_size", "rodent_hip_bvh_counts"]
+                  "rodent_load_buffer", "rodent_load_bvh2_tri1", "rodent_load_bvh4_tri4", "rodent_load_bvh8_tri4", "rodent_load_png",
+                      "rodent_load_jpg",
+                  "rodent_cpu_get_primary_stream", "rodent_cpu_get_secondary_stream", "clock_us", "rodent_hip_buffer_size",
+                      "rodent_hip_bvh_counts"]
 
 _ready = False
 
@@ -93,7 +101,8 @@ class Renderer:
 
     MAPPINGS = {"auto": -1, "streaming": 0, "megakernel": 1}       # per scene / mapping_gpu.impala:308-369 / :371-474
 
-    def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming", capacity=0, sort=None, overlap=None, fused_sort=None, lds_image=None,
+    def __init__(self, scene, width, height, spp=4, max_path_len=64, dev=0, mapping="streaming", capacity=0, sort=None, overlap=None,
+        fused_sort=None, lds_image=None,
                  trace_persistent=None, fused_compact=None, mega_joint=None, trace_refill=None, hit_records_aos=None):
         """Options left at None take the library's default, or what the option's RODENT_HIP_* environment variable says."""
         import torch
@@ -101,27 +110,39 @@ class Renderer:
             raise RuntimeError("rodent_amd: no GPU visible (the renderer has no CPU fallback)")
         self.dev, self.width, self.height, self.spp = dev, width, height, spp
         l = lib()
-        keep = [np.ascontiguousarray(getattr(scene, n)) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris", "materials", "lights", "light_ids")]
+        keep = [np.ascontiguousarray(getattr(scene, n)) for n in ("vertices", "normals", "face_normals", "indices", "nodes", "tris",
+            "materials", "lights", "light_ids")]
         tex = [np.ascontiguousarray(getattr(scene, n)) for n in ("texcoords", "textures", "texels")]
         desc = SceneDesc(*[a.ctypes.data_as(vp) for a in keep], len(scene.vertices), scene.num_tris, len(scene.nodes), len(scene.tris),
-                         len(scene.materials), len(scene.lights), *[a.ctypes.data_as(vp) for a in tex], len(scene.textures), len(scene.texels))
+                         len(scene.materials), len(scene.lights), *[a.ctypes.data_as(vp) for a in tex], len(scene.textures),
+                             len(scene.texels))
         l.rodent_hip_set_device(dev)
         l.rodent_hip_render_defaults(dev)                    # options of an earlier Renderer in this process do not leak into this one
         l.rodent_hip_scene_create(dev, C.byref(desc))
         l.rodent_hip_render_config(dev, spp, max_path_len)
         l.rodent_hip_render_mapping(dev, self.MAPPINGS[mapping])
         l.rodent_hip_render_capacity(dev, capacity)          # rays per stream, 0 = default (32 Mi)
-        for value, setter in ((sort, l.rodent_hip_render_sort),                    # sort hit rays by material before shading (reference behaviour)
+        # sort hit rays by material before shading (reference behaviour)
+        for value, setter in ((sort, l.rodent_hip_render_sort),
                               (overlap, l.rodent_hip_render_overlap),              # shadow rays on a second HIP stream
-                              (hit_records_aos, l.rodent_hip_render_hit_records),  # hit records of the loop's streams as 20-byte records (default) / the ABI's five arrays
-                              (fused_sort, l.rodent_hip_render_fused_sort),        # the sort computes a permutation, the shader gathers through it
-                              (lds_image, l.rodent_hip_render_lds_image),          # stream traversal kernels stage the top of the BVH in LDS
-                              (trace_persistent, l.rodent_hip_render_trace_persistent),   # 0 / 1 / 2: 2-wave kernels + second stream / persistent / joint persistent launch (default: per scene)
-                              (mega_joint, l.rodent_hip_render_mega_joint),               # megakernel: shadow ray + next path ray of a lane in one loop (measured slower) / the reference's sequence of loops (default)
-                              (fused_compact, l.rodent_hip_render_fused_compact)):        # the shader writes continuing rays to their compacted slots
+                              # hit records of the loop's streams as 20-byte records (default) / the ABI's five arrays
+                              (hit_records_aos, l.rodent_hip_render_hit_records),
+                              # the sort computes a permutation, the shader gathers through it
+                              (fused_sort, l.rodent_hip_render_fused_sort),
+                              # stream traversal kernels stage the top of the BVH in LDS
+                              (lds_image, l.rodent_hip_render_lds_image),
+                              # 0 / 1 / 2: 2-wave kernels + second stream / persistent / joint persistent launch (default: per scene)
+                              (trace_persistent, l.rodent_hip_render_trace_persistent),
+                              # megakernel: shadow ray + next path ray of a lane in one loop (measured slower) / the reference's sequence of
+                              # loops (default)
+                              (mega_joint, l.rodent_hip_render_mega_joint),
+                              # the shader writes continuing rays to their compacted slots
+                              (fused_compact, l.rodent_hip_render_fused_compact)):
             if value is not None:
                 setter(dev, int(value))
-        if trace_refill is not None:                         # persistent traversal launches: lane refill once that many lanes of a wave are idle: n or (bounce rays, shadow rays); 0 = whole chunks
+        # persistent traversal launches: lane refill once that many lanes of a wave are idle: n or (bounce rays, shadow rays); 0 = whole
+        # chunks
+        if trace_refill is not None:
             bounce, shadow = trace_refill if isinstance(trace_refill, (tuple, list)) else (trace_refill, trace_refill)
             l.rodent_hip_render_trace_refill(dev, int(bounce), int(shadow))
         l.setup_interface(width, height)
@@ -136,7 +157,8 @@ class Renderer:
         return {0: "streaming", 1: "megakernel"}[lib().rodent_hip_render_mapping_in_effect(self.dev)]
 
     def trace_refill(self):
-        """(idle lanes that trigger a refill while a wave draws bounce rays, ... shadow rays) of the persistent traversal launches; (0, 0) = whole chunks."""
+        """(idle lanes that trigger a refill while a wave draws bounce rays, ... shadow rays) of the persistent traversal launches; (0, 0) =
+        whole chunks."""
         v = lib().rodent_hip_render_trace_refill_in_effect(self.dev)
         return v & 255, v >> 8
 
@@ -152,7 +174,8 @@ class Renderer:
         lib().rodent_hip_render_rows(self.dev, C.byref(st), iter_, y0, y1, None)
 
     def render_tiles(self, cam, iter_, tile_rows, first_tile, tile_stride):
-        """The interleaved row tiles first_tile, first_tile + tile_stride, ... of tile_rows rows each (GPU k of K: first_tile = k, tile_stride = K)."""
+        """The interleaved row tiles first_tile, first_tile + tile_stride, ... of tile_rows rows each (GPU k of K: first_tile = k,
+        tile_stride = K)."""
         st = make_settings(cam)
         lib().rodent_hip_render_tiles(self.dev, C.byref(st), iter_, tile_rows, first_tile, tile_stride, None)
 
@@ -183,7 +206,8 @@ class RayStream(C.Structure):
 
 
 class PrimaryStream(C.Structure):
-    _fields_ = [("rays", RayStream)] + [(n, vp) for n in ("geom_id", "prim_id", "t", "u", "v", "rnd", "mis", "contrib_r", "contrib_g", "contrib_b", "depth")] + \
+    _fields_ = [("rays", RayStream)] + [(n, vp) for n in ("geom_id", "prim_id", "t", "u", "v", "rnd", "mis", "contrib_r", "contrib_g",
+        "contrib_b", "depth")] + \
                [("size", i32), ("pad", i32)]
 
 
@@ -193,13 +217,17 @@ class SecondaryStream(C.Structure):
 
 def stage_lib():
     l = lib()
-    l.rodent_gpu_get_first_primary_stream.argtypes = [i32, C.POINTER(PrimaryStream), i32]; l.rodent_gpu_get_first_primary_stream.restype = None
-    l.rodent_gpu_get_second_primary_stream.argtypes = [i32, C.POINTER(PrimaryStream), i32]; l.rodent_gpu_get_second_primary_stream.restype = None
+    l.rodent_gpu_get_first_primary_stream.argtypes = [i32, C.POINTER(PrimaryStream),
+        i32]; l.rodent_gpu_get_first_primary_stream.restype = None
+    l.rodent_gpu_get_second_primary_stream.argtypes = [i32, C.POINTER(PrimaryStream),
+        i32]; l.rodent_gpu_get_second_primary_stream.restype = None
     l.rodent_gpu_get_secondary_stream.argtypes = [i32, C.POINTER(SecondaryStream), i32]; l.rodent_gpu_get_secondary_stream.restype = None
     l.rodent_get_film_data.argtypes = [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]; l.rodent_get_film_data.restype = None
-    l.hip_generate_rays.argtypes = [i32, C.POINTER(PrimaryStream), i32, i32, i32, C.POINTER(Settings), i32, i32, i32, i32, i32, vp]; l.hip_generate_rays.restype = None
+    l.hip_generate_rays.argtypes = [i32, C.POINTER(PrimaryStream), i32, i32, i32, C.POINTER(Settings), i32, i32, i32, i32, i32,
+        vp]; l.hip_generate_rays.restype = None
     l.hip_traverse_primary.argtypes = [i32, C.POINTER(PrimaryStream), vp]; l.hip_traverse_primary.restype = None
-    l.hip_sort_primary.argtypes = [i32, C.POINTER(PrimaryStream), C.POINTER(PrimaryStream), C.POINTER(i32), vp]; l.hip_sort_primary.restype = None
+    l.hip_sort_primary.argtypes = [i32, C.POINTER(PrimaryStream), C.POINTER(PrimaryStream), C.POINTER(i32),
+        vp]; l.hip_sort_primary.restype = None
     l.hip_shade.argtypes = [i32, C.POINTER(PrimaryStream), C.POINTER(SecondaryStream), i32, vp]; l.hip_shade.restype = None
     l.hip_traverse_secondary.argtypes = [i32, C.POINTER(SecondaryStream), vp]; l.hip_traverse_secondary.restype = None
     l.hip_compact_primary.argtypes = [i32, C.POINTER(PrimaryStream), C.POINTER(PrimaryStream), vp]; l.hip_compact_primary.restype = i32

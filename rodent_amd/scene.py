@@ -13,7 +13,8 @@ from . import build, formats as F
 MATERIAL = np.dtype([("kd", "<f4", (3,)), ("type", "<i4"), ("ks", "<f4", (3,)), ("ns", "<f4"), ("tf", "<f4", (3,)), ("ni", "<f4"),
                      ("mix_k", "<f4"), ("emissive", "<i4"), ("tex_kd", "<i4"), ("tex_ks", "<i4")])
 TEXTURE = np.dtype([("width", "<i4"), ("height", "<i4"), ("offset", "<u4"), ("pad", "<i4")])
-LIGHT = np.dtype([("v0", "<f4", (4,)), ("v1", "<f4", (4,)), ("v2", "<f4", (4,)), ("n", "<f4", (3,)), ("inv_area", "<f4"), ("color", "<f4", (4,))])
+LIGHT = np.dtype([("v0", "<f4", (4,)), ("v1", "<f4", (4,)), ("v2", "<f4", (4,)), ("n", "<f4", (3,)), ("inv_area", "<f4"),
+    ("color", "<f4", (4,))])
 assert MATERIAL.itemsize == 64 and LIGHT.itemsize == 80
 MAGIC = 0x43534452
 

@@ -32,7 +32,8 @@ CAMERAS = {
     "plant": ((-1900.0, 760.0, -1150.0), (1.0, -0.18, 0.62), (0.0, 1.0, 0.0), 65.0),
 }
 # point lights of the "ao" ray class (ray_gen shadow, tools/ray_gen/ray_gen.cpp:60-85): rays from the light to the camera rays' hit points
-LIGHTS = {"atrium": (0.0, 1450.0, 0.0), "gallery": (0.0, 1450.0, 0.0), "crown": (600.0, 1500.0, 900.0), "plant": (0.0, 1350.0, 0.0), "cornell": (0.0, 1.9, 0.0)}
+LIGHTS = {"atrium": (0.0, 1450.0, 0.0), "gallery": (0.0, 1450.0, 0.0), "crown": (600.0, 1500.0, 900.0), "plant": (0.0, 1350.0, 0.0),
+    "cornell": (0.0, 1.9, 0.0)}
 GENERATED = {"gallery": 4, "crown": 4, "plant": 4}          # scene_gen kinds built straight to a .bvh, with their default detail
 PRIMARY_TMAX, RANDOM_TMAX = 5000.0, 1.0
 
@@ -73,7 +74,8 @@ def scene_bvh(scene: str) -> Path:
 
 
 def scene_obj(scene: str) -> Path:
-    """OBJ (+ atrium.mtl beside it) of a scene, for the renderer's converter: the atrium, or a generated kind ("gallery", "crown/2", ...)."""
+    """OBJ (+ atrium.mtl beside it) of a scene, for the renderer's converter: the atrium, or a generated kind ("gallery", "crown/2",
+    ...)."""
     DATA.mkdir(parents=True, exist_ok=True)
     kind, _, detail = scene.partition("/")
     if kind == "cornell":
@@ -90,7 +92,8 @@ def scene_obj(scene: str) -> Path:
     return out
 
 
-# Emissive panels ("light" of atrium.mtl, facing down) for the renderer's frames of the generated stress scenes: (centre x, y, z, half size).
+# Emissive panels ("light" of atrium.mtl, facing down) for the renderer's frames of the generated stress scenes: (centre x, y, z, half
+# size).
 # Appended to the OBJ only -- the traversal matrix builds its .bvh straight from the generator (scene_bvh) and does not see them.
 PANELS = {"crown": [(0.0, 950.0, 0.0, 450.0)],
           "plant": [(x, 1390.0, z, 150.0) for x in (-1300.0, 0.0, 1300.0) for z in (-600.0, 600.0)]}

@@ -96,7 +96,8 @@ def pad_bvh2_depth(nodes, levels):
     inf = np.float32(np.inf)
     for i in range(levels):
         out[i]["bounds"] = box + box
-        out[i]["child"] = [levels + 1, i + 2 if i + 1 < levels else levels + 2]      # dummy (index `levels`), next wrapper / old root (index levels + 1)
+        # dummy (index `levels`), next wrapper / old root (index levels + 1)
+        out[i]["child"] = [levels + 1, i + 2 if i + 1 < levels else levels + 2]
     out[levels]["bounds"] = [inf, -inf] * 6
     out[levels]["child"] = [0, 0]
     return out
@@ -110,7 +111,8 @@ def write_textured_scene(d):
     from PIL import Image
     d.mkdir(parents=True, exist_ok=True)
     yy, xx = np.mgrid[0:32, 0:32]
-    checker = np.where(((xx // 4 + yy // 4) % 2)[..., None] == 0, np.array([230, 230, 40], np.uint8), np.array([30, 60, 200], np.uint8)).astype(np.uint8)
+    checker = np.where(((xx // 4 + yy // 4) % 2)[..., None] == 0, np.array([230, 230, 40], np.uint8),
+        np.array([30, 60, 200], np.uint8)).astype(np.uint8)
     checker[:4, :4] = (255, 0, 0)                                     # orientation marker: top-left of the file
     Image.fromarray(checker, "RGB").save(d / "checker.png")
     grad = np.stack([xx * 8, yy * 8, 255 - xx * 4], -1).astype(np.uint8)

@@ -48,7 +48,8 @@ def main():
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         d = Path(d)
-        print(subprocess.run([str(tool), str(G / "cornell_box.obj"), str(G / "cornell-refbuilt.bvh")], check=True, capture_output=True, text=True).stdout)
+        r = subprocess.run([str(tool), str(G / "cornell_box.obj"), str(G / "cornell-refbuilt.bvh")], check=True, capture_output=True, text=True)
+        print(r.stdout)
         dec = atrium_obj(d)
         print(subprocess.run([str(tool), str(dec), str(d / "a.bvh")], check=True, capture_output=True, text=True).stdout)
         with open(d / "a.bvh", "rb") as f, gzip.GzipFile(G / "atrium-decimated-refbuilt.bvh.gz", "wb", mtime=0) as z:

@@ -34,14 +34,17 @@ def test_library_exports_every_declared_symbol(native_build):
 
 def test_introspection_without_gpu(native_build):
     from rodent_amd import abi
-    assert abi.variants(2)[:2] == ["top", "fast"] and abi.variants(4)[:2] == ["top", "single"] and abi.variants(8)[:2] == ["top", "single"] and abi.variants(3) == []
-    assert "k_bvh2_top_auto" in abi.kernel_name(2, 0) and "k_bvh2_single" in abi.kernel_name(2, 1) and "k_wide_top_persist<true,8" in abi.kernel_name(8, 0, any_hit=True) and "k_wide_single<false,4" in abi.kernel_name(4, 1)
+    assert abi.variants(2)[:2] == ["top", "fast"] and abi.variants(4)[:2] == ["top", "single"] and abi.variants(8)[:2] == ["top",
+        "single"] and abi.variants(3) == []
+    assert "k_bvh2_top_auto" in abi.kernel_name(2, 0) and "k_bvh2_single" in abi.kernel_name(2,
+        1) and "k_wide_top_persist<true,8" in abi.kernel_name(8, 0, any_hit=True) and "k_wide_single<false,4" in abi.kernel_name(4, 1)
     assert abi.lib().rodent_hip_device_count() >= 0
     # the product library ships the default mappings only: the measured-and-lost kernels and the instrumented builds
     # are in the lab build (RODENT_HIP_LAB=1)
     if not abi.LAB:
         assert abi.lib().rodent_hip_is_lab_build() == 0
-        assert abi.variants(2) == ["top", "fast", "fast-noxcd", "phased", "sorted", "refill"] and not any(n.startswith(("stats-", "trace-")) for w in (2, 4, 8) for n in abi.variants(w))
+        assert abi.variants(2) == ["top", "fast", "fast-noxcd", "phased", "sorted",
+            "refill"] and not any(n.startswith(("stats-", "trace-")) for w in (2, 4, 8) for n in abi.variants(w))
 
 
 def test_no_cpu_fallback(native_build):
@@ -61,7 +64,8 @@ def test_product_does_not_import_oracle():
         assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), py
         if py.name != "build.py":
             assert "oracle" not in text, py
-    for src in list((ROOT / "rodent_amd").rglob("*.hip")) + list((ROOT / "rodent_amd").rglob("*.cpp")) + list((ROOT / "rodent_amd").rglob("*.h")):
+    for src in list((ROOT / "rodent_amd").rglob("*.hip")) + list((ROOT / "rodent_amd").rglob("*.cpp")) + list((ROOT
+        / "rodent_amd").rglob("*.h")):
         for line in src.read_text().splitlines():
             if line.strip().startswith("#include"):
                 assert "oracle" not in line, src
@@ -115,7 +119,8 @@ def test_rays_roundtrip_and_errors(tmp_path, cornell):
 
 def test_ray_gen_primary_matches_formula(tmp_path, native_build):
     out = tmp_path / "p.rays"
-    subprocess.run([native_build.BIN_DIR / "ray_gen", "primary", "0", "1", "2.7", "0", "0", "-1", "0", "1", "0", "60", "8", "4", out], check=True)
+    subprocess.run([native_build.BIN_DIR / "ray_gen", "primary", "0", "1", "2.7", "0", "0", "-1", "0", "1", "0", "60", "8", "4", out],
+        check=True)
     raw = np.fromfile(out, "<f4").reshape(4, 8, 6)
     assert np.all(raw[..., :3] == np.float32([0, 1, 2.7]))
     scale = np.float32(np.tan(60 * (np.pi / 360.0)))
@@ -151,7 +156,8 @@ def test_cli_errors(native_build, cornell):
     assert r.returncode == 1 and "Unknown option" in r.stderr
     r = subprocess.run([bt, "-bvh", "x", "-ray", "y", "-gpu", "cuda"], capture_output=True, text=True)
     assert r.returncode == 1 and "Unknown GPU platform" in r.stderr
-    for flag in ("-s", "--single", "-p", "--packet"):                          # the reference's CPU variants are not options of this tool: it says where they live
+    # the reference's CPU variants are not options of this tool: it says where they live
+    for flag in ("-s", "--single", "-p", "--packet"):
         r = subprocess.run([bt, "-bvh", "x", "-ray", "y", flag, "-gpu", "hip"], capture_output=True, text=True)
         assert r.returncode == 1 and "CPU traversal variants" in r.stderr and "oracle/cpu_bench_traversal.py" in r.stderr
     r = subprocess.run([bt, "--help"], capture_output=True, text=True)
@@ -197,13 +203,16 @@ def test_top_image_node_set_is_a_breadth_first_prefix(cornell):
 
 
 def test_packet_model_reproduces_the_oracle_at_threshold_65():
-    """scripts/model_packet.py (the wave-packet traversal that was modelled and not built): with every subtree falling back at the
-    root (T = 65) the model IS the per-lane kernel and must reproduce oracle B1 bit for bit (the script asserts it), and no packet mode may change
+    """scripts/model_packet.py (the wave-packet traversal that was modelled and not built): with every subtree falling back at
+    the
+    root (T = 65) the model IS the per-lane kernel and must reproduce oracle B1 bit for bit (the script asserts it), and no packet mode may
+    change
     a hit record on the Cornell fixtures."""
     import subprocess, sys
     from conftest import ROOT
     for rays, tmax in (("cornell-primary-64x64.rays", "5000"), ("cornell-random-4096.rays", "1")):
-        r = subprocess.run([sys.executable, str(ROOT / "scripts/model_packet.py"), "--bvh", str(ROOT / "tests/golden/cornell.bvh"), "--rays", str(ROOT / "tests/golden" / rays),
+        r = subprocess.run([sys.executable, str(ROOT / "scripts/model_packet.py"), "--bvh", str(ROOT / "tests/golden/cornell.bvh"),
+            "--rays", str(ROOT / "tests/golden" / rays),
                             "--tmax", tmax, "--thresholds", "8,32", "--buildable"], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         assert "hits == B1: yes" in r.stdout

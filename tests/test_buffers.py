@@ -20,7 +20,8 @@ def cases():
     yield "random", rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes()
     yield "floats", np.repeat(rng.normal(size=5000).astype("<f4"), 3).tobytes()
     yield "long-literals-then-match", rng.integers(0, 256, 60_000, dtype=np.uint8).tobytes() * 2
-    yield "far-match", (rng.integers(0, 256, 66_000, dtype=np.uint8).tobytes() + b"\\x00" * 100) * 2      # offset beyond 65535: must not be used
+    # offset beyond 65535: must not be used
+    yield "far-match", (rng.integers(0, 256, 66_000, dtype=np.uint8).tobytes() + b"\\x00" * 100) * 2
     yield "runs", b"".join(bytes([k % 251]) * (k % 37 + 1) for k in range(20000))
 
 
@@ -44,7 +45,8 @@ def test_corrupt_buffers_are_rejected(native_build, tmp_path):
     tool = native_build.BIN_DIR / "buffer_tool"
     F.write_buffer_file(tmp_path / "ok.bin", np.arange(5000, dtype="<i4"))
     good = (tmp_path / "ok.bin").read_bytes()
-    for label, bad in (("truncated", good[:-7]), ("wrong size", good[:3] + b"\\x7f" + good[4:]), ("bad offset", good[:8] + b"\\x00\\x01\\x00" + good[11:])):
+    for label, bad in (("truncated", good[:-7]), ("wrong size", good[:3] + b"\\x7f" + good[4:]),
+        ("bad offset", good[:8] + b"\\x00\\x01\\x00" + good[11:])):
         (tmp_path / "bad.bin").write_bytes(bad)
         r = subprocess.run([tool, "unpack", tmp_path / "bad.bin", tmp_path / "x"], capture_output=True, text=True)
         assert r.returncode != 0 and "Invalid buffer file" in r.stderr, label
@@ -71,8 +73,10 @@ def test_converter_writes_and_reads_the_reference_data_directory(native_build, t
     n8, t8 = F.read_bvh(GOLDEN / "cornell.bvh", F.BVH8_TRI4)
     F.write_bvh_bin(theirs / "bvh.bin", n8, t8)                   # a BVH8/Tri4 layout the loader must skip (interface.cpp:450-451)
     F.write_bvh_bin(theirs / "bvh.bin", nodes, tris, append=True)
-    r = subprocess.run([conv, GOLDEN / "cornell_box.obj", "-o", tmp_path / "d.rscene", "--verify-data-dir", theirs], capture_output=True, text=True, check=True)
+    r = subprocess.run([conv, GOLDEN / "cornell_box.obj", "-o", tmp_path / "d.rscene", "--verify-data-dir", theirs], capture_output=True,
+        text=True, check=True)
     assert "match the converted scene" in r.stdout
     F.write_buffer_file(theirs / "indices.bin", sc.indices[::-1])
-    r = subprocess.run([conv, GOLDEN / "cornell_box.obj", "-o", tmp_path / "d.rscene", "--verify-data-dir", theirs], capture_output=True, text=True)
+    r = subprocess.run([conv, GOLDEN / "cornell_box.obj", "-o", tmp_path / "d.rscene", "--verify-data-dir", theirs], capture_output=True,
+        text=True)
     assert r.returncode != 0 and "differ from the converted scene" in r.stderr

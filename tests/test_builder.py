@@ -97,7 +97,8 @@ def write_obj(path, verts, faces):
 def test_single_triangle_scene(tmp_path, native_build, oracle):
     """A single-leaf scene still gets a root node whose second slot is empty (bvh.h:218-224)."""
     write_obj(tmp_path / "one.obj", [(0, 0, 0), (1, 0, 0), (0, 1, 0)], [(0, 1, 2)])
-    subprocess.run([native_build.BIN_DIR / "bvh_extractor", "-obj", tmp_path / "one.obj", "-o", tmp_path / "one.bvh"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([native_build.BIN_DIR / "bvh_extractor", "-obj", tmp_path / "one.obj", "-o", tmp_path / "one.bvh"], check=True,
+        stdout=subprocess.DEVNULL)
     n2, t1 = F.read_bvh(tmp_path / "one.bvh", F.BVH2_TRI1)
     assert len(n2) == 1 and n2["child"][0][1] == 0 and n2["child"][0][0] == ~0
     # (no exactly-zero direction components: the reference's octant/safe_rcp combination mishandles those)
@@ -144,7 +145,8 @@ def test_spatial_splits_on_mixed_sizes(tmp_path, native_build, oracle):
 
 
 def test_no_spatial_flag_gives_one_ref_per_triangle(tmp_path, native_build, cornell):
-    subprocess.run([native_build.BIN_DIR / "bvh_extractor", "-obj", cornell.bvh_path.parent / "cornell_box.obj", "-o", tmp_path / "c.bvh", "--no-spatial"],
+    subprocess.run([native_build.BIN_DIR / "bvh_extractor", "-obj", cornell.bvh_path.parent / "cornell_box.obj", "-o", tmp_path / "c.bvh",
+        "--no-spatial"],
                    check=True, stdout=subprocess.DEVNULL)
     _, t1 = F.read_bvh(tmp_path / "c.bvh", F.BVH2_TRI1)
     assert len(t1) == 36
@@ -153,23 +155,28 @@ def test_no_spatial_flag_gives_one_ref_per_triangle(tmp_path, native_build, corn
 def test_obj_without_faces_is_an_error_not_a_crash(tmp_path, native_build):
     """A mesh with vertices but no faces used to make one empty leaf and out.back() on an empty vector (exit 139)."""
     (tmp_path / "empty.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\n")
-    for tool, args in (("bvh_extractor", ["-obj", tmp_path / "empty.obj", "-o", tmp_path / "e.bvh"]), ("converter", [tmp_path / "empty.obj", "-o", tmp_path / "e.rscene"])):
+    for tool, args in (("bvh_extractor", ["-obj", tmp_path / "empty.obj", "-o", tmp_path / "e.bvh"]),
+        ("converter", [tmp_path / "empty.obj", "-o", tmp_path / "e.rscene"])):
         r = subprocess.run([native_build.BIN_DIR / tool, *args], capture_output=True, text=True)
         assert r.returncode == 1 and "no faces" in r.stderr, (tool, r.returncode, r.stderr)
 
 
 def test_converter_builder_parameters(tmp_path, native_build, oracle):
-    """converter --bvh-leaf / --bvh-traversal-cost (the sweep of DESIGN 3.4.2): larger leaves and a dearer inner node give smaller hierarchies that are
-    still valid BVH2 blocks and still trace to the exhaustive checker's hits; the defaults are the reference's parameters (2 references, cost 1)."""
+    """converter --bvh-leaf / --bvh-traversal-cost (the sweep of DESIGN 3.4.2): larger leaves and a dearer inner node give smaller
+    hierarchies that are
+    still valid BVH2 blocks and still trace to the exhaustive checker's hits; the defaults are the reference's parameters (2 references,
+    cost 1)."""
     from conftest import ROOT, write_textured_hall
     from rodent_amd import build, raygen, scene as S
     obj = write_textured_hall(tmp_path)
     scenes = {}
-    for name, args in (("default", []), ("explicit", ["--bvh-leaf", "2", "--bvh-traversal-cost", "1"]), ("leaf8", ["--bvh-leaf", "8"]), ("cost3", ["--bvh-traversal-cost", "3"])):
+    for name, args in (("default", []), ("explicit", ["--bvh-leaf", "2", "--bvh-traversal-cost", "1"]), ("leaf8", ["--bvh-leaf", "8"]),
+        ("cost3", ["--bvh-traversal-cost", "3"])):
         out = tmp_path / f"{name}.rscene"
         subprocess.run([str(build.BIN_DIR / "converter"), str(obj), "-o", str(out), *args], check=True, stdout=subprocess.DEVNULL)
         scenes[name] = S.Scene(out)
-    assert scenes["default"].nodes.tobytes() == scenes["explicit"].nodes.tobytes() and scenes["default"].tris.tobytes() == scenes["explicit"].tris.tobytes()
+    assert scenes["default"].nodes.tobytes() == scenes["explicit"].nodes.tobytes() and scenes["default"].tris.tobytes() == scenes[
+        "explicit"].tris.tobytes()
     assert len(scenes["leaf8"].nodes) < 0.5 * len(scenes["default"].nodes) and len(scenes["cost3"].nodes) < len(scenes["default"].nodes)
     b = np.asarray(scenes["default"].nodes["bounds"][0]).reshape(2, 6)
     lo, hi = np.minimum(b[0, 0::2], b[1, 0::2]), np.maximum(b[0, 1::2], b[1, 1::2])
@@ -181,12 +188,15 @@ def test_converter_builder_parameters(tmp_path, native_build, oracle):
         got, _ = oracle.traverse(2, sc.nodes, sc.tris, rays)
         assert np.array_equal(got["tri_id"] >= 0, ref["tri_id"] >= 0)
         hit = ref["tri_id"] >= 0
-        assert np.allclose(got["t"][hit], ref["t"][hit], rtol=1e-5, atol=0)                 # another hierarchy: the same surfaces (ties may name another triangle)
+        # another hierarchy: the same surfaces (ties may name another triangle)
+        assert np.allclose(got["t"][hit], ref["t"][hit], rtol=1e-5, atol=0)
 
 
 def test_stress_scenes_get_emissive_panels_for_the_renderer(native_build, tmp_path):
-    """scene_gen's crown and plant are geometry only; scenes.scene_obj appends emissive panels (material "light", facing down) so that the renderer
-    has something that emits -- the converter must find them as lights, and the panels must not touch the .bvh route of the traversal matrix."""
+    """scene_gen's crown and plant are geometry only; scenes.scene_obj appends emissive panels (material "light", facing down) so that the
+    renderer
+    has something that emits -- the converter must find them as lights, and the panels must not touch the .bvh route of the traversal
+    matrix."""
     from rodent_amd import scene as S, scenes
     for kind, panels in scenes.PANELS.items():
         obj = scenes.scene_obj(f"{kind}/1")

@@ -43,7 +43,8 @@ for root in (0, world - 1):
     mine = torch.full_like(t, -1.0); mine[y0t:y1t] = t[y0t:y1t]
     got = parallel.gather_film_to_root(mine, dist, root)
     assert (got is None) == (rank != root) and (got is None or torch.equal(got, t))
-    mine = torch.full_like(t, -1.0)                                                  # interleaved tiles of 2 rows: 4 tiles, the last of one row
+    # interleaved tiles of 2 rows: 4 tiles, the last of one row
+    mine = torch.full_like(t, -1.0)
     for a_, b_ in parallel.row_tiles(7, rank, world, 2): mine[a_:b_] = t[a_:b_]
     got = parallel.gather_film_to_root(mine, dist, root, tile_rows=2)
     assert (got is None) == (rank != root) and (got is None or torch.equal(got, t))
@@ -79,7 +80,8 @@ def test_partitions_cover_exactly():
                 assert (owner[a:b] == -1).all() and 0 <= a < b <= n
                 owner[a:b] = r
         assert (owner >= 0).all() and all(owner[y] == (y // rows) % w for y in range(n))
-    assert sum(b - a for a, b in parallel.row_tiles(2160, 0, 8)) == 17 * 16 and sum(b - a for a, b in parallel.row_tiles(2160, 7, 8)) == 16 * 16
+    assert sum(b - a for a, b in parallel.row_tiles(2160, 0, 8)) == 17 * 16 and sum(b - a for a,
+        b in parallel.row_tiles(2160, 7, 8)) == 16 * 16
 
 
 def test_cpp_hosts_partition_like_the_python_hosts(native_build):
@@ -100,8 +102,10 @@ def test_gather_transport_falls_back_when_rccl_does_not_come_up(native_build):
     rccl_unused_reason; the GPU suite runs the fallback gather itself: test_bench_traversal_cli) with an injected failure, a real
     ncclCommInitAll error, ranks sharing devices, and the normal case."""
     tool = native_build.BIN_DIR / "partition_check"
-    ask = lambda *a: subprocess.run([str(tool), "transport", *[str(x) for x in a]], check=True, capture_output=True, text=True).stdout.strip()
-    assert ask(8, 8, 0, 0) == "rccl" and ask(2, 8, 0, 0) == "rccl" and ask(1, 1, 0, 1) == "rccl"       # (one rank: nothing to gather, nothing to fall back from)
+    ask = lambda *a: subprocess.run([str(tool), "transport", *[str(x) for x in a]], check=True, capture_output=True,
+        text=True).stdout.strip()
+    # (one rank: nothing to gather, nothing to fall back from)
+    assert ask(8, 8, 0, 0) == "rccl" and ask(2, 8, 0, 0) == "rccl" and ask(1, 1, 0, 1) == "rccl"
     assert ask(8, 8, 0, 1) == "peer copies: RODENT_FORCE_RCCL_INIT_FAILURE"
     assert ask(8, 8, 0, 0, "unhandled system error") == "peer copies: ncclCommInitAll: unhandled system error"
     assert ask(3, 1, 1, 0) == "peer copies: RODENT_SHARE_GPUS: 3 ranks on 1 device(s)" and ask(2, 8, 1, 0) == "rccl"
@@ -114,8 +118,10 @@ def test_two_rank_gloo_bands_and_hits(native_build, tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
-    procs = [subprocess.Popen([sys.executable, str(script), str(ROOT), str(tmp_path / "c.rscene"), str(ROOT / "tests/golden/cornell-random-4096.rays")],
-                              env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(ROOT), str(tmp_path / "c.rscene"),
+        str(ROOT / "tests/golden/cornell-random-4096.rays")],
+                              env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                  text=True) for r in range(world)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert f"DIST_OK {world}" in outs[0]

@@ -63,13 +63,17 @@ def test_all_benchmark_rays_bit_exact(gpu, oracle, dumps, width, kind):
 
 @pytest.mark.parametrize("scene,limit", [("atrium", 1.17), ("refbuilt", 1.17), ("cornell", 1.35)])
 def test_default_mapping_is_not_slower_than_the_one_chunk_kernel_where_it_is_selected(gpu, scene, limit, tmp_path):
-    """The default BVH2 mapping switches from the one-chunk kernel ("fast") to the persistent LDS-image kernel at 393 216 rays (589 824 until round 4), with
+    """The default BVH2 mapping switches from the one-chunk kernel ("fast") to the persistent LDS-image kernel at 393 216 rays (589 824
+    until round 4), with
     a 255-record image and 15-entry stack windows -- constants tuned on the atrium's primary camera (profiles/r02_threshold_sweep.txt).
     From that size on it must not lose to "fast" by more than 17 %: on the benchmark scene, on the decimated atrium as the
-    REFERENCE's builder lays it out (tests/golden/atrium-decimated-refbuilt.bvh.gz), primary and random rays.  One switch point serves both ray
-    kinds (the host does not know which it got): at 393 216 rays camera rays are still 10 % faster through "fast" (0.118 against 0.130 ms, level
+    REFERENCE's builder lays it out (tests/golden/atrium-decimated-refbuilt.bvh.gz), primary and random rays.  One switch point serves both
+    ray
+    kinds (the host does not know which it got): at 393 216 rays camera rays are still 10 % faster through "fast" (0.118 against 0.130 ms,
+    level
     from 589 824 on) while segments are 18 % faster through the persistent kernel from 262 144 on (profiles/r05_threshold_sweep_grid.txt) --
-    the smaller loss decides.  On a tree that fits the image whole (Cornell, 16 nodes) the persistent launch's fixed cost (~3 us of a 23 us launch
+    the smaller loss decides.  On a tree that fits the image whole (Cornell, 16 nodes) the persistent launch's fixed cost (~3 us of a 23 us
+    launch
     since round 5, 12 us before: profiles/r05_fixed_costs.txt) shows at the switch point: measured 10 ... 15 % there, 35 % allowed."""
     import gzip
     import torch
@@ -99,7 +103,8 @@ def test_default_mapping_is_not_slower_than_the_one_chunk_kernel_where_it_is_sel
     try:                                                               # (this module runs on the shipped switch point throughout)
         for w, h in ((1024, 384), (1024, 576), (1024, 1024)):
             n = w * h
-            for kind, rays in (("primary", raygen.primary_rays(*cam, w, h, 0.0, 5000.0)), ("random", raygen.random_rays(lo, hi, n, 42, 0.0, 1.0))):
+            for kind, rays in (("primary", raygen.primary_rays(*cam, w, h, 0.0, 5000.0)),
+                ("random", raygen.random_rays(lo, hi, n, 42, 0.0, 1.0))):
                 rd = gpu.to_device(rays, 0); hd = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
                 fast, top = timed(names.index("fast"), rd, hd, n), timed(names.index("top"), rd, hd, n)
                 assert top <= limit * fast, (scene, n, kind, top, fast)
@@ -137,7 +142,8 @@ def test_deep_stacks_cost_no_cliff(gpu, oracle, dumps):
         n = len(r)
         depth = oracle.ray_depths(deep_nodes, tris, r)
         share = float((depth >= 15).mean())
-        assert share >= (0.01 if kind == "primary" else 0.005), (kind, share)          # profiles/r02_stack_depth.txt: 1.34 % / 0.72 % need 8 entries unpadded
+        # profiles/r02_stack_depth.txt: 1.34 % / 0.72 % need 8 entries unpadded
+        assert share >= (0.01 if kind == "primary" else 0.005), (kind, share)
         ref, _ = oracle.traverse(2, deep_nodes, tris, r)
         ref_plain, _ = oracle.traverse(2, nodes, tris, r)
         assert ref.tobytes() == ref_plain.tobytes()                                    # the padding changes no hit
@@ -147,9 +153,11 @@ def test_deep_stacks_cost_no_cliff(gpu, oracle, dumps):
         rd = gpu.to_device(r, 0); hd = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
         gpu.traverse_async(deep, rd, hd, n, False, 0, st); torch.cuda.synchronize()
         spilled = gpu.read_stats()[7]
-        assert spilled >= int(share * n), (kind, spilled, share)                      # blocks moved out: at least one per ray deeper than the window
+        # blocks moved out: at least one per ray deeper than the window
+        assert spilled >= int(share * n), (kind, spilled, share)
         t_plain, t_deep = timed(plain, rd, hd, n), timed(deep, rd, hd, n)
-        print(f"deep stacks, {kind}: {share:.2%} of the rays beyond the window, {spilled} blocks spilled, {t_deep:.4f} ms against {t_plain:.4f} ms unpadded")
+        print(f"deep stacks, {kind}: {share:.2%} of the rays beyond the window, {spilled} blocks spilled, {t_deep:.4f} ms against "
+            f"{t_plain:.4f} ms unpadded")
         assert t_deep <= 1.5 * t_plain, (kind, t_deep, t_plain)
     gpu.check_errors(0)
 
@@ -186,9 +194,11 @@ def atrium_reference(oracle, atrium_scene):
     return film, counts
 
 
-@pytest.mark.parametrize("mapping,sort,capacity", [("streaming", True, 0), ("streaming", False, 0), ("streaming", True, 50_000), ("megakernel", True, 0)])
+@pytest.mark.parametrize("mapping,sort,capacity", [("streaming", True, 0), ("streaming", False, 0), ("streaming", True, 50_000),
+    ("megakernel", True, 0)])
 def test_atrium_path_trace_matches_oracle(R, atrium_scene, atrium_reference, mapping, sort, capacity):
-    """BASELINE config 5's scene through every mapping: deep stacks, nine materials (diffuse, diffuse + Phong mixes), 12 emitter triangles."""
+    """BASELINE config 5's scene through every mapping: deep stacks, nine materials (diffuse, diffuse + Phong mixes), 12 emitter
+    triangles."""
     f = ATRIUM_FRAME
     film_o, counts = atrium_reference
     r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], mapping=mapping, sort=sort, capacity=capacity)
@@ -210,7 +220,8 @@ def test_atrium_fused_sort_matches_oracle(R, atrium_scene, atrium_reference):
     assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
 
 
-@pytest.mark.parametrize("mode,sort,fused_sort,capacity", [(0, True, False, 0), (1, True, False, 0), (2, True, False, 60_000), (1, False, False, 45_000), (2, False, False, 0),
+@pytest.mark.parametrize("mode,sort,fused_sort,capacity",
+    [(0, True, False, 0), (1, True, False, 0), (2, True, False, 60_000), (1, False, False, 45_000), (2, False, False, 0),
                                                            (1, True, True, 0), (2, True, True, 50_000)])
 def test_atrium_compaction_modes_match_oracle(R, atrium_scene, atrium_reference, mode, sort, fused_sort, capacity):
     """rodent_hip_render_fused_compact: 0 = shade in place, then gpu_compact_primary (mapping_gpu.impala:267-300) as a pass of its
@@ -219,7 +230,8 @@ def test_atrium_compaction_modes_match_oracle(R, atrium_scene, atrium_reference,
     the gathering shader, with regeneration into a small stream: same ray counts, same film."""
     f = ATRIUM_FRAME
     film_o, counts = atrium_reference
-    r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], sort=sort, fused_sort=fused_sort, fused_compact=mode, capacity=capacity)
+    r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], sort=sort, fused_sort=fused_sort, fused_compact=mode,
+        capacity=capacity)
     r.render(atrium_camera(f["W"], f["H"]), f["IT"])
     c = r.counters(); film_g = r.film(); r.close()
     assert (c["primary_rays"], c["shadow_rays"], c["generated"]) == (counts[0], counts[1], f["W"] * f["H"] * f["SPP"])     # exact
@@ -235,7 +247,8 @@ def test_atrium_joint_traversal_launch_renders_the_same_frame(R, atrium_scene, s
     W, H, SPP, MAXLEN = 640, 360, 8, 8                                    # 1.8 M paths, 700 000-ray streams: three refills
     cam = atrium_camera(W, H)
     out = {}
-    for mode in (0, 1, 2):                                                # 2-wave kernels + second stream / persistent kernels / joint (the default for this scene)
+    # 2-wave kernels + second stream / persistent kernels / joint (the default for this scene)
+    for mode in (0, 1, 2):
         r = R.Renderer(atrium_scene, W, H, SPP, MAXLEN, mapping="streaming", sort=sort, trace_persistent=mode, capacity=700_000)
         r.render(cam, 3)
         out[mode] = (r.counters(), r.film()); r.close()
@@ -248,19 +261,24 @@ def test_atrium_joint_traversal_launch_renders_the_same_frame(R, atrium_scene, s
 
 
 def test_atrium_deep_stacks_in_the_renderer(R, atrium_scene):
-    """The renderer's traversal kernels on a hierarchy whose stacks outgrow the lanes' 15-row LDS windows (the atrium under ten padding levels,
-    conftest.pad_bvh2_depth: every ray's deepest stack + 10, hits unchanged): the persistent kernels spill in place (k_trace_refill: the per-scene
-    default; k_trace_persist: whole chunks), the one-chunk kernels hand such rays to k_trace_deep (64 workgroups), the megakernel keeps its scratch
+    """The renderer's traversal kernels on a hierarchy whose stacks outgrow the lanes' 15-row LDS windows (the atrium under ten padding
+    levels,
+    conftest.pad_bvh2_depth: every ray's deepest stack + 10, hits unchanged): the persistent kernels spill in place (k_trace_refill: the
+    per-scene
+    default; k_trace_persist: whole chunks), the one-chunk kernels hand such rays to k_trace_deep (64 workgroups), the megakernel keeps its
+    scratch
     stack.  Same ray counts as the unpadded scene, the same film up to the order of the atomic adds, no overflow."""
     import copy
     from conftest import pad_bvh2_depth
-    W, H, SPP, MAXLEN = 640, 360, 8, 8                                    # 1.8 M paths, 700 000-ray streams: above the persistent kernels' threshold
+    # 1.8 M paths, 700 000-ray streams: above the persistent kernels' threshold
+    W, H, SPP, MAXLEN = 640, 360, 8, 8
     cam = atrium_camera(W, H)
     r = R.Renderer(atrium_scene, W, H, SPP, MAXLEN, mapping="streaming", capacity=700_000)
     r.render(cam, 3)
     c0, f0 = r.counters(), r.film(); r.close()
     deep = copy.copy(atrium_scene)
-    deep.nodes = pad_bvh2_depth(atrium_scene.nodes, 10)                  # (a stack of 5 entries on the plain scene -- a fifth of the rays -- now needs 15)
+    # (a stack of 5 entries on the plain scene -- a fifth of the rays -- now needs 15)
+    deep.nodes = pad_bvh2_depth(atrium_scene.nodes, 10)
     assert len(deep.nodes) == len(atrium_scene.nodes) + 11
     for label, opts in (("joint launch, lane refill (the default for this scene)", dict(mapping="streaming")),
                         ("joint launch, whole chunks", dict(mapping="streaming", trace_persistent=2, trace_refill=(0, 0))),
@@ -340,7 +358,8 @@ def test_atrium_row_bands_equal_the_frame(R, atrium_scene, atrium_reference, ban
 def test_atrium_interleaved_row_tiles_equal_the_frame(R, atrium_scene, atrium_reference, gpus, tile_rows, mapping):
     """Load-balanced sharding of config 5 (SURVEY 8e "interleaved 16-row tiles"; the reference deals tiles dynamically,
     render/mapping_gpu.impala:374-420): GPU k of K renders row tiles k, k + K, ... (rodent_hip_render_tiles); all K shares rendered one
-    after the other into one film equal the full frame -- 144 rows in 16-row tiles (9 tiles: shares of unequal size) and in 10-row tiles (a ragged last tile of 4 rows)."""
+    after the other into one film equal the full frame -- 144 rows in 16-row tiles (9 tiles: shares of unequal size) and in 10-row tiles (a
+    ragged last tile of 4 rows)."""
     f = ATRIUM_FRAME
     film_o, counts = atrium_reference
     cam = atrium_camera(f["W"], f["H"])
@@ -348,7 +367,8 @@ def test_atrium_interleaved_row_tiles_equal_the_frame(R, atrium_scene, atrium_re
     primary = shadow = 0
     for k in range(gpus):
         r.render_tiles(cam, f["IT"], tile_rows, k, gpus)
-        c = r.counters(); primary += c["primary_rays"]; shadow += c["shadow_rays"]      # the counters of the WHOLE call: one launch per tile (megakernel), a ragged last tile
+        # the counters of the WHOLE call: one launch per tile (megakernel), a ragged last tile
+        c = r.counters(); primary += c["primary_rays"]; shadow += c["shadow_rays"]
     film_g = r.film(); r.close()
     assert (primary, shadow) == (counts[0], counts[1])
     assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL)
@@ -358,13 +378,16 @@ def test_atrium_interleaved_row_tiles_equal_the_frame(R, atrium_scene, atrium_re
 @pytest.mark.parametrize("aos", [False, True])
 @pytest.mark.parametrize("sort", [False, True])
 def test_atrium_hit_record_layouts_render_the_same_frame(R, atrium_scene, atrium_reference, aos, sort):
-    """rodent_hip_render_hit_records: the loop's streams keep a hit as one 20-byte record in the memory of the geom_id / prim_id / t / u / v arrays
-    (default) or in those five arrays (the ABI's layout, which the stage-level entry points always use and which the loop falls back to while the
+    """rodent_hip_render_hit_records: the loop's streams keep a hit as one 20-byte record in the memory of the geom_id / prim_id / t / u / v
+    arrays
+    (default) or in those five arrays (the ABI's layout, which the stage-level entry points always use and which the loop falls back to
+    while the
     sort by material is on): same ray counts, same film, small streams (every traversal kernel of the loop) and large ones."""
     f = ATRIUM_FRAME
     film_o, counts = atrium_reference
     for capacity in (20000, 0):
-        r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], mapping="streaming", sort=sort, hit_records_aos=aos, capacity=capacity)
+        r = R.Renderer(atrium_scene, f["W"], f["H"], f["SPP"], f["MAXLEN"], mapping="streaming", sort=sort, hit_records_aos=aos,
+            capacity=capacity)
         r.render(atrium_camera(f["W"], f["H"]), f["IT"])
         c = r.counters(); film_g = r.film(); r.close()
         assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1]), (aos, sort, capacity)
@@ -372,9 +395,12 @@ def test_atrium_hit_record_layouts_render_the_same_frame(R, atrium_scene, atrium
 
 
 def test_stage_level_streams_that_are_no_slabs_take_the_chunk_kernel(R, atrium_scene):
-    """k_trace_refill takes its streams as slabs (one base + k x capacity: what rodent_gpu_get_*_stream hands out); a caller's struct may point anywhere
-    (driver.impala:24-61 is a struct of pointers), and such a stream must go through k_trace_persist with the same result.  600 000 shadow rays of the atrium
-    (above the persistent kernels' minimum) through hip_traverse_secondary with lane refill on: once as the library's slab, once with tmin / tmax / colour arrays
+    """k_trace_refill takes its streams as slabs (one base + k x capacity: what rodent_gpu_get_*_stream hands out); a caller's struct may
+    point anywhere
+    (driver.impala:24-61 is a struct of pointers), and such a stream must go through k_trace_persist with the same result.  600 000 shadow
+    rays of the atrium
+    (above the persistent kernels' minimum) through hip_traverse_secondary with lane refill on: once as the library's slab, once with tmin /
+    tmax / colour arrays
     moved to other allocations -- the film gets exactly the same contributions (compared per pixel to the order of the atomic adds)."""
     import ctypes as C
     import torch

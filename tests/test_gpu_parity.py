@@ -117,7 +117,8 @@ def test_chunk_mapping_is_a_bijection(gpu, cornell, cornell_dev, n):
     for width in (4, 8):                                       # the wide kernels use the same mapping
         wn = gpu.variants(width)
         wide = {}
-        for name in ("top", "single", "single-noxcd"):            # "top": tickets of the persistent form (k_wide_top_persist), as the BVH2 default
+        # "top": tickets of the persistent form (k_wide_top_persist), as the BVH2 default
+        for name in ("top", "single", "single-noxcd"):
             hd = torch.full((n * 16,), 0xFF, dtype=torch.uint8, device="cuda:0")
             gpu.traverse_async(cornell_dev[width], rd, hd, n, False, wn.index(name))
             torch.cuda.synchronize()
@@ -149,7 +150,8 @@ def test_launches_on_several_streams_may_overlap(gpu, oracle):
                 hd.fill_(0xFF)
             torch.cuda.synchronize()
             for k, (rays, ref, rd, hd, st) in enumerate(sets):
-                gpu.traverse_async(bvh, rd, hd, len(rays), False, (v + k) % len(variants(gpu, 2)) if rep % 2 else v, st)     # same / mixed mappings in flight
+                # same / mixed mappings in flight
+                gpu.traverse_async(bvh, rd, hd, len(rays), False, (v + k) % len(variants(gpu, 2)) if rep % 2 else v, st)
             torch.cuda.synchronize()
             for rays, ref, rd, hd, st in sets:
                 assert gpu.from_device(hd, F.HIT1).tobytes() == ref.tobytes(), (rep, gpu.variants(2)[v])
@@ -211,16 +213,20 @@ def test_deep_stack_falls_back_to_global_stack(gpu, oracle):
 
 @pytest.mark.parametrize("depth", [16, 23, 40, 63])
 def test_deep_stacks_in_the_persistent_kernels(gpu, oracle, depth):
-    """The same through the persistent kernels (rodent_hip_top_min_rays(0): the default mapping's k_bvh2_top_auto / k_bvh2_top_refill, "refill", and the
-    wide kernels' persistent form), at depths around every block boundary of the spill (15 + 7 k entries) up to the reference's capacity of 63
-    entries (stack.impala:53: 64 slots, one of them the sentinel), 30 000 rays of which a third miss, coherent and shuffled (the refill loop), twice
+    """The same through the persistent kernels (rodent_hip_top_min_rays(0): the default mapping's k_bvh2_top_auto / k_bvh2_top_refill,
+    "refill", and the
+    wide kernels' persistent form), at depths around every block boundary of the spill (15 + 7 k entries) up to the reference's capacity of
+    63
+    entries (stack.impala:53: 64 slots, one of them the sentinel), 30 000 rays of which a third miss, coherent and shuffled (the refill
+    loop), twice
     (the second launch runs on the image the first one built), closest and any hit."""
     from conftest import chain_bvh2
     nodes, tris = chain_bvh2(depth)
     rng = np.random.default_rng(depth)
     n = 30000
     org = np.zeros((n, 3), "<f4"); org[:, :2] = rng.uniform(-4, 4, (n, 2)); org[::3, 0] += 50.0
-    d = np.tile(np.float32([0.001, 0.002, 1.0]), (n, 1)); d[:, :2] += rng.uniform(-1e-4, 1e-4, (n, 2)).astype("<f4")      # no common direction: the refill loop
+    # no common direction: the refill loop
+    d = np.tile(np.float32([0.001, 0.002, 1.0]), (n, 1)); d[:, :2] += rng.uniform(-1e-4, 1e-4, (n, 2)).astype("<f4")
     rays = F.make_rays(org, d, 0.0, 1000.0)
     bvh = gpu.DeviceBvh(2, nodes, tris, 0)
     gpu.lib().rodent_hip_top_min_rays(0)
@@ -231,7 +237,8 @@ def test_deep_stacks_in_the_persistent_kernels(gpu, oracle, depth):
                 assert st["max_stack"] == depth
             for v in variants(gpu, 2):
                 for rep in range(2):
-                    assert gpu.traverse(bvh, rays, any_hit=any_hit, variant=v).tobytes() == ref.tobytes(), (gpu.variants(2)[v], any_hit, rep)
+                    assert gpu.traverse(bvh, rays, any_hit=any_hit, variant=v).tobytes() == ref.tobytes(), (gpu.variants(2)[v], any_hit,
+                        rep)
         gpu.read_stats()
         gpu.traverse(bvh, rays, variant=0)
         assert gpu.read_stats()[7] > 0
@@ -258,12 +265,14 @@ def test_random_triangle_soups_bit_exact(gpu, oracle, native_build, tmp_path, se
             f.write("v %.9g %.9g %.9g\n" % tuple(v))
         for k in range(nt):
             f.write("f %d %d %d\n" % (3 * k + 1, 3 * k + 2, 3 * k + 3))
-    subprocess.run([native_build.BIN_DIR / "bvh_extractor", "-obj", tmp_path / "soup.obj", "-o", tmp_path / "soup.bvh"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([native_build.BIN_DIR / "bvh_extractor", "-obj", tmp_path / "soup.obj", "-o", tmp_path / "soup.bvh"], check=True,
+        stdout=subprocess.DEVNULL)
     n = 6000
     org = rng.uniform(-14, 14, (n, 3)).astype(np.float32)
     d = rng.normal(0, 1, (n, 3)).astype(np.float32)
     d[:500, rng.integers(0, 3, 500)] *= 1.0                     # (general rays)
-    d[500:800] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 300)] * rng.choice([-1, 1], (300, 1))   # axis-parallel: the reference's slab test culls them
+    # axis-parallel: the reference's slab test culls them
+    d[500:800] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 300)] * rng.choice([-1, 1], (300, 1))
     aim = tri.reshape(-1, 3)[rng.integers(0, 3 * nt, 1500)]
     d[800:2300] = aim - org[800:2300]                           # aimed at vertices (ties between neighbours)
     mid = 0.5 * (tri[rng.integers(0, nt, 700), 0] + tri[rng.integers(0, nt, 700), 1])
@@ -359,9 +368,11 @@ def test_full_size_properties(gpu, atrium, kind):
 def test_bench_traversal_cli(gpu, native_build, oracle, cornell, tmp_path):
     """The CLI keeps the reference's stdout protocol (bench_traversal.cpp:294,381-391) and .fbuf."""
     out = tmp_path / "o.fbuf"
-    cmd = [native_build.BIN_DIR / "bench_traversal", "-bvh", cornell.bvh_path, "-ray", cornell.bvh_path.parent / "cornell-primary-64x64.rays",
+    cmd = [native_build.BIN_DIR / "bench_traversal", "-bvh", cornell.bvh_path, "-ray",
+        cornell.bvh_path.parent / "cornell-primary-64x64.rays",
            "--tmin", "0.01", "--tmax", "5000", "--bench", "3", "--warmup", "1", "-o", out]
-    for extra, name in ((["-gpu", "amdgpu"], "bvh2_gpu"), (["-gpu", "hip", "--variant", "1"], "bvh2_gpu"), (["-gpu", "hip", "--bvh-width", "4"], "bvh4_gpu"),
+    for extra, name in ((["-gpu", "amdgpu"], "bvh2_gpu"), (["-gpu", "hip", "--variant", "1"], "bvh2_gpu"),
+        (["-gpu", "hip", "--bvh-width", "4"], "bvh4_gpu"),
                         (["-gpu", "hip", "--bvh-width", "8"], "bvh8_gpu")):
         r = subprocess.run(cmd + extra, capture_output=True, text=True, check=True)
         lines = r.stdout.strip().splitlines()
@@ -383,16 +394,20 @@ def test_bench_traversal_cli(gpu, native_build, oracle, cornell, tmp_path):
         assert np.array_equal(hits["t"], cornell.expected["bvh2_gpu.primary_tmin.closest"]["t"]) and (hits["tri_id"] >= 0).all()
     r = subprocess.run(cmd + ["-gpu", "hip", "-ngpu", str(have + 1)], capture_output=True, text=True)
     assert r.returncode != 0 and "No such GPU device(s)" in r.stderr
-    # The K > 1 path on however few GPUs the box has: RODENT_SHARE_GPUS=1 puts the K ranks' threads, ray ranges and Hit1 pieces on the
-    # devices there are; RCCL cannot place two ranks on one device, so the gather takes its fallback (one hipMemcpyPeerAsync per piece) and says so; the tool
+    # The K > 1 path on however few GPUs the box has: RODENT_SHARE_GPUS=1 puts the K ranks' threads, ray ranges and Hit1
+    # pieces on the
+    # devices there are; RCCL cannot place two ranks on one device, so the gather takes its fallback (one hipMemcpyPeerAsync per piece) and
+    # says so; the tool
     # then checks the assembled array against one device's trace of all rays by itself.  An injected RCCL failure takes the same branch.
     import os
     for k, env in ((3, {"RODENT_SHARE_GPUS": "1"}), (min(have, 2), {"RODENT_FORCE_RCCL_INIT_FAILURE": "1"})):
         if k < 2:
             continue
-        r = subprocess.run(cmd + ["-gpu", "hip", "-ngpu", str(k), "--hits", tmp_path / "h.bin"], capture_output=True, text=True, env=dict(os.environ, **env))
+        r = subprocess.run(cmd + ["-gpu", "hip", "-ngpu", str(k), "--hits", tmp_path / "h.bin"], capture_output=True, text=True,
+            env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr
-        assert f"# GPUs: {k}" in r.stdout and "# Collective: hipMemcpyPeerAsync per piece" in r.stdout and "WARNING: RCCL is not used" in r.stderr
+        assert f"# GPUs: {k}" in r.stdout and "# Collective: hipMemcpyPeerAsync per piece" in r.stdout
+        assert "WARNING: RCCL is not used" in r.stderr
         assert "# Check: the gathered Hit1 array EQUALS" in r.stdout and "# Kernel ms per rank" in r.stdout
         hits = np.fromfile(tmp_path / "h.bin", F.HIT1)
         assert np.array_equal(hits["t"], cornell.expected["bvh2_gpu.primary_tmin.closest"]["t"])
@@ -403,27 +418,40 @@ def test_bench_py_contract(native_build):
     reports every ray of both sets bit-exact against the oracle (variant 0 = what the driver runs)."""
     import json, sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1"], capture_output=True, text=True, check=True, cwd=ROOT)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1"], capture_output=True, text=True,
+        check=True, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f32" and d[
+        "vs_baseline"] is None and "workload" in d["config"]
     rf = d["roofline"]
-    # ONE top-level roofline: VALU issue against the guide's 2-cycle rate (the live node-fetch bound stands in while the committed counter pass is stale): a fraction
-    # never above 1; the measured and the algorithmic HBM fractions side by side at the top level, the latter labelled as a count of cache hits
-    assert rf["bound"] in ("valu_issue", "vmem_node_fetch") and 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3
-    assert rf["bound"] != "valu_issue" or (rf["peak"] == 1162.0 and 0 < rf["frac_of_measured_loop_mix_ceiling"] <= 1.0 and 0 < rf["lane_utilisation"] <= 1.0)
-    # BASELINE's "fraction of HBM roofline" is ONE key: roofline.hbm (measured fabric bytes of the committed --pmc passes / kernel time / 8 TB/s); the survey's
+    # ONE top-level roofline: VALU issue against the guide's 2-cycle rate (the live node-fetch bound stands in while the committed counter
+    # pass is stale): a fraction
+    # never above 1; the measured and the algorithmic HBM fractions side by side at the top level, the latter labelled as a count of cache
+    # hits
+    assert rf["bound"] in ("valu_issue",
+        "vmem_node_fetch") and 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3
+    assert rf["bound"] != "valu_issue" or (rf["peak"] == 1162.0 and 0 < rf["frac_of_measured_loop_mix_ceiling"] <= 1.0
+        and 0 < rf["lane_utilisation"] <= 1.0)
+    # BASELINE's "fraction of HBM roofline" is ONE key: roofline.hbm (measured fabric bytes of the committed --pmc passes / kernel time / 8
+    # TB/s); the survey's
     # bytes-per-visit figure is a count of cache hits and is named so (it is no fraction: > 1 on a cache-resident tree)
     assert rf["cache_served_bytes_over_hbm_peak"] > 0 and "hbm_algorithmic_frac" not in rf and "compulsory_frac" in rf["hbm"]
-    assert rf["traffic"] is None or (0 < rf["hbm"]["measured_frac"] < 1.0 and rf["hbm"]["traffic_over_compulsory"] > 0.9 and rf["hbm"]["write_amplification"] > 0.9)
+    assert rf["traffic"] is None or (0 < rf["hbm"]["measured_frac"] < 1.0 and rf["hbm"]["traffic_over_compulsory"] > 0.9
+        and rf["hbm"]["write_amplification"] > 0.9)
     assert "random_Mrays_s" in d["config"] and "random_with_kind_hint_Mrays_s" in d["config"]
-    # the other scene classes and the any-hit ray class ride along (VERDICT r4 item 1): every cell's sample checked against the oracle inside bench.py
-    assert d["config"]["scene_classes_parity"] is True and d["config"]["ao_Mrays_s"] > 500 and set(d["extra"]["scenes"]) >= {"gallery", "crown", "plant"}
-    assert all(d["extra"]["scenes"][k][c]["beyond_window_share"] < 0.5 for k in ("gallery", "crown", "plant") for c in ("primary", "random", "ao"))
-    assert rf["hbm_algorithmic"]["bound"] == "hbm" and rf["hbm_algorithmic"]["peak_GBps"] == 8000.0 and rf["hbm_algorithmic"]["bytes_per_ray"] > 48
+    # the other scene classes and the any-hit ray class ride along (VERDICT r4 item 1): every cell's sample checked against the oracle
+    # inside bench.py
+    assert d["config"]["scene_classes_parity"] is True and d["config"]["ao_Mrays_s"] > 500 and set(d["extra"]["scenes"]) >= {"gallery",
+        "crown", "plant"}
+    assert all(d["extra"]["scenes"][k][c]["beyond_window_share"] < 0.5 for k in ("gallery", "crown", "plant") for c in ("primary",
+        "random", "ao"))
+    assert rf["hbm_algorithmic"]["bound"] == "hbm" and rf["hbm_algorithmic"]["peak_GBps"] == 8000.0 and rf["hbm_algorithmic"][
+        "bytes_per_ray"] > 48
     assert 0 < rf["binding"]["vmem_node_fetch"]["frac"] < 1.0 and 0 < rf["random"]["binding"]["vmem_node_fetch"]["frac"] < 1.2
     # counter-derived figures are quoted only from a profile of THESE kernel sources (rodent_amd/provenance.py)
     from rodent_amd import provenance
@@ -433,10 +461,14 @@ def test_bench_py_contract(native_build):
     assert ("valu_issue" in rf["binding"]) == current and ("counters_not_quoted" in rf["binding"]) == (not current)
     assert not current or 1.0 < rf["binding"]["occupancy"]["resident_waves_per_simd_time_averaged_profiled"] <= 8.0
     rd = d["extra"]["render"]
-    for cfg, (w, h, spp) in (("cfg4_cornell_1920x1080_64spp_len4", (1920, 1080, 64)), ("cfg5_atrium_3840x2160_256spp_len8", (3840, 2160, 256))):
+    for cfg, (w, h, spp) in (("cfg4_cornell_1920x1080_64spp_len4", (1920, 1080, 64)),
+        ("cfg5_atrium_3840x2160_256spp_len8", (3840, 2160, 256))):
         e = rd[cfg]
-        assert (e["width"], e["height"], e["spp"]) == (w, h, spp) and e["auto"]["Msamples_s"] > 100 and e["auto"]["rays"]["generated"] == w * h * spp
-        assert e["auto_mapping"] in ("streaming", "megakernel") and all(m in e for m in ("streaming", "streaming_sorted", "megakernel")) and e["streaming_sorted"]["Msamples_s"] > 100
+        assert (e["width"], e["height"], e["spp"]) == (w, h,
+            spp) and e["auto"]["Msamples_s"] > 100 and e["auto"]["rays"]["generated"] == w * h * spp
+        assert e["auto_mapping"] in ("streaming",
+            "megakernel") and all(m in e for m in ("streaming", "streaming_sorted",
+            "megakernel")) and e["streaming_sorted"]["Msamples_s"] > 100
     assert rd["cpu_baseline"]["cfg4_cornell_1920x1080_64spp_len4"]["Msamples_s"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["passes"] >= 10 and "sample" in cb
@@ -448,8 +480,10 @@ def test_bench_py_contract(native_build):
 
 
 def test_bench_py_with_two_ranks(native_build):
-    """The N > 1 code path of bench.py -- strong partition as `value` (BASELINE's metric: ONE 1 Mi-ray set, contiguous ranges, Hit1 gather to rank 0 after the
-    timed region, assembled array equal to a single-GPU trace), weak partition beside it (1 Mi rays per GPU), config 5 as interleaved 16-row tiles with a film gather -- with two
+    """The N > 1 code path of bench.py -- strong partition as `value` (BASELINE's metric: ONE 1 Mi-ray set, contiguous ranges, Hit1 gather
+    to rank 0 after the
+    timed region, assembled array equal to a single-GPU trace), weak partition beside it (1 Mi rays per GPU), config 5 as interleaved 16-row
+    tiles with a film gather -- with two
     ranks.  On a box with one GPU the ranks share it and the collectives go through gloo (RODENT_BENCH_SHARE_GPUS / _BACKEND);
     with two or more GPUs this is the driver's RCCL launch."""
     import json, os, sys
@@ -458,17 +492,21 @@ def test_bench_py_with_two_ranks(native_build):
     env = dict(os.environ, MASTER_PORT="29541")
     if torch.cuda.device_count() < 2:
         env.update(RODENT_BENCH_BACKEND="gloo", RODENT_BENCH_SHARE_GPUS="1")
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--render-spp5", "2"], capture_output=True, text=True, cwd=ROOT, env=env)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--render-spp5", "2"],
+        capture_output=True, text=True, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rays_per_gpu_per_step"] == (1 << 19) and d["value"] > 1000 and "per GPU" not in d["config"]["workload"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rays_per_gpu_per_step"] == (1 << 19) and d[
+        "value"] > 1000 and "per GPU" not in d["config"]["workload"]
     e = d["extra"]
     assert e["strong_scaling_check"] == {"primary_equal_to_single_gpu": True, "random_equal_to_single_gpu": True}
-    assert e["weak_scaling"]["rays_per_gpu_per_step"] == (1 << 20) and e["weak_scaling"]["Mrays_s"] > 1000 and len(e["weak_scaling"]["kernel_ms_per_rank[primary,random]"]) == 2
+    assert e["weak_scaling"]["rays_per_gpu_per_step"] == (1 << 20) and e["weak_scaling"]["Mrays_s"] > 1000 and len(
+        e["weak_scaling"]["kernel_ms_per_rank[primary,random]"]) == 2
     assert e["strong_scaling"]["rays_per_gpu_per_step"] == (1 << 19) and e["strong_scaling"]["Mrays_s"] == d["value"]
-    assert d["config"]["strong_scaling_Mrays_s[primary,random]"][0] == e["strong_scaling"]["Mrays_s"] and "predicted_scaling_x" in d["config"]
+    assert d["config"]["strong_scaling_Mrays_s[primary,random]"][0] == e["strong_scaling"]["Mrays_s"] and "predicted_scaling_x" in d[
+        "config"]
     assert e["all_rays_bit_exact_vs_oracle"] == {"primary": True, "random": True}          # rank 0's range against the oracle
     c5 = e["render"]["cfg5_atrium_3840x2160_256spp_len8"]
     # rank 0: tiles 0, 2, ..., 134 of 135
@@ -510,14 +548,16 @@ def test_schedule_history_only_reorders_the_chunks(gpu, oracle, cornell, cornell
     gpu.lib().rodent_hip_schedule_history(1)
     try:
         # (100 rays and 34 x 64 rays: stripes of exactly two chunks -- the follow-up kernel's rank count reads its keys four at a time)
-        for k, n in enumerate((100_000, 100_000, 100_000, 70_001, 70_001, 100_000, 4096 * 64 + 7, 4096 * 64 + 7, 100, 100, 100, 34 * 64, 34 * 64, 34 * 64)):
+        for k, n in enumerate((100_000, 100_000, 100_000, 70_001, 70_001, 100_000, 4096 * 64 + 7, 4096 * 64 + 7, 100, 100, 100, 34 * 64,
+            34 * 64, 34 * 64)):
             rays = np.tile(base, (n + len(base) - 1) // len(base))[:n].copy()
             rays["org"][:, 0] += (np.arange(n, dtype=np.float32) % 977) * 1e-4
             if k == 2:
                 rays = rays[::-1].copy()                       # same count, other rays: the history mispredicts, nothing else
             rd = gpu.to_device(rays, 0)
             hd = torch.full((n * 16,), 0xFF, dtype=torch.uint8, device="cuda:0")
-            torch.cuda.synchronize()                            # (the fill runs on torch's stream, the launch on `st`: without this the fill can land on top of the hits)
+            # (the fill runs on torch's stream, the launch on `st`: without this the fill can land on top of the hits)
+            torch.cuda.synchronize()
             gpu.traverse_async(cornell_dev[2], rd, hd, n, False, top, st)
             gpu.check_errors(0, st)
             ref, _ = oracle.traverse(2, nodes, tris, rays)
@@ -553,9 +593,12 @@ def test_default_mapping_switches_kernels_at_its_size_threshold(gpu, oracle, cor
 
 @pytest.mark.gpu
 def test_camera_rays_in_image_order_are_traced_as_tiles(gpu, oracle, cornell, cornell_dev):
-    """Round 5: the default BVH2 kernel recognises the pixels of an image, row by row (the reference's primary-ray dumps, tools/ray_gen/ray_gen.cpp:20-58), from 66 of
-    the rays and gives every wavefront an 8 x 8-pixel tile instead of 64 pixels of a row (detect_ray_grid, traversal_top.h; stats[2] = the width it used).  Whatever it
-    recognises -- widths that are no multiple of 8, heights that are not (the last rows stay in list order), two images in one list, normalised directions, segments in no order,
+    """Round 5: the default BVH2 kernel recognises the pixels of an image, row by row (the reference's primary-ray dumps,
+    tools/ray_gen/ray_gen.cpp:20-58), from 66 of
+    the rays and gives every wavefront an 8 x 8-pixel tile instead of 64 pixels of a row (detect_ray_grid, traversal_top.h; stats[2] = the
+    width it used).  Whatever it
+    recognises -- widths that are no multiple of 8, heights that are not (the last rows stay in list order), two images in one list,
+    normalised directions, segments in no order,
     a width forced on rays that are no image at all -- every Hit1 record is the oracle's, in its ray's place."""
     import torch
     from rodent_amd import raygen, scenes
@@ -586,35 +629,47 @@ def test_camera_rays_in_image_order_are_traced_as_tiles(gpu, oracle, cornell, co
             ref, _ = oracle.traverse(wide, *cornell.blocks[wide], rays, algo="gpu")
             assert got.tobytes() == ref.tobytes(), (wide, len(rays), expect_width, force)
 
-    for w, h, expect in ((256, 64, 256), (1024, 24, 1024), (136, 50, 136), (1000, 16, 1000), (1004, 12, 0), (128, 40, 128), (120, 40, 0), (8192, 8, 8192), (8200, 8, 0), (1920, 33, 1920)):
+    for w, h, expect in ((256, 64, 256), (1024, 24, 1024), (136, 50, 136), (1000, 16, 1000), (1004, 12, 0), (128, 40, 128), (120, 40, 0),
+        (8192, 8, 8192), (8200, 8, 0), (1920, 33, 1920)):
         run(raygen.primary_rays(*cam, w, h, 0.0, 5000.0), expect)
     image = raygen.primary_rays(*cam, 256, 64, 0.0, 5000.0)
     run(image, 0, force=0)                                               # switched off: list order
-    run(np.concatenate([image, image[::-1]]), 256)                      # a second image behind the first (here: the same pixels backwards) is traced by the first one's tiles
+    # a second image behind the first (here: the same pixels backwards) is traced by the first one's tiles
+    run(np.concatenate([image, image[::-1]]), 256)
     unit = image.copy()
     unit["dir"] /= np.linalg.norm(unit["dir"], axis=1, keepdims=True)
-    run(unit, None)                                                      # normalised directions are no ray_gen dump: recognised or not, the hits are right
+    # normalised directions are no ray_gen dump: recognised or not, the hits are right
+    run(unit, None)
     segments = raygen.random_rays(lo, hi, 40_000, 7, 0.0, 1.0)
     run(segments, 0)
-    # An image AND segments in one list: the width is recognised, the image's waves trace tiles, the segments' waves refill lanes -- and both must map the
-    # launch's positions onto its rays the same way.  Heights that are no multiple of 8: the image's last rows share a band of 8 rows with segments.
-    for w, h, expect in ((256, 60, 256), (1024, 20, 1024), (136, 53, None)):      # (136 x 53 = 7 208 rays: the probes beyond them are segments -- recognised or not)
+    # An image AND segments in one list: the width is recognised, the image's waves trace tiles, the segments' waves refill
+    # lanes -- and both must map the
+    # launch's positions onto its rays the same way.  Heights that are no multiple of 8: the image's last rows share a band of 8 rows with
+    # segments.
+    # (136 x 53 = 7 208 rays: the probes beyond them are segments -- recognised or not)
+    for w, h, expect in ((256, 60, 256), (1024, 20, 1024), (136, 53, None)):
         run(np.concatenate([raygen.primary_rays(*cam, w, h, 0.0, 5000.0), segments]), expect)
     run(np.concatenate([segments[:1000], image]), None)               # (segments first: whatever is recognised, the hits are right)
-    # per-pixel lists that are no camera dump (the width is read from the pixel BELOW ray 0 being a near neighbour: multiples of 128 that divide the ray count)
+    # per-pixel lists that are no camera dump (the width is read from the pixel BELOW ray 0 being a near neighbour: multiples of 128 that
+    # divide the ray count)
     light = np.array([0.0, 1.9, 0.0], np.float32)
     for w, h, expect in ((256, 64, 256), (1024, 24, 1024), (384, 40, 384), (200, 64, 0)):
         cam_rays = raygen.primary_rays(*cam, w, h, 0.0, 5000.0)
         t = oracle.traverse(2, nodes, tris, cam_rays)[0]["t"]
-        run(raygen.shadow_rays(light, cam_rays, t, 0.0, 0.999), expect)                       # ray_gen's shadow mode: from a light to the hit points (the suite's "ao" class)
+        # ray_gen's shadow mode: from a light to the hit points (the suite's "ao" class)
+        run(raygen.shadow_rays(light, cam_rays, t, 0.0, 0.999), expect)
         hit_points = cam_rays["org"] + t[:, None] * cam_rays["dir"]
-        run(F.make_rays(hit_points.astype(np.float32), (light - hit_points).astype(np.float32), 0.001, 0.999), expect)   # a renderer's: from the hit points to the light
-        run(raygen.shadow_rays(light, cam_rays, t, 0.0, 0.999)[: w * h - 7], 0 if expect else 0)   # a count the width does not divide: list order
+        # a renderer's: from the hit points to the light
+        run(F.make_rays(hit_points.astype(np.float32), (light - hit_points).astype(np.float32), 0.001, 0.999), expect)
+        # a count the width does not divide: list order
+        run(raygen.shadow_rays(light, cam_rays, t, 0.0, 0.999)[: w * h - 7], 0 if expect else 0)
     run(segments, 64, force=64)                                          # (no chunk loop for these: the width is noted and unused)
-    run(image, 64, force=64)                                             # a WRONG width on camera rays: any width is a one-to-one map of the launch's positions onto its rays
+    # a WRONG width on camera rays: any width is a one-to-one map of the launch's positions onto its rays
+    run(image, 64, force=64)
     run(image, 1024, force=1024)
     run(image, 0, force=1004)                                            # (no multiple of 8: unused)
-    run(image[:300], 256)                                                # (recognised from rays 0, 64, 128 and 256; no whole band of 8 rows: nothing to tile)
+    # (recognised from rays 0, 64, 128 and 256; no whole band of 8 rows: nothing to tile)
+    run(image[:300], 256)
     run(image[:200], 0)                                                  # fewer rays than the probes need
     # launches under the shipped threshold take the one-chunk kernel, which maps its chunks the same way (it keeps no statistics)
     gpu.lib().rodent_hip_top_min_rays(-1)
@@ -632,8 +687,10 @@ def test_camera_rays_in_image_order_are_traced_as_tiles(gpu, oracle, cornell, co
 def test_default_mapping_chooses_chunks_or_refill_by_itself(gpu, oracle, cornell, cornell_dev):
     """BASELINE config 3 ("ray compaction on") without a variant argument: the default kernel (k_bvh2_top_auto) traces rays that share an
     origin as whole chunks and refills idle lanes otherwise (stats[5]: workgroups that chose the refill loop).  With the ray-kind hint ON
-    (rodent_hip_ray_kind_hint; off by default) a list -- same pointer, same count -- that was incoherent throughout goes to the refill kernel proper
-    from its second launch on (stats[4]), and back when the caller puts coherent rays into the same buffer.  Hits are the oracle's in every case."""
+    (rodent_hip_ray_kind_hint; off by default) a list -- same pointer, same count -- that was incoherent throughout goes to the refill
+    kernel proper
+    from its second launch on (stats[4]), and back when the caller puts coherent rays into the same buffer.  Hits are the oracle's in every
+    case."""
     import torch
     top = gpu.variants(2).index("top")
     nodes, tris = cornell.blocks[2]
@@ -654,18 +711,22 @@ def test_default_mapping_chooses_chunks_or_refill_by_itself(gpu, oracle, cornell
         gpu.check_errors(0)
         assert gpu.from_device(hd, F.HIT1).tobytes() == expected[id(rays)].tobytes()
         st = gpu.read_stats(0)
-        return st[4] > 0, st[5] > 0                                                # (the refill kernel ran, the default kernel's waves chose the refill loop)
+        # (the refill kernel ran, the default kernel's waves chose the refill loop)
+        return st[4] > 0, st[5] > 0
     try:
         for hint in (True, False):
             gpu.ray_kind_hint(hint)
             rd.copy_(gpu.to_device(incoherent, 0))
             first = launch(incoherent)
-            assert first in ((False, True), (True, False)), first                  # (a hint left by an earlier list at this address may already apply)
+            # (a hint left by an earlier list at this address may already apply)
+            assert first in ((False, True), (True, False)), first
             assert launch(incoherent) == ((True, False) if hint else (False, True))
             rd.copy_(gpu.to_device(coherent, 0))
-            launch(coherent)                                                       # whichever kernel: the hits are right, and it reports what it saw
+            # whichever kernel: the hits are right, and it reports what it saw
+            launch(coherent)
             assert launch(coherent) == (False, False)
             assert launch(coherent) == (False, False)
     finally:
-        gpu.ray_kind_hint(False)                                                       # the shipped default (round 5): kernel selection does not depend on earlier launches
+        # the shipped default (round 5): kernel selection does not depend on earlier launches
+        gpu.ray_kind_hint(False)
         gpu.lib().rodent_hip_top_min_rays(0)

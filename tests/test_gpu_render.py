@@ -33,7 +33,8 @@ def R(native_build):
 def test_film_matches_oracle(R, oracle, cornell_scene, spp, max_len, iters):
     W, H = 200, 120
     cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
-    r = R.Renderer(cornell_scene, W, H, spp, max_len, sort=bool(iters % 2))     # with the sort by material (the reference's loop) and without (the default)
+    # with the sort by material (the reference's loop) and without (the default)
+    r = R.Renderer(cornell_scene, W, H, spp, max_len, sort=bool(iters % 2))
     film_o = None
     for it in range(iters):
         r.render(cam, it)
@@ -162,12 +163,15 @@ def test_rodent_cli_ngpu(native_build, tmp_path):
     """`rodent --ngpu K` (BASELINE config 5's partition in the C++ host): K = 1 is the single-GPU renderer; with as many GPUs
     as the box has, row bands + one RCCL gather reproduce the single-GPU image; more GPUs than the box has is an error, not a crash."""
     import torch
-    have = torch.cuda.device_count()           # (torch first: it brings its own HIP runtime, and that one has to initialise before the library's)
+    # (torch first: it brings its own HIP runtime, and that one has to initialise before the library's)
+    have = torch.cuda.device_count()
     imgs = {}
     for k in sorted({1, min(have, 2), have}):
         out = tmp_path / f"n{k}.png"
-        cmd = [str(native_build.BIN_DIR / "rodent"), "--scene", str(GOLDEN / "cornell_box.obj"), "--eye", "0", "1", "2.7", "--dir", "0", "0", "-1", "--up", "0", "1", "0",
-               "--width", "200", "--height", "123", "--spp", "4", "--bench", "3", "--target", "amdgpu-streaming", "--ngpu", str(k), "-o", str(out)]
+        cmd = [str(native_build.BIN_DIR / "rodent"), "--scene", str(GOLDEN / "cornell_box.obj"), "--eye", "0", "1", "2.7", "--dir", "0",
+            "0", "-1", "--up", "0", "1", "0",
+               "--width", "200", "--height", "123", "--spp", "4", "--bench", "3", "--target", "amdgpu-streaming", "--ngpu", str(k), "-o",
+                   str(out)]
         res = subprocess.run(cmd, capture_output=True, text=True, check=True)
         assert "(min/med/max Msamples/s)" in res.stdout and (k == 1 or f"# GPUs: {k}" in res.stdout)
         imgs[k] = np.asarray(Image.open(out).convert("RGB"), dtype=np.int32)
@@ -248,12 +252,15 @@ def test_renderer_on_a_hierarchy_deeper_than_the_lds_window(R, oracle, cornell_s
     for i, t in enumerate(cornell_scene.tris):
         first.setdefault(int(t["prim_id"]) & 0x7FFFFFFF, i)
     tris = cornell_scene.tris[sorted(first.values())].copy()
-    tris["prim_id"] = (tris["prim_id"].astype(np.int64) | 0x80000000).astype(np.uint32).view(np.int32) if tris["prim_id"].dtype.kind == "i" else tris["prim_id"] | 0x80000000
+    tris["prim_id"] = (tris["prim_id"].astype(np.int64) | 0x80000000).astype(np.uint32).view(np.int32) if tris[
+        "prim_id"].dtype.kind == "i" else tris["prim_id"] | 0x80000000
     n = len(tris)
-    v0 = tris["v0"].astype(np.float64); v1 = v0 - tris["e1"]; v2 = v0 + tris["e2"]            # Tri1 stores e1 = v0 - v1, e2 = v2 - v0 (converter.cpp:365-380)
+    # Tri1 stores e1 = v0 - v1, e2 = v2 - v0 (converter.cpp:365-380)
+    v0 = tris["v0"].astype(np.float64); v1 = v0 - tris["e1"]; v2 = v0 + tris["e2"]
     # every box is the scene's box (loose bounds are legal): each ray enters both children of every node at the same distance, the
     # strict `<` sends it into the rest first and the leaf goes on the stack -- 35 entries at the bottom of the chain
-    lo = np.tile(np.minimum(np.minimum(v0, v1), v2).min(0) - 1e-3, (n, 1)); hi = np.tile(np.maximum(np.maximum(v0, v1), v2).max(0) + 1e-3, (n, 1))
+    lo = np.tile(np.minimum(np.minimum(v0, v1), v2).min(0) - 1e-3, (n, 1)); hi = np.tile(np.maximum(np.maximum(v0, v1), v2).max(0) + 1e-3,
+        (n, 1))
     rest_lo, rest_hi = lo, hi
     nodes = np.zeros(n - 1, F.NODE2)
     for k in range(n - 1):
@@ -305,7 +312,8 @@ def test_megakernel_matches_oracle(R, oracle, cornell_scene, spp, max_len, W, H)
     """The persistent-threads mapping (mapping_gpu.impala:371-474): same paths, same ray counts, per-path colour sums;
     ragged tiles (film not a multiple of the tile side), spp that is not a power of two, spp > 1024 (tile side 1)."""
     cam = S.camera_settings((0, 1, 2.7), (0, 0, -1), (0, 1, 0), 60, W, H)
-    r = R.Renderer(cornell_scene, W, H, spp, max_len, mapping="megakernel", mega_joint=(W % 2 == 0))      # both loop structures: k_mega / k_mega_joint
+    # both loop structures: k_mega / k_mega_joint
+    r = R.Renderer(cornell_scene, W, H, spp, max_len, mapping="megakernel", mega_joint=(W % 2 == 0))
     film_o = None
     for it in range(2):
         r.render(cam, it)
@@ -328,7 +336,8 @@ def test_rodent_cli_megakernel_target(native_build, tmp_path):
     imgs = {}
     for target in ("amdgpu-streaming", "amdgpu-megakernel"):
         out = tmp_path / (target + ".png")
-        cmd = [str(native_build.BIN_DIR / "rodent"), "--scene", str(GOLDEN / "cornell_box.obj"), "--eye", "0", "1", "2.7", "--dir", "0", "0", "-1",
+        cmd = [str(native_build.BIN_DIR / "rodent"), "--scene", str(GOLDEN / "cornell_box.obj"), "--eye", "0", "1", "2.7", "--dir", "0",
+            "0", "-1",
                "--up", "0", "1", "0", "--width", "300", "--height", "200", "--spp", "8", "--bench", "4", "--target", target, "-o", str(out)]
         res = subprocess.run(cmd, capture_output=True, text=True, check=True)
         assert "(min/med/max Msamples/s)" in res.stdout
@@ -364,7 +373,8 @@ def test_textured_scene_matches_oracle(R, oracle, textured_scene, mapping):
 def test_rodent_cli_renders_textured_obj(native_build, textured_scene, tmp_path):
     _, d = textured_scene
     out = tmp_path / "room.png"
-    subprocess.run([native_build.BIN_DIR / "rodent", "--scene", d / "room.obj", "--eye", "0.3", "1.0", "3.2", "--dir", "-0.1", "-0.25", "-1",
+    subprocess.run([native_build.BIN_DIR / "rodent", "--scene", d / "room.obj", "--eye", "0.3", "1.0", "3.2", "--dir", "-0.1", "-0.25",
+        "-1",
                     "--up", "0", "1", "0", "--fov", "50", "--width", "240", "--height", "160", "--spp", "8", "--bench", "4", "-o", out],
                    capture_output=True, text=True, check=True)
     im = np.asarray(Image.open(out).convert("RGB"), dtype=np.float32)
@@ -385,8 +395,10 @@ def test_stream_traversal_hands_deep_rays_to_the_follow_up_kernel(R, oracle):
     ntri = len(tris)
     mat = np.zeros(1, S.MATERIAL); mat["kd"] = 0.5; mat["type"] = 1
     light = np.zeros(1, S.LIGHT); light["inv_area"] = 1.0
-    scene = SimpleNamespace(vertices=np.zeros((3 * ntri, 4), "<f4"), normals=np.zeros((3 * ntri, 4), "<f4"), face_normals=np.zeros((ntri, 4), "<f4"),
-                            indices=np.zeros((ntri, 4), "<i4"), nodes=nodes, tris=tris, materials=mat, lights=light, light_ids=np.zeros(ntri, "<i4"),
+    scene = SimpleNamespace(vertices=np.zeros((3 * ntri, 4), "<f4"), normals=np.zeros((3 * ntri, 4), "<f4"),
+        face_normals=np.zeros((ntri, 4), "<f4"),
+                            indices=np.zeros((ntri, 4), "<i4"), nodes=nodes, tris=tris, materials=mat, lights=light,
+                                light_ids=np.zeros(ntri, "<i4"),
                             texcoords=np.zeros((0, 4), "<f4"), textures=np.zeros(0, S.TEXTURE), texels=np.zeros(0, "<u4"), num_tris=ntri)
     n = 1000
     rng = np.random.default_rng(3)
@@ -436,7 +448,8 @@ def test_every_bsdf_matches_oracle(R, oracle, materials_scene, mapping, sort, ov
     one room: the GPU shader takes the same paths as the oracle -- ray counts exact, film within tolerance."""
     W, H = 150, 100
     cam = S.camera_settings((0, 1, 2.6), (0, -0.05, -1), (0, 1, 0), 60, W, H)
-    r = R.Renderer(materials_scene, W, H, 4, 12, mapping=mapping, sort=sort, overlap=overlap, capacity=30000)     # 60 000 paths: refills too
+    # 60 000 paths: refills too
+    r = R.Renderer(materials_scene, W, H, 4, 12, mapping=mapping, sort=sort, overlap=overlap, capacity=30000)
     film_o = None
     for it in range(2):
         r.render(cam, it)
@@ -467,7 +480,8 @@ def test_device_film_view_aliases_the_library_film(R, cornell_scene):
 
 
 def test_mid_size_textured_scene_gets_the_rules_it_should(R, oracle, textured_hall):
-    """The per-scene rules on a third kind of scene: a textured hall of ~9 500 triangles, a few thousand BVH nodes -- far above the
+    """The per-scene rules on a third kind of scene: a textured hall of ~9 500 triangles, a few thousand BVH nodes -- far above
+    the
     128 nodes up to which the megakernel is chosen (render.hip resolve_mapping), below the 16 384 from which the traversal launches refill
     idle lanes (resolve_refill).  The library must choose the streaming loop without lane refill, both mappings must trace the oracle's
     paths through the textures, and the choice must not lose to the alternative by more than the run-to-run spread."""
@@ -486,26 +500,31 @@ def test_mid_size_textured_scene_gets_the_rules_it_should(R, oracle, textured_ha
         assert (c["primary_rays"], c["shadow_rays"]) == (counts[0], counts[1]), mapping
         assert np.allclose(film_g, film_o, rtol=FILM_RTOL, atol=FILM_ATOL), mapping
     ms = {}
-    for mapping in ("streaming", "megakernel"):                      # the rule against the measurement, at a frame size where the mappings differ
+    # the rule against the measurement, at a frame size where the mappings differ
+    for mapping in ("streaming", "megakernel"):
         r = R.Renderer(sc, 1280, 720, 16, 8, mapping=mapping)
         cam2 = S.camera_settings((0.3, 1.0, 3.2), (-0.1, -0.25, -1), (0, 1, 0), 55, 1280, 720)
         r.render_rows(cam2, 0, 0, 720)
         t = []
         for it in range(3):
-            torch.cuda.synchronize(); t0 = time.perf_counter(); r.render_rows(cam2, it, 0, 720); torch.cuda.synchronize(); t.append(time.perf_counter() - t0)
+            torch.cuda.synchronize(); t0 = time.perf_counter(); r.render_rows(cam2, it, 0,
+                720); torch.cuda.synchronize(); t.append(time.perf_counter() - t0)
         ms[mapping] = min(t) * 1e3
         r.close()
     assert ms["streaming"] <= 1.15 * ms["megakernel"], ms
 
 
 def test_shading_through_indices_and_normals_still_matches_oracle(native_build):
-    """The shader reads a hit's face normal and vertex normals from ONE gathered 48-byte record per triangle (SceneDev::tri_shade, built at scene creation);
-    RODENT_HIP_TRI_SHADE=0 keeps the reference's path through indices -> normals (geometry.impala:21-54).  The switch is read once per process, so the
+    """The shader reads a hit's face normal and vertex normals from ONE gathered 48-byte record per triangle (SceneDev::tri_shade, built at
+    scene creation);
+    RODENT_HIP_TRI_SHADE=0 keeps the reference's path through indices -> normals (geometry.impala:21-54).  The switch is read once per
+    process, so the
     oracle comparisons of this module run again in a process that has it off."""
     import os, sys
     from conftest import ROOT
     env = dict(os.environ, RODENT_HIP_TRI_SHADE="0")
     r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_gpu_render.py"), "-m", "gpu", "-q", "-x", "-k",
-                        "test_film_matches_oracle or test_textured_scene_matches_oracle or test_every_bsdf_matches_oracle or test_megakernel_matches_oracle"],
+                        "test_film_matches_oracle or test_textured_scene_matches_oracle or test_every_bsdf_matches_oracle or "
+                            "test_megakernel_matches_oracle"],
                        capture_output=True, text=True, cwd=ROOT, env=env)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

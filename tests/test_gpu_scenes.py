@@ -1,9 +1,15 @@
-"""The other scene classes of the reference's benchmark suite (benchmarks/benchmark.py:16-44: crown, san-miguel, powerplant beside sponza) and its
-third ray class, at test size: seeded stand-ins (rodent_amd/host/stress_scenes.cpp, atrium.cpp at a higher detail) built by the in-tree builder
-where the test runs -- a dense organic surface (crown/1: 262 K small triangles), a hall of long thin triangles (plant/1: 520 K triangles, 3.6 M
-references after spatial splits, tree depth 30+) and the atrium at four times its triangle count (gallery/2) -- traced with 256 Ki camera rays,
-256 Ki random segments and 256 Ki "ao" rays (ray_gen shadow, tools/ray_gen/ray_gen.cpp:60-85: from a point light to the camera rays' hit points,
-any hit, tmax 0.999).  Every shipped BVH2 mapping: the whole Hit1 record of every ray bit for bit against oracle B1 (any hit: the oracle's record
+"""The other scene classes of the reference's benchmark suite (benchmarks/benchmark.py:16-44: crown, san-miguel, powerplant beside sponza)
+and its
+third ray class, at test size: seeded stand-ins (rodent_amd/host/stress_scenes.cpp, atrium.cpp at a higher detail) built by the in-tree
+builder
+where the test runs -- a dense organic surface (crown/1: 262 K small triangles), a hall of long thin triangles (plant/1: 520 K triangles,
+3.6 M
+references after spatial splits, tree depth 30+) and the atrium at four times its triangle count (gallery/2) -- traced with 256 Ki camera
+rays,
+256 Ki random segments and 256 Ki "ao" rays (ray_gen shadow, tools/ray_gen/ray_gen.cpp:60-85: from a point light to the camera rays' hit
+points,
+any hit, tmax 0.999).  Every shipped BVH2 mapping: the whole Hit1 record of every ray bit for bit against oracle B1 (any hit: the oracle's
+record
 as well -- same visit order).  Full-size figures: scripts/scene_matrix.py, profiles/r05_scene_matrix.txt, bench.py extra.scenes."""
 import numpy as np
 import pytest
@@ -36,7 +42,8 @@ def test_scene_classes_bit_exact(gpu, oracle, scene):
     assert st["max_stack"] < 64 and (ref_p["tri_id"] >= 0).mean() > 0.3
     sets = {"primary": (prim, False, ref_p), "random": (raygen.random_rays(lo, hi, 1 << 18, 42, 0.0, scenes.RANDOM_TMAX), False, None),
             "ao": (raygen.shadow_rays(scenes.LIGHTS[kind], prim, ref_p["t"], 0.0, 0.999), True, None)}
-    gpu.lib().rodent_hip_top_min_rays(0)                      # 256 Ki rays are below the switch point: send the default mapping through its persistent kernel as well
+    # 256 Ki rays are below the switch point: send the default mapping through its persistent kernel as well
+    gpu.lib().rodent_hip_top_min_rays(0)
     try:
         for name, (rays, any_hit, ref) in sets.items():
             if ref is None:
@@ -45,7 +52,8 @@ def test_scene_classes_bit_exact(gpu, oracle, scene):
             for v in gpu.order_preserving_variants(2):
                 got = gpu.traverse(bvh, rays, any_hit=any_hit, variant=v)
                 bad = np.nonzero((got.view("<u4").reshape(-1, 4) != ref.view("<u4").reshape(-1, 4)).any(axis=1))[0]
-                assert len(bad) == 0, f"{scene} {name} {gpu.variants(2)[v]}: {len(bad)} rays differ, first {bad[0]}: {got[bad[0]]} vs {ref[bad[0]]}"
+                assert len(bad) == 0, f"{scene} {name} {gpu.variants(2)[v]}: {len(bad)} rays differ, first {bad[0]}: {got[bad[0]]} vs " \
+                    f"{ref[bad[0]]}"
     finally:
         gpu.lib().rodent_hip_top_min_rays(-1)
     gpu.check_errors(0)
@@ -54,8 +62,10 @@ def test_scene_classes_bit_exact(gpu, oracle, scene):
 @pytest.mark.parametrize("scene", ["crown/1", "plant/1"])
 @pytest.mark.parametrize("mapping", ["auto", "megakernel"])
 def test_stress_scenes_path_traced_match_oracle(native_build, oracle, scene, mapping, tmp_path):
-    """The renderer on the two stress scenes (lit by the panels scenes.PANELS appends to their OBJ: the generators make geometry only): a small frame through the
-    library's own choice of mapping and through the megakernel against the render oracle -- ray counts exact, film within the order of the atomic adds.  The full-size
+    """The renderer on the two stress scenes (lit by the panels scenes.PANELS appends to their OBJ: the generators make geometry only): a
+    small frame through the
+    library's own choice of mapping and through the megakernel against the render oracle -- ray counts exact, film within the order of the
+    atomic adds.  The full-size
     frames are measured by scripts/refill_rule_check.py (profiles/r05_refill_rule_check.txt)."""
     import torch
     from rodent_amd import render as R, scene as S, scenes

@@ -69,7 +69,8 @@ def write_adam7(path, rgb):
             raw += b"".join(b"\x00" + row.tobytes() for row in sub)
     def chunk(t, d):
         return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
-    path.write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    path.write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + chunk(b"IDAT",
+        zlib.compress(raw)) + chunk(b"IEND", b""))
     return path
 
 
@@ -97,7 +98,8 @@ def test_jpeg_close_to_pil(native_build, tmp_path, subsampling, gray, restart):
     assert frac > 0.99, frac
 
 
-@pytest.mark.parametrize("subsampling,gray,restart,quality,size", [(0, False, 0, 92, (83, 61)), (2, False, 0, 92, (83, 61)), (1, False, 0, 75, (130, 47)), (0, True, 0, 92, (83, 61)),
+@pytest.mark.parametrize("subsampling,gray,restart,quality,size",
+    [(0, False, 0, 92, (83, 61)), (2, False, 0, 92, (83, 61)), (1, False, 0, 75, (130, 47)), (0, True, 0, 92, (83, 61)),
                                                                    (2, False, 3, 60, (200, 150)), (2, False, 0, 30, (64, 64))])
 def test_progressive_jpeg_close_to_pil(native_build, tmp_path, subsampling, gray, restart, quality, size):
     """SOF2 files (spectral selection + successive approximation: DC first / refinement scans, AC bands with end-of-band runs,
@@ -130,7 +132,8 @@ def test_progressive_jpeg_close_to_pil(native_build, tmp_path, subsampling, gray
 def test_arithmetic_coded_jpeg_is_rejected(native_build, tmp_path):
     Image.fromarray(picture(40, 40), "RGB").save(tmp_path / "p.jpg")
     data = bytearray((tmp_path / "p.jpg").read_bytes())
-    i = data.index(b"\xff\xc0"); data[i + 1] = 0xC9                                               # SOF9: extended sequential, arithmetic coding
+    # SOF9: extended sequential, arithmetic coding
+    i = data.index(b"\xff\xc0"); data[i + 1] = 0xC9
     (tmp_path / "a.jpg").write_bytes(bytes(data))
     r = subprocess.run([native_build.BIN_DIR / "tex_dump", tmp_path / "a.jpg", tmp_path / "o"], capture_output=True, text=True)
     assert r.returncode != 0 and "arithmetic" in r.stderr

@@ -155,7 +155,8 @@ def test_deep_stack_chain(oracle):
     """A 40-deep push chain (fits the reference's 64-entry stack); 70 deep overflows it."""
     from conftest import chain_bvh2
     nodes, tris = chain_bvh2(40)
-    rays = F.make_rays([[0.1, 0.2, 0.0], [0.1, 0.2, 0.0], [50.0, 0.2, 0.0]], [[0.001, 0.002, 1.0], [0.001, 0.002, 1.0], [0.001, 0.002, 1.0]], 0.0, 1000.0)
+    rays = F.make_rays([[0.1, 0.2, 0.0], [0.1, 0.2, 0.0], [50.0, 0.2, 0.0]],
+        [[0.001, 0.002, 1.0], [0.001, 0.002, 1.0], [0.001, 0.002, 1.0]], 0.0, 1000.0)
     hits, st = oracle.traverse(2, nodes, tris, rays)
     assert st["max_stack"] == 40
     assert hits["tri_id"].tolist() == [0, 0, -1] and abs(hits["t"][0] - 200.0) < 1e-3
@@ -192,7 +193,8 @@ def test_config0_cpu_bench_traversal_plumbing(oracle, cornell, tmp_path):
     import subprocess, sys
     from conftest import ROOT, GOLDEN
     out = tmp_path / "cpu.fbuf"
-    cmd = [sys.executable, str(ROOT / "oracle" / "cpu_bench_traversal.py"), "-bvh", str(cornell.bvh_path), "-ray", str(GOLDEN / "cornell-primary-64x64.rays"),
+    cmd = [sys.executable, str(ROOT / "oracle" / "cpu_bench_traversal.py"), "-bvh", str(cornell.bvh_path), "-ray",
+        str(GOLDEN / "cornell-primary-64x64.rays"),
            "--tmin", "0.01", "--tmax", "5000", "-s", "--bvh-width", "8", "--warmup", "1", "--bench", "2", "-o", str(out)]
     r = subprocess.run(cmd, capture_output=True, text=True, check=True)
     lines = r.stdout.strip().splitlines()

@@ -36,7 +36,8 @@ def intree(native_build, tmp_path_factory):
     dec = MR.atrium_obj(d)
     out = {}
     for name, obj in (("cornell", GOLDEN / "cornell_box.obj"), ("atrium", dec)):
-        subprocess.run([native_build.BIN_DIR / "bvh_extractor", "-obj", obj, "-o", d / f"{name}.bvh"], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run([native_build.BIN_DIR / "bvh_extractor", "-obj", obj, "-o", d / f"{name}.bvh"], check=True,
+            stdout=subprocess.DEVNULL)
         out[name] = d / f"{name}.bvh"
     return out
 
@@ -129,7 +130,8 @@ def test_intree_builder_against_the_reference_builder(oracle, refbuilt, intree, 
     first_o = {int(p) & 0x7FFFFFFF: i for i, p in reversed(list(enumerate(ot["prim_id"])))}
     for pid in range(0, num_r, max(1, num_r // 200)):
         a, b = rt[first_r[pid]], ot[first_o[pid]]
-        assert np.array_equal(a["v0"], b["v0"]) and np.array_equal(a["e1"], b["e1"]) and np.array_equal(a["e2"], b["e2"]) and a["geom_id"] == b["geom_id"]
+        assert np.array_equal(a["v0"], b["v0"]) and np.array_equal(a["e1"], b["e1"]) and np.array_equal(a["e2"],
+            b["e2"]) and a["geom_id"] == b["geom_id"]
     sah_r, leaves_r, refs_r = sah_bvh2(rn, rt)
     sah_o, leaves_o, refs_o = sah_bvh2(on, ot)
     assert refs_r == len(rt) and refs_o == len(ot)
@@ -194,7 +196,8 @@ def test_lds_image_follows_the_callers_nodes(native_build, oracle, refbuilt, int
     abi.lib().rodent_hip_top_min_rays(0)
     try:
         used = []
-        for nodes, tris in ((a_nodes, a_tris), (a_nodes, a_tris), (b_nodes, b_tris), (b_nodes, b_tris), (a_nodes, a_tris), (a_nodes, a_tris)):
+        for nodes, tris in ((a_nodes, a_tris), (a_nodes, a_tris), (b_nodes, b_tris), (b_nodes, b_tris), (a_nodes, a_tris),
+            (a_nodes, a_tris)):
             bvh.nodes[:nodes.nbytes].copy_(torch.from_numpy(nodes.view(np.uint8).reshape(-1).copy()))
             bvh.tris[:tris.nbytes].copy_(torch.from_numpy(tris.view(np.uint8).reshape(-1).copy()))
             torch.cuda.synchronize()

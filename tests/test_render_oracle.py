@@ -63,7 +63,8 @@ def test_rng_and_seed(oracle):
     assert l.oracle_seed(3, 7, 100, 200) == h
 
 
-@pytest.mark.parametrize("mtype,kd,ks,ns", [(1, (0.7, 0.6, 0.5), (0, 0, 0), 1.0), (2, (0, 0, 0), (0.8, 0.8, 0.8), 20.0), (3, (0.5, 0.4, 0.3), (0.3, 0.3, 0.3), 10.0)])
+@pytest.mark.parametrize("mtype,kd,ks,ns", [(1, (0.7, 0.6, 0.5), (0, 0, 0), 1.0), (2, (0, 0, 0), (0.8, 0.8, 0.8), 20.0),
+    (3, (0.5, 0.4, 0.3), (0.3, 0.3, 0.3), 10.0)])
 def test_bsdf_sampling_is_consistent(oracle, mtype, kd, ks, ns):
     """sample().pdf equals pdf() of the sampled direction, directions are unit and in the upper hemisphere,
     and the estimator E[f cos / pdf] stays below 1 (energy conservation)."""
@@ -75,7 +76,8 @@ def test_bsdf_sampling_is_consistent(oracle, mtype, kd, ks, ns):
     out_dir = np.float32([0.3, 0.1, 0.9]); out_dir /= np.linalg.norm(out_dir)
     n = 20000
     res = np.zeros((n, 10), "<f4")
-    l.oracle_bsdf_samples(m.ctypes.data_as(C.c_void_p), out_dir.ctypes.data_as(C.c_void_p), C.c_uint32(99), res.ctypes.data_as(C.c_void_p), C.c_int32(n))
+    l.oracle_bsdf_samples(m.ctypes.data_as(C.c_void_p), out_dir.ctypes.data_as(C.c_void_p), C.c_uint32(99), res.ctypes.data_as(C.c_void_p),
+        C.c_int32(n))
     d, pdf, cosv, col, pdf_eval = res[:, :3], res[:, 3], res[:, 4], res[:, 5:8], res[:, 8]
     valid = col.sum(axis=1) > 0
     assert valid.mean() > 0.5
@@ -135,11 +137,13 @@ def test_corrupt_scene_files_are_rejected(native_build, cornell_scene, tmp_path)
     # an emissive material but an empty light table (every light id 0): the shader would read lights[0]
     nbt, nm, nl = struct.unpack_from("<3I", good, 28)
     lights_at = nodes_at + 64 * nn + 48 * nbt + 64 * nm
-    cases["emitter without a light table"] = good[:36] + struct.pack("<I", 0) + good[40:lights_at] + bytes(4 * nt) + good[lights_at + 80 * nl + 4 * nt:]
+    cases["emitter without a light table"] = good[:36] + struct.pack("<I",
+        0) + good[40:lights_at] + bytes(4 * nt) + good[lights_at + 80 * nl + 4 * nt:]
     tool = native_build.BIN_DIR / "rodent"
     for label, data in cases.items():
         (tmp_path / "bad.rscene").write_bytes(data)
-        r = subprocess.run([tool, "--scene", tmp_path / "bad.rscene", "--bench", "1", "--width", "16", "--height", "16"], capture_output=True, text=True)
+        r = subprocess.run([tool, "--scene", tmp_path / "bad.rscene", "--bench", "1", "--width", "16", "--height", "16"],
+            capture_output=True, text=True)
         assert r.returncode != 0 and "Cannot load scene" in r.stderr, (label, r.stderr)
 
 

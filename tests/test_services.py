@@ -39,7 +39,8 @@ def test_cpu_stream_slabs_keep_the_reference_carving(native_build):
     base = p.rays.id
     names = ["org_x", "org_y", "org_z", "dir_x", "dir_y", "dir_z", "tmin", "tmax"]
     assert [getattr(p.rays, n) - base for n in names] == [4 * cap * (k + 1) for k in range(8)]
-    assert [getattr(p, n) - base for n in ("geom_id", "prim_id", "t", "u", "v", "rnd", "mis", "contrib_r", "contrib_g", "contrib_b", "depth")] == [4 * cap * k for k in range(9, 20)]
+    assert [getattr(p, n) - base for n in ("geom_id", "prim_id", "t", "u", "v", "rnd", "mis", "contrib_r", "contrib_g", "contrib_b",
+        "depth")] == [4 * cap * k for k in range(9, 20)]
     assert [getattr(s, n) - s.rays.id for n in ("prim_id", "color_r", "color_g", "color_b")] == [4 * cap * k for k in range(9, 13)]
     # host memory: writable from here
     C.memset(base, 0, 4 * cap * 20)
@@ -53,7 +54,8 @@ def test_cpu_stream_slabs_keep_the_reference_carving(native_build):
 def data_dir(native_build, tmp_path_factory):
     d = tmp_path_factory.mktemp("svc")
     data = d / "data"; data.mkdir()
-    subprocess.run([native_build.BIN_DIR / "converter", GOLDEN / "cornell_box.obj", "-o", d / "c.rscene", "--data-dir", data], check=True, capture_output=True)
+    subprocess.run([native_build.BIN_DIR / "converter", GOLDEN / "cornell_box.obj", "-o", d / "c.rscene", "--data-dir", data], check=True,
+        capture_output=True)
     # the reference's CPU targets also store BVH4 / BVH8 layouts in bvh.bin (converter.cpp:428-438): append them
     for block in (F.BVH4_TRI4, F.BVH8_TRI4):
         n, t = F.read_bvh(GOLDEN / "cornell.bvh", block)
@@ -122,6 +124,7 @@ def test_missing_files_abort_like_the_reference(native_build, tmp_path):
     """error() in interface.cpp:436,462 prints and aborts: run in a child process."""
     import sys
     code = ("import ctypes, sys; sys.path.insert(0, %r); from rodent_amd import render as R; l = R.lib(); "
-            "n, t = ctypes.c_void_p(), ctypes.c_void_p(); l.rodent_load_bvh2_tri1(0, b'/nonexistent/bvh.bin', ctypes.byref(n), ctypes.byref(t))") % str(GOLDEN.parents[1])
+            "n, t = ctypes.c_void_p(), ctypes.c_void_p(); l.rodent_load_bvh2_tri1(0, b'/nonexistent/bvh.bin', ctypes.byref(n), "
+                "ctypes.byref(t))") % str(GOLDEN.parents[1])
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "Cannot open BVH" in r.stderr

@@ -1,6 +1,7 @@
 """The reference-held pin for the traversal: its own CTest, restated (cmake/test/run_traversal.cmake:1-9, tools/CMakeLists.txt:24-31).
 
-    bench_traversal -bvh testing/sponza.bvh -ray testing/sponza-primary.rays --bench 1 --warmup 0 --tmin 0.01 --tmax 5000 -o out.fbuf <variant>
+    bench_traversal -bvh testing/sponza.bvh -ray testing/sponza-primary.rays --bench 1 --warmup 0 --tmin 0.01 --tmax 5000 -o out.fbuf
+    <variant>
     fbuf2png -n out.fbuf out.png
     compare -metric MSE testing/ref-primary.png out.png            (ImageMagick: fails on any difference)
 
@@ -23,7 +24,8 @@ from rodent_amd import scenes
 
 SPONZA = [scenes.DATA / "sponza.bvh", scenes.DATA / "sponza-primary.rays"]
 MISSING = [str(p.relative_to(ROOT)) for p in SPONZA if not p.exists()]
-needs_sponza = pytest.mark.skipif(bool(MISSING), reason="the reference's Sponza blobs are absent from its checkout (.MISSING_LARGE_BLOBS); supply "
+needs_sponza = pytest.mark.skipif(bool(MISSING),
+    reason="the reference's Sponza blobs are absent from its checkout (.MISSING_LARGE_BLOBS); supply "
                                   + ", ".join(MISSING) + " to pin the traversal against testing/ref-primary.png")
 CTEST_ARGS = ["--bench", "1", "--warmup", "0", "--tmin", "0.01", "--tmax", "5000"]
 
@@ -45,9 +47,11 @@ def test_the_reference_image_is_a_fixture():
 
 @needs_sponza
 def test_oracle_matches_ref_primary(native_build, tmp_path):
-    """The CPU restatement (oracle B2 through the reference's CLI, oracle/cpu_bench_traversal.py --single --bvh-width 4 = CTest `single_bvh4`)."""
+    """The CPU restatement (oracle B2 through the reference's CLI, oracle/cpu_bench_traversal.py --single --bvh-width 4 = CTest
+    `single_bvh4`)."""
     fbuf, png = tmp_path / "o.fbuf", tmp_path / "o.png"
-    subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_bench_traversal.py"), "-bvh", str(SPONZA[0]), "-ray", str(SPONZA[1]), *CTEST_ARGS,
+    subprocess.run([sys.executable, str(ROOT / "oracle" / "cpu_bench_traversal.py"), "-bvh", str(SPONZA[0]), "-ray", str(SPONZA[1]),
+        *CTEST_ARGS,
                     "--single", "--bvh-width", "4", "-o", str(fbuf)], check=True, capture_output=True)
     subprocess.run([native_build.BIN_DIR / "fbuf2png", "-n", fbuf, png], check=True)
     mse, pixels = differs_from_reference(png)

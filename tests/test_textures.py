@@ -39,7 +39,8 @@ def test_converter_builds_texture_tables(textured_scene):
 def test_missing_texture_becomes_black_dummy(native_build, tmp_path):
     (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 1 1\nmap_Kd nothere.png\nnewmtl l\nKe 1 1 1\n")
     (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nusemtl a\nf 1/1 2/1 3/1\nusemtl l\nf 1/1 3/1 2/1\n")
-    r = subprocess.run([native_build.BIN_DIR / "converter", tmp_path / "m.obj", "-o", tmp_path / "m.rscene"], capture_output=True, text=True, check=True)
+    r = subprocess.run([native_build.BIN_DIR / "converter", tmp_path / "m.obj", "-o", tmp_path / "m.rscene"], capture_output=True,
+        text=True, check=True)
     assert "Cannot load texture 'nothere.png'" in r.stderr
     sc = S.Scene(tmp_path / "m.rscene")
     assert len(sc.textures) == 1 and sc.textures[0]["width"] == 1 and sc.texels.tolist() == [0]
@@ -66,7 +67,8 @@ def bilinear_ref(img, uv):
 def test_oracle_texture_lookup_is_repeat_bilinear(oracle, textured_scene):
     sc, d = textured_scene
     rng = np.random.default_rng(7)
-    uv = np.concatenate([rng.uniform(-3, 3, (400, 2)), [[0, 0], [1, 1], [0.999999, 0.5], [-1e-9, 0.25], [2.5, -0.25], [31.5 / 32, 31.5 / 32]]]).astype("<f4")
+    uv = np.concatenate([rng.uniform(-3, 3, (400, 2)),
+        [[0, 0], [1, 1], [0.999999, 0.5], [-1e-9, 0.25], [2.5, -0.25], [31.5 / 32, 31.5 / 32]]]).astype("<f4")
     for k, name in ((0, "checker.png"), (2, "spec.tga")):
         got = oracle.tex_lookup(sc, k, uv)
         assert np.array_equal(got, bilinear_ref(load_like_reference(d / name), uv))
@@ -81,7 +83,8 @@ def test_per_hit_material_follows_the_textures(oracle, textured_scene):
     # floor: kd = the checker at the interpolated texture coordinate (vertex 0 has vt (0,0), vertex 1 (2.5,0), vertex 2 (2.5,2.5))
     for u, v in ((0.1, 0.2), (0.33, 0.33), (0.7, 0.05)):
         m = oracle.hit_material(sc, floor_prim, u, v)
-        tc = (np.float32(1 - u - v) * sc.texcoords[sc.indices[floor_prim, 0], :2] + np.float32(u) * sc.texcoords[sc.indices[floor_prim, 1], :2]
+        tc = (np.float32(1 - u - v) * sc.texcoords[sc.indices[floor_prim, 0], :2] + np.float32(u) * sc.texcoords[sc.indices[floor_prim, 1],
+            :2]
               + np.float32(v) * sc.texcoords[sc.indices[floor_prim, 2], :2])
         assert np.allclose(m["kd"], oracle.tex_lookup(sc, 0, tc[None])[0], atol=2e-6)
         assert m["type"] == 1 and m["tex_kd"] == 1
@@ -89,7 +92,8 @@ def test_per_hit_material_follows_the_textures(oracle, textured_scene):
     ks_seen = set()
     for u in np.linspace(0.02, 0.9, 23):
         m = oracle.hit_material(sc, back_prim, float(u), 0.05)
-        lum = lambda c: np.float32(c[0]) * np.float32(0.2126) + np.float32(c[1]) * np.float32(0.7152) + np.float32(c[2]) * np.float32(0.0722)
+        lum = lambda c: np.float32(c[0]) * np.float32(0.2126) + np.float32(c[1]) * np.float32(0.7152) + np.float32(c[2]) * np.float32(
+            0.0722)
         ls, ld = lum(m["ks"]), lum(m["kd"])
         assert np.isclose(m["mix_k"], 0.0 if ls + ld == 0 else ls / (ls + ld), rtol=1e-6)
         ks_seen.add(round(float(m["ks"][0]), 3))
