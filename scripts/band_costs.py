@@ -40,8 +40,10 @@ def timed(fn):
 
 whole = timed(lambda: r.render_rows(cam, 0, 0, h))
 samples = a.spp * w * h
-print(f"atrium {w}x{h} x {a.spp} spp, path length 8, mapping {r.mapping_name()}: whole frame on one GPU {whole:.1f} ms = {samples / whole / 1e3:.1f} Msamples/s")
-print(f"{'GPUs':>4s} {'partition':>22s} | per-rank ms" + " " * 58 + "| mean / max = efficiency | predicted Msamples/s (film gather not included)")
+print(f"atrium {w}x{h} x {a.spp} spp, path length 8, mapping {r.mapping_name()}: whole frame on one GPU {whole:.1f} ms = "
+    f"{samples / whole / 1e3:.1f} Msamples/s")
+print(f"{'GPUs':>4s} {'partition':>22s} | per-rank ms" + " " * 58
+    + "| mean / max = efficiency | predicted Msamples/s (film gather not included)")
 for n in [int(x) for x in a.gpus.split(",")]:
     for kind in (["bands"] + (["tiles"] if a.tiles else [])):
         ms = []
@@ -52,5 +54,7 @@ for n in [int(x) for x in a.gpus.split(",")]:
             else:
                 ms.append(timed(lambda: r.render_tiles(cam, 0, a.tile_rows, rank, n)))
         label = f"{h // n}-row bands" if kind == "bands" else f"{a.tile_rows}-row tiles, stride {n}"
-        print(f"{n:4d} {label:>22s} | " + " ".join(f"{x:7.1f}" for x in ms).ljust(69) + f"| {np.mean(ms):7.1f} / {max(ms):7.1f} = {np.mean(ms) / max(ms):.3f}   | {samples / max(ms) / 1e3:8.1f}  ({samples / max(ms) / 1e3 / (samples / whole / 1e3):.2f} x one GPU)", flush=True)
+        print(f"{n:4d} {label:>22s} | " + " ".join(f"{x:7.1f}"
+            for x in ms).ljust(69) + f"| {np.mean(ms):7.1f} / {max(ms):7.1f} = {np.mean(ms) / max(ms):.3f}   | "
+            f"{samples / max(ms) / 1e3:8.1f}  ({samples / max(ms) / 1e3 / (samples / whole / 1e3):.2f} x one GPU)", flush=True)
 r.close()

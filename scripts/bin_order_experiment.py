@@ -1,7 +1,10 @@
 #!/usr/bin/env python
-"""What ordering incoherent rays by the cell of their origin is worth to the CURRENT kernels (the follow-up of scripts/xcd_affinity_experiment.py, whose
-control -- eight bins laid out contiguously -- gained 10 %): the random segments reordered ON THE HOST into 2^3 / 4^3 / 8^3 / 16^3 cells of the scene box
-(cells in Morton order, rays inside a cell in their original order), traced by the default mapping (the refill kernel, from the second launch on) and by
+"""What ordering incoherent rays by the cell of their origin is worth to the CURRENT kernels (the follow-up of
+scripts/xcd_affinity_experiment.py, whose
+control -- eight bins laid out contiguously -- gained 10 %): the random segments reordered ON THE HOST into 2^3 / 4^3 / 8^3 / 16^3 cells of
+the scene box
+(cells in Morton order, rays inside a cell in their original order), traced by the default mapping (the refill kernel, from the second
+launch on) and by
 whole chunks.  The time of the sort itself is NOT included: this bounds what an in-launch counting sort may cost.
 usage: RODENT_HIP_LAB=1 python scripts/bin_order_experiment.py [--steps 20]"""
 import argparse, sys
@@ -49,6 +52,7 @@ for count in (1 << 20, 1 << 23):
     rays = raygen.random_rays(lo, hi, count, 42, 0.0, 1.0)
     org = np.asarray(rays["org"], np.float64)
     print(f"{count} random segments")
-    for label, order in [("as generated", np.arange(count))] + [(f"{1 << bits}^3 cells of the origin", np.argsort(cell_key(org, bits), kind="stable")) for bits in (1, 2, 3, 4)]:
+    for label, order in [("as generated", np.arange(count))] + [(f"{1 << bits}^3 cells of the origin",
+        np.argsort(cell_key(org, bits), kind="stable")) for bits in (1, 2, 3, 4)]:
         r = np.ascontiguousarray(rays[order])
         print(f"   {label:32s} " + "   ".join(f"{vn}: {timed(v, r):.4f} ms" for vn, v in variants), flush=True)

@@ -68,11 +68,13 @@ def morton_order(org, cells):
 
 l.hip_generate_rays(0, C.byref(p), cap, 0, cap, C.byref(st), 0, W, H, 0, SPP, None)
 totals = {}
-print(f"{'bounce':>6s} {'kind':>8s} {'rays':>9s} " + " ".join(f"{c:>12s}" for c in ("stream order", "8 cells", "64 cells", "512 cells", "4096 cells")) + "   ms per pass")
+print(f"{'bounce':>6s} {'kind':>8s} {'rays':>9s} " + " ".join(f"{c:>12s}" for c in ("stream order", "8 cells", "64 cells", "512 cells",
+    "4096 cells")) + "   ms per pass")
 bounce = 0
 while p.size > 0 and bounce < MAXLEN + 1:
     l.hip_traverse_primary(0, C.byref(p), None)
-    l.hip_sort_primary(0, C.byref(p), C.byref(q), ends, None)       # the stage-level shader wants the misses dropped (mapping_gpu.impala:347-357)
+    # the stage-level shader wants the misses dropped (mapping_gpu.impala:347-357)
+    l.hip_sort_primary(0, C.byref(p), C.byref(q), ends, None)
     p, q = q, p
     n = ends[G - 1]
     l.hip_shade(0, C.byref(p), C.byref(s), n, None)
@@ -90,5 +92,6 @@ while p.size > 0 and bounce < MAXLEN + 1:
     p, q = q, p
     bounce += 1
 for kind, t in totals.items():
-    print(f"{'sum':>6s} {kind:>8s} {'':9s} " + " ".join(f"{v:12.4f}" for v in t) + "   ratio to stream order: " + " ".join(f"{t[0] / v:.3f}" for v in t))
+    print(f"{'sum':>6s} {kind:>8s} {'':9s} " + " ".join(f"{v:12.4f}"
+        for v in t) + "   ratio to stream order: " + " ".join(f"{t[0] / v:.3f}" for v in t))
 r.close()

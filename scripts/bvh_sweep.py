@@ -29,11 +29,13 @@ prim = raygen.primary_rays(eye, d, up, fov, 512, 512, 0.0, 5000.0)
 rnd = None
 first_counts = None
 print(f"atrium, {w}x{h} x {a.spp} spp, path length 8; oracle visits per ray on 512 x 512 camera rays and 256 Ki random segments")
-print(f"{'leaf':>4s} {'Ct':>4s} | {'nodes':>7s} {'refs':>7s} | {'camera: inner':>13s} {'tris':>6s} {'steps':>6s} | {'random: inner':>13s} {'tris':>6s} {'steps':>6s} | {'frame ms':>8s} {'Msamples/s':>10s}")
+print(f"{'leaf':>4s} {'Ct':>4s} | {'nodes':>7s} {'refs':>7s} | {'camera: inner':>13s} {'tris':>6s} {'steps':>6s} | {'random: inner':>13s} "
+    f"{'tris':>6s} {'steps':>6s} | {'frame ms':>8s} {'Msamples/s':>10s}")
 for leaf in [int(x) for x in a.leaf.split(",")]:
     for ct in [float(x) for x in a.ct.split(",")]:
         out = Path("/tmp") / f"atrium_l{leaf}_c{ct}.rscene"
-        subprocess.run([str(build.BIN_DIR / "converter"), str(obj), "-o", str(out), "--bvh-leaf", str(leaf), "--bvh-traversal-cost", str(ct)], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run([str(build.BIN_DIR / "converter"), str(obj), "-o", str(out), "--bvh-leaf", str(leaf), "--bvh-traversal-cost",
+            str(ct)], check=True, stdout=subprocess.DEVNULL)
         sc = S.Scene(out)
         nodes, tris = sc.nodes, sc.tris
         if rnd is None:
@@ -54,5 +56,7 @@ for leaf in [int(x) for x in a.leaf.split(",")]:
         counts = (c["primary_rays"], c["shadow_rays"])
         first_counts = first_counts or counts
         best = float(np.median(ms[1:]))
-        print(f"{leaf:4d} {ct:4.1f} | {len(nodes):7d} {len(tris):7d} | {sp['inner_per_ray']:13.2f} {sp['prims_per_ray']:6.2f} {sp['inner_per_ray'] + sp['prims_per_ray']:6.2f} | "
-              f"{sr['inner_per_ray']:13.2f} {sr['prims_per_ray']:6.2f} {sr['inner_per_ray'] + sr['prims_per_ray']:6.2f} | {best:8.1f} {a.spp * w * h / best / 1e3:10.1f}" + ("" if counts == first_counts else f"  RAY COUNTS DIFFER {counts}"), flush=True)
+        print(f"{leaf:4d} {ct:4.1f} | {len(nodes):7d} {len(tris):7d} | {sp['inner_per_ray']:13.2f} {sp['prims_per_ray']:6.2f} "
+            f"{sp['inner_per_ray'] + sp['prims_per_ray']:6.2f} | "
+              f"{sr['inner_per_ray']:13.2f} {sr['prims_per_ray']:6.2f} {sr['inner_per_ray'] + sr['prims_per_ray']:6.2f} | {best:8.1f} "
+                  f"{a.spp * w * h / best / 1e3:10.1f}" + ("" if counts == first_counts else f"  RAY COUNTS DIFFER {counts}"), flush=True)

@@ -27,5 +27,6 @@ for rep in range(2):
             torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
         c = r.counters()
         best = float(np.median(ms[1:]))
-        print(f"capacity {cap >> 20:3d} Mi rays: {best:8.1f} ms = {a.spp * w * h / best / 1e3:7.1f} Msamples/s ({r.mapping_name()}); iterations {c['iterations']}", flush=True)
+        print(f"capacity {cap >> 20:3d} Mi rays: {best:8.1f} ms = {a.spp * w * h / best / 1e3:7.1f} Msamples/s ({r.mapping_name()}); "
+            f"iterations {c['iterations']}", flush=True)
         r.close()

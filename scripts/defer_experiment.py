@@ -23,7 +23,8 @@ path = scenes.scene_bvh(a.scene)
 bvh = abi.DeviceBvh.load(path, 2, 0)
 eye, d, up, fov = scenes.CAMERAS[a.scene]
 lo, hi = raygen.scene_bounds(F.read_bvh(path, F.BVH4_TRI4)[0])
-sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0), "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
+sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0),
+    "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
 if a.big:
     sets["random8Mi"] = raygen.random_rays(lo, hi, 1 << 23, 43, 0.0, 1.0)
 names = abi.variants(2)
@@ -54,7 +55,8 @@ def ulps(x, y):
 
 
 base = {}
-print(f"scene {a.scene}; ms = mean of {a.steps} back-to-back launches (HIP events); diff = rays whose record differs from the default's: ids / t (max ulps)")
+print(f"scene {a.scene}; ms = mean of {a.steps} back-to-back launches (HIP events); diff = rays whose record differs from the default's: "
+    f"ids / t (max ulps)")
 print(f"{'variant':22s} " + " ".join(f"{k + (' any' if any_hit else ''):>30s}" for k in sets for any_hit in (False, True)))
 for v in todo:
     cells = []
@@ -87,4 +89,5 @@ for v in [i for i, nm in enumerate(names) if nm.startswith("stats-defer")]:
         abi.traverse(bvh, rays, variant=v)
         st = abi.read_stats(0)
         rounds, lanes = int(st[3]), int(st[4])
-        print(f"{names[v]:22s} {k:8s} drain rounds per ray {rounds * 64 / len(rays):.2f} (wave rounds {rounds}), lanes busy in a round {lanes / max(1, rounds) / 64:.3f}, triangle tests per ray {lanes / len(rays):.3f}")
+        print(f"{names[v]:22s} {k:8s} drain rounds per ray {rounds * 64 / len(rays):.2f} (wave rounds {rounds}), lanes busy in a round "
+            f"{lanes / max(1, rounds) / 64:.3f}, triangle tests per ray {lanes / len(rays):.3f}")

@@ -33,5 +33,6 @@ for it in range(a.frames + 1):
     torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
 c = r.counters()
 best = float(np.median(ms[1:]))
-print(f"{Path(str(rscene)).name} {len(sc.nodes)} nodes {w}x{h} x {a.spp} spp len {a.len} ({r.mapping_name()}): {best:.1f} ms = {a.spp * w * h / best / 1e3:.1f} Msamples/s; rays {c['primary_rays']} + {c['shadow_rays']} shadow", flush=True)
+print(f"{Path(str(rscene)).name} {len(sc.nodes)} nodes {w}x{h} x {a.spp} spp len {a.len} ({r.mapping_name()}): {best:.1f} ms = "
+    f"{a.spp * w * h / best / 1e3:.1f} Msamples/s; rays {c['primary_rays']} + {c['shadow_rays']} shadow", flush=True)
 r.close()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Camera rays as 8 x 8-pixel tiles instead of 64-pixel row segments per wave (RODENT_HIP_RAY_GRID=<image width>, experiment): kernel ms of the default mapping on the
-primary set of a scene, and the hits' bytes against the run without it.  usage: RODENT_HIP_RAY_GRID=1024 python scripts/grid_experiment.py [scene] [width]"""
+"""Camera rays as 8 x 8-pixel tiles instead of 64-pixel row segments per wave (RODENT_HIP_RAY_GRID=<image width>, experiment): kernel ms of
+the default mapping on the
+primary set of a scene, and the hits' bytes against the run without it.  usage: RODENT_HIP_RAY_GRID=1024 python scripts/grid_experiment.py
+[scene] [width]"""
 import os, sys, hashlib
 from pathlib import Path
 import numpy as np
@@ -30,5 +32,6 @@ for h in (w, w + 4):                                       # a height that is no
         e1.record(st); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 30)
     got = abi.from_device(hd, F.HIT1)
-    print(f"{scene} {w}x{h} grid={os.environ.get('RODENT_HIP_RAY_GRID', '0')}: {best:.4f} ms  {n / best / 1e3:.1f} Mrays/s  hits sha {hashlib.sha1(got.tobytes()).hexdigest()[:12]}", flush=True)
+    print(f"{scene} {w}x{h} grid={os.environ.get('RODENT_HIP_RAY_GRID', '0')}: {best:.4f} ms  {n / best / 1e3:.1f} Mrays/s  hits sha "
+        f"{hashlib.sha1(got.tobytes()).hexdigest()[:12]}", flush=True)
 abi.check_errors(0)

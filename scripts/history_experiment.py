@@ -42,7 +42,8 @@ for step in (0.0, 0.1, 0.5, 1.0, 2.0, 5.0, 15.0):
         for k in range(FRAMES):
             ev[k][0].record(st); abi.traverse_async(bvh, frames[k], hits[k], n, False, 0, st); ev[k][1].record(st)
         torch.cuda.synchronize()
-        out[mode] = (float(np.median([s.elapsed_time(e) for s, e in ev[1:]])), hits)      # frame 0 follows the LAST frame of the warm-up: skipped
+        # frame 0 follows the LAST frame of the warm-up: skipped
+        out[mode] = (float(np.median([s.elapsed_time(e) for s, e in ev[1:]])), hits)
     abi.lib().rodent_hip_schedule_history(0)
     same = all(torch.equal(a, b) for a, b in zip(out[0][1], out[1][1]))
     print(f"{step:21.1f} deg {out[0][0]:15.4f} {out[1][0]:14.4f} {out[0][0] / out[1][0]:6.3f}x  {same}")

@@ -31,8 +31,11 @@ rows = [("python ctypes call overhead (hipGetDevice)", lambda: hip.hipGetDevice(
         ("hipMemGetAddressRange", lambda: hip.hipMemGetAddressRange(C.byref(base), C.byref(size), ptr)),
         ("hipEventRecord (null stream)", lambda: hip.hipEventRecord(ev[0], None)),
         ("hipStreamSynchronize (idle null stream)", lambda: hip.hipStreamSynchronize(None)),
-        ("hipMemcpyAsync D2H 80 B into pinned + hipStreamSynchronize", lambda: (hip.hipMemcpyAsync(pinned, ptr, 80, 2, None), hip.hipStreamSynchronize(None))),
-        ("hipEventRecord x 2 + hipStreamSynchronize + hipEventElapsedTime", lambda: (hip.hipEventRecord(ev[0], None), hip.hipEventRecord(ev[1], None), hip.hipStreamSynchronize(None), hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[1])))]
+        ("hipMemcpyAsync D2H 80 B into pinned + hipStreamSynchronize",
+            lambda: (hip.hipMemcpyAsync(pinned, ptr, 80, 2, None), hip.hipStreamSynchronize(None))),
+        ("hipEventRecord x 2 + hipStreamSynchronize + hipEventElapsedTime",
+            lambda: (hip.hipEventRecord(ev[0], None), hip.hipEventRecord(ev[1], None), hip.hipStreamSynchronize(None),
+            hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[1])))]
 for name, fn in rows:
     print(f"{per_call(fn):8.2f} us  {name}")
 
@@ -42,13 +45,15 @@ eye, d, up, fov = scenes.CAMERAS["atrium"]
 rays = raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0)
 rd = abi.to_device(rays, 0); hd = torch.zeros(len(rays) * 16, dtype=torch.uint8, device="cuda:0")
 l = abi.lib()
-call = lambda: l.amdgpu_intersect_single_ray1_bvh2_tri1(0, bvh.nodes.data_ptr(), bvh.tris.data_ptr(), rd.data_ptr(), hd.data_ptr(), len(rays))
+call = lambda: l.amdgpu_intersect_single_ray1_bvh2_tri1(0, bvh.nodes.data_ptr(), bvh.tris.data_ptr(), rd.data_ptr(), hd.data_ptr(),
+    len(rays))
 for _ in range(20): call()
 k0 = l.rodent_hip_get_kernel_time(); t0 = time.perf_counter()
 n = 200
 for _ in range(n): call()
 wall = (time.perf_counter() - t0) / n * 1e6; kern = (l.rodent_hip_get_kernel_time() - k0) / n
-print(f"amdgpu_intersect_single_ray1_bvh2_tri1, 1 Mi primary rays: {wall:.2f} us wall per call, {kern:.2f} us of kernels by the library's account -> {wall - kern:.2f} us of host")
+print(f"amdgpu_intersect_single_ray1_bvh2_tri1, 1 Mi primary rays: {wall:.2f} us wall per call, {kern:.2f} us of kernels by the library's "
+    f"account -> {wall - kern:.2f} us of host")
 st = torch.cuda.current_stream()
 for _ in range(20): abi.traverse_async(bvh, rd, hd, len(rays), False, 0, st)
 torch.cuda.synchronize(); t0 = time.perf_counter()

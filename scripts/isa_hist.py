@@ -25,8 +25,10 @@ def main():
             elif line.startswith("\t") and t and not t.startswith((".", ";")):
                 ins.append(t)
         ops = Counter(i.split()[0] for i in ins)
-        kinds = lambda c: {"valu": sum(v for k, v in c.items() if k.startswith("v_")), "salu": sum(v for k, v in c.items() if k.startswith("s_")),
-                           "vmem": sum(v for k, v in c.items() if k.startswith(("global_", "buffer_", "flat_", "scratch_"))), "lds": sum(v for k, v in c.items() if k.startswith("ds_"))}
+        kinds = lambda c: {"valu": sum(v for k, v in c.items() if k.startswith("v_")),
+            "salu": sum(v for k, v in c.items() if k.startswith("s_")),
+                           "vmem": sum(v for k, v in c.items() if k.startswith(("global_", "buffer_", "flat_", "scratch_"))),
+                               "lds": sum(v for k, v in c.items() if k.startswith("ds_"))}
         vg = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
         print(f"{name[:100]}\n  instructions {len(ins)} {kinds(ops)} vgpr {vg.group(1) if vg else '?'}")
         # loops: backward branches

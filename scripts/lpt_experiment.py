@@ -18,7 +18,8 @@ nodes, tris = F.read_bvh(path, F.BVH2_TRI1)
 eye, d, up, fov = scenes.CAMERAS["atrium"]
 n4, _ = F.read_bvh(path, F.BVH4_TRI4)
 lo, hi = raygen.scene_bounds(n4)
-sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0), "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
+sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0),
+    "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
 names = abi.variants(2)
 STRIPES, GROUP = 64, 32
 
@@ -56,8 +57,10 @@ for k, rays in sets.items():
         full[s] = c[np.argsort(-cost[c], kind="stable")]
         second[s, half:] = c[half:][np.argsort(-cost[c[half:]], kind="stable")]
     groups = per_stripe // GROUP
-    inter = np.concatenate([np.arange(0, groups, 2), np.arange(1, groups, 2)])                     # even 32-chunk groups of the stripe first, then the odd ones
-    orders["even groups first, then odd groups (stateless)"] = np.stack([pos[s].reshape(groups, GROUP)[inter].ravel() for s in range(STRIPES)])
+    # even 32-chunk groups of the stripe first, then the odd ones
+    inter = np.concatenate([np.arange(0, groups, 2), np.arange(1, groups, 2)])
+    orders["even groups first, then odd groups (stateless)"] = np.stack([pos[s].reshape(groups, GROUP)[inter].ravel()
+        for s in range(STRIPES)])
     rev = np.arange(groups)[::-1]
     orders["groups in reverse order (stateless)"] = np.stack([pos[s].reshape(groups, GROUP)[rev].ravel() for s in range(STRIPES)])
     orders["longest first (whole stripe)"] = full

@@ -14,9 +14,11 @@ for line in (P / f"{tag}_ubench_valu_peak.txt").read_text().splitlines():
         valu[m.group(1).strip()] = float(m.group(3))
 fetch = {}
 for line in (P / f"{tag}_ubench_vmem_peak.txt").read_text().splitlines():
-    m = re.match(r"(.+?)\s{2,}(lane-per-node|4-lanes-per-node)\s+lanes\s+(\d+)%:\s+[\d.]+ ms\s+([\d.]+) node fetches/ns\s+([\d.]+) load instr/us/CU", line)
+    m = re.match(r"(.+?)\s{2,}(lane-per-node|4-lanes-per-node)\s+lanes\s+(\d+)%:\s+[\d.]+ ms\s+([\d.]+) node fetches/ns\s+([\d.]+) load "
+        r"instr/us/CU", line)
     if m and m.group(2) == "lane-per-node":
-        fetch.setdefault(m.group(1).strip(), {})[m.group(3)] = {"node_fetches_per_ns": float(m.group(4)), "load_instr_per_us_per_cu": float(m.group(5))}
+        fetch.setdefault(m.group(1).strip(), {})[m.group(3)] = {"node_fetches_per_ns": float(m.group(4)),
+            "load_instr_per_us_per_cu": float(m.group(5))}
 out = {
     "source": [f"profiles/{tag}_ubench_valu_peak.txt", f"profiles/{tag}_ubench_vmem_peak.txt"],
     "valu_issue_wave_instr_per_us_per_simd_8_waves": valu,

@@ -49,7 +49,8 @@ for k in [int(x) for x in a.keep.split(",")]:
         (Path("/tmp") / "atrium.mtl").write_text(mtl)
         decimate(k, dst)
     cases.append((f"atrium 1/{k}", dst if k > 1 else src, scenes.CAMERAS["atrium"]))
-print(f"{'scene':14s} {'triangles':>9s} {'BVH nodes':>9s} {'streaming':>10s} {'megakernel':>10s}   Msamples/s at {W}x{H}x{a.spp} spp, path length {LEN};  library's choice")
+print(f"{'scene':14s} {'triangles':>9s} {'BVH nodes':>9s} {'streaming':>10s} {'megakernel':>10s}   Msamples/s at {W}x{H}x{a.spp} spp, path "
+    f"length {LEN};  library's choice")
 for name, obj, (eye, d, up, fov) in cases:
     sc = S.convert(obj, Path("/tmp") / "sweep.rscene")
     cam = S.camera_settings(eye, d, up, fov, W, H)
@@ -64,4 +65,5 @@ for name, obj, (eye, d, up, fov) in cases:
         rates[mapping] = a.spp * W * H / float(np.median(secs)) / 1e6
         r.close()
     best = max(rates, key=rates.get)
-    print(f"{name:14s} {sc.num_tris:9d} {len(sc.nodes):9d} {rates['streaming']:10.1f} {rates['megakernel']:10.1f}   faster: {best:10s} chosen: {choice}{'' if best == choice else '   <-- not the faster one'}", flush=True)
+    print(f"{name:14s} {sc.num_tris:9d} {len(sc.nodes):9d} {rates['streaming']:10.1f} {rates['megakernel']:10.1f}   faster: {best:10s} "
+        f"chosen: {choice}{'' if best == choice else '   <-- not the faster one'}", flush=True)

@@ -40,17 +40,23 @@ ap.add_argument("--tile", default="", help="THxTW: re-chunk the dump (a WIDTH-wi
 ap.add_argument("--width", type=int, default=1024)
 ap.add_argument("--thresholds", default="8,16,24,32,48")
 ap.add_argument("--limit", type=int, default=0, help="only the first N rays")
-ap.add_argument("--buildable", action="store_true", help="also mode 2: no masks on the shared stack, fallback decided at the parent, at most --keep-limit kept entries per lane, 15-entry windows")
+ap.add_argument("--buildable", action="store_true",
+    help="also mode 2: no masks on the shared stack, fallback decided at the parent, at most --keep-limit kept entries per lane, 15-entry "
+    "windows")
 ap.add_argument("--keep-limit", type=int, default=8)
-ap.add_argument("--steal", default="", help="i0:every[,i0:every...]: also mode 3, the per-lane kernel with work stealing inside the wave from iteration i0 on, every `every` iterations")
+ap.add_argument("--steal", default="",
+    help="i0:every[,i0:every...]: also mode 3, the per-lane kernel with work stealing inside the wave from iteration i0 on, every `every` "
+    "iterations")
 a = ap.parse_args()
 
 so = Path("/tmp/model_packet.so")
 src = ROOT / "scripts/model_packet.c"
 if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, (ROOT / "oracle/traversal_oracle.c").stat().st_mtime):
-    subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-shared", str(src), "-lm", "-o", str(so)], check=True)
+    subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-shared", str(src), "-lm", "-o",
+        str(so)], check=True)
 lib = C.CDLL(str(so))
-COUNTS = np.dtype([(k, "<u4") for k in ("p_node_img", "p_node_mem", "p_tri", "p_lanes_node", "p_lanes_tri", "f_it_node", "f_it_mixed", "f_it_tri",
+COUNTS = np.dtype([(k, "<u4") for k in ("p_node_img", "p_node_mem", "p_tri", "p_lanes_node", "p_lanes_tri", "f_it_node", "f_it_mixed",
+    "f_it_tri",
                                         "f_lane_steps", "f_phases", "max_deferred", "window_overflows")])
 lib.model_packet.restype = C.c_int
 lib.model_packet.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p] * 3
@@ -72,10 +78,12 @@ chunks = (n + 63) // 64
 in_image = np.zeros(len(nodes), np.uint8)
 in_image[topimage.image_nodes(nodes)] = 1
 ref, stats = O.traverse(2, nodes, tris, rays, any_hit=a.any)
-print(f"{a.rays}{' tiles ' + a.tile if a.tile else ''}: {n} rays, {chunks} chunks; B1 visits per ray: {stats['inner_per_ray']:.2f} inner nodes, {stats['prims_per_ray']:.2f} triangles")
+print(f"{a.rays}{' tiles ' + a.tile if a.tile else ''}: {n} rays, {chunks} chunks; B1 visits per ray: {stats['inner_per_ray']:.2f} inner "
+    f"nodes, {stats['prims_per_ray']:.2f} triangles")
 
 # ---- price list (VALU wave-instructions; cycles of a wave running alone) --------------------------------------------------
-# per-lane loop: scripts/isa_hist.py on k_bvh2_top_persist: 67 node lanes only, 132 both kinds; triangle lanes only ~ 132 - 67 + 10
+# per-lane loop: scripts/isa_hist.py on k_bvh2_top_persist: 67 node lanes only, 132 both kinds; triangle lanes only ~ 132 -
+# 67 + 10
 V_LANE = {"node": 67, "mixed": 132, "tri": 75}
 # packet steps (estimates from the operation list: 6 v_pk_fma + 12 min/max + 2 cmp for the two slabs, the near-child preference,
 # mask bookkeeping on the SALU; a triangle: 3 sub, 2 cross, 4 dot, prodsign, compares, one IEEE division, 3 mul, 4 cndmask)
@@ -83,7 +91,8 @@ V_PNODE, V_PTRI = 30, 55
 CYC_VALU_ALONE, CYC_VALU_FULL = 5.7, 3.1
 # load latency a step waits for when the wave runs alone (cycles at 2.4 GHz): the per-lane iteration's 1250 cycles = 100 VALU x 5.7 + ~680
 LAT_LANE = 680
-LAT_PNODE_IMG, LAT_PNODE_MEM, LAT_PTRI = 230, 450, 300          # ds_read broadcast + SALU decisions; scalar / uniform load (children prefetched); triangle record
+# ds_read broadcast + SALU decisions; scalar / uniform load (children prefetched); triangle record
+LAT_PNODE_IMG, LAT_PNODE_MEM, LAT_PTRI = 230, 450, 300
 GHZ = 2.4
 
 
@@ -172,7 +181,8 @@ assert base_hits.tobytes() == ref.tobytes(), "T = 65 must reproduce oracle B1"
 bv, ba = price(base_counts)
 bt = schedule(bv, ba)
 bit = base_counts["f_it_node"].astype(np.int64) + base_counts["f_it_mixed"] + base_counts["f_it_tri"]
-print(f"existing kernel (T = 65; hits == B1: yes): wave iterations per chunk {bit.mean():.1f} (longest {bit.max()}), lane utilisation {base_counts['f_lane_steps'].sum() / (64.0 * bit.sum()):.3f}, "
+print(f"existing kernel (T = 65; hits == B1: yes): wave iterations per chunk {bit.mean():.1f} (longest {bit.max()}), lane utilisation "
+    f"{base_counts['f_lane_steps'].sum() / (64.0 * bit.sum()):.3f}, "
       f"VALU {bv.sum() / 1e6:.1f} M wave-instructions, longest chunk alone {ba.max() / GHZ / 1e3:.1f} us, modelled launch {bt:.1f} us")
 kinds = {k: int(base_counts["f_it_" + k].sum()) for k in ("node", "mixed", "tri")}
 print("  its iterations by kind: " + ", ".join(f"{k} {v / bit.sum():.1%}" for k, v in kinds.items()))
@@ -180,11 +190,15 @@ lanes_by_it, its_by_it = profile[:512].astype(np.float64), profile[512:].astype(
 print("  where its lanes idle -- iteration index: share of the launch's wave iterations, lanes active in them")
 for lo, hi in ((0, 10), (10, 20), (20, 30), (30, 40), (40, 60), (60, 100), (100, 512)):
     w = its_by_it[lo:hi].sum()
-    print(f"    iterations {lo:3d}..{hi - 1:3d}: {w / its_by_it.sum():6.1%} of the wave iterations at {lanes_by_it[lo:hi].sum() / max(1.0, 64.0 * w):5.1%} of the lanes")
+    print(f"    iterations {lo:3d}..{hi - 1:3d}: {w / its_by_it.sum():6.1%} of the wave iterations at "
+        f"{lanes_by_it[lo:hi].sum() / max(1.0, 64.0 * w):5.1%} of the lanes")
 print()
-hdr = f"{'mode':10s} {'T':>3s} | {'pkt node img/mem':>17s} {'pkt tri':>8s} {'lanes/visit':>11s} | {'lane iters':>10s} {'(longest)':>9s} {'lane util':>9s} {'max kept':>8s} | {'VALU M':>8s} {'vs now':>6s} | {'longest alone us':>16s} {'launch us':>9s} {'vs now':>6s} | {'t differs':>9s} {'id differs':>10s}"
+hdr = f"{'mode':10s} {'T':>3s} | {'pkt node img/mem':>17s} {'pkt tri':>8s} {'lanes/visit':>11s} | {'lane iters':>10s} {'(longest)':>9s} " \
+    f"{'lane util':>9s} {'max kept':>8s} | {'VALU M':>8s} {'vs now':>6s} | {'longest alone us':>16s} {'launch us':>9s} {'vs now':>6s} | " \
+    f"{'t differs':>9s} {'id differs':>10s}"
 print(hdr)
-V_STEAL_PER_ITERATION, V_STEAL_EVENT = 3, 45        # the shared tmax is read from LDS every iteration; a stealing event moves 13 ray registers through ds_bpermute
+# the shared tmax is read from LDS every iteration; a stealing event moves 13 ray registers through ds_bpermute
+V_STEAL_PER_ITERATION, V_STEAL_EVENT = 3, 45
 ap_modes = [(("immediate", 0, int(x)), ("deferred", 1, int(x))) for x in a.thresholds.split(",") if x]
 ap_modes = [m for pair in zip(*ap_modes) for m in pair] if ap_modes else []
 ap_modes = sorted(ap_modes, key=lambda m: m[1])
@@ -199,7 +213,8 @@ for mode_name, mode, T in ap_modes:
         hits, c, hist = run(mode, T + (a.keep_limit << 8 if mode == 2 else 0))
         v, al = price(c)
         if mode == 3:
-            extra = V_STEAL_PER_ITERATION * (c["f_it_node"].astype(np.float64) + c["f_it_mixed"] + c["f_it_tri"]) + V_STEAL_EVENT * c["f_phases"]
+            extra = V_STEAL_PER_ITERATION * (c["f_it_node"].astype(np.float64) + c["f_it_mixed"] + c["f_it_tri"]) + V_STEAL_EVENT * c[
+                "f_phases"]
             v, al = v + extra, al + extra * CYC_VALU_ALONE
         tl = schedule(v, al)
         it = c["f_it_node"].astype(np.int64) + c["f_it_mixed"] + c["f_it_tri"]
@@ -210,5 +225,9 @@ for mode_name, mode, T in ap_modes:
         else:
             tdiff = int((hits["t"].view(np.uint32) != ref["t"].view(np.uint32)).sum())
             iddiff = int((hits["tri_id"] != ref["tri_id"]).sum())
-        print(f"{mode_name:10s} {T & 255:3d} | {c['p_node_img'].mean():8.1f}/{c['p_node_mem'].mean():8.1f} {c['p_tri'].mean():8.1f} {lanes_per_visit:11.1f} | {it.mean():10.1f} {it.max():9d} "
-              f"{c['f_lane_steps'].sum() / max(1.0, 64.0 * it.sum()):9.3f} {str(c['max_deferred'].max()) + ('/' + str(int(c['window_overflows'].sum())) if mode == 2 else ''):>8s} | {v.sum() / 1e6:8.1f} {bv.sum() / v.sum():6.2f} | {al.max() / GHZ / 1e3:16.1f} {tl:9.1f} {bt / tl:6.2f} | {tdiff:9d} {iddiff:10d}")
+        print(f"{mode_name:10s} {T & 255:3d} | {c['p_node_img'].mean():8.1f}/{c['p_node_mem'].mean():8.1f} {c['p_tri'].mean():8.1f} "
+            f"{lanes_per_visit:11.1f} | {it.mean():10.1f} {it.max():9d} "
+              f"{c['f_lane_steps'].sum() / max(1.0, 64.0 * it.sum()):9.3f} "
+                  f"{str(c['max_deferred'].max()) + ('/' + str(int(c['window_overflows'].sum())) if mode == 2 else ''):>8s} | "
+                  f"{v.sum() / 1e6:8.1f} {bv.sum() / v.sum():6.2f} | {al.max() / GHZ / 1e3:16.1f} {tl:9.1f} {bt / tl:6.2f} | {tdiff:9d} "
+                  f"{iddiff:10d}")

@@ -30,6 +30,8 @@ def run(remaining, caps):
 base = run(steps, [])
 print(f"baseline: wave-iterations {base[0]}, critical path {base[1]} iterations, lane utilisation bound {base[3] / (base[0] * 64):.3f}")
 import itertools
-for caps_ in ([caps] if caps else [[k] for k in (16, 24, 32, 40, 48, 64, 80)] + [[a, b] for a in (24, 32, 40, 48) for b in (24, 32, 48, 64)] + [[32, 32, 32], [24, 24, 24, 24], [32, 32, 32, 32], [40, 40, 40]]):
+for caps_ in ([caps] if caps else [[k] for k in (16, 24, 32, 40, 48, 64, 80)] + [[a, b] for a in (24, 32, 40, 48) for b in (24, 32, 48,
+    64)] + [[32, 32, 32], [24, 24, 24, 24], [32, 32, 32, 32], [40, 40, 40]]):
     t, c, w, ls = run(steps, caps_)
-    print(f"caps {str(caps_):22s}: wave-iterations {t} ({t / base[0]:.3f} of baseline), lane util {ls / (t * 64):.3f}, critical path {c} iterations, phases (waves, iterations, longest) {w}")
+    print(f"caps {str(caps_):22s}: wave-iterations {t} ({t / base[0]:.3f} of baseline), lane util {ls / (t * 64):.3f}, critical path {c} "
+        f"iterations, phases (waves, iterations, longest) {w}")

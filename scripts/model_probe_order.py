@@ -1,12 +1,17 @@
 #!/usr/bin/env python
-"""Model of VERDICT r5 item 3 (CPU only: the oracle's per-ray step counts, no GPU): what a STATELESS in-launch cost probe could be worth to the default
-mapping's 1 Mi-ray launch.  The launch: 64 stripes x 128 resident waves; stripe s owns the 32-chunk groups g = s mod 64 (8 groups = 256 chunks at 1 Mi rays);
-a wave's first chunk is its rank in the stripe (groups 0..3 of the stripe), the counter hands out the rest in order.  A chunk costs max(steps of its rays) wave
-iterations; list scheduling per stripe at a fixed iteration time (the replay that matched the hardware to a few per cent in round 2, LAB_NOTES 3.1.1).
+"""Model of VERDICT r5 item 3 (CPU only: the oracle's per-ray step counts, no GPU): what a STATELESS in-launch cost probe could be worth to
+the default
+mapping's 1 Mi-ray launch.  The launch: 64 stripes x 128 resident waves; stripe s owns the 32-chunk groups g = s mod 64 (8 groups = 256
+chunks at 1 Mi rays);
+a wave's first chunk is its rank in the stripe (groups 0..3 of the stripe), the counter hands out the rest in order.  A chunk costs
+max(steps of its rays) wave
+iterations; list scheduling per stripe at a fixed iteration time (the replay that matched the hardware to a few per cent in round 2,
+LAB_NOTES 3.1.1).
 Orders compared:
   default        groups in list order
   history        every stripe's chunks longest first by their TRUE cost (what rodent_hip_schedule_history reaches on identical launches)
-  probe-1ray     the proposal: one ray per group (ray 0 of the group's middle chunk) traced first; groups in descending order of its step count; the probing wave
+  probe-1ray     the proposal: one ray per group (ray 0 of the group's middle chunk) traced first; groups in descending order of its step
+  count; the probing wave
                  starts its own first chunk late by the longest probe ray
   probe-8rays    eight rays per group (ray 0 of every fourth chunk), otherwise the same
   group-oracle   groups in descending order of their TRUE maximum chunk cost (the ceiling of any group-granular order)
@@ -48,8 +53,10 @@ def span(cost, order_of_stripe, late=None):
 
 
 def span_capped(cost, groups, est_ray, cap):
-    """The buildable form: the first generation starts at t = 0 on the default groups; one wave per stripe traces the probe rays for at most `cap` iterations
-    (estimate = min(steps, cap)) and starts its own first chunk `cap` late; a draw before t = cap takes the next chunk in default order, a draw after it the
+    """The buildable form: the first generation starts at t = 0 on the default groups; one wave per stripe traces the probe rays for at most
+    `cap` iterations
+    (estimate = min(steps, cap)) and starts its own first chunk `cap` late; a draw before t = cap takes the next chunk in default order, a
+    draw after it the
     next chunk of the undrawn group with the highest estimate."""
     worst = 0.0
     for s in range(STRIPES):
@@ -98,13 +105,15 @@ def study(name, steps):
     late1 = [float(est1[stripe_groups(s)].max()) for s in range(STRIPES)]
     late8 = [float(est8[stripe_groups(s)].max()) for s in range(STRIPES)]
     rows = [("default", default), ("history (true chunk costs, stateful)", history), ("probe-1ray", span(cost, by_estimate(est1), late1)),
-            ("probe-8rays", span(cost, by_estimate(est8), late8)), ("group-oracle (ceiling of group-granular orders)", span(cost, by_estimate(true_max)))]
+            ("probe-8rays", span(cost, by_estimate(est8), late8)),
+                ("group-oracle (ceiling of group-granular orders)", span(cost, by_estimate(true_max)))]
     for cap in (24, 32, 48, 64, 96):
         rows.append((f"probe-1ray, known after {cap} iterations (buildable)", span_capped(cost, groups, est1, cap)))
     rows.append(("true group maximum, known after 48 iterations", span_capped(cost, groups, true_max, 48)))
     rows.append(("true group maximum, known at t = 0, first generation on default groups", span_capped(cost, groups, true_max + 1e6, 0)))
     corr1 = np.corrcoef(est1, true_max)[0, 1]
-    print(f"{name}: {chunks} chunks, mean chunk {cost.mean():.1f} iterations, longest {cost.max():.0f}; work per slot {cost.sum() / (STRIPES * WAVES):.1f}; "
+    print(f"{name}: {chunks} chunks, mean chunk {cost.mean():.1f} iterations, longest {cost.max():.0f}; work per slot "
+        f"{cost.sum() / (STRIPES * WAVES):.1f}; "
           f"corr(probe ray, group's longest chunk) {corr1:.2f}")
     for label, v in rows:
         print(f"    {label:52s} span {v:7.1f} iterations   {default / v:5.3f} x default")

@@ -33,4 +33,5 @@ for path in sys.argv[2:]:
     print(f"{path}: {total / len(rays):.1f} inner-node visits per ray")
     for d in range(1, 13):
         top = depth < d
-        print(f"  top {d:2d} levels ({int(top.sum()):5d} nodes, {int(top.sum()) * 64 / 1024:7.1f} KB): {visits[top].sum() / total:6.1%} of the visits")
+        print(f"  top {d:2d} levels ({int(top.sum()):5d} nodes, {int(top.sum()) * 64 / 1024:7.1f} KB): {visits[top].sum() / total:6.1%} of "
+            f"the visits")

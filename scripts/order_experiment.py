@@ -60,15 +60,19 @@ orders = {"default (top half of the image first)": lambda k, m: k,
           "bit-reversed (every generation samples the whole image)": lambda k, m: bitrev(k, (m - 1).bit_length()),
           "odd group slots first": lambda k, m: (2 * k + 1) % m if k < m // 2 else (2 * (k - m // 2)) % m,
           "middle out": lambda k, m: (m // 2 + (k + 1) // 2 * (1 if k % 2 else -1)) % m}
-sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0), "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0),
+sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0),
+    "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0),
         "primary 2048x1024": raygen.primary_rays(eye, d, up, fov, 2048, 1024, 0.0, 5000.0)}
-if a.cameras:                                        # other views of the same scene: from the far end, looking up, looking down, from a corner
+# other views of the same scene: from the far end, looking up, looking down, from a corner
+if a.cameras:
     c = 0.5 * (lo + hi); e = np.asarray(eye, np.float32)
     for label, (e2, d2) in {"from the other end": (2 * c - e + np.array([0, 2 * (e[1] - c[1]), 0], np.float32), -np.asarray(d, np.float32)),
                             "looking up": (e, np.asarray(d, np.float32) + np.array([0, 0.6, 0], np.float32)),
                             "looking down": (e, np.asarray(d, np.float32) + np.array([0, -0.6, 0], np.float32)),
-                            "across": (c + np.array([0, 0, 0.4 * (hi[2] - lo[2])], np.float32), np.array([0.3, -0.1, -1], np.float32))}.items():
-        sets["primary, " + label] = raygen.primary_rays(tuple(float(x) for x in e2), tuple(float(x) for x in d2), up, fov, 1024, 1024, 0.0, 5000.0)
+                            "across": (c + np.array([0, 0, 0.4 * (hi[2] - lo[2])], np.float32),
+                                np.array([0.3, -0.1, -1], np.float32))}.items():
+        sets["primary, " + label] = raygen.primary_rays(tuple(float(x) for x in e2), tuple(float(x) for x in d2), up, fov, 1024, 1024, 0.0,
+            5000.0)
     sets["primary 2048x2048"] = raygen.primary_rays(eye, d, up, fov, 2048, 2048, 0.0, 5000.0)
 v = names.index("top-userperm")
 for sname, rays in sets.items():

@@ -25,5 +25,7 @@ for d in sorted(p for p in out.glob(prefix + "*") if p.is_dir()):
     for (k, name), v in sorted(agg.items()):
         print(f"   {k[:58]:58s} {name:40s} n={len(v):3d} {sum(v) / len(v):18.1f}")
         result.setdefault(d.name, {}).setdefault(k, {})[name] = sum(v) / len(v)
-result["_meta"] = provenance.stamp("render" if any(w.startswith(("k_trace", "k_shade", "k_scatter", "k_bin", "k_mega", "k_generate")) for w in sys.argv[3:]) else "traversal")   # bench.py quotes the counters only while this hash holds
+# bench.py quotes the counters only while this hash holds
+result["_meta"] = provenance.stamp("render" if any(w.startswith(("k_trace", "k_shade", "k_scatter", "k_bin", "k_mega", "k_generate"))
+    for w in sys.argv[3:]) else "traversal")
 json.dump(result, open(out / f"{prefix}_counters.json", "w"), indent=1)

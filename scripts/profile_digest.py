@@ -30,7 +30,8 @@ def counters(path):
     agg = defaultdict(list)
     if f:
         for r in csv.DictReader(open(f)):
-            agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+            agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""),
+                r["Counter_Name"])].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
@@ -52,6 +53,7 @@ for k, t in traffic.items():
         # reads) is reported separately because node fetches here are 16-B scattered loads (uncalibrated).
         t["hbm_bytes_raw"] = (t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024
         t["hbm_bytes_fetch_x2"] = (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024
-        print(f"== traffic per launch [{k}]: raw {(t['hbm_bytes_raw']) / 1e6:.1f} MB, with x2 FETCH correction {t['hbm_bytes_fetch_x2'] / 1e6:.1f} MB")
+        print(f"== traffic per launch [{k}]: raw {(t['hbm_bytes_raw']) / 1e6:.1f} MB, with x2 FETCH correction "
+            f"{t['hbm_bytes_fetch_x2'] / 1e6:.1f} MB")
 traffic["_meta"] = provenance.stamp("traversal")      # bench.py quotes the traffic only while this hash holds
 json.dump(traffic, open(out / f"{tag}_traffic.json", "w"), indent=1)

@@ -13,7 +13,8 @@ from rodent_amd import abi, formats as F, parallel, raygen, scenes
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=30)
-ap.add_argument("--variants", default="top", help="comma-separated mapping names (lab build: e.g. top,fast-pf0,fast-pf48): one table per mapping")
+ap.add_argument("--variants", default="top",
+    help="comma-separated mapping names (lab build: e.g. top,fast-pf0,fast-pf48): one table per mapping")
 ap.add_argument("--worlds", default="2,4,8")
 a = ap.parse_args()
 path = scenes.scene_bvh("atrium")
@@ -21,7 +22,8 @@ bvh = abi.DeviceBvh.load(path, 2, 0)
 eye, d, up, fov = scenes.CAMERAS["atrium"]
 n4, _ = F.read_bvh(path, F.BVH4_TRI4)
 lo, hi = raygen.scene_bounds(n4)
-sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0), "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
+sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0),
+    "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
 
 
 VARIANT = 0
@@ -48,7 +50,8 @@ for vname, name, rays in [(v, k, r) for v in a.variants.split(",") for k, r in s
     if vname != "top":
         print(f"== mapping {vname}")
     print(f"{name}: {n} rays on one GPU {one:.4f} ms = {n / one / 1e3:.0f} Mrays/s")
-    print(f"  {'GPUs':>4s} {'partition':>24s} | per-rank ms" + " " * 52 + "| mean / max      | predicted Mrays/s (Hit1 gather outside the timed region)")
+    print(f"  {'GPUs':>4s} {'partition':>24s} | per-rank ms" + " " * 52
+        + "| mean / max      | predicted Mrays/s (Hit1 gather outside the timed region)")
     for world in [int(x) for x in a.worlds.split(",")]:
         for kind in ("contiguous ranges", "interleaved 2048-ray groups"):
             ms = []
@@ -61,4 +64,5 @@ for vname, name, rays in [(v, k, r) for v in a.variants.split(",") for k, r in s
                     idx = (g[:, None] * 2048 + np.arange(2048)[None, :]).ravel()
                     share = rays[idx[idx < n]]
                 ms.append(timed(np.ascontiguousarray(share)))
-            print(f"  {world:4d} {kind:>24s} | " + " ".join(f"{x:7.4f}" for x in ms).ljust(63) + f"| {np.mean(ms):.4f} / {max(ms):.4f} | {n / max(ms) / 1e3:8.0f}  ({one / max(ms):.2f} x one GPU)", flush=True)
+            print(f"  {world:4d} {kind:>24s} | " + " ".join(f"{x:7.4f}"
+                for x in ms).ljust(63) + f"| {np.mean(ms):.4f} / {max(ms):.4f} | {n / max(ms) / 1e3:8.0f}  ({one / max(ms):.2f} x one GPU)", flush=True)

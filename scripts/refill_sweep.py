@@ -20,7 +20,8 @@ a = ap.parse_args()
 W, H = (int(x) for x in a.size.split("x"))
 SPP, LEN = a.spp, 8
 scenes.scene_bvh("atrium")
-cases = {"atrium": (scenes.DATA / "atrium.obj", scenes.CAMERAS["atrium"]), "cornell": (scenes.GOLDEN / "cornell_box.obj", scenes.CAMERAS["cornell"])}
+cases = {"atrium": (scenes.DATA / "atrium.obj", scenes.CAMERAS["atrium"]),
+    "cornell": (scenes.GOLDEN / "cornell_box.obj", scenes.CAMERAS["cornell"])}
 
 
 def decimated(keep_every):
@@ -53,7 +54,8 @@ for name in a.scenes.split(","):
     if name.startswith("atrium/"):
         cases[name] = (decimated(int(name.split("/")[1])), scenes.CAMERAS["atrium"])
 idles = [tuple(int(y) for y in x.split(":")) if ":" in x else int(x) for x in a.idle.split(",")]
-print(f"{'scene':10s} " + " ".join(f"{'idle ' + str(i).replace(' ', ''):>12s}" for i in idles) + f"   Msamples/s, streaming mapping, joint persistent launch, {W}x{H}x{SPP} spp, path length {LEN}")
+print(f"{'scene':10s} " + " ".join(f"{'idle ' + str(i).replace(' ', ''):>12s}"
+    for i in idles) + f"   Msamples/s, streaming mapping, joint persistent launch, {W}x{H}x{SPP} spp, path length {LEN}")
 for name in a.scenes.split(","):
     obj, (eye, d, up, fov) = cases[name]
     sc = S.convert(obj, Path("/tmp") / "refill.rscene")

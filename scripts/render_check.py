@@ -35,4 +35,5 @@ for it in range(ITERS):
 dt = time.time() - t0
 img = R.tonemap(r.film(), ITERS)
 Image.fromarray(img).save("gpurun_out/cornell_gpu.png")
-print("1080x720 x %d spp: %.2f s -> %.1f Msamples/s; counters(last frame) %s" % (SPP * ITERS, dt, SPP * ITERS * W * H / dt / 1e6, r.counters()))
+print("1080x720 x %d spp: %.2f s -> %.1f Msamples/s; counters(last frame) %s" % (SPP * ITERS, dt, SPP * ITERS * W * H / dt / 1e6,
+    r.counters()))

@@ -51,7 +51,8 @@ def main():
         out = Path("/tmp") / f"{path.stem}.rank{rank}.rscene"
         scene = S.convert(path, out)
     cam = S.camera_settings(a.eye, a.dir, a.up, a.fov, a.width, a.height)
-    r = R.Renderer(scene, a.width, a.height, a.spp, a.max_path_len, dev=local, mapping={"amdgpu-streaming": "streaming", "amdgpu-megakernel": "megakernel"}[a.target])
+    r = R.Renderer(scene, a.width, a.height, a.spp, a.max_path_len, dev=local,
+        mapping={"amdgpu-streaming": "streaming", "amdgpu-megakernel": "megakernel"}[a.target])
     y0, y1 = parallel.row_band(a.height, rank, world)
     rates = []
     for it in range(a.bench):
@@ -75,7 +76,8 @@ def main():
             Image.fromarray(R.tonemap(film, a.bench)).save(a.output)
             print(f"Image saved to '{a.output}'")
         rates.sort()
-        print(f"# {rates[0]:g}/{rates[len(rates) // 2]:g}/{rates[-1]:g} (min/med/max Msamples/s)  [{world} GPU(s), rows {a.height} -> bands of ~{a.height // world}]")
+        print(f"# {rates[0]:g}/{rates[len(rates) // 2]:g}/{rates[-1]:g} (min/med/max Msamples/s)  [{world} GPU(s), rows {a.height} -> bands "
+            f"of ~{a.height // world}]")
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 

@@ -27,7 +27,8 @@ for mapping in ("streaming", "megakernel"):
             for (k, cn), v in agg.items():
                 c[k][cn] = sum(v) / len(v)
     print(f"== {cfg} {mapping}: {command}")
-    print(f"{'kernel':34s} {'calls/frame':>11s} {'avg us':>9s} {'ms/frame':>9s} {'FETCH MB':>9s} {'WRITE MB':>9s} {'HBM TB/s (2 x FETCH + WRITE)':>30s}")
+    print(f"{'kernel':34s} {'calls/frame':>11s} {'avg us':>9s} {'ms/frame':>9s} {'FETCH MB':>9s} {'WRITE MB':>9s} "
+        f"{'HBM TB/s (2 x FETCH + WRITE)':>30s}")
     res = {}
     for k, (calls, us) in sorted(dur.items(), key=lambda x: -x[1][0] * x[1][1]):
         if not k.startswith("k_"):

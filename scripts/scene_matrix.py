@@ -50,7 +50,8 @@ def measure(scene, steps=20, variants=("top", "fast", "refill"), pmc=False, quie
     rec = {"references": len(tris), "triangles": int(len(np.unique(tris["prim_id"] & 0x7FFFFFFF))),
            "nodes": len(nodes), "bvh_MB": round((nodes.nbytes + tris.nbytes) / 1e6, 1), "build_or_load_s": round(build_s, 1)}
     if not pmc:
-        say(f"== {scene}: {rec['triangles']} triangles, {rec['references']} references, {rec['nodes']} nodes, {rec['bvh_MB']} MB ({build_s:.1f} s to build / load)", flush=True)
+        say(f"== {scene}: {rec['triangles']} triangles, {rec['references']} references, {rec['nodes']} nodes, {rec['bvh_MB']} MB "
+            f"({build_s:.1f} s to build / load)", flush=True)
     for kind, (rays, any_hit) in sets.items():
         n = len(rays)
         rd = abi.to_device(rays, 0); hd = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
@@ -58,11 +59,13 @@ def measure(scene, steps=20, variants=("top", "fast", "refill"), pmc=False, quie
             abi.traverse_async(bvh, rd, hd, n, any_hit, 0, st); torch.cuda.synchronize()
             continue
         cell = {}
-        for rep in range(2):                                   # two rounds over the mappings, the better one counts: whoever is measured first on fresh buffers runs cold
+        # two rounds over the mappings, the better one counts: whoever is measured first on fresh buffers runs cold
+        for rep in range(2):
             for vname in variants:
                 ms = round(timed(bvh, rd, hd, n, any_hit, names.index(vname), steps), 4)
                 cell[vname + "_ms"] = min(ms, cell.get(vname + "_ms", ms))
-        if kind == "ao":                                       # these rays are pixels in image order too, but no ray_gen dump (dir = hit point - light): the width on trust
+        # these rays are pixels in image order too, but no ray_gen dump (dir = hit point - light): the width on trust
+        if kind == "ao":
             abi.ray_grid(1024)
             cell["top_width_given_ms"] = min(round(timed(bvh, rd, hd, n, any_hit, 0, steps), 4) for rep in range(2))
             abi.ray_grid(-1)
@@ -73,16 +76,20 @@ def measure(scene, steps=20, variants=("top", "fast", "refill"), pmc=False, quie
         got = abi.from_device(hd, F.HIT1)
         sample = np.arange(0, n, 32)
         ref, stt = O.traverse(2, nodes, tris, rays[sample], any_hit=any_hit)
-        cell["sample_parity"] = bool(got[sample].tobytes() == ref.tobytes()) if not any_hit else bool(np.array_equal(got[sample]["tri_id"] >= 0, ref["tri_id"] >= 0))
+        cell["sample_parity"] = bool(got[sample].tobytes() == ref.tobytes()) if not any_hit else bool(
+            np.array_equal(got[sample]["tri_id"] >= 0, ref["tri_id"] >= 0))
         depth = O.ray_depths(nodes, tris, rays[sample], any_hit=any_hit)
         cell.update({"Mrays_s": round(n / cell[variants[0] + "_ms"] / 1e3, 1), "hit_share": round(float((got["tri_id"] >= 0).mean()), 4),
                      "inner_per_ray": round(stt["inner_per_ray"], 2), "prims_per_ray": round(stt["prims_per_ray"], 2),
-                     "stack_mean": round(float(depth.mean()), 2), "stack_max": int(depth.max()), "beyond_window_share": round(float((depth >= 15).mean()), 5),
+                     "stack_mean": round(float(depth.mean()), 2), "stack_max": int(depth.max()),
+                         "beyond_window_share": round(float((depth >= 15).mean()), 5),
                      "stack_histogram": np.bincount(depth, minlength=1).tolist()})
         rec[kind] = cell
         say(f"  {kind:8s} {cell['Mrays_s']:8.1f} Mrays/s  " + "  ".join(f"{v} {cell[v + '_ms']:.4f} ms" for v in variants) +
-            f"  parity {cell['sample_parity']}  visits/ray {cell['inner_per_ray']:.1f} + {cell['prims_per_ray']:.1f}  stack mean {cell['stack_mean']:.1f} max {cell['stack_max']} "
-            f"beyond window {cell['beyond_window_share']:.3%} spilled {cell['spilled_blocks']}  hits {cell['hit_share']:.3f}  tiles of width {cell['tiles_of_width']}" +
+            f"  parity {cell['sample_parity']}  visits/ray {cell['inner_per_ray']:.1f} + {cell['prims_per_ray']:.1f}  stack mean "
+                f"{cell['stack_mean']:.1f} max {cell['stack_max']} "
+            f"beyond window {cell['beyond_window_share']:.3%} spilled {cell['spilled_blocks']}  hits {cell['hit_share']:.3f}  tiles of "
+                f"width {cell['tiles_of_width']}" +
             (f"  (width given: {cell['top_width_given_ms']:.4f} ms)" if "top_width_given_ms" in cell else ""), flush=True)
         del rd, hd
     abi.check_errors(0)

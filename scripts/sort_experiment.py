@@ -44,12 +44,14 @@ def timed(r):
 
 
 org, end = rays["org"], rays["org"] + rays["dir"]
-octant = ((rays["dir"][:, 0] < 0).astype(np.uint64) | ((rays["dir"][:, 1] < 0).astype(np.uint64) << 1) | ((rays["dir"][:, 2] < 0).astype(np.uint64) << 2))
+octant = ((rays["dir"][:, 0] < 0).astype(np.uint64) | ((rays["dir"][:, 1] < 0).astype(np.uint64) << 1) | ((rays["dir"][:,
+    2] < 0).astype(np.uint64) << 2))
 print(f"{'order':44s} {'ms':>8s} {'Mrays/s':>9s}")
 print(f"{'file order':44s} {timed(rays):8.4f}")
 for bits in (4,):
     keys = {f"morton(origin) {bits} bits/axis": morton(org, bits),
-            f"morton(origin) {bits} b + morton(end) {min(bits, 4)} b": (morton(org, bits) << np.uint64(3 * min(bits, 4))) | morton(end, min(bits, 4)),
+            f"morton(origin) {bits} b + morton(end) {min(bits, 4)} b": (morton(org, bits) << np.uint64(3 * min(bits, 4))) | morton(end,
+                min(bits, 4)),
             f"morton(origin) {bits} b + octant": (morton(org, bits) << np.uint64(3)) | octant,
             f"morton(midpoint) {bits} bits/axis": morton(0.5 * (org + end), bits)}
     for name, k in keys.items():

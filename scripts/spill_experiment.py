@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""A/B of one library build (RODENT_HIP_LIB): the default mapping on the atrium's 1 Mi primary / random rays, plain and under 7 padding levels
+"""A/B of one library build (RODENT_HIP_LIB): the default mapping on the atrium's 1 Mi primary / random rays, plain and under 7 padding
+levels
 (tests/conftest.pad_bvh2_depth: 1.3 % / 0.7 % of the rays outgrow the LDS window).  One line per build."""
 import sys
 from pathlib import Path
@@ -12,7 +13,8 @@ path = scenes.scene_bvh("atrium")
 nodes, tris = F.read_bvh(path, F.BVH2_TRI1)
 eye, d, up, fov = scenes.CAMERAS["atrium"]
 lo, hi = raygen.scene_bounds(F.read_bvh(path, F.BVH4_TRI4)[0])
-sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0), "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
+sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0),
+    "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
 bvhs = {"plain": abi.DeviceBvh(2, nodes, tris, 0), "deep": abi.DeviceBvh(2, pad_bvh2_depth(nodes, 7), tris, 0)}
 st = torch.cuda.current_stream()
 out = []

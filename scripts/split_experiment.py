@@ -16,7 +16,8 @@ bvh = abi.DeviceBvh.load(path, 2, 0)
 eye, d, up, fov = scenes.CAMERAS["atrium"]
 n4, _ = F.read_bvh(path, F.BVH4_TRI4)
 lo, hi = raygen.scene_bounds(n4)
-sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0), "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
+sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0),
+    "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
 main = torch.cuda.current_stream()
 
 
@@ -58,5 +59,7 @@ for name, rays in sets.items():
                 got = np.empty(n, F.HIT1)
                 for i, (rd, hd, m) in zip(idx, parts):
                     got[i] = abi.from_device(hd, F.HIT1)[:m]
-                print(f"   {k} parts, {layout:28s} {'persistent kernel forced' if forced else 'default mapping (one-chunk kernel at this size)':48s} {ms:.4f} ms ({base / ms:.3f} x)  identical {got.tobytes() == ref.tobytes()}", flush=True)
+                print(f"   {k} parts, {layout:28s} "
+                    f"{'persistent kernel forced' if forced else 'default mapping (one-chunk kernel at this size)':48s} {ms:.4f} ms "
+                    f"({base / ms:.3f} x)  identical {got.tobytes() == ref.tobytes()}", flush=True)
     abi.lib().rodent_hip_top_min_rays(-1)

@@ -13,7 +13,8 @@ from rodent_amd import abi, formats as F, raygen, scenes
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--small", action="store_true", help="1 Mi-ray sets only")
-ap.add_argument("--variants", default="top,top-nohint,top-chunks,refill", help="top-nohint = the default with rodent_hip_ray_kind_hint(0): the in-kernel choice alone")
+ap.add_argument("--variants", default="top,top-nohint,top-chunks,refill",
+    help="top-nohint = the default with rodent_hip_ray_kind_hint(0): the in-kernel choice alone")
 a = ap.parse_args()
 
 path = scenes.scene_bvh("atrium")
@@ -52,6 +53,7 @@ for any_hit in (False, True):
             if label.startswith("steal") and not any_hit:      # order-changing: how many rays differ from the first row (t bits / ids)
                 same.append((int((h["t"].view("<u4") != base[k]["t"].view("<u4")).sum()), int((h["tri_id"] != base[k]["tri_id"]).sum())))
             else:
-                same.append(h.tobytes() == base[k].tobytes() if not any_hit else bool(((h["tri_id"] >= 0) == (base[k]["tri_id"] >= 0)).all()))
+                same.append(h.tobytes() == base[k].tobytes() if not any_hit
+                    else bool(((h["tri_id"] >= 0) == (base[k]["tri_id"] >= 0)).all()))
             del rd, hd
         print(f"{v}:{label:26s} " + " ".join(f"{x:16.4f}" for x in row) + f"  {same}", flush=True)

@@ -53,7 +53,8 @@ def timed(bvh, k, any_hit, v):
     return float(np.median([s.elapsed_time(e) for s, e in ev])), abi.from_device(hd, F.HIT1)
 
 
-print(f"{'layout:variant':30s} " + " ".join(f"{k + ' ms':>14s} {'Mrays/s':>9s}" for k in sets) + "   any-hit: " + " ".join(f"{k + ' ms':>14s}" for k in sets))
+print(f"{'layout:variant':30s} " + " ".join(f"{k + ' ms':>14s} {'Mrays/s':>9s}"
+    for k in sets) + "   any-hit: " + " ".join(f"{k + ' ms':>14s}" for k in sets))
 for width in [int(x) for x in a.widths.split(",")]:
     bvh = abi.DeviceBvh.load(path, width, 0)
     names = abi.variants(width)
@@ -70,5 +71,6 @@ for width in [int(x) for x in a.widths.split(",")]:
             ms_any, ha = timed(bvh, k, True, v)
             anycols.append(ms_any)
             ok &= bool(((ha["tri_id"] >= 0) == (base[k]["tri_id"] >= 0)).all())
-        print(f"BVH{width}:{names[v]:24s} " + " ".join(f"{c:14.4f}" if i % 2 == 0 else f"{c:9.1f}" for i, c in enumerate(cols)) + "            " +
+        print(f"BVH{width}:{names[v]:24s} " + " ".join(f"{c:14.4f}" if i % 2 == 0 else f"{c:9.1f}" for i,
+            c in enumerate(cols)) + "            " +
               " ".join(f"{c:14.4f}" for c in anycols) + ("" if ok else "   RESULTS DIFFER"), flush=True)

@@ -49,7 +49,8 @@ for scene in a.scenes.split(","):
     else:
         lo, hi = raygen.scene_bounds(F.read_bvh(path, F.BVH4_TRI4)[0])
     print(f"== {scene}: {bvh.num_nodes} nodes, {bvh.num_tris} triangles")
-    print(f"{'rays':>10s} {'primary: fast ms':>17s} {'top ms':>9s} {'top/fast':>9s}   {'random: fast ms':>16s} {'top ms':>9s} {'top/fast':>9s}")
+    print(f"{'rays':>10s} {'primary: fast ms':>17s} {'top ms':>9s} {'top/fast':>9s}   {'random: fast ms':>16s} {'top ms':>9s} "
+        f"{'top/fast':>9s}")
     for w, h in ((256, 256), (512, 256), (512, 512), (768, 512), (1024, 576), (1024, 768), (1024, 1024), (2048, 1024)):
         rays = raygen.primary_rays(eye, d, up, fov, w, h, 0.0, 5000.0)
         n = len(rays)

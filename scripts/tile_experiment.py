@@ -84,7 +84,8 @@ for w, h in sizes:
     base_ms = timed(names.index("top"), rd, hd, n, steps)
     ref = abi.from_device(hd, F.HIT1).tobytes()
     it0 = cost_ray.reshape(-1, 64).max(1)
-    print(f"{w}x{h}: default kernel, scanline chunks: {base_ms:.4f} ms = {n / base_ms / 1e3:.0f} Mrays/s; model: {it0.mean():.2f} iterations per chunk, lane utilisation {cost_ray.sum() / (it0.sum() * 64):.3f}")
+    print(f"{w}x{h}: default kernel, scanline chunks: {base_ms:.4f} ms = {n / base_ms / 1e3:.0f} Mrays/s; model: {it0.mean():.2f} "
+        f"iterations per chunk, lane utilisation {cost_ray.sum() / (it0.sum() * 64):.3f}")
     cases = [("identity through the permutation", np.arange(n, dtype=np.int32))]
     for th, tw in ((2, 32), (4, 16), (8, 8), (16, 4)):
         cases.append((f"{th}x{tw} tiles, row-major", tile_perm(w, h, th, tw)))
@@ -101,6 +102,7 @@ for w, h in sizes:
         ms = timed(v, rd, hd, n, steps)
         same = abi.from_device(hd, F.HIT1).tobytes() == ref
         it = cost_ray[perm].reshape(-1, 64).max(1)
-        print(f"   {label:62s} {ms:.4f} ms ({base_ms / ms:.3f} x) {n / ms / 1e3:7.0f} Mrays/s  identical {same}   model: {it.mean():.2f} it/chunk, util {cost_ray.sum() / (it.sum() * 64):.3f}", flush=True)
+        print(f"   {label:62s} {ms:.4f} ms ({base_ms / ms:.3f} x) {n / ms / 1e3:7.0f} Mrays/s  identical {same}   model: {it.mean():.2f} "
+            f"it/chunk, util {cost_ray.sum() / (it.sum() * 64):.3f}", flush=True)
     abi.lib().rodent_hip_debug_set_perm(0, None)
     del rd, hd

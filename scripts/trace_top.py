@@ -16,7 +16,8 @@ bvh = abi.DeviceBvh.load(path, 2, 0)
 eye, d, up, fov = scenes.CAMERAS["atrium"]
 n4, _ = F.read_bvh(path, F.BVH4_TRI4)
 lo, hi = raygen.scene_bounds(n4)
-sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0), "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
+sets = {"primary": raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, 5000.0),
+    "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, 1.0)}
 v = abi.variants(2).index("trace-top")
 abi.read_trace(arm_only=True)
 
@@ -45,10 +46,13 @@ for k, rays in sets.items():
     wave = (tr[:, 3] >> 32).astype(int); ticket = (tr[:, 3] & 0xFFFFFFFF).astype(int)
     dur = end - start
     second = ticket >= 128          # 512 workgroups x 16 waves / 64 stripes
-    print(f"{k}: {len(tr)} chunks, span {end.max():.1f} us; chunk duration mean {dur.mean():.1f} p50 {np.median(dur):.1f} p99 {np.percentile(dur, 99):.1f} max {dur.max():.1f} us; "
+    print(f"{k}: {len(tr)} chunks, span {end.max():.1f} us; chunk duration mean {dur.mean():.1f} p50 {np.median(dur):.1f} p99 "
+        f"{np.percentile(dur, 99):.1f} max {dur.max():.1f} us; "
           f"iterations mean {it.mean():.1f} max {it.max():.0f}; us per iteration mean {(dur / np.maximum(it, 1)).mean():.3f}")
-    print(f"   first generation: start max {start[~second].max():.1f}, end mean {end[~second].mean():.1f} max {end[~second].max():.1f}; drawn chunks: start mean {start[second].mean():.1f} max {start[second].max():.1f}, end max {end[second].max():.1f}")
-    print("   first-generation start times (us): p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(start[~second], [1, 10, 50, 90, 99, 100])))
+    print(f"   first generation: start max {start[~second].max():.1f}, end mean {end[~second].mean():.1f} max {end[~second].max():.1f}; "
+        f"drawn chunks: start mean {start[second].mean():.1f} max {start[second].max():.1f}, end max {end[second].max():.1f}")
+    print("   first-generation start times (us): p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f"
+        % tuple(np.percentile(start[~second], [1, 10, 50, 90, 99, 100])))
     ts = np.linspace(0, end.max(), 21)[1:-1]
     print("   chunks in flight at 5%..95% of the span:", [int(((start <= t) & (end > t)).sum()) for t in ts])
     last = np.argsort(-end)[:6]
@@ -56,9 +60,12 @@ for k, rays in sets.items():
     # iteration time under load vs at the end
     for lab, m in (("started before 20 us", start < 20), ("started after 60 us", start > 60)):
         if m.sum():
-            print(f"   {lab}: {int(m.sum())} chunks, us/iteration {(dur[m] / np.maximum(it[m], 1)).mean():.3f}, duration mean {dur[m].mean():.1f}")
+            print(f"   {lab}: {int(m.sum())} chunks, us/iteration {(dur[m] / np.maximum(it[m], 1)).mean():.3f}, duration mean "
+                f"{dur[m].mean():.1f}")
     order = np.argsort(start)
-    print(f"   replay of the measured durations on 8192 slots: in start order {replay(dur[order]):.1f} us, longest first {replay(np.sort(dur)[::-1]):.1f} us, "
+    print(f"   replay of the measured durations on 8192 slots: in start order {replay(dur[order]):.1f} us, longest first "
+        f"{replay(np.sort(dur)[::-1]):.1f} us, "
           f"lower bounds: work / slots {dur.sum() / 8192:.1f} us, longest chunk {dur.max():.1f} us")
     # the same with durations rescaled to iterations x the unloaded rate (what the chain of the longest ray costs alone)
-    print(f"   critical chain: {it.max():.0f} iterations x {np.percentile(dur / np.maximum(it, 1), 5):.3f} us (fastest 5 % of the chunks) = {it.max() * np.percentile(dur / np.maximum(it, 1), 5):.1f} us")
+    print(f"   critical chain: {it.max():.0f} iterations x {np.percentile(dur / np.maximum(it, 1), 5):.3f} us (fastest 5 % of the chunks) = "
+        f"{it.max() * np.percentile(dur / np.maximum(it, 1), 5):.1f} us")

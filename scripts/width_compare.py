@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""BVH2 / BVH4 / BVH8 default mappings side by side on the benchmark scene: 1 Mi camera rays (closest hit, any hit), 1 Mi ao rays (any hit), 1 Mi random segments (closest hit, any hit).
+"""BVH2 / BVH4 / BVH8 default mappings side by side on the benchmark scene: 1 Mi camera rays (closest hit, any hit), 1 Mi ao rays (any hit),
+1 Mi random segments (closest hit, any hit).
 ms per launch from one event pair around 30 launches, best of 3.  usage: python scripts/width_compare.py [scene]"""
 import sys
 from pathlib import Path
@@ -17,7 +18,8 @@ lo, hi = raygen.scene_bounds2(n2)
 prim = raygen.primary_rays(eye, d, up, fov, 1024, 1024, 0.0, scenes.PRIMARY_TMAX)
 bvh2 = abi.DeviceBvh(2, n2, t2, 0)
 hits = abi.traverse(bvh2, prim)
-sets = {"camera": prim, "ao": raygen.shadow_rays(scenes.LIGHTS[scene.split("/")[0]], prim, hits["t"], 0.0, 0.999), "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, scenes.RANDOM_TMAX)}
+sets = {"camera": prim, "ao": raygen.shadow_rays(scenes.LIGHTS[scene.split("/")[0]], prim, hits["t"], 0.0, 0.999),
+    "random": raygen.random_rays(lo, hi, 1 << 20, 42, 0.0, scenes.RANDOM_TMAX)}
 bvhs = {2: bvh2, 4: abi.DeviceBvh.load(path, 4, 0), 8: abi.DeviceBvh.load(path, 8, 0)}
 
 
@@ -40,5 +42,6 @@ print(f"== {scene}: ms per launch of 1 Mi rays, default mapping of each layout  
 for name, rays in sets.items():
     n = len(rays); rd = abi.to_device(rays, 0); hd = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
     for any_hit in ((False, True) if name != "ao" else (True,)):
-        print(f"   {name:8s} {'any hit    ' if any_hit else 'closest hit'}                                              " + "  ".join(f"{timed(bvhs[w], rd, hd, n, any_hit):8.4f}" for w in (2, 4, 8)), flush=True)
+        print(f"   {name:8s} {'any hit    ' if any_hit else 'closest hit'}                                              "
+            + "  ".join(f"{timed(bvhs[w], rd, hd, n, any_hit):8.4f}" for w in (2, 4, 8)), flush=True)
 abi.check_errors(0)

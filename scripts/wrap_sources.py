@@ -1,13 +1,19 @@
 #!/usr/bin/env python
-"""Wraps over-long lines of the repository's sources (product sources at <= 140 columns) WITHOUT changing what they mean, and proves it:
+"""Wraps over-long lines of the repository's sources (product sources at <= 140 columns) WITHOUT changing what they mean,
+and proves it:
   C / C++ / HIP   the token stream (comments and white space dropped, adjacent string literals merged) must be identical before and after;
   Python          the syntax tree (docstrings compared with white space collapsed) must be identical before and after;
-a file whose check fails is left untouched and reported.  Lines that cannot be broken safely (inside raw strings, tables in comments wider than the limit
+a file whose check fails is left untouched and reported.  Lines that cannot be broken safely (inside raw strings, tables in comments wider
+than the limit
 with no spaces, ...) are left as they are and listed.
-What it does to a long line: a trailing comment moves to its own line(s) ABOVE the code; comment text is wrapped at spaces; code is broken at the best of
--- a statement boundary, the opening brace of a one-line block, a comma (the shallower the better), a logical / ternary operator, an assignment, an arithmetic
-operator, any space outside literals -- at or before the limit, continuation lines indented by 4 (a new statement keeps the indent); a preprocessor
-definition gets backslashes; a string literal that alone exceeds the limit is split into adjacent literals at a space.  Python: breaks only inside brackets
+What it does to a long line: a trailing comment moves to its own line(s) ABOVE the code; comment text is wrapped at spaces; code is broken
+at the best of
+-- a statement boundary, the opening brace of a one-line block, a comma (the shallower the better), a logical / ternary operator, an
+assignment, an arithmetic
+operator, any space outside literals -- at or before the limit, continuation lines indented by 4 (a new statement keeps the indent); a
+preprocessor
+definition gets backslashes; a string literal that alone exceeds the limit is split into adjacent literals at a space.  Python: breaks only
+inside brackets
 (a backslash where there are none), f-strings split outside their braces.
 usage: python scripts/wrap_sources.py [--limit 140] [--check] files..."""
 import argparse
@@ -58,7 +64,8 @@ def c_scan(line, in_block):
 
 
 def c_tokens(text):
-    """Token stream of C-family source for the equivalence check: identifiers / numbers / punctuation, strings with adjacent literals merged;
+    """Token stream of C-family source for the equivalence check: identifiers / numbers / punctuation, strings with adjacent literals
+    merged;
     comments, white space and backslash-newlines dropped."""
     text = text.replace("\\\n", " ")
     out, in_block = [], False
@@ -166,7 +173,8 @@ def split_string_literal(code, marks, limit, indent):
 
 
 def break_c_code(code, indent, limit, suffix=""):
-    """Pieces of one C-family code line, each (with `suffix` appended: the backslash of a preprocessor definition) within the limit where possible.
+    """Pieces of one C-family code line, each (with `suffix` appended: the backslash of a preprocessor definition) within the limit where
+    possible.
     A new statement of the line's own block goes back to `indent`, anything else continues at indent + 4."""
     pieces, room, cont, carry = [], limit - len(suffix), indent + "    ", 0
     while len(code) > room:
@@ -194,7 +202,8 @@ COMMENT_LINE = re.compile(r"^(\s*)(//[/!]?)( ?)(.*)$")
 
 def plain_text(body):
     """A comment line that may be joined with its neighbours: running text -- no table columns, no list item, no deeper indent."""
-    return bool(body) and not body.startswith((" ", "-", "*", "#", "|")) and "   " not in body.rstrip() and not re.match(r"^(\d+\.|\w\)|[A-Za-z_]+:$)", body)
+    return bool(body) and not body.startswith((" ", "-", "*", "#",
+        "|")) and "   " not in body.rstrip() and not re.match(r"^(\d+\.|\w\)|[A-Za-z_]+:$)", body)
 
 
 def wrap_comment_line(indent, lead, body, limit):
@@ -209,7 +218,8 @@ def wrap_comment_line(indent, lead, body, limit):
 
 
 def reflow_comment_paragraphs(lines, limit):
-    """Consecutive //-comment lines of running text (same indent) form a paragraph; a paragraph with an over-long line is re-wrapped as a whole."""
+    """Consecutive //-comment lines of running text (same indent) form a paragraph; a paragraph with an over-long line is re-wrapped as a
+    whole."""
     out, i, in_block = [], 0, False
     while i < len(lines):
         m = COMMENT_LINE.match(lines[i]) if not in_block else None
@@ -226,7 +236,8 @@ def reflow_comment_paragraphs(lines, limit):
         prefix = m.group(1) + m.group(2) + " "
         fitting = [len(l) for l in block if len(l) <= limit]
         width = max(fitting) if fitting else limit
-        # the author's own paragraph breaks inside the block: a line that ends a sentence although the next line's first word would have fitted
+        # the author's own paragraph breaks inside the block: a line that ends a sentence although the next line's first word would have
+        # fitted
         para = []
         for k, l in enumerate(block):
             para.append(l)
@@ -248,7 +259,8 @@ def wrap_c_file(text, limit):
     out, in_block, skipped = [], False, []
     lines = reflow_comment_paragraphs(text.split("\n"), limit)
     skip_until = 0
-    continued = False                                             # the previous line ended with a backslash: this one belongs to its directive
+    # the previous line ended with a backslash: this one belongs to its directive
+    continued = False
     for ln, line in enumerate(lines, 1):
         if ln <= skip_until:
             continue
@@ -320,7 +332,8 @@ def wrap_c_file(text, limit):
 # ------------------------------------------------------------------------------------------------------------------------------------
 def py_norm(tree):
     for node in ast.walk(tree):
-        if isinstance(node, (ast.Module, ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)) and node.body and isinstance(node.body[0], ast.Expr) \
+        if isinstance(node, (ast.Module, ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)) and node.body and isinstance(node.body[0],
+            ast.Expr) \
                 and isinstance(getattr(node.body[0], "value", None), ast.Constant) and isinstance(node.body[0].value.value, str):
             node.body[0].value.value = " ".join(node.body[0].value.value.split())
     return ast.dump(tree)
@@ -366,7 +379,8 @@ def break_py_line(line, limit, toks, base_depth):
                     w = 6.0 - 0.8 * depth
                 elif s in ("and", "or", "if", "else", "for") and typ == tokenize.NAME:
                     w = 5.0 - 0.8 * depth
-                elif typ == tokenize.OP and s in ("+", "-", "*", "/", "%", "|", "&", "==", "!=", "<", ">", "<=", ">=") and prev[0] != tokenize.OP:
+                elif typ == tokenize.OP and s in ("+", "-", "*", "/", "%", "|", "&", "==", "!=", "<", ">", "<=",
+                    ">=") and prev[0] != tokenize.OP:
                     w = 3.0 - 0.5 * depth
                 elif prev[1] in ("(", "[", "{"):
                     w = 2.0 - 0.5 * depth
@@ -387,7 +401,8 @@ def break_py_line(line, limit, toks, base_depth):
                         tail_src = cont + sp[1] + cur_line[b:]
                         pieces.append(head)
                         shift = len(cont) + len(sp[1]) - b
-                        cur_toks = [(typ, sp[1], len(cont), len(cont) + len(sp[1]), depth)] + [(t, s2, a2 + shift, b2 + shift, d2) for t, s2, a2, b2, d2 in cur_toks[k + 1:]]
+                        cur_toks = [(typ, sp[1], len(cont), len(cont) + len(sp[1]), depth)] + [(t, s2, a2 + shift, b2 + shift, d2) for t,
+                            s2, a2, b2, d2 in cur_toks[k + 1:]]
                         cur_line = tail_src
                         done = True
                     break
@@ -409,7 +424,8 @@ def wrap_py_file(text, limit):
     # the lines of docstrings (their white space is free: the syntax-tree comparison collapses it); other multi-line strings are data
     doc_lines = set()
     for node in ast.walk(ast.parse(text)):
-        if isinstance(node, (ast.Module, ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)) and node.body and isinstance(node.body[0], ast.Expr) \
+        if isinstance(node, (ast.Module, ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)) and node.body and isinstance(node.body[0],
+            ast.Expr) \
                 and isinstance(getattr(node.body[0], "value", None), ast.Constant) and isinstance(node.body[0].value.value, str):
             doc_lines.update(range(node.body[0].lineno, node.body[0].end_lineno + 1))
     # tokens per physical line with bracket depth; which lines lie inside a multi-line string

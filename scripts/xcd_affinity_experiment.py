@@ -2,7 +2,8 @@
 """XCD-affine placement of incoherent rays.  Each XCD has its own 4 MB L2 and the kernels hand 2048-ray groups to the
 stripes round-robin (group j -> stripe j % 64 -> XCD j % 8), so every L2 sees rays from everywhere in the 22 MB hierarchy.  The experiment
 reorders the random segments ON THE HOST so that the rays whose origin (or midpoint) lies in octant x of the scene box land in groups of
-XCD x -- eight bins and an affinity, no finer sort -- and times the unchanged kernels; controls: the same bins laid out contiguously (sorted,
+XCD x -- eight bins and an affinity, no finer sort -- and times the unchanged kernels; controls: the same bins laid out contiguously
+(sorted,
 but every XCD still sees every bin), and a random shuffle.  Hits are compared as sets (the rays are the same rays).
 usage: RODENT_HIP_LAB=1 python scripts/xcd_affinity_experiment.py [--steps 20]"""
 import argparse, sys
@@ -20,7 +21,8 @@ bvh = abi.DeviceBvh.load(path, 2, 0)
 n4, _ = F.read_bvh(path, F.BVH4_TRI4)
 lo, hi = raygen.scene_bounds(n4)
 names = abi.variants(2)
-variants = [("default (refill kernel after the first launch)", names.index("top"))] + ([("whole chunks", names.index("top-chunks"))] if "top-chunks" in names else [])
+variants = [("default (refill kernel after the first launch)", names.index("top"))] + ([("whole chunks", names.index("top-chunks"))]
+    if "top-chunks" in names else [])
 
 
 def timed(v, rays):
@@ -40,13 +42,16 @@ def timed(v, rays):
 
 def octant(points):
     c = 0.5 * (lo + hi)
-    return ((points[:, 0] > c[0]).astype(np.int64) | ((points[:, 1] > c[1]).astype(np.int64) << 1) | ((points[:, 2] > c[2]).astype(np.int64) << 2))
+    return ((points[:, 0] > c[0]).astype(np.int64) | ((points[:, 1] > c[1]).astype(np.int64) << 1) | ((points[:,
+        2] > c[2]).astype(np.int64) << 2))
 
 
 def xcd_layout(bins, n):
-    """order[k] = ray index: the rays of bin x fill the 2048-ray groups j with j % 8 == x in order; what does not fit its own XCD's groups fills the holes"""
+    """order[k] = ray index: the rays of bin x fill the 2048-ray groups j with j % 8 == x in order; what does not fit its own XCD's groups
+    fills the holes"""
     groups = (n + 2047) // 2048
-    slots = [np.concatenate([np.arange(j * 2048, min((j + 1) * 2048, n)) for j in range(x, groups, 8)] or [np.zeros(0, np.int64)]) for x in range(8)]
+    slots = [np.concatenate([np.arange(j * 2048, min((j + 1) * 2048, n)) for j in range(x, groups, 8)] or [np.zeros(0, np.int64)])
+        for x in range(8)]
     order = np.full(n, -1, np.int64)
     spill = []
     for x in range(8):
@@ -78,5 +83,6 @@ for count in (1 << 20, 1 << 23):
             ms, h = timed(v, r)
             back = np.empty_like(h); back[order] = h
             base.setdefault(vname, back)
-            row.append(f"{vname}: {ms:.4f} ms = {count / ms / 1e3:6.0f} Mrays/s (hits {'identical' if back.tobytes() == base[vname].tobytes() else 'DIFFER'})")
+            row.append(f"{vname}: {ms:.4f} ms = {count / ms / 1e3:6.0f} Mrays/s (hits "
+                f"{'identical' if back.tobytes() == base[vname].tobytes() else 'DIFFER'})")
         print(f"   {label:72s} " + "   ".join(row), flush=True)
