@@ -528,3 +528,19 @@ def test_shading_through_indices_and_normals_still_matches_oracle(native_build):
                             "test_megakernel_matches_oracle"],
                        capture_output=True, text=True, cwd=ROOT, env=env)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_miss_records_up_front_still_match_oracle(native_build):
+    """Round 6: k_trace_refill stores a closest-hit ray's miss record when the ray retires without an accepted triangle (the default);
+    RODENT_HIP_LAZY_MISS=0 keeps round 5's record up front.  The switch is read once per process, so the film / ray-count comparisons of
+    this module and the scene-class frames run again in a process that has it off."""
+    import os, sys
+    from conftest import ROOT
+    env = dict(os.environ, RODENT_HIP_LAZY_MISS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_gpu_render.py"), str(ROOT / "tests" / "test_gpu_atrium.py"),
+                        "-m", "gpu", "-q", "-x", "-k", "test_film_matches_oracle or test_textured_scene_matches_oracle or "
+                        "test_capacity_regeneration or test_atrium_compaction_modes_match_oracle"],
+                       capture_output=True, text=True, cwd=ROOT, env=env)
+    import re
+    passed = re.search(r"(\d+) passed", r.stdout)
+    assert r.returncode == 0 and passed and int(passed.group(1)) >= 12, r.stdout[-2000:] + r.stderr[-2000:]      # (16 cases: Cornell + atrium)
