@@ -245,3 +245,171 @@ template <bool ANY, int LDS_N, int PEND, int TOPN, int WAVES, int REFILL, int DR
         stream, nodes, tris, rays, hits, n, s.ctl(), s.deep_list,
                        s.top_image, s.tickets, max_id, s.spill, g_ray_grid);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Triangle turns WITH deferral (round 6, second form; LAB_NOTES 12.1's last paragraph put to the test).  No rounds of its own: a lane keeps
+// ONE pending leaf in a register (`pleaf`: ~first triangle, 0 = none) and walks on; in every P-th iteration (a "turn") -- and whenever no
+// lane of the wave can take a node step -- the lanes that hold a pending leaf test ONE triangle of it INSTEAD of their node step, in the
+// same iteration and behind the same wait as the other lanes' node steps.  A triangle test costs one lane slot, as in the shipped loop; the
+// triangle half of the step is issued in 1 / P of the iterations.  Per ray: the order of its triangle tests is the reference's; between
+// noting a leaf and testing it the ray walks on against a stale tmax (at most P - 1 iterations).  Any-hit records are bit-identical;
+// closest-hit rays may report another triangle at the same distance (see the head of this file).  Only the refill loop differs from
+// k_bvh2_top_auto: waves whose rays share an origin or a direction run the shipped chunk loop.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+template <bool ANY, int LDS_N, int WPG>
+__device__ __forceinline__ void turn_step(Lane& L, int& pleaf, bool turn, const Bases& base, Hit1* __restrict__ hits, lds_int* sp_limit,
+    Ctl* ctl,
+                                          lds_int* image, int* __restrict__ spill) {
+    const bool do_tri = turn && pleaf != 0, is_node = !do_tri && L.top > 0, in_image = is_node && L.top >= kLdsTag;
+    vf4 q0, q1, q2;
+    vi2 ch;
+    int popped;
+    const unsigned idx = (unsigned)(do_tri ? ~pleaf : L.top), stride = do_tri ? (unsigned)sizeof(Tri1) : (unsigned)sizeof(Node2);
+    const gptr addr = (do_tri ? base.tri : base.node) + (size_t)idx * stride;
+    joint_fetch3(q0, q1, q2, ch, popped, do_tri || (is_node && !in_image), in_image, (unsigned)(size_t)image + (unsigned)(L.top - kLdsTag),
+        addr,
+                 addr + (do_tri ? 40u : 48u), L.sp);
+    if (is_node) {
+        float te0, te1;
+        const bool h0 = slab_canonical(L.ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
+        const bool h1 = slab_canonical(L.ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;
+        const bool c0first = te0 < te1, both = h0 && h1, any = h0 || h1;
+        const int first = both ? (c0first ? ch.x : ch.y) : (h0 ? ch.x : ch.y), second = c0first ? ch.y : ch.x;
+        const bool note = any && first < 0 && pleaf == 0;                           // the next child is a leaf and the register is free
+        pleaf = note ? first : pleaf;
+        const bool push = both && !note, pop = !any || (note && !both);
+        L.sp[kWave] = second;                                                       // (only kept when `push`)
+        L.top = pop ? popped : (note ? second : first);
+        L.sp += push ? kWave : (pop ? -kWave : 0);
+        if (push && L.sp >= sp_limit) stack_spill<LDS_N>(L.sp, L.top, sp_limit, spill, WPG, &ctl->err, &ctl->stats[7]);
+    } else if (do_tri) {
+        const int prim_id = __float_as_int(q2.w);
+        const float nx = cross_x(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z), ny = cross_y(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
+        const float nz = cross_z(q1.x, q1.y, q1.z, q2.x, q2.y, q2.z);
+        float t, u, v;
+        bool found = false;
+        if (intersect_tri(L.ray, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, nx, ny, nz, t, u, v)) {
+            store_hit(hits, L.ray_id, prim_id & 0x7FFFFFFF, t, u, v);
+            L.ray.tmax = t; found = true;
+        }
+        if (ANY && found) { L.top = 0; pleaf = 0; }                                 // the ray is done: what is left of its stack is dropped
+        else pleaf = prim_id < 0 ? 0 : pleaf - 1;                                   // sentinel: the leaf is done; else ~(j + 1)
+    // a leaf off the stack and a free register: note it, pop
+    } else {
+        pleaf = L.top;
+        L.top = popped;
+        L.sp -= kWave;
+    }
+    if (L.top >= kSpillMark) stack_reload<LDS_N>(L.sp, L.top, sp_limit, spill, WPG);
+}
+
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int P>
+__global__ __launch_bounds__(kWave * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void
+    k_bvh2_top_turns(const Node2* __restrict__ nodes, const Tri1* __restrict__ tris, const Ray1* __restrict__ rays,
+        Hit1* __restrict__ hits, int n,
+                     Ctl* ctl, int* __restrict__ deep_list, int4* __restrict__ top_image, int* __restrict__ tickets, int max_id, int* spill,
+                     int grid_w) {
+    constexpr int kStackInts = WAVES * (LDS_N + 1) * kWave, kGroupRays = 32 * kWave;
+    static_assert((kStackInts + TOPN * 16) * 4 * (32 / WAVES) <= 160 * 1024, "32 waves per CU must fit their stacks and images in LDS");
+    __shared__ __attribute__((aligned(16))) int lds_raw[kStackInts + TOPN * 16];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    lds_int* col = (lds_int*)lds_raw + wave * (LDS_N + 1) * kWave + lane;
+    lds_int* image = (lds_int*)lds_raw + kStackInts;
+    const int root = stage_top_image<TOPN, kWave * WAVES>(nodes, (const int4*)top_image, image, (lds_int*)lds_raw, ctl, max_id)
+        ? kLdsTag : 1;
+    if (root != 1 && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&ctl->stats[6], 1ull);
+    const int stripe = blockIdx.x % kStripes, stripe_waves = (gridDim.x / kStripes) * WAVES;
+    int* counter = tickets + stripe * kCounterStride;
+    const auto ray_of = [&](int t) { return ((t / kGroupRays) * kStripes + stripe) * kGroupRays + t % kGroupRays; };
+    lds_int* const sp_limit = col + LDS_N * kWave;
+    const Bases base = make_bases(nodes, tris);
+    int t = stripe_rank(wave) * kWave;
+    bool coherent = true;
+    if (ray_of(t) < n) {
+        const int r = ray_of(t + lane);
+        const float4* p = reinterpret_cast<const float4*>(rays + (r < n ? r : ray_of(t)));
+        const float4 o = p[0], d = p[1];
+        if (grid_w < 0) grid_w = detect_ray_grid(rays, n);
+        coherent = wave_rays_coherent(o.x, o.y, o.z, d.x, d.y, d.z, r < n);
+    }
+    if (!coherent && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&ctl->stats[5], 1ull);
+    grid_w = __builtin_amdgcn_readfirstlane(grid_w > 0 && (grid_w & 7) == 0 ? grid_w : 0);
+    const int tiled_rays = tiled_ray_count(grid_w, n);
+    if (coherent) {
+        for (;;) {                                                           // the shipped chunk loop
+            int first_ray = ray_of(t);
+            if (first_ray >= n) break;
+            int r = ray_of(t + lane);
+            if (first_ray < tiled_rays) r = tile_ray(first_ray, lane, grid_w);
+            Lane L = start_lane(rays, hits, r < n ? r : -1, first_ray, col);
+            if (L.top != 0) L.top = root;
+            while (__ballot(L.top != 0)) {
+                if (L.top != 0) bvh2_step<ANY, false, true, false, false, false, LDS_N, WAVES>(L, base, hits, sp_limit, ctl, deep_list,
+                    false, nullptr,
+                                                                                              image, nullptr, spill);
+            }
+            int t_next = 0;
+            if (lane == 0) t_next = atomicAdd(counter, kWave);
+            t = stripe_waves * kWave + __builtin_amdgcn_readfirstlane(t_next);
+        }
+    } else {
+        const auto ray_at = [&](int pos) { return pos < tiled_rays ? tile_ray_at(pos, grid_w) : pos; };
+        Lane L;
+        int pleaf = 0;
+        {
+            const int r = ray_at(ray_of(t + lane));
+            L = start_lane(rays, hits, r < n ? r : -1, 0, col);
+            if (L.top != 0) L.top = root;
+        }
+        bool more = true;
+        for (int it = 0;; it++) {
+            const unsigned long long live = __ballot(L.top != 0 || pleaf != 0);
+            if (more && __popcll(live) <= kWave - REFILL) {
+                const int want = kWave - __popcll(live);
+                int first = 0;
+                if (lane == 0) first = atomicAdd(counter, want);
+                first = stripe_waves * kWave + __builtin_amdgcn_readfirstlane(first);
+                more = ray_of(first) < n;
+                if (L.top == 0 && pleaf == 0) {
+                    const int pos = ray_of(first + __popcll(~live & ((1ull << lane) - 1ull)));
+                    if (pos < n) {
+                        const int rr = ray_at(pos);
+                        L = start_lane(rays, hits, rr, rr, col);
+                        L.top = root;
+                    }
+                }
+                continue;
+            }
+            if (live == 0) break;
+            const bool can_walk = L.top > 0 || (L.top < 0 && pleaf == 0);
+            const bool turn = it % P == P - 1 || __ballot(can_walk) == 0ull;
+            if (can_walk || (turn && pleaf != 0)) turn_step<ANY, LDS_N, WAVES>(L, pleaf, turn, base, hits, sp_limit, ctl, image, spill);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) lds_raw[0] = __hip_atomic_fetch_add(&ctl->counter, 1, __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!lds_raw[0] || wave != 0) return;
+    const int deep = __hip_atomic_load(&ctl->deep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (deep > 0) __threadfence();
+    const bool stale = __hip_atomic_load(&ctl->reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    finish_launch<ANY>(nodes, tris, rays, hits, ctl, deep_list, (lds_int*)lds_raw, tickets, 0, 1, deep);
+    if (stale) {
+        build_top_image(nodes, top_image, TOPN, (lds_int*)lds_raw);
+        if (lane == 0) ctl->reserved = 0;
+    }
+}
+
+template <bool ANY, int LDS_N, int TOPN, int WAVES, int REFILL, int P> void L_turns(LAUNCH_ARGS) {
+    const int max_id = top_kernel_ids(nodes, n);
+    if (max_id == 0) { L_single<ANY, 16, 32>(s, nodes, tris, rays, hits, n, stream); return; }
+    ensure_deep_list(s, n);
+    ensure_top_buffers(s);
+    const int groups = spill_checked(((s.num_cus * (32 / WAVES) + kStripes - 1) / kStripes) * kStripes, WAVES);
+    ensure_spill(s, groups * WAVES);
+    s.top_image_nodes = nullptr; s.order_rays = 0;
+    hipLaunchKernelGGL((k_bvh2_top_turns<ANY, LDS_N, TOPN, WAVES, REFILL, P>), dim3(groups), dim3(kWave * WAVES), 0, stream, nodes, tris,
+        rays, hits,
+                       n, s.ctl(), s.deep_list, s.top_image, s.tickets, max_id, s.spill, g_ray_grid);
+}
