@@ -246,7 +246,7 @@ template <bool ANY, int LDS_N, int PEND, int TOPN, int WAVES, int REFILL, int DR
                        s.top_image, s.tickets, max_id, s.spill, g_ray_grid);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------------------
+// -----------------------------------------------------------------------------------------------------------------------------------------
 // Triangle turns WITH deferral (round 6, second form; LAB_NOTES 12.1's last paragraph put to the test).  No rounds of its own: a lane keeps
 // ONE pending leaf in a register (`pleaf`: ~first triangle, 0 = none) and walks on; in every P-th iteration (a "turn") -- and whenever no
 // lane of the wave can take a node step -- the lanes that hold a pending leaf test ONE triangle of it INSTEAD of their node step, in the
@@ -255,7 +255,7 @@ template <bool ANY, int LDS_N, int PEND, int TOPN, int WAVES, int REFILL, int DR
 // noting a leaf and testing it the ray walks on against a stale tmax (at most P - 1 iterations).  Any-hit records are bit-identical;
 // closest-hit rays may report another triangle at the same distance (see the head of this file).  Only the refill loop differs from
 // k_bvh2_top_auto: waves whose rays share an origin or a direction run the shipped chunk loop.
-// ---------------------------------------------------------------------------------------------------------------------------------------------
+// -----------------------------------------------------------------------------------------------------------------------------------------
 template <bool ANY, int LDS_N, int WPG>
 __device__ __forceinline__ void turn_step(Lane& L, int& pleaf, bool turn, const Bases& base, Hit1* __restrict__ hits, lds_int* sp_limit,
     Ctl* ctl,

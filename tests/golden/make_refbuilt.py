@@ -48,7 +48,8 @@ def main():
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         d = Path(d)
-        r = subprocess.run([str(tool), str(G / "cornell_box.obj"), str(G / "cornell-refbuilt.bvh")], check=True, capture_output=True, text=True)
+        cmd = [str(tool), str(G / "cornell_box.obj"), str(G / "cornell-refbuilt.bvh")]
+        r = subprocess.run(cmd, check=True, capture_output=True, text=True)
         print(r.stdout)
         dec = atrium_obj(d)
         print(subprocess.run([str(tool), str(dec), str(d / "a.bvh")], check=True, capture_output=True, text=True).stdout)
