@@ -538,9 +538,10 @@ def test_miss_records_up_front_still_match_oracle(native_build):
     from conftest import ROOT
     env = dict(os.environ, RODENT_HIP_LAZY_MISS="0")
     files = [str(ROOT / "tests" / "test_gpu_render.py"), str(ROOT / "tests" / "test_gpu_atrium.py")]
-    r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-k", "test_film_matches_oracle or test_textured_scene_matches_oracle or "
-                        "test_capacity_regeneration or test_atrium_compaction_modes_match_oracle"],
-                       capture_output=True, text=True, cwd=ROOT, env=env)
+    which = "test_film_matches_oracle or test_textured_scene_matches_oracle or test_capacity_regeneration or " \
+        "test_atrium_compaction_modes_match_oracle"
+    r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-k", which], capture_output=True, text=True,
+        cwd=ROOT, env=env)
     import re
     passed = re.search(r"(\d+) passed", r.stdout)
     # (16 cases: Cornell + atrium)
