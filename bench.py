@@ -1,46 +1,37 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark: Mrays/s of the HIP BVH traversal (BASELINE.json), renderer frame rates beside it.
 
-  python bench.py --gpus N --steps K --warmup W [--strong]
+  python bench.py --gpus N --steps K --warmup W [--weak]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Step  = one closest-hit traversal pass over one 1 048 576-ray batch resident in HBM
-        (config[1] of BASELINE.json: <scene>.bvh + <scene>-primary.rays, tmax 5000).
-        The random batch (config[2], tmax 1) is timed the same way and reported in "extra".
-Scene = "sponza" if data/sponza.{bvh,-primary.rays,-random.rays} were supplied, otherwise the
-        regenerable procedural "atrium" (the reference checkout lacks the Sponza blobs).
-value = rays traced by all ranks per second / 1e6, kernel passes only (rays, BVH and hit
-        buffers resident in HBM; H2D/D2H excluded like bench_traversal.cpp:124-135).
+Step  = one closest-hit traversal pass over one 1 048 576-ray batch resident in HBM (config[1] of BASELINE.json: <scene>.bvh +
+        <scene>-primary.rays, tmax 5000).  The random batch (config[2], tmax 1) is timed the same way and reported in "extra".
+Scene = "sponza" if data/sponza.{bvh,-primary.rays,-random.rays} were supplied, otherwise the regenerable procedural "atrium" (the
+        reference checkout lacks the Sponza blobs).
+value = rays traced by all ranks per second / 1e6, kernel passes only (rays, BVH and hit buffers resident in HBM; H2D / D2H excluded
+        like bench_traversal.cpp:124-135).
 N > 1 = no data-path collective: the BVH is replicated, rays are independent units.  BOTH partitions are timed:
         strong (`value`, "scaling": "strong" -- BASELINE's metric is ONE 1 Mi-ray dump at 1 / 2 / 4 / 8 GPUs): rank r
-        traces the
-        contiguous range ray_range(n, r, N) of the SAME set the N = 1 run traces; after the timed region one RCCL gather brings the Hit1
-        ranges
-        to rank 0, which compares the assembled array with its own trace of the whole set (`extra.strong_scaling_check`);
-        weak (`extra.weak_scaling`, `config.weak_scaling_Mrays_s`; `--weak` makes it `value`): rank r traces sub-pixel sample r of N through
-        the
-        same 1024 x 1024 pixel grid (primary) / seed 42 + r (random): 1 Mi rays per GPU per step, per-GPU work fixed.
+        traces the contiguous range ray_range(n, r, N) of the SAME set the N = 1 run traces; after the timed region one RCCL gather brings
+        the Hit1 ranges to rank 0, which compares the assembled array with its own trace of the whole set (`extra.strong_scaling_check`);
+        weak (`extra.weak_scaling`, `config.weak_scaling_Mrays_s`; `--weak` makes it `value`): rank r traces sub-pixel sample r of N
+        through the same 1024 x 1024 pixel grid (primary) / seed 42 + r (random): 1 Mi rays per GPU per step, per-GPU work fixed.
         ONE 1 Mi-ray launch is latency-bound (its longest rays do not shard): `config.predicted_scaling_x` holds what one GPU predicts.
-roofline: ONE bound, stated once: VALU issue.  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU of the committed
-counter
-        pass of THIS kernel on THESE sources) / live kernel time / SIMDs; peak = the guide's 2 cycles per wave64 VALU instruction at the
-        clock measured
-        in the calibration loop (MI355X_MICROARCH.md: 1 162 wave-instructions per us per SIMD at 2 323 MHz); frac = achieved / peak.  Beside
-        it, each
-        one division away from a file under profiles/: `frac_of_measured_loop_mix_ceiling` (the same rate against the microbenchmarked
-        ceiling of the
-        loop's own instruction classes), `lane_utilisation`, `roofline.hbm` (BASELINE's "fraction of HBM roofline": `traffic`, the
-        FETCH_SIZE x 2 +
-        WRITE_SIZE bytes of separate --pmc passes, / kernel time / 8 TB/s = measured_frac; compulsory_frac, traffic_over_compulsory,
-        write_amplification) and
-        `cache_served_bytes_over_hbm_peak` (SURVEY 8(d)'s bytes per ray x rays / kernel time / 8 TB/s: > 1, because the 22 MB BVH is served
-        by LDS / L1 / L2 /
-        MALL -- a count of cache hits, no fraction, labelled so).  Counter-derived figures are only quoted while the profile's source
-        hash matches the kernels' sources (rodent_amd/provenance.py); a stale profile is reported as such and the live node-fetch bound
-        stands in.
-render  (`extra.render`): BASELINE configs 4 and 5 through the renderer ABI -- Cornell 1920 x 1080, 64 spp, path length 4 and the
-        config-5 scene at 3840 x 2160, 256 spp, path length 8 (one GPU: the whole frame; N GPUs: row bands + one film gather
-        to rank 0), streaming and megakernel mappings, Msamples/s = spp * w * h / frame seconds / 1e6 (driver.cpp:300).
+roofline = ONE bound, stated once: VALU issue.  achieved = VALU wave-instructions per launch (SQ_INSTS_VALU of the committed
+        counter pass of THIS kernel on THESE sources) / live kernel time / SIMDs; peak = the guide's 2 cycles per wave64 VALU instruction
+        at the clock measured in the calibration loop (MI355X_MICROARCH.md: 1 162 wave-instructions per us per SIMD at 2 323 MHz); frac =
+        achieved / peak.  Beside it, each one division away from a file under profiles/: `frac_of_measured_loop_mix_ceiling` (the same
+        rate against the microbenchmarked ceiling of the loop's own instruction classes), `lane_utilisation`, `roofline.hbm` (BASELINE's
+        "fraction of HBM roofline": measured_frac = `traffic`, the FETCH_SIZE x 2 + WRITE_SIZE bytes of separate --pmc passes, / kernel
+        time / 8 TB/s; compulsory_frac, traffic_over_compulsory, write_amplification) and `cache_served_bytes_over_hbm_peak` (SURVEY
+        8(d)'s bytes per ray x rays / kernel time / 8 TB/s: > 1, because the 22 MB BVH is served by LDS / L1 / L2 / MALL -- a count of
+        cache hits, no fraction, labelled so).  Counter-derived figures are only quoted while the profile's source hash matches the
+        kernels' sources (rodent_amd/provenance.py); a stale profile is reported as such and the live node-fetch bound stands in.
+render = `extra.render`: BASELINE configs 4 and 5 through the renderer ABI -- Cornell 1920 x 1080, 64 spp, path length 4 and the config-5
+        scene at 3840 x 2160, 256 spp, path length 8 (one GPU: the whole frame; N GPUs: interleaved 16-row tiles + one film gather to
+        rank 0), streaming and megakernel mappings, Msamples/s = spp * w * h / frame seconds / 1e6 (driver.cpp:300).
+Code  = this file holds the contract (arguments, ranks, the JSON line); benchlib/ holds the sections: timing.py (the timed region),
+        traversal.py (partitions, side measurements, CPU baseline), render.py (renderer section), profiles.py (committed profiles, rooflines).
 """
 from __future__ import annotations
 
