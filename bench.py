@@ -31,7 +31,7 @@ render = `extra.render`: BASELINE configs 4 and 5 through the renderer ABI -- Co
         scene at 3840 x 2160, 256 spp, path length 8 (one GPU: the whole frame; N GPUs: interleaved 16-row tiles + one film gather to
         rank 0), streaming and megakernel mappings, Msamples/s = spp * w * h / frame seconds / 1e6 (driver.cpp:300).
 Code  = this file holds the contract (arguments, ranks, the JSON line); benchlib/ holds the sections: timing.py (the timed region),
-        traversal.py (partitions, side measurements, CPU baseline), render.py (renderer section), profiles.py (committed profiles, rooflines).
+        traversal.py (partitions, side measurements, CPU baseline), render.py (renderer section), profiles.py (profiles, rooflines).
 """
 from __future__ import annotations
 

@@ -12,14 +12,11 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def time_passes(abi, torch, bvh, rays_dev, hits_dev, n, variant, steps, warmup, dist, any_hit=False):
     """W untimed + K timed launches, back to back on one stream.  Returns (wall seconds for the K steps [max over ranks is taken by the
-    caller],
-    average launch duration in ms from ONE pair of HIP events around the timed region on the launch stream, ... and, from a second, untimed
-    pass with an
-    event pair around every single launch, the median and minimum of those).  Until round 4 the timed region itself carried an event pair
-    per step:
-    two marker packets between every two kernels cost 17 us per 0.18 ms step (profiles/r05_host_call_costs.txt: 174.9 us per launch back to
-    back
-    against 192.3 with them) -- time the benchmark spent measuring itself."""
+    caller], average launch duration in ms from ONE pair of HIP events around the timed region on the launch stream, ... and, from a second,
+    untimed pass with an event pair around every single launch, the median and minimum of those).  Until round 4 the timed region itself
+    carried an event pair per step: two marker packets between every two kernels cost 17 us per 0.18 ms step
+    (profiles/r05_host_call_costs.txt: 174.9 us per launch back to back against 192.3 with them) -- time the benchmark spent measuring
+    itself."""
     stream = torch.cuda.current_stream()
     for _ in range(warmup):
         abi.traverse_async(bvh, rays_dev, hits_dev, n, any_hit, variant, stream)

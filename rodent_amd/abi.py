@@ -191,8 +191,7 @@ def ray_kind_hint(enable: bool):
 
 def ray_grid(width: int = -1):
     """rodent_hip_ray_grid: -1 = the default BVH2 kernel recognises camera rays in image order and traces them as 8 x 8-pixel tiles
-    (default),
-    0 = never, > 0 = that image width on trust (hit records do not depend on it)."""
+    (default), 0 = never, > 0 = that image width on trust (hit records do not depend on it)."""
     lib().rodent_hip_ray_grid(int(width))
 
 

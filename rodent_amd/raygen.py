@@ -72,8 +72,7 @@ def scene_bounds2(nodes2):
 def shadow_rays(light, rays, t, tmin=0.0, tmax=1.0):
     """ray_gen's third mode (tools/ray_gen/ray_gen.cpp:60-85): from a point light towards the hit points of a previous pass -- org = light,
     dir = (org + t * dir) - light, t = the .fbuf of that pass (the miss value where a ray hit nothing).  Traced any-hit with tmax just under
-    1
-    this is the suite's occlusion class (benchmarks/benchmark.py:36-41 "ao": -any, short tmax)."""
+    1 this is the suite's occlusion class (benchmarks/benchmark.py:36-41 "ao": -any, short tmax)."""
     light = np.asarray(light, f32)
     hit = rays["org"] + np.asarray(t, f32)[:, None] * rays["dir"]
     return F.make_rays(np.broadcast_to(light, hit.shape), (hit - light).astype(f32), tmin, tmax)

@@ -3,8 +3,7 @@
 render (parallel.row_band = host/partition.h split_range) is rendered alone with rodent_hip_render_rows and timed; a frame takes as long as
 its slowest band, so efficiency = mean / max and predicted Msamples/s = samples / max.  With --tiles the same for interleaved row tiles
 (rodent_hip_render_tiles: rank r renders tiles r, r + N, ... of --tile-rows rows each; reference tile arithmetic
-render/mapping_gpu.impala:374-420).
-usage: python scripts/band_costs.py [--spp 256] [--tiles] [--tile-rows 16] [--gpus 2,4,8]"""
+render/mapping_gpu.impala:374-420). usage: python scripts/band_costs.py [--spp 256] [--tiles] [--tile-rows 16] [--gpus 2,4,8]"""
 import argparse, sys, time
 from pathlib import Path
 import numpy as np

@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """One ray set, one size, the default mapping: a few launches with HIP-event times -- the command scripts/big_launch_counters.sh puts under
 rocprofv3 --pmc to get the issue counters of the 16 Mi-ray launch (the valu_issue block at the size where the kernel is
-not a tail).
-usage: python scripts/big_launch_counters.py [--side 4096] [--random N]"""
+not a tail). usage: python scripts/big_launch_counters.py [--side 4096] [--random N]"""
 import argparse, sys
 from pathlib import Path
 import numpy as np

@@ -1,12 +1,9 @@
 #!/usr/bin/env python
 """What ordering incoherent rays by the cell of their origin is worth to the CURRENT kernels (the follow-up of
-scripts/xcd_affinity_experiment.py, whose
-control -- eight bins laid out contiguously -- gained 10 %): the random segments reordered ON THE HOST into 2^3 / 4^3 / 8^3 / 16^3 cells of
-the scene box
-(cells in Morton order, rays inside a cell in their original order), traced by the default mapping (the refill kernel, from the second
-launch on) and by
-whole chunks.  The time of the sort itself is NOT included: this bounds what an in-launch counting sort may cost.
-usage: RODENT_HIP_LAB=1 python scripts/bin_order_experiment.py [--steps 20]"""
+scripts/xcd_affinity_experiment.py, whose control -- eight bins laid out contiguously -- gained 10 %): the random segments reordered ON THE
+HOST into 2^3 / 4^3 / 8^3 / 16^3 cells of the scene box (cells in Morton order, rays inside a cell in their original order), traced by the
+default mapping (the refill kernel, from the second launch on) and by whole chunks.  The time of the sort itself is NOT included: this
+bounds what an in-launch counting sort may cost. usage: RODENT_HIP_LAB=1 python scripts/bin_order_experiment.py [--steps 20]"""
 import argparse, sys
 from pathlib import Path
 import numpy as np

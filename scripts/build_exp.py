@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """An experiment build of the HIP library beside the shipped one: python scripts/build_exp.py <name> [-DMACRO ...]  ->
-rodent_amd/lib/exp_<name>.so
-(loaded with RODENT_HIP_LIB=rodent_amd/lib/exp_<name>.so; abi.py skips the source-digest check for such a library)."""
+rodent_amd/lib/exp_<name>.so (loaded with RODENT_HIP_LIB=rodent_amd/lib/exp_<name>.so; abi.py skips the source-digest check for such a
+library)."""
 import subprocess, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))

@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """Digest of scripts/calibrate_fetch_size.sh: per vmem_peak dispatch (its second, timed launch of every pattern) the known 64-byte node
-fetches
-against FETCH_SIZE (KiB units of 1024 B) and the TCC counters."""
+fetches against FETCH_SIZE (KiB units of 1024 B) and the TCC counters."""
 import csv, sys
 from collections import defaultdict
 from pathlib import Path

@@ -1,11 +1,9 @@
 #!/usr/bin/env python
 """Wave-cooperative BVH8 for any-hit rays (lab variant "coop" of the BVH8 table: one ray per octet of lanes, csrc/lab/coop8_kernel.h;
-VERDICT r5 item 6) against the
-one-ray-per-lane BVH8 default and the BVH2 default: 1 Mi camera rays, ao rays (ray_gen's shadow mode) and random segments, any hit; ms per
-launch (30 launches, best of 3).
-Parity: the cooperative kernel's Hit1 records against the one-ray-per-lane kernel's (the same visit order: bit for bit) and its occlusion
-answers against the oracle's (B1g).
-usage: RODENT_HIP_LAB=1 python scripts/coop8_experiment.py [scene]"""
+VERDICT r5 item 6) against the one-ray-per-lane BVH8 default and the BVH2 default: 1 Mi camera rays, ao rays (ray_gen's shadow mode) and
+random segments, any hit; ms per launch (30 launches, best of 3). Parity: the cooperative kernel's Hit1 records against the one-ray-per-lane
+kernel's (the same visit order: bit for bit) and its occlusion answers against the oracle's (B1g). usage: RODENT_HIP_LAB=1 python
+scripts/coop8_experiment.py [scene]"""
 import sys
 from pathlib import Path
 import numpy as np

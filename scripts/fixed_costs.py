@@ -1,9 +1,7 @@
 #!/usr/bin/env python
 """What a launch costs before it traces anything: the Cornell box (16 nodes; a ray is a handful of steps) at ray counts from one chunk up,
-through the one-chunk kernel ("fast"),
-the persistent LDS-image kernel forced (rodent_hip_top_min_rays(0): "top", "refill") and the wide layouts' kernels.  ms per launch from one
-event pair around 50 back-to-back launches.
-usage: python scripts/fixed_costs.py"""
+through the one-chunk kernel ("fast"), the persistent LDS-image kernel forced (rodent_hip_top_min_rays(0): "top", "refill") and the wide
+layouts' kernels.  ms per launch from one event pair around 50 back-to-back launches. usage: python scripts/fixed_costs.py"""
 import os, sys
 from pathlib import Path
 import numpy as np

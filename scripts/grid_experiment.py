@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """Camera rays as 8 x 8-pixel tiles instead of 64-pixel row segments per wave (RODENT_HIP_RAY_GRID=<image width>, experiment): kernel ms of
-the default mapping on the
-primary set of a scene, and the hits' bytes against the run without it.  usage: RODENT_HIP_RAY_GRID=1024 python scripts/grid_experiment.py
-[scene] [width]"""
+the default mapping on the primary set of a scene, and the hits' bytes against the run without it.  usage: RODENT_HIP_RAY_GRID=1024 python
+scripts/grid_experiment.py [scene] [width]"""
 import os, sys, hashlib
 from pathlib import Path
 import numpy as np

@@ -1,9 +1,8 @@
 #!/usr/bin/env python
-"""How much of the schedule history's gain survives when the rays CHANGE from launch to launch (rodent_hip_schedule_history:
-chunks traced longest first by the previous launch's per-chunk cost): 1 Mi primary rays of the atrium from a camera that turns
-by a fixed angle (and moves along its view direction) every frame, history off / on; every frame's hits are compared with the
-history-off run of the same frame.
-usage: python scripts/history_experiment.py"""
+"""How much of the schedule history's gain survives when the rays CHANGE from launch to launch (rodent_hip_schedule_history: chunks traced
+longest first by the previous launch's per-chunk cost): 1 Mi primary rays of the atrium from a camera that turns by a fixed angle (and moves
+along its view direction) every frame, history off / on; every frame's hits are compared with the history-off run of the same frame. usage:
+python scripts/history_experiment.py"""
 import sys
 from pathlib import Path
 import numpy as np

@@ -54,10 +54,8 @@ def span(cost, order_of_stripe, late=None):
 
 def span_capped(cost, groups, est_ray, cap):
     """The buildable form: the first generation starts at t = 0 on the default groups; one wave per stripe traces the probe rays for at most
-    `cap` iterations
-    (estimate = min(steps, cap)) and starts its own first chunk `cap` late; a draw before t = cap takes the next chunk in default order, a
-    draw after it the
-    next chunk of the undrawn group with the highest estimate."""
+    `cap` iterations (estimate = min(steps, cap)) and starts its own first chunk `cap` late; a draw before t = cap takes the next chunk in
+    default order, a draw after it the next chunk of the undrawn group with the highest estimate."""
     worst = 0.0
     for s in range(STRIPES):
         gs = np.arange(s, groups, STRIPES)

@@ -1,8 +1,7 @@
 #!/usr/bin/env python
-"""What LDS-staged top-of-tree nodes could take off the vector-memory path: the share of B1's inner-node visits that
-falls on the top D levels of the hierarchy (2^D - 1 nodes at most), per ray set, from the oracle's per-node visit
-counts (oracle.binding.node_visits).
-usage: python scripts/model_top_levels.py data/atrium.bvh data/atrium-primary.rays [data/atrium-random.rays ...]"""
+"""What LDS-staged top-of-tree nodes could take off the vector-memory path: the share of B1's inner-node visits that falls on the top D
+levels of the hierarchy (2^D - 1 nodes at most), per ray set, from the oracle's per-node visit counts (oracle.binding.node_visits). usage:
+python scripts/model_top_levels.py data/atrium.bvh data/atrium-primary.rays [data/atrium-random.rays ...]"""
 import sys
 from pathlib import Path
 

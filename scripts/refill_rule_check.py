@@ -1,11 +1,9 @@
 #!/usr/bin/env python
 """The renderer's lane-refill thresholds (include/rodent_render.h: 40 / 40 from 16 384 nodes, fitted on the atrium) on all four scene
-classes: atrium, gallery,
-crown, plant through the streaming mapping with the joint launch, thresholds (bounce : shadow) swept; ray counts must agree exactly with the
-library's choice,
-films up to the order of the atomic adds.  Each cell is timed twice (in two passes over the table) and the better median counts.
-usage: python scripts/refill_rule_check.py [--size 3840x2160] [--spp 16] [--frames 3] [--scenes atrium,gallery,crown,plant] [--idle
-24,32,40,48,32:40,40:32]"""
+classes: atrium, gallery, crown, plant through the streaming mapping with the joint launch, thresholds (bounce : shadow) swept; ray counts
+must agree exactly with the library's choice, films up to the order of the atomic adds.  Each cell is timed twice (in two passes over the
+table) and the better median counts. usage: python scripts/refill_rule_check.py [--size 3840x2160] [--spp 16] [--frames 3] [--scenes
+atrium,gallery,crown,plant] [--idle 24,32,40,48,32:40,40:32]"""
 import argparse, sys, time
 from pathlib import Path
 import numpy as np

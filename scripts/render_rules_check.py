@@ -1,12 +1,9 @@
 #!/usr/bin/env python
 """The renderer's per-scene rules (include/rodent_render.h: megakernel up to 128 nodes, joint persistent launch above, lane refill 40 / 40
-from 16 384 nodes)
-on a scene 16 x the size of the one they were fitted on: the gallery (the atrium at 4.2 M triangles, 2.3 M nodes) at 1920 x 1080, path
-length 8 --
-what the library chooses (auto) against the choices it did not make.  Also RODENT_HIP_SHADOW_ORDER 0 / 1 / 2 on the atrium at config 5's
-size:
-any-hit rays need no near-first order; films must agree (occlusion does not depend on the order).
-usage: python scripts/render_rules_check.py [--spp 16] [--frames 2] [--scene gallery]"""
+from 16 384 nodes) on a scene 16 x the size of the one they were fitted on: the gallery (the atrium at 4.2 M triangles, 2.3 M nodes) at 1920
+x 1080, path length 8 -- what the library chooses (auto) against the choices it did not make.  Also RODENT_HIP_SHADOW_ORDER 0 / 1 / 2 on the
+atrium at config 5's size: any-hit rays need no near-first order; films must agree (occlusion does not depend on the
+order). usage: python scripts/render_rules_check.py [--spp 16] [--frames 2] [--scene gallery]"""
 import argparse, os, subprocess, sys, time
 from pathlib import Path
 import numpy as np

@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """A/B of one library build (RODENT_HIP_LIB): the default mapping on the atrium's 1 Mi primary / random rays, plain and under 7 padding
-levels
-(tests/conftest.pad_bvh2_depth: 1.3 % / 0.7 % of the rays outgrow the LDS window).  One line per build."""
+levels (tests/conftest.pad_bvh2_depth: 1.3 % / 0.7 % of the rays outgrow the LDS window).  One line per build."""
 import sys
 from pathlib import Path
 import numpy as np

@@ -1,10 +1,8 @@
 #!/usr/bin/env python
 """Re-wraps the paragraphs and list items of Markdown files so that no line exceeds 140 columns -- counted in BYTES of UTF-8 as `awk 'length
-> 140'`
-counts them in the C locale (an arrow or a multiplication sign is three bytes) -- leaving code blocks, tables and headings as they are.
-Consecutive
-lines of a paragraph (or of a list item with its hanging indent) are joined first, so repeated runs are stable.
-usage: python scripts/wrap_markdown.py files..."""
+> 140'` counts them in the C locale (an arrow or a multiplication sign is three bytes) -- leaving code blocks, tables and headings as they
+are. Consecutive lines of a paragraph (or of a list item with its hanging indent) are joined first, so repeated runs are stable. usage:
+python scripts/wrap_markdown.py files..."""
 import re
 import sys
 

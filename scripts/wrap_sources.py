@@ -65,8 +65,7 @@ def c_scan(line, in_block):
 
 def c_tokens(text):
     """Token stream of C-family source for the equivalence check: identifiers / numbers / punctuation, strings with adjacent literals
-    merged;
-    comments, white space and backslash-newlines dropped."""
+    merged; comments, white space and backslash-newlines dropped."""
     text = text.replace("\\\n", " ")
     out, in_block = [], False
     for line in text.split("\n"):
@@ -174,8 +173,7 @@ def split_string_literal(code, marks, limit, indent):
 
 def break_c_code(code, indent, limit, suffix=""):
     """Pieces of one C-family code line, each (with `suffix` appended: the backslash of a preprocessor definition) within the limit where
-    possible.
-    A new statement of the line's own block goes back to `indent`, anything else continues at indent + 4."""
+    possible. A new statement of the line's own block goes back to `indent`, anything else continues at indent + 4."""
     pieces, room, cont, carry = [], limit - len(suffix), indent + "    ", 0
     while len(code) > room:
         marks, _ = c_scan(code, False)

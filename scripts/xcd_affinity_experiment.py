@@ -1,11 +1,10 @@
 #!/usr/bin/env python
 """XCD-affine placement of incoherent rays.  Each XCD has its own 4 MB L2 and the kernels hand 2048-ray groups to the
 stripes round-robin (group j -> stripe j % 64 -> XCD j % 8), so every L2 sees rays from everywhere in the 22 MB hierarchy.  The experiment
-reorders the random segments ON THE HOST so that the rays whose origin (or midpoint) lies in octant x of the scene box land in groups of
-XCD x -- eight bins and an affinity, no finer sort -- and times the unchanged kernels; controls: the same bins laid out contiguously
-(sorted,
-but every XCD still sees every bin), and a random shuffle.  Hits are compared as sets (the rays are the same rays).
-usage: RODENT_HIP_LAB=1 python scripts/xcd_affinity_experiment.py [--steps 20]"""
+reorders the random segments ON THE HOST so that the rays whose origin (or midpoint) lies in octant x of the scene box land in groups of XCD
+x -- eight bins and an affinity, no finer sort -- and times the unchanged kernels; controls: the same bins laid out contiguously (sorted,
+but every XCD still sees every bin), and a random shuffle.  Hits are compared as sets (the rays are the same rays). usage: RODENT_HIP_LAB=1
+python scripts/xcd_affinity_experiment.py [--steps 20]"""
 import argparse, sys
 from pathlib import Path
 import numpy as np

@@ -204,10 +204,8 @@ def test_top_image_node_set_is_a_breadth_first_prefix(cornell):
 
 def test_packet_model_reproduces_the_oracle_at_threshold_65():
     """scripts/model_packet.py (the wave-packet traversal that was modelled and not built): with every subtree falling back at
-    the
-    root (T = 65) the model IS the per-lane kernel and must reproduce oracle B1 bit for bit (the script asserts it), and no packet mode may
-    change
-    a hit record on the Cornell fixtures."""
+    the root (T = 65) the model IS the per-lane kernel and must reproduce oracle B1 bit for bit (the script asserts it), and no packet mode
+    may change a hit record on the Cornell fixtures."""
     import subprocess, sys
     from conftest import ROOT
     for rays, tmax in (("cornell-primary-64x64.rays", "5000"), ("cornell-random-4096.rays", "1")):

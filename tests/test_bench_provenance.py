@@ -62,10 +62,8 @@ def test_counters_are_quoted_only_from_a_profile_of_these_sources_and_this_kerne
 
 def test_the_top_level_roofline_is_valu_issue_against_the_guides_rate(bench, tmp_path):
     """ONE roofline: VALU issue against the guide's 2-cycle rate at the measured clock; the measured loop-mix ceiling
-    and the lane
-    utilisation ride along; the round-2 figure 771 is gone from the calibration bench.py reads.  The live node-fetch bound stands in only
-    while the
-    committed counter pass does not belong to the running sources."""
+    and the lane utilisation ride along; the round-2 figure 771 is gone from the calibration bench.py reads.  The live node-fetch bound
+    stands in only while the committed counter pass does not belong to the running sources."""
     from rodent_amd import provenance
     b = {"vmem_node_fetch": {"frac": 0.80, "achieved": 1, "peak": 2, "unit": "fetches/ns"},
         "valu_issue": {"frac": 0.35, "achieved": 3, "peak": 4, "unit": "i"}, "lds_fetch": {"frac": 0.9}}

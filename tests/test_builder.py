@@ -163,9 +163,8 @@ def test_obj_without_faces_is_an_error_not_a_crash(tmp_path, native_build):
 
 def test_converter_builder_parameters(tmp_path, native_build, oracle):
     """converter --bvh-leaf / --bvh-traversal-cost (the sweep of DESIGN 3.4.2): larger leaves and a dearer inner node give smaller
-    hierarchies that are
-    still valid BVH2 blocks and still trace to the exhaustive checker's hits; the defaults are the reference's parameters (2 references,
-    cost 1)."""
+    hierarchies that are still valid BVH2 blocks and still trace to the exhaustive checker's hits; the defaults are the reference's
+    parameters (2 references, cost 1)."""
     from conftest import ROOT, write_textured_hall
     from rodent_amd import build, raygen, scene as S
     obj = write_textured_hall(tmp_path)
@@ -194,9 +193,8 @@ def test_converter_builder_parameters(tmp_path, native_build, oracle):
 
 def test_stress_scenes_get_emissive_panels_for_the_renderer(native_build, tmp_path):
     """scene_gen's crown and plant are geometry only; scenes.scene_obj appends emissive panels (material "light", facing down) so that the
-    renderer
-    has something that emits -- the converter must find them as lights, and the panels must not touch the .bvh route of the traversal
-    matrix."""
+    renderer has something that emits -- the converter must find them as lights, and the panels must not touch the .bvh route of the
+    traversal matrix."""
     from rodent_amd import scene as S, scenes
     for kind, panels in scenes.PANELS.items():
         obj = scenes.scene_obj(f"{kind}/1")

@@ -64,17 +64,14 @@ def test_all_benchmark_rays_bit_exact(gpu, oracle, dumps, width, kind):
 @pytest.mark.parametrize("scene,limit", [("atrium", 1.17), ("refbuilt", 1.17), ("cornell", 1.35)])
 def test_default_mapping_is_not_slower_than_the_one_chunk_kernel_where_it_is_selected(gpu, scene, limit, tmp_path):
     """The default BVH2 mapping switches from the one-chunk kernel ("fast") to the persistent LDS-image kernel at 393 216 rays (589 824
-    until round 4), with
-    a 255-record image and 15-entry stack windows -- constants tuned on the atrium's primary camera (profiles/r02_threshold_sweep.txt).
-    From that size on it must not lose to "fast" by more than 17 %: on the benchmark scene, on the decimated atrium as the
-    REFERENCE's builder lays it out (tests/golden/atrium-decimated-refbuilt.bvh.gz), primary and random rays.  One switch point serves both
-    ray
-    kinds (the host does not know which it got): at 393 216 rays camera rays are still 10 % faster through "fast" (0.118 against 0.130 ms,
-    level
-    from 589 824 on) while segments are 18 % faster through the persistent kernel from 262 144 on (profiles/r05_threshold_sweep_grid.txt) --
-    the smaller loss decides.  On a tree that fits the image whole (Cornell, 16 nodes) the persistent launch's fixed cost (~3 us of a 23 us
-    launch
-    since round 5, 12 us before: profiles/r05_fixed_costs.txt) shows at the switch point: measured 10 ... 15 % there, 35 % allowed."""
+    until round 4), with a 255-record image and 15-entry stack windows -- constants tuned on the atrium's primary camera
+    (profiles/r02_threshold_sweep.txt). From that size on it must not lose to "fast" by more than 17 %: on the benchmark scene, on the
+    decimated atrium as the REFERENCE's builder lays it out (tests/golden/atrium-decimated-refbuilt.bvh.gz), primary and random rays.  One
+    switch point serves both ray kinds (the host does not know which it got): at 393 216 rays camera rays are still 10 % faster through
+    "fast" (0.118 against 0.130 ms, level from 589 824 on) while segments are 18 % faster through the persistent kernel from 262 144 on
+    (profiles/r05_threshold_sweep_grid.txt) -- the smaller loss decides.  On a tree that fits the image whole (Cornell, 16 nodes) the
+    persistent launch's fixed cost (~3 us of a 23 us launch since round 5, 12 us before: profiles/r05_fixed_costs.txt) shows at the switch
+    point: measured 10 ... 15 % there, 35 % allowed."""
     import gzip
     import torch
     from rodent_amd import raygen, scenes
@@ -262,12 +259,10 @@ def test_atrium_joint_traversal_launch_renders_the_same_frame(R, atrium_scene, s
 
 def test_atrium_deep_stacks_in_the_renderer(R, atrium_scene):
     """The renderer's traversal kernels on a hierarchy whose stacks outgrow the lanes' 15-row LDS windows (the atrium under ten padding
-    levels,
-    conftest.pad_bvh2_depth: every ray's deepest stack + 10, hits unchanged): the persistent kernels spill in place (k_trace_refill: the
-    per-scene
-    default; k_trace_persist: whole chunks), the one-chunk kernels hand such rays to k_trace_deep (64 workgroups), the megakernel keeps its
-    scratch
-    stack.  Same ray counts as the unpadded scene, the same film up to the order of the atomic adds, no overflow."""
+    levels, conftest.pad_bvh2_depth: every ray's deepest stack + 10, hits unchanged): the persistent kernels spill in place (k_trace_refill:
+    the per-scene default; k_trace_persist: whole chunks), the one-chunk kernels hand such rays to k_trace_deep (64 workgroups), the
+    megakernel keeps its scratch stack.  Same ray counts as the unpadded scene, the same film up to the order of the atomic adds, no
+    overflow."""
     import copy
     from conftest import pad_bvh2_depth
     # 1.8 M paths, 700 000-ray streams: above the persistent kernels' threshold
@@ -379,10 +374,8 @@ def test_atrium_interleaved_row_tiles_equal_the_frame(R, atrium_scene, atrium_re
 @pytest.mark.parametrize("sort", [False, True])
 def test_atrium_hit_record_layouts_render_the_same_frame(R, atrium_scene, atrium_reference, aos, sort):
     """rodent_hip_render_hit_records: the loop's streams keep a hit as one 20-byte record in the memory of the geom_id / prim_id / t / u / v
-    arrays
-    (default) or in those five arrays (the ABI's layout, which the stage-level entry points always use and which the loop falls back to
-    while the
-    sort by material is on): same ray counts, same film, small streams (every traversal kernel of the loop) and large ones."""
+    arrays (default) or in those five arrays (the ABI's layout, which the stage-level entry points always use and which the loop falls back
+    to while the sort by material is on): same ray counts, same film, small streams (every traversal kernel of the loop) and large ones."""
     f = ATRIUM_FRAME
     film_o, counts = atrium_reference
     for capacity in (20000, 0):
@@ -396,12 +389,10 @@ def test_atrium_hit_record_layouts_render_the_same_frame(R, atrium_scene, atrium
 
 def test_stage_level_streams_that_are_no_slabs_take_the_chunk_kernel(R, atrium_scene):
     """k_trace_refill takes its streams as slabs (one base + k x capacity: what rodent_gpu_get_*_stream hands out); a caller's struct may
-    point anywhere
-    (driver.impala:24-61 is a struct of pointers), and such a stream must go through k_trace_persist with the same result.  600 000 shadow
-    rays of the atrium
-    (above the persistent kernels' minimum) through hip_traverse_secondary with lane refill on: once as the library's slab, once with tmin /
-    tmax / colour arrays
-    moved to other allocations -- the film gets exactly the same contributions (compared per pixel to the order of the atomic adds)."""
+    point anywhere (driver.impala:24-61 is a struct of pointers), and such a stream must go through k_trace_persist with the same result.
+    600 000 shadow rays of the atrium (above the persistent kernels' minimum) through hip_traverse_secondary with lane refill on: once as
+    the library's slab, once with tmin / tmax / colour arrays moved to other allocations -- the film gets exactly the same contributions
+    (compared per pixel to the order of the atomic adds)."""
     import ctypes as C
     import torch
     W, H, SPP = 640, 480, 2

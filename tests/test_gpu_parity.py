@@ -214,12 +214,9 @@ def test_deep_stack_falls_back_to_global_stack(gpu, oracle):
 @pytest.mark.parametrize("depth", [16, 23, 40, 63])
 def test_deep_stacks_in_the_persistent_kernels(gpu, oracle, depth):
     """The same through the persistent kernels (rodent_hip_top_min_rays(0): the default mapping's k_bvh2_top_auto / k_bvh2_top_refill,
-    "refill", and the
-    wide kernels' persistent form), at depths around every block boundary of the spill (15 + 7 k entries) up to the reference's capacity of
-    63
-    entries (stack.impala:53: 64 slots, one of them the sentinel), 30 000 rays of which a third miss, coherent and shuffled (the refill
-    loop), twice
-    (the second launch runs on the image the first one built), closest and any hit."""
+    "refill", and the wide kernels' persistent form), at depths around every block boundary of the spill (15 + 7 k entries) up to the
+    reference's capacity of 63 entries (stack.impala:53: 64 slots, one of them the sentinel), 30 000 rays of which a third miss, coherent
+    and shuffled (the refill loop), twice (the second launch runs on the image the first one built), closest and any hit."""
     from conftest import chain_bvh2
     nodes, tris = chain_bvh2(depth)
     rng = np.random.default_rng(depth)
@@ -481,11 +478,9 @@ def test_bench_py_contract(native_build):
 
 def test_bench_py_with_two_ranks(native_build):
     """The N > 1 code path of bench.py -- strong partition as `value` (BASELINE's metric: ONE 1 Mi-ray set, contiguous ranges, Hit1 gather
-    to rank 0 after the
-    timed region, assembled array equal to a single-GPU trace), weak partition beside it (1 Mi rays per GPU), config 5 as interleaved 16-row
-    tiles with a film gather -- with two
-    ranks.  On a box with one GPU the ranks share it and the collectives go through gloo (RODENT_BENCH_SHARE_GPUS / _BACKEND);
-    with two or more GPUs this is the driver's RCCL launch."""
+    to rank 0 after the timed region, assembled array equal to a single-GPU trace), weak partition beside it (1 Mi rays per GPU), config 5
+    as interleaved 16-row tiles with a film gather -- with two ranks.  On a box with one GPU the ranks share it and the collectives go
+    through gloo (RODENT_BENCH_SHARE_GPUS / _BACKEND); with two or more GPUs this is the driver's RCCL launch."""
     import json, os, sys
     import torch
     from conftest import ROOT
@@ -594,12 +589,10 @@ def test_default_mapping_switches_kernels_at_its_size_threshold(gpu, oracle, cor
 @pytest.mark.gpu
 def test_camera_rays_in_image_order_are_traced_as_tiles(gpu, oracle, cornell, cornell_dev):
     """Round 5: the default BVH2 kernel recognises the pixels of an image, row by row (the reference's primary-ray dumps,
-    tools/ray_gen/ray_gen.cpp:20-58), from 66 of
-    the rays and gives every wavefront an 8 x 8-pixel tile instead of 64 pixels of a row (detect_ray_grid, traversal_top.h; stats[2] = the
-    width it used).  Whatever it
-    recognises -- widths that are no multiple of 8, heights that are not (the last rows stay in list order), two images in one list,
-    normalised directions, segments in no order,
-    a width forced on rays that are no image at all -- every Hit1 record is the oracle's, in its ray's place."""
+    tools/ray_gen/ray_gen.cpp:20-58), from 66 of the rays and gives every wavefront an 8 x 8-pixel tile instead of 64 pixels of a row
+    (detect_ray_grid, traversal_top.h; stats[2] = the width it used).  Whatever it recognises -- widths that are no multiple of 8, heights
+    that are not (the last rows stay in list order), two images in one list, normalised directions, segments in no order, a width forced on
+    rays that are no image at all -- every Hit1 record is the oracle's, in its ray's place."""
     import torch
     from rodent_amd import raygen, scenes
     top = gpu.variants(2).index("top")
@@ -688,9 +681,8 @@ def test_default_mapping_chooses_chunks_or_refill_by_itself(gpu, oracle, cornell
     """BASELINE config 3 ("ray compaction on") without a variant argument: the default kernel (k_bvh2_top_auto) traces rays that share an
     origin as whole chunks and refills idle lanes otherwise (stats[5]: workgroups that chose the refill loop).  With the ray-kind hint ON
     (rodent_hip_ray_kind_hint; off by default) a list -- same pointer, same count -- that was incoherent throughout goes to the refill
-    kernel proper
-    from its second launch on (stats[4]), and back when the caller puts coherent rays into the same buffer.  Hits are the oracle's in every
-    case."""
+    kernel proper from its second launch on (stats[4]), and back when the caller puts coherent rays into the same buffer.  Hits are the
+    oracle's in every case."""
     import torch
     top = gpu.variants(2).index("top")
     nodes, tris = cornell.blocks[2]

@@ -481,10 +481,9 @@ def test_device_film_view_aliases_the_library_film(R, cornell_scene):
 
 def test_mid_size_textured_scene_gets_the_rules_it_should(R, oracle, textured_hall):
     """The per-scene rules on a third kind of scene: a textured hall of ~9 500 triangles, a few thousand BVH nodes -- far above
-    the
-    128 nodes up to which the megakernel is chosen (render.hip resolve_mapping), below the 16 384 from which the traversal launches refill
-    idle lanes (resolve_refill).  The library must choose the streaming loop without lane refill, both mappings must trace the oracle's
-    paths through the textures, and the choice must not lose to the alternative by more than the run-to-run spread."""
+    the 128 nodes up to which the megakernel is chosen (render.hip resolve_mapping), below the 16 384 from which the traversal launches
+    refill idle lanes (resolve_refill).  The library must choose the streaming loop without lane refill, both mappings must trace the
+    oracle's paths through the textures, and the choice must not lose to the alternative by more than the run-to-run spread."""
     import time, torch
     sc = textured_hall
     assert 128 < len(sc.nodes) < 16384, len(sc.nodes)
@@ -516,10 +515,8 @@ def test_mid_size_textured_scene_gets_the_rules_it_should(R, oracle, textured_ha
 
 def test_shading_through_indices_and_normals_still_matches_oracle(native_build):
     """The shader reads a hit's face normal and vertex normals from ONE gathered 48-byte record per triangle (SceneDev::tri_shade, built at
-    scene creation);
-    RODENT_HIP_TRI_SHADE=0 keeps the reference's path through indices -> normals (geometry.impala:21-54).  The switch is read once per
-    process, so the
-    oracle comparisons of this module run again in a process that has it off."""
+    scene creation); RODENT_HIP_TRI_SHADE=0 keeps the reference's path through indices -> normals (geometry.impala:21-54).  The switch is
+    read once per process, so the oracle comparisons of this module run again in a process that has it off."""
     import os, sys
     from conftest import ROOT
     env = dict(os.environ, RODENT_HIP_TRI_SHADE="0")

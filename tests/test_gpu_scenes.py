@@ -63,10 +63,9 @@ def test_scene_classes_bit_exact(gpu, oracle, scene):
 @pytest.mark.parametrize("mapping", ["auto", "megakernel"])
 def test_stress_scenes_path_traced_match_oracle(native_build, oracle, scene, mapping, tmp_path):
     """The renderer on the two stress scenes (lit by the panels scenes.PANELS appends to their OBJ: the generators make geometry only): a
-    small frame through the
-    library's own choice of mapping and through the megakernel against the render oracle -- ray counts exact, film within the order of the
-    atomic adds.  The full-size
-    frames are measured by scripts/refill_rule_check.py (profiles/r05_refill_rule_check.txt)."""
+    small frame through the library's own choice of mapping and through the megakernel against the render oracle -- ray counts exact, film
+    within the order of the atomic adds.  The full-size frames are measured by scripts/refill_rule_check.py
+    (profiles/r05_refill_rule_check.txt)."""
     import torch
     from rodent_amd import render as R, scene as S, scenes
     assert torch.cuda.is_available()

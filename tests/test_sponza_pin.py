@@ -1,9 +1,8 @@
 """The reference-held pin for the traversal: its own CTest, restated (cmake/test/run_traversal.cmake:1-9, tools/CMakeLists.txt:24-31).
 
     bench_traversal -bvh testing/sponza.bvh -ray testing/sponza-primary.rays --bench 1 --warmup 0 --tmin 0.01 --tmax 5000 -o out.fbuf
-    <variant>
-    fbuf2png -n out.fbuf out.png
-    compare -metric MSE testing/ref-primary.png out.png            (ImageMagick: fails on any difference)
+    <variant> fbuf2png -n out.fbuf out.png compare -metric MSE testing/ref-primary.png out.png            (ImageMagick: fails on any
+    difference)
 
 The three Sponza blobs are missing from the reference checkout (.MISSING_LARGE_BLOBS: testing/sponza.bvh, sponza-primary.rays,
 sponza-random.rays), so these tests SKIP until someone drops them into data/ -- bench.py and rodent_amd.scenes.default_scene() switch
