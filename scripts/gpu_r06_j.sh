@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6, call J: the node's child ids fetched for lanes on a node only (exp_idsnodes: -DRODENT_JOINT_IDS_NODES_ONLY=1) against the default build:
-# parity of both suites' traversal / renderer cores, traversal ABI A/B, frame-rate A/B
+# parity of both suites' traversal / renderer cores, traversal ABI A/B, frame-rate A/B.  (The macro was an experiment patch to joint_fetch / joint_fetch_off --
+# s_and_b64 exec, exec, node_mask + s_cbranch_execz in front of the dwordx2 load -- that lost and was not committed: LAB_NOTES 12.7.)
 mkdir -p gpurun_out/r06; export TMPDIR=/tmp
 OUT=gpurun_out/r06
 RODENT_HIP_LIB=rodent_amd/lib/exp_idsnodes.so timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_atrium.py tests/test_gpu_render.py -m gpu -q -x -k "not bench_py and not cli and not through_indices and not up_front" 2>&1 | tail -3
