@@ -52,8 +52,7 @@ from benchlib.render import RENDER_CONFIGS, render_cpu_baseline, render_section,
 from benchlib.traversal import Bench, cpu_baseline, scene_matrix_rows, side_measurements, timed_partitions  # noqa: E402
 
 # what one GPU predicts for N (every rank's share timed alone: profiles/r06_range_costs.txt, r05_range_costs.txt, r04_band_costs.txt): ONE 1
-# Mi-ray
-# set does not shard its tail -- with the cost balanced every rank still holds a chunk of ~190 wave iterations
+# Mi-ray set does not shard its tail -- with the cost balanced every rank still holds a chunk of ~190 wave iterations
 PREDICTED_SCALING = {"strong_1Mi_primary_contiguous_ranges": {"2": 1.27, "4": 1.63, "8": 1.90},
     "strong_1Mi_random": {"2": 1.33, "4": 1.72, "8": 2.05},
                      "cfg5_frame_interleaved_16_row_tiles": {"2": 1.99, "4": 3.99, "8": 7.94}, "weak": "1 Mi rays per GPU: ~N",
@@ -167,8 +166,7 @@ def main():
                    "collective_backend": backend},
         "extra": {"random_Mrays_s": round(part["value_rnd"], 3), "random_ms_per_step": round(1e3 * part["wall_r"] / steps_r, 5),
                   # mean: HIP events around the whole timed region / steps; single_*: each launch between its own event pair in a second
-                  # pass
-                  # (adds the dispatch latency)
+                  # pass (adds the dispatch latency)
                   "primary_kernel_ms": {"mean": round(k_mean, 5), "single_launch_median": round(k_med, 5),
                       "single_launch_min": round(k_min, 5)},
                   "random_kernel_ms": {"mean": round(kr_mean, 5), "single_launch_median": round(kr_med, 5),

@@ -134,9 +134,8 @@ def binding_bounds(kernel, ray_set, rays, steps_per_ray, kernel_ms, lds_steps_pe
         out["wave_cycles_waiting_frac_profiled"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
     if "SQ_WAVE_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
         # wavefront occupancy: SQ_WAVE_CYCLES counts quad-cycles of resident waves (MI355X_MICROARCH.md), GRBM_GUI_ACTIVE the busy cycles of
-        # the
-        # eight XCDs -> resident waves per SIMD averaged over the launch, against the 8 the hardware holds (the kernel's 64 VGPRs and
-        # 80 KB of LDS per 16-wave workgroup admit all 8: what is missing from 8 is the launch's fill and drain)
+        # the eight XCDs -> resident waves per SIMD averaged over the launch, against the 8 the hardware holds (the kernel's 64 VGPRs and 80
+        # KB of LDS per 16-wave workgroup admit all 8: what is missing from 8 is the launch's fill and drain)
         waves = 4.0 * c["SQ_WAVE_CYCLES"] / ((c["GRBM_GUI_ACTIVE"] / 8.0) * cal["simds"])
         out["occupancy"] = {"resident_waves_per_simd_time_averaged_profiled": round(waves, 2), "max_waves_per_simd": 8,
             "frac": round(waves / 8.0, 4),

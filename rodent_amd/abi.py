@@ -91,9 +91,8 @@ def variants(width):
 
 
 # Mappings that do NOT keep the reference's per-ray visit order (lab build only: work stealing inside the wave, measured and lost): last-bit
-# ties in t
-# resolve to another triangle.  Every shipped mapping reproduces the reference kernel bit for bit (tests/).
-# (round 6: deferred leaves / triangle turns with deferral visit a superset of the nodes)
+# ties in t resolve to another triangle.  Every shipped mapping reproduces the reference kernel bit for bit (tests/). (round 6: deferred
+# leaves / triangle turns with deferral visit a superset of the nodes)
 ORDER_CHANGING = ("steal", "defer-", "stats-defer", "turns-p")
 
 

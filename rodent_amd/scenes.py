@@ -93,8 +93,7 @@ def scene_obj(scene: str) -> Path:
 
 
 # Emissive panels ("light" of atrium.mtl, facing down) for the renderer's frames of the generated stress scenes: (centre x, y, z, half
-# size).
-# Appended to the OBJ only -- the traversal matrix builds its .bvh straight from the generator (scene_bvh) and does not see them.
+# size). Appended to the OBJ only -- the traversal matrix builds its .bvh straight from the generator (scene_bvh) and does not see them.
 PANELS = {"crown": [(0.0, 950.0, 0.0, 450.0)],
           "plant": [(x, 1390.0, z, 150.0) for x in (-1300.0, 0.0, 1300.0) for z in (-600.0, 600.0)]}
 

@@ -392,10 +392,9 @@ def test_bench_traversal_cli(gpu, native_build, oracle, cornell, tmp_path):
     r = subprocess.run(cmd + ["-gpu", "hip", "-ngpu", str(have + 1)], capture_output=True, text=True)
     assert r.returncode != 0 and "No such GPU device(s)" in r.stderr
     # The K > 1 path on however few GPUs the box has: RODENT_SHARE_GPUS=1 puts the K ranks' threads, ray ranges and Hit1
-    # pieces on the
-    # devices there are; RCCL cannot place two ranks on one device, so the gather takes its fallback (one hipMemcpyPeerAsync per piece) and
-    # says so; the tool
-    # then checks the assembled array against one device's trace of all rays by itself.  An injected RCCL failure takes the same branch.
+    # pieces on the devices there are; RCCL cannot place two ranks on one device, so the gather takes its fallback (one hipMemcpyPeerAsync
+    # per piece) and says so; the tool then checks the assembled array against one device's trace of all rays by itself.  An injected RCCL
+    # failure takes the same branch.
     import os
     for k, env in ((3, {"RODENT_SHARE_GPUS": "1"}), (min(have, 2), {"RODENT_FORCE_RCCL_INIT_FAILURE": "1"})):
         if k < 2:
@@ -427,16 +426,14 @@ def test_bench_py_contract(native_build):
         "vs_baseline"] is None and "workload" in d["config"]
     rf = d["roofline"]
     # ONE top-level roofline: VALU issue against the guide's 2-cycle rate (the live node-fetch bound stands in while the committed counter
-    # pass is stale): a fraction
-    # never above 1; the measured and the algorithmic HBM fractions side by side at the top level, the latter labelled as a count of cache
-    # hits
+    # pass is stale): a fraction never above 1; the measured and the algorithmic HBM fractions side by side at the top level, the latter
+    # labelled as a count of cache hits
     assert rf["bound"] in ("valu_issue",
         "vmem_node_fetch") and 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3
     assert rf["bound"] != "valu_issue" or (rf["peak"] == 1162.0 and 0 < rf["frac_of_measured_loop_mix_ceiling"] <= 1.0
         and 0 < rf["lane_utilisation"] <= 1.0)
     # BASELINE's "fraction of HBM roofline" is ONE key: roofline.hbm (measured fabric bytes of the committed --pmc passes / kernel time / 8
-    # TB/s); the survey's
-    # bytes-per-visit figure is a count of cache hits and is named so (it is no fraction: > 1 on a cache-resident tree)
+    # TB/s); the survey's bytes-per-visit figure is a count of cache hits and is named so (it is no fraction: > 1 on a cache-resident tree)
     assert rf["cache_served_bytes_over_hbm_peak"] > 0 and "hbm_algorithmic_frac" not in rf and "compulsory_frac" in rf["hbm"]
     assert rf["traffic"] is None or (0 < rf["hbm"]["measured_frac"] < 1.0 and rf["hbm"]["traffic_over_compulsory"] > 0.9
         and rf["hbm"]["write_amplification"] > 0.9)
@@ -636,10 +633,8 @@ def test_camera_rays_in_image_order_are_traced_as_tiles(gpu, oracle, cornell, co
     segments = raygen.random_rays(lo, hi, 40_000, 7, 0.0, 1.0)
     run(segments, 0)
     # An image AND segments in one list: the width is recognised, the image's waves trace tiles, the segments' waves refill
-    # lanes -- and both must map the
-    # launch's positions onto its rays the same way.  Heights that are no multiple of 8: the image's last rows share a band of 8 rows with
-    # segments.
-    # (136 x 53 = 7 208 rays: the probes beyond them are segments -- recognised or not)
+    # lanes -- and both must map the launch's positions onto its rays the same way.  Heights that are no multiple of 8: the image's last
+    # rows share a band of 8 rows with segments. (136 x 53 = 7 208 rays: the probes beyond them are segments -- recognised or not)
     for w, h, expect in ((256, 60, 256), (1024, 20, 1024), (136, 53, None)):
         run(np.concatenate([raygen.primary_rays(*cam, w, h, 0.0, 5000.0), segments]), expect)
     run(np.concatenate([segments[:1000], image]), None)               # (segments first: whatever is recognised, the hits are right)
