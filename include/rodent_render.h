@@ -99,12 +99,9 @@ void    rodent_hip_render_capacity(int32_t dev, int32_t rays);
  * stays one call away.  Same paths, same ray counts; RODENT_HIP_SORT=0|1 sets the initial value, `rodent --sort` / `--no-sort`. */
 void    rodent_hip_render_sort(int32_t dev, int32_t enable);
 /* Hit records inside the library's own wavefront loop: 1 (default) = one 20-byte record per ray in the memory of the stream's geom_id /
- * prim_id /
- * t / u / v arrays (one 16-byte + one 4-byte store per record instead of five scattered 4-byte stores: the traversal launches' write
- * traffic),
- * 0 = the ABI's five arrays.  The stage-level entry points (hip_traverse_primary, hip_shade, ...) always use the five arrays, and so does
- * the
- * loop when the sort by material is on.  RODENT_HIP_HIT_AOS. */
+ * prim_id / t / u / v arrays (one 16-byte + one 4-byte store per record instead of five scattered 4-byte stores: the traversal launches'
+ * write traffic), 0 = the ABI's five arrays.  The stage-level entry points (hip_traverse_primary, hip_shade, ...) always use the five
+ * arrays, and so does the loop when the sort by material is on.  RODENT_HIP_HIT_AOS. */
 void    rodent_hip_render_hit_records(int32_t dev, int32_t aos);
 /* 1 (default): the shadow rays of a bounce are traced on a second HIP stream beside the compaction, regeneration and the
  * next closest-hit pass; 0: one stream.  Same film up to the order of the atomic adds.  RODENT_HIP_OVERLAP=0|1.

@@ -133,27 +133,22 @@ int32_t rodent_hip_check_errors(int32_t dev, void* stream);
 
 /* Introspection / plumbing. */
 /* anydsl_get_kernel_time() of the AnyDSL runtime, which the reference's bench_traversal brackets its GPU calls with
- * (tools/bench_traversal/bench_traversal.cpp:125-133): microseconds of KERNEL time accumulated over the synchronous entry points above
- * (HIP events around what a call enqueues, after the context's buffers have been allocated: the call's synchronisation is not in it; where
- * a mapping
- * is two kernels -- launches under rodent_hip_top_min_rays: the one-chunk kernel and its follow-up -- the microsecond between them is.  One
- * sum per
- * process over all devices, like the reference's; one synchronous call at a time per (device, null stream). */
+ * (tools/bench_traversal/bench_traversal.cpp:125-133): microseconds of KERNEL time accumulated over the synchronous entry points above (HIP
+ * events around what a call enqueues, after the context's buffers have been allocated: the call's synchronisation is not in it; where a
+ * mapping is two kernels -- launches under rodent_hip_top_min_rays: the one-chunk kernel and its follow-up -- the microsecond between them
+ * is.  One sum per process over all devices, like the reference's; one synchronous call at a time per (device, null stream). */
 uint64_t    rodent_hip_get_kernel_time(void);
 int32_t     rodent_hip_device_count(void);              /* 0 when no GPU is visible */
 int32_t     rodent_hip_num_variants(int32_t bvh_width); /* bvh_width: 2, 4 or 8 */
 /* The phased BVH2 mappings ("phased-*": capped phases with ray compaction in between) take the single kernel for launches
- * of fewer than this many rays (default 262 144: less than one round of resident waves); < 0 restores the default, 0 makes
- * every launch phased (tests). */
+ * of fewer than this many rays (default 262 144: less than one round of resident waves); < 0 restores the default, 0 makes every launch
+ * phased (tests). */
 void        rodent_hip_phased_min_rays(int32_t rays);
 /* The default BVH2 mapping ("top": top of the tree staged in LDS, persistent workgroups) takes the one-chunk-per-workgroup
  * kernel ("fast") for launches of fewer than this many rays (default 393 216: the measured cross-over of the two kernels, 589 824 until
- * round 4 --
- * staging and validating the image in every workgroup does not pay below that); < 0 restores the default, 0 sends every launch through the
- * LDS-image kernel (tests).
- * The default BVH4 / BVH8 mapping ("top": persistent workgroups that stage the top 85 / 73 nodes themselves) switches to ITS one-chunk
- * kernel
- * ("single") at the same size. */
+ * round 4 -- staging and validating the image in every workgroup does not pay below that); < 0 restores the default, 0 sends every launch
+ * through the LDS-image kernel (tests). The default BVH4 / BVH8 mapping ("top": persistent workgroups that stage the top 85 / 73 nodes
+ * themselves) switches to ITS one-chunk kernel ("single") at the same size. */
 void        rodent_hip_top_min_rays(int32_t rays);
 /* Schedule history of the default BVH2 mapping (off by default; RODENT_HIP_SCHEDULE_HISTORY=1): every launch records how many
  * wave iterations each 64-ray chunk took, and the next launch of the SAME ray count on that (device, stream) traces its chunks
@@ -163,30 +158,21 @@ void        rodent_hip_top_min_rays(int32_t rays);
  * throughput-bound: measured -8 % at 16 Mi). */
 void        rodent_hip_schedule_history(int32_t enable);
 /* Ray-kind hint of the default BVH2 mapping (OFF by default from round 5 on; RODENT_HIP_KIND_HINT=1).  The default kernel decides per
- * wavefront,
- * once, from the first 64 rays the wave draws, whether they share an origin or a direction (traced as whole 64-ray chunks) or not (idle
- * lanes are
- * refilled: the compaction of BASELINE config 3; reference: render/mapping_gpu.impala:267-300 compacts unconditionally) -- no state between
- * launches.
- * With the hint on, every workgroup also notes what it saw in a host-visible word, and a list -- same pointer, same count -- that all
- * workgroups
- * of the earlier launches found incoherent is traced by the kernel specialised for that ("refill") from its second launch on (+2 ... 4 % on
- * random
- * segments): kernel selection then depends on earlier launches and, for asynchronous callers, on when they finished.  Hit records never
- * depend on it. */
+ * wavefront, once, from the first 64 rays the wave draws, whether they share an origin or a direction (traced as whole 64-ray chunks) or
+ * not (idle lanes are refilled: the compaction of BASELINE config 3; reference: render/mapping_gpu.impala:267-300 compacts unconditionally)
+ * -- no state between launches. With the hint on, every workgroup also notes what it saw in a host-visible word, and a list -- same
+ * pointer, same count -- that all workgroups of the earlier launches found incoherent is traced by the kernel specialised for that
+ * ("refill") from its second launch on (+2 ... 4 % on random segments): kernel selection then depends on earlier launches and, for
+ * asynchronous callers, on when they finished.  Hit records never depend on it. */
 void        rodent_hip_ray_kind_hint(int32_t enable);
 /* Camera rays in image order (round 5; RODENT_HIP_RAY_GRID).  The reference's primary-ray dumps are the pixels of an image row by row
- * (tools/ray_gen/ray_gen.cpp:20-58:
- * dir = d + kx r + ky u, not normalised).  Which rays share a wavefront is the callee's business: the default BVH2 kernel recognises such a
- * list from 66 of its rays --
- * no state between launches, no probe launch -- and gives every wavefront an 8 x 8-pixel tile instead of 64 pixels of one row (the rays of
- * a tile finish closer together and
- * share more nodes: 1 Mi camera rays on the atrium 0.178 -> 0.167 ms).  Per-pixel lists that are no camera dump (ray_gen's shadow mode,
- * tools/ray_gen/ray_gen.cpp:60-85;
- * a renderer's shadow rays in pixel order) are recognised when the width is a multiple of 128 that divides the ray count.  Hit records and
- * their places in `hits` do not change.
- * width: -1 = recognise (default), 0 = never (list order, as until round 4), > 0 = take this image width on trust (experiments; multiples
- * of 8 only, others mean 0). */
+ * (tools/ray_gen/ray_gen.cpp:20-58: dir = d + kx r + ky u, not normalised).  Which rays share a wavefront is the callee's business: the
+ * default BVH2 kernel recognises such a list from 66 of its rays -- no state between launches, no probe launch -- and gives every wavefront
+ * an 8 x 8-pixel tile instead of 64 pixels of one row (the rays of a tile finish closer together and share more nodes: 1 Mi camera rays on
+ * the atrium 0.178 -> 0.167 ms).  Per-pixel lists that are no camera dump (ray_gen's shadow mode, tools/ray_gen/ray_gen.cpp:60-85; a
+ * renderer's shadow rays in pixel order) are recognised when the width is a multiple of 128 that divides the ray count.  Hit records and
+ * their places in `hits` do not change. width: -1 = recognise (default), 0 = never (list order, as until round 4), > 0 = take this image
+ * width on trust (experiments; multiples of 8 only, others mean 0). */
 void        rodent_hip_ray_grid(int32_t width);
 /* 1 = librodent_hip_lab.so (-DRODENT_HIP_LAB: also the measured-and-lost kernels) */
 int32_t     rodent_hip_is_lab_build(void);
@@ -194,13 +180,11 @@ const char* rodent_hip_variant_name(int32_t bvh_width, int32_t variant);
 const char* rodent_hip_kernel_name(int32_t bvh_width, int32_t variant, int32_t any_hit);
 const char* rodent_hip_version(void);
 /* Digest of the sources this binary was compiled from (rodent_amd/build.py source_digest(): sha256 over the files of csrc/, the host code
- * the
- * library links and every header): a prebuilt library can be checked against the sources lying next to it. */
+ * the library links and every header): a prebuilt library can be checked against the sources lying next to it. */
 const char* rodent_hip_source_digest(void);
 /* Debug aid: reads and clears the 8 phase counters of the instrumented "stats-*" variants
- * ([0] descent iterations, [1] lanes active in them, [2] leaf iterations, [3] lanes, [4] refills,
- * [5] lanes refilled, [6] outer iterations); from the shipped BVH2 mappings: [2] image width a launch traced 8 x 8 tiles of, [4] launches
- * of the refill kernel by the
+ * ([0] descent iterations, [1] lanes active in them, [2] leaf iterations, [3] lanes, [4] refills, [5] lanes refilled, [6] outer
+ * iterations); from the shipped BVH2 mappings: [2] image width a launch traced 8 x 8 tiles of, [4] launches of the refill kernel by the
  * ray-kind hint, [5] launches whose first wavefront chose the refill loop, [6] launches that ran on a validated LDS image, [7] stack blocks
  * spilled + rays handed to the deep pass. */
 void        rodent_hip_read_stats(int32_t dev, uint64_t* out8);

@@ -752,9 +752,8 @@ void k_trace_refill(SceneDev sc, StreamSlab pslab, int n_primary, int coherent_f
             if (is_node) {
                 float te0, te1;
                 // -(o * 1/d) is computed here, not carried (make_rayx's product, the same value): three multiplications per node step for
-                // three
-                // registers -- with them in the lane state the register allocator puts three ray components into scratch and reloads them
-                // in every step
+                // three registers -- with them in the lane state the register allocator puts three ray components into scratch and reloads
+                // them in every step
                 RayX rr = L.ray; rr.iox = -(rr.ox * rr.idx); rr.ioy = -(rr.oy * rr.idy); rr.ioz = -(rr.oz * rr.idz);
                 const bool h0 = slab_canonical(rr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, te0) && ch.x != 0;
                 const bool h1 = slab_canonical(rr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, te1) && ch.y != 0;

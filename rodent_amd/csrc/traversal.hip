@@ -396,21 +396,16 @@ __device__ __forceinline__ void finish_lane_reg(const Lane& L, const Ray1* __res
 // -> 0.281, crown 0.1845 -> 0.1875; profiles/r05_grid_tiles.txt). Every wave looks at rays 0, 64 and 128, 256, ... 8192 (one probe per
 // lane, in flight with the wave's first rays) and reads them two ways:
 // 1. a ray_gen dump of camera rays (the reference's tools/ray_gen/ray_gen.cpp:20-58): dir = d + kx(column) r + ky(row) u, not normalised.
-// Along a row the direction advances by a
-//    constant step e, so (dir[i] - dir[0]) . e / |e|^2 is the column of ray i -- it climbs with i and falls back to 0 where the next row
-// starts: the first probe whose column is
-//    less than half its index lies in the second row, width = index - column, and the other probes must sit in the columns that width
-// predicts.  Any width, exactly.
+//    Along a row the direction advances by a constant step e, so (dir[i] - dir[0]) . e / |e|^2 is the column of ray i -- it climbs with i
+//    and falls back to 0 where the next row starts: the first probe whose column is less than half its index lies in the second row, width
+//    = index - column, and the other probes must sit in the columns that width predicts.  Any width, exactly.
 // 2. any other per-pixel list (ray_gen's shadow mode -- from a light to the camera rays' hit points, ray_gen.cpp:60-85, the suite's "ao"
-// class --, normalised camera rays, a
-//    renderer's shadow or reflection rays in pixel order): probe k is 128 k pixels along the list; in an image of width 128 k* it is the
-// pixel k* ... BELOW ray 0, a near neighbour,
-//    while the probes before it are 128, 256, ... pixels away along the row.  Distance = |org - org0|^2 and |dir - dir0|^2, each in units
-// of probe 1's: the first probe closer than
-//    an eighth of probe 1 gives the width (a multiple of 128 that divides the ray count); the probe two rows down must be near as well and
-// the probe after it about as far as
-//    probe 1.  Measured on the ao rays (1 Mi, profiles/r05_scene_matrix.txt): gallery 0.290 -> 0.217 ms, plant 0.095 -> 0.081, atrium 0.156
-// -> 0.151, crown level.
+//    class --, normalised camera rays, a renderer's shadow or reflection rays in pixel order): probe k is 128 k pixels along the list; in
+//    an image of width 128 k* it is the pixel k* ... BELOW ray 0, a near neighbour, while the probes before it are 128, 256, ... pixels
+//    away along the row.  Distance = |org - org0|^2 and |dir - dir0|^2, each in units of probe 1's: the first probe closer than an eighth
+//    of probe 1 gives the width (a multiple of 128 that divides the ray count); the probe two rows down must be near as well and the probe
+//    after it about as far as probe 1.  Measured on the ao rays (1 Mi, profiles/r05_scene_matrix.txt): gallery 0.290 -> 0.217 ms, plant
+//    0.095 -> 0.081, atrium 0.156 -> 0.151, crown level.
 // Wave-uniform, and the same in every wave of a launch (same rays, same arithmetic).  0 = not recognised: rays in list order, as until
 // round 4.  A wrong answer would cost speed, never hits -- any width maps the launch's positions onto its rays one to one
 // (k_bvh2_top_auto).

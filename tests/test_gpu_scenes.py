@@ -1,16 +1,11 @@
 """The other scene classes of the reference's benchmark suite (benchmarks/benchmark.py:16-44: crown, san-miguel, powerplant beside sponza)
-and its
-third ray class, at test size: seeded stand-ins (rodent_amd/host/stress_scenes.cpp, atrium.cpp at a higher detail) built by the in-tree
-builder
-where the test runs -- a dense organic surface (crown/1: 262 K small triangles), a hall of long thin triangles (plant/1: 520 K triangles,
-3.6 M
-references after spatial splits, tree depth 30+) and the atrium at four times its triangle count (gallery/2) -- traced with 256 Ki camera
-rays,
-256 Ki random segments and 256 Ki "ao" rays (ray_gen shadow, tools/ray_gen/ray_gen.cpp:60-85: from a point light to the camera rays' hit
-points,
-any hit, tmax 0.999).  Every shipped BVH2 mapping: the whole Hit1 record of every ray bit for bit against oracle B1 (any hit: the oracle's
-record
-as well -- same visit order).  Full-size figures: scripts/scene_matrix.py, profiles/r05_scene_matrix.txt, bench.py extra.scenes."""
+and its third ray class, at test size: seeded stand-ins (rodent_amd/host/stress_scenes.cpp, atrium.cpp at a higher detail) built by the
+in-tree builder where the test runs -- a dense organic surface (crown/1: 262 K small triangles), a hall of long thin triangles (plant/1: 520
+K triangles, 3.6 M references after spatial splits, tree depth 30+) and the atrium at four times its triangle count (gallery/2) -- traced
+with 256 Ki camera rays, 256 Ki random segments and 256 Ki "ao" rays (ray_gen shadow, tools/ray_gen/ray_gen.cpp:60-85: from a point light to
+the camera rays' hit points, any hit, tmax 0.999).  Every shipped BVH2 mapping: the whole Hit1 record of every ray bit for bit against
+oracle B1 (any hit: the oracle's record as well -- same visit order).  Full-size figures: scripts/scene_matrix.py,
+profiles/r05_scene_matrix.txt, bench.py extra.scenes."""
 import numpy as np
 import pytest
 
