@@ -4,17 +4,15 @@ and proves it:
   C / C++ / HIP   the token stream (comments and white space dropped, adjacent string literals merged) must be identical before and after;
   Python          the syntax tree (docstrings compared with white space collapsed) must be identical before and after;
 a file whose check fails is left untouched and reported.  Lines that cannot be broken safely (inside raw strings, tables in comments wider
-than the limit
-with no spaces, ...) are left as they are and listed.
-What it does to a long line: a trailing comment moves to its own line(s) ABOVE the code; comment text is wrapped at spaces; code is broken
-at the best of
--- a statement boundary, the opening brace of a one-line block, a comma (the shallower the better), a logical / ternary operator, an
-assignment, an arithmetic
-operator, any space outside literals -- at or before the limit, continuation lines indented by 4 (a new statement keeps the indent); a
-preprocessor
-definition gets backslashes; a string literal that alone exceeds the limit is split into adjacent literals at a space.  Python: breaks only
-inside brackets
-(a backslash where there are none), f-strings split outside their braces.
+than the limit with no spaces, ...) are left as they are and listed.
+
+What it does to a long line: a trailing comment moves to its own line(s) ABOVE the code; comment text is wrapped at spaces (a paragraph of
+running text is re-wrapped as a whole, a table row keeps its columns); code is broken at the best of -- a statement boundary, the opening
+brace of a one-line block, a comma (the shallower the better), a logical / ternary operator, an assignment, an arithmetic operator, any
+space outside literals -- at or before the limit, continuation lines indented by 4 (a new statement keeps the indent); a preprocessor
+definition gets backslashes; a string literal that alone exceeds the limit is split into adjacent literals at a space.  Python: breaks
+only inside brackets, f-strings split outside their braces, docstring text wrapped.
+
 usage: python scripts/wrap_sources.py [--limit 140] [--check] files..."""
 import argparse
 import ast
